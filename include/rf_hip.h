@@ -1,0 +1,146 @@
+/*
+ * rf_hip.h -- C ABI of librf_hip.so: the MI355X (gfx950) kernels under the Routeformer hot path.
+ *
+ * The reference (meakbiyik/routeformer) is pure Python and has no FFI of its own; every arithmetic
+ * op on its hot path is an ATen call.  Each entry point below replaces the ATen work of the cited
+ * reference lines (paths relative to /root/reference).  All entry points:
+ *   - take raw DEVICE pointers, sizes and a hipStream_t (passed as void*); no torch types;
+ *   - never allocate: workspaces are passed in; all launches are asynchronous on `stream`;
+ *   - return 0 on success, a negative RF_E* code on bad arguments / launch failure (no exceptions).
+ * Activations are fp32 in HBM.  `prec` selects the matrix-core input type of the dense
+ * contractions: 0 = exact fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16 inputs / fp32 accumulate
+ * (v_mfma_f32_16x16x32_bf16, operands rounded to bf16 while staging into LDS).
+ */
+#ifndef RF_HIP_H
+#define RF_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RF_OK 0
+#define RF_EINVAL (-1)
+#define RF_ELAUNCH (-2)
+#define RF_EUNSUPPORTED (-3)
+
+#define RF_ACT_NONE 0
+#define RF_ACT_RELU 1
+#define RF_ACT_GELU 2 /* erf form, F.gelu default (cross_modal_transformer.py:221,286) */
+#define RF_ACT_ELU 3
+
+int rf_version(void);
+/* Last HIP error string seen by the library on this thread (for diagnostics). */
+const char* rf_last_error(void);
+
+/* ---- dense contraction -------------------------------------------------------------------
+ * C[M,N] = epi( A[M,K] * B[K,N] ),  A[m,k] = A[m*lda_m + k*lda_k],  B[k,n] = B[k*ldb_k + n*ldb_n].
+ * epi(v) : v += bias[n];  if (preact) preact[m,n] = v;  v = act(v);
+ *          if (dact_mode) v *= act'(dact_src[m,n]) (1: relu mask src>0, 2: gelu'(src), 3: elu'(src));
+ *          if (residual) v += residual[(m % res_rows), n];   (res_before_act: add before act)
+ * Replaces nn.Linear / Conv1d(k=1) forward+backward GEMMs: cross_modal_transformer.py:177-180,
+ * 189-198,215-216,281-282,423,496; gps_backbone/layers/SelfAttentionFamily.py:176-192;
+ * layers/TransformerEncoderDecoder.py:36-37,50-51,98-99; Informer.py:102.
+ * splitk > 1 needs workspace of splitk*M*N floats (deterministic two-pass reduction). */
+int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k,
+            int64_t ldb_n, float* C, int64_t ldc, int M, int N, int K, const float* bias,
+            const float* residual, int64_t ldr, int res_rows, int res_before_act, int act,
+            float* preact, int64_t ldp, const float* dact_src, int64_t ldd, int dact_mode,
+            int prec, int splitk, float* workspace, void* stream);
+
+/* out[n] = sum_m X[m*ldx + n] (bias gradients).  workspace: parts*N floats, parts = rf_colsum_parts(M,N). */
+int rf_colsum_parts(int M, int N);
+int rf_colsum(const float* X, int64_t ldx, int M, int N, float* out, float* workspace, void* stream);
+
+/* ---- conv2d as implicit GEMM over NHWC (frozen HRNet-16 trunk, inference only) -------------
+ * y[n,ho,wo,co] = act( sum_{kh,kw,ci} x[n,ho*s-p+kh,wo*s-p+kw,ci] * w[co,kh,kw,ci] + bias[co]
+ *                      (+ residual[n,ho,wo,co]) )
+ * BatchNorm2d(eval) is folded into w/bias by the host.  x has row pitch `cin` (channels innermost),
+ * y is written with channel pitch ldy at channel offset 0 of the given pointer.
+ * Replaces Conv2d+BN+ReLU(+add) of inverse_form_layers/hrnetv2.py:45-61,79-99,434-440. */
+int rf_conv2d_nhwc(const float* x, const float* w, const float* bias, const float* residual,
+                   float* y, int N, int H, int W, int cin, int cout, int ksize, int stride, int pad,
+                   int Ho, int Wo, int64_t ldy, int64_t ldres, int relu, int prec, void* stream);
+
+/* Stem: frame gather + fp16->fp32 + conv0 (3->3, k2 s2, no BN; hrnetv2.py:292-293,432-433).
+ * video: (B,T,3,H,W) fp16 (video_is_f32=0) or fp32 (=1); frame_idx[F] picks frames (routeformer.py:418-421);
+ * y: (B*F, H/2, W/2, 4) fp32 NHWC with a zero 4th channel. w: (3,3,2,2) as in the state dict. */
+int rf_stem_conv0(const void* video, int video_is_f32, const int32_t* frame_idx, const float* w,
+                  float* y, int B, int T, int F, int H, int W, void* stream);
+
+/* y[n,ho,wo,c] = (accumulate ? y : 0) + (addend ? addend[n,ho,wo,c] : 0) + bilinear(x)[n,ho,wo,c]
+ * (align_corners=False), optional ReLU afterwards; y has channel pitch ldy, addend is dense (pitch C).
+ * hrnetv2.py:266-271,453-498. */
+int rf_upsample_bilinear_nhwc(const float* x, const float* addend, float* y, int N, int Hi, int Wi,
+                              int C, int Ho, int Wo, int64_t ldy, int accumulate, int relu,
+                              void* stream);
+
+/* out = relu?(a + b) elementwise over n floats (fuse-layer identity terms). */
+int rf_add_relu(const float* a, const float* b, float* out, int64_t n, int relu, void* stream);
+
+/* AdaptiveAvgPool2d((8,8)) on NHWC + token layout + the constant -1 row:
+ * x (N,H,W,C) -> tokens (N,65,C); InverseForm.py:66-67 + routeformer.py:478-487. */
+int rf_avgpool8_tokens(const float* x, float* tokens, int N, int H, int W, int C, void* stream);
+
+/* ---- sequence ops ---------------------------------------------------------------------------
+ * Circular unfold for Conv1d(k=3, padding_mode="circular"): x (B,L,C) -> cols (B,Lout,3C),
+ * Lout = L + 2*pad - 2, cols[b,l,t*C+c] = x[b,(l+t-pad) mod L,c]; fold is its adjoint (gradient).
+ * cross_modal_transformer.py:352-369; layers/Embedding.py:28-46; TransformerEncoderDecoder.py:12-18. */
+int rf_unfold3_circular(const float* x, float* cols, int B, int L, int C, int pad, void* stream);
+int rf_fold3_circular(const float* dcols, float* dx, int B, int L, int C, int pad, void* stream);
+
+/* LayerNorm over the last dim (eps 1e-5) of s = x (+ residual); saves xhat and rstd for backward.
+ * cross_modal_transformer.py:283-284,297,301,421. cols <= 1024. */
+int rf_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                     float* y, float* xhat, float* rstd, int rows, int cols, float eps, void* stream);
+/* dx = d(loss)/d(s); dgamma/dbeta reduced deterministically through `workspace`
+ * (rf_layernorm_bwd_parts(rows)*2*cols floats). */
+int rf_layernorm_bwd_parts(int rows);
+int rf_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma,
+                     float* dx, float* dgamma, float* dbeta, float* workspace, int rows, int cols,
+                     void* stream);
+
+/* Informer distilling layer tail: BatchNorm1d (train: batch stats, eval: running stats) -> ELU ->
+ * MaxPool1d(3,2,1) on (B,L,C), C innermost.  layers/TransformerEncoderDecoder.py:19-28.
+ * stats: mean[C], var[C] (biased) computed by rf_bn_stats in train mode. */
+int rf_bn_stats(const float* x, float* mean, float* var, int rows, int C, void* stream);
+int rf_bn_elu_pool_fwd(const float* x, const float* mean, const float* var, const float* gamma,
+                       const float* beta, float* y, int32_t* argmax, int B, int L, int C, float eps,
+                       void* stream);
+/* dx for the whole BN(train)->ELU->pool chain; dgamma/dbeta too.  training=0: stats are constants. */
+int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const float* x, const float* mean,
+                       const float* var, const float* gamma, const float* beta, float* dx,
+                       float* dgamma, float* dbeta, float* workspace, int B, int L, int C, float eps,
+                       int training, void* stream);
+
+/* ---- attention ------------------------------------------------------------------------------
+ * One workgroup per (batch, head).  q[(b*LQ+l)*q_ld + h*E + e] etc. (row pitches in floats).
+ * mode 0: full softmax(scale*QK^T)V          (cross_modal_transformer.py:51-69)
+ * mode 1: ProbSparse, unmasked               (cross_modal_transformer.py:88-166)
+ * mode 2: ProbSparse, masked (ProbMask+cumsum context)
+ * index_sample: int32 [LQ, sample_k], shared by all (b,h) (host RNG, :95).
+ * top_idx: int32 [B,H,n_top] selected query rows, ascending; written unless force_top (then read).
+ * out_layout 0: ctx[b,l,h,:] (cross-modal variant), 1: ctx[b,h,l,:] (GPS variant,
+ * layers/SelfAttentionFamily.py:165 -- the un-transposed "head scramble"). */
+int rf_attn_fwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
+                int64_t v_ld, float* ctx, int out_layout, const int32_t* index_sample,
+                int32_t* top_idx, int force_top, int B, int H, int LQ, int LK, int E, int sample_k,
+                int n_top, int mode, float scale, void* stream);
+int rf_attn_bwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
+                int64_t v_ld, const float* dctx, int out_layout, const int32_t* top_idx, float* dq,
+                float* dk, float* dv, int64_t dq_ld, int64_t dk_ld, int64_t dv_ld, int B, int H,
+                int LQ, int LK, int E, int n_top, int mode, float scale, void* stream);
+
+/* ---- optimizer (experiments/full_comparison.py:694-702,829-830) -------------------------------
+ * sumsq[0] += sum g^2 over n floats (caller zeroes sumsq). */
+int rf_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
+/* AdamW with global-norm clipping fused: g *= min(1, max_norm/(sqrt(sumsq)+1e-6)); decoupled
+ * weight decay; bias-corrected moments (torch.optim.AdamW semantics).  max_norm<=0 disables. */
+int rf_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
+                  float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
+                  float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RF_HIP_H */

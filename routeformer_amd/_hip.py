@@ -1,0 +1,79 @@
+"""ctypes binding of ``csrc/librf_hip.so`` (C ABI declared in ``include/rf_hip.h``).
+
+There is NO fallback: if the shared library is missing or a call fails, this raises.  Tensors are
+passed as raw device pointers; every call is asynchronous on the caller's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librf_hip.so")
+
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+
+# name -> argtypes, mirroring include/rf_hip.h exactly (checked by tests/test_abi.py)
+SIGNATURES = {
+    "rf_gemm": [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _I, _P, _L, _P, _L,
+                _I, _I, _I, _P, _P],
+    "rf_colsum_parts": [_I, _I],
+    "rf_colsum": [_P, _L, _I, _I, _P, _P, _P],
+    "rf_conv2d_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _I, _I, _P],
+    "rf_stem_conv0": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "rf_upsample_bilinear_nhwc": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _I, _I, _P],
+    "rf_add_relu": [_P, _P, _P, _L, _I, _P],
+    "rf_avgpool8_tokens": [_P, _P, _I, _I, _I, _I, _P],
+    "rf_unfold3_circular": [_P, _P, _I, _I, _I, _I, _P],
+    "rf_fold3_circular": [_P, _P, _I, _I, _I, _I, _P],
+    "rf_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "rf_layernorm_bwd_parts": [_I],
+    "rf_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "rf_bn_stats": [_P, _P, _P, _I, _I, _P],
+    "rf_bn_elu_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "rf_bn_elu_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
+    "rf_attn_fwd": [_P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "rf_attn_bwd": [_P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _I,
+                    _I, _I, _F, _P],
+    "rf_sumsq": [_P, _L, _P, _P],
+    "rf_adamw_clip": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _I, _F, _P],
+    "rf_version": [],
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (loads on first use; raises loudly when it is not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} is missing: build it with `make -C routeformer_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "routeformer_amd has no CPU / eager fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        handle.rf_last_error.restype = ctypes.c_char_p
+        handle.rf_last_error.argtypes = []
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().rf_last_error()
+        raise HipLibraryError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or NULL for None)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,372 @@
+// Attention for the Routeformer hot path: full softmax attention and Informer "ProbSparse"
+// attention (unmasked / masked), forward and backward.  One workgroup (256 threads = 4 waves) per
+// (batch, head); the whole K, V (and Q) head slice lives in LDS (L <= 320, E <= 128: <= 160 KB).
+//
+// ProbSparse forward (cross_modal_transformer.py:88-166, restated in SURVEY.md A.3):
+//   1. M[q] = max_j Q[q].K[idx[q,j]] - (sum_j Q[q].K[idx[q,j]]) / L_K      (fp32, idx from the host RNG)
+//   2. top = the n_top queries with the largest M (ties: lower index first)
+//   3. selected rows:  ctx[q] = softmax(scale * Q[q] K^T (masked: keys <= q)) V
+//   4. other rows:     ctx[q] = mean_s V[s]  (unmasked)   |   cumsum_{s<=q} V[s]  (masked)
+// Sequence lengths here are tiny, so the kernels are latency-bound by design;
+// rows are spread over lanes and reductions use wave shuffles.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int NW = NT / 64;
+
+struct AttnP {
+  const float *q, *k, *v;
+  long q_ld, k_ld, v_ld;
+  float* ctx;
+  const float* dctx;
+  int out_layout;
+  const int32_t* idx;
+  int32_t* top;
+  int force_top;
+  float *dq, *dk, *dv;
+  long dq_ld, dk_ld, dv_ld;
+  int B, H, LQ, LK, E, sample_k, n_top, mode;
+  float scale;
+};
+
+__device__ __forceinline__ long ctx_off(const AttnP& p, int b, int h, int l) {
+  return p.out_layout == 0 ? (((long)b * p.LQ + l) * p.H + h) * p.E : (((long)b * p.H + h) * p.LQ + l) * p.E;
+}
+
+// Load an (L x E) head slice into LDS with row pitch EP (= E + 1, odd-ish -> conflict-free columns).
+__device__ __forceinline__ void load_head(float* S, const float* G, long ld, int b, int h, int L, int E,
+                                          int EP, int tid) {
+  const float* base = G + (long)b * L * ld + (long)h * E;
+  for (int i = tid; i < L * E; i += NT) {
+    const int l = i / E, e = i - l * E;
+    S[l * EP + e] = base[(long)l * ld + e];
+  }
+}
+
+// Select the n_top rows of M (size LQ): sel[q] = position among the selected (ascending q) or -1.
+__device__ void select_top(const float* Ms, int* sel, int* top_list, int LQ, int n_top, int tid) {
+  for (int q = tid; q < LQ; q += NT) {
+    const float mq = Ms[q];
+    int rank = 0;
+    for (int o = 0; o < LQ; ++o) {
+      const float mo = Ms[o];
+      rank += (mo > mq) || (mo == mq && o < q);
+    }
+    sel[q] = rank < n_top ? 1 : 0;
+  }
+  __syncthreads();
+  for (int q = tid; q < LQ; q += NT) {
+    if (sel[q]) {
+      int pos = 0;
+      for (int o = 0; o < q; ++o) pos += sel[o];
+      top_list[pos] = q;
+    }
+  }
+  __syncthreads();
+  for (int q = tid; q < LQ; q += NT) {
+    if (sel[q]) {
+      int pos = 0;
+      for (int o = 0; o < q; ++o) pos += sel[o];
+      sel[q] = pos;
+    } else {
+      sel[q] = -1;
+    }
+  }
+  __syncthreads();
+}
+
+// LDS carve (floats): Qs[LQ*EP] Ks[LK*EP] Vs[LK*EP] Ps[NW*LK] Ms[LQ] | ints: sel[LQ] top[n_top]
+__global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int LQ = p.LQ, LK = p.LK, E = p.E, EP = E + 1;
+  float* Qs = smem;
+  float* Ks = Qs + LQ * EP;
+  float* Vs = Ks + LK * EP;
+  float* Ps = Vs + LK * EP;
+  float* Ms = Ps + NW * LK;
+  int* sel = reinterpret_cast<int*>(Ms + LQ);
+  int* top_list = sel + LQ;
+
+  load_head(Qs, p.q, p.q_ld, b, h, LQ, E, EP, tid);
+  load_head(Ks, p.k, p.k_ld, b, h, LK, E, EP, tid);
+  load_head(Vs, p.v, p.v_ld, b, h, LK, E, EP, tid);
+  __syncthreads();
+
+  int n_sel;
+  if (p.mode == 0) {
+    n_sel = LQ;
+    for (int q = tid; q < LQ; q += NT) { sel[q] = q; top_list[q] = q; }
+    __syncthreads();
+  } else {
+    n_sel = p.n_top;
+    int32_t* gtop = p.top + ((long)b * p.H + h) * p.n_top;
+    if (p.force_top) {
+      for (int q = tid; q < LQ; q += NT) sel[q] = -1;
+      __syncthreads();
+      for (int i = tid; i < n_sel; i += NT) { top_list[i] = gtop[i]; sel[gtop[i]] = i; }
+      __syncthreads();
+    } else {
+      // (1) sparsity measure from the sampled keys
+      for (int q = tid; q < LQ; q += NT) {
+        const int32_t* iq = p.idx + (long)q * p.sample_k;
+        float mx = -INFINITY, sm = 0.f;
+        for (int j = 0; j < p.sample_k; ++j) {
+          const int kk = iq[j];
+          float d = 0.f;
+          for (int e = 0; e < E; ++e) d = fmaf(Qs[q * EP + e], Ks[kk * EP + e], d);
+          mx = fmaxf(mx, d);
+          sm += d;
+        }
+        Ms[q] = mx - sm / (float)LK;
+      }
+      __syncthreads();
+      // (2) top-u queries
+      select_top(Ms, sel, top_list, LQ, n_sel, tid);
+      for (int i = tid; i < n_sel; i += NT) gtop[i] = top_list[i];
+    }
+    // (4) lazy rows: mean(V) or cumsum(V)
+    for (int d = tid; d < E; d += NT) {
+      if (p.mode == 1) {
+        float s = 0.f;
+        for (int l = 0; l < LK; ++l) s += Vs[l * EP + d];
+        s /= (float)LK;
+        for (int ql = 0; ql < LQ; ++ql)
+          if (sel[ql] < 0) p.ctx[ctx_off(p, b, h, ql) + d] = s;
+      } else {
+        float s = 0.f;
+        for (int ql = 0; ql < LQ; ++ql) {
+          s += Vs[ql * EP + d];
+          if (sel[ql] < 0) p.ctx[ctx_off(p, b, h, ql) + d] = s;
+        }
+      }
+    }
+  }
+
+  // (3) active rows: one wave per selected query, keys spread over lanes
+  float* Pw = Ps + wave * LK;
+  for (int si = wave; si < n_sel; si += NW) {
+    const int q = top_list[si];
+    const int kmax = (p.mode == 2) ? q + 1 : LK;  // masked: keys s <= q
+    float mx = -INFINITY;
+    for (int s = lane; s < kmax; s += 64) {
+      float d = 0.f;
+      for (int e = 0; e < E; ++e) d = fmaf(Qs[q * EP + e], Ks[s * EP + e], d);
+      d *= p.scale;
+      Pw[s] = d;
+      mx = fmaxf(mx, d);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int s = lane; s < kmax; s += 64) {
+      const float e_ = expf(Pw[s] - mx);
+      Pw[s] = e_;
+      sum += e_;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    // Pw is written and read by the same wave only; LDS ops of one wave are ordered.
+    for (int d = lane; d < E; d += 64) {
+      float a = 0.f;
+      for (int s = 0; s < kmax; ++s) a = fmaf(Pw[s], Vs[s * EP + d], a);
+      p.ctx[ctx_off(p, b, h, q) + d] = a * inv;
+    }
+  }
+}
+
+// Backward.  LDS carve (floats): Ks[LK*EP] Vs[LK*EP] Qsel[n*EP] dCsel[n*EP] P[n*LK] dS[n*LK]
+//            colsum[E] | ints: top[n] sel[LQ]
+__global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int LQ = p.LQ, LK = p.LK, E = p.E, EP = E + 1;
+  const int n_sel = (p.mode == 0) ? LQ : p.n_top;
+  float* Ks = smem;
+  float* Vs = Ks + LK * EP;
+  float* Qsel = Vs + LK * EP;
+  float* dCsel = Qsel + n_sel * EP;
+  float* P = dCsel + n_sel * EP;
+  float* dS = P + (long)n_sel * LK;
+  float* colsum = dS + (long)n_sel * LK;
+  int* top_list = reinterpret_cast<int*>(colsum + E);
+  int* sel = top_list + n_sel;
+
+  load_head(Ks, p.k, p.k_ld, b, h, LK, E, EP, tid);
+  load_head(Vs, p.v, p.v_ld, b, h, LK, E, EP, tid);
+  for (int q = tid; q < LQ; q += NT) sel[q] = (p.mode == 0) ? q : -1;
+  __syncthreads();
+  if (p.mode == 0) {
+    for (int i = tid; i < n_sel; i += NT) top_list[i] = i;
+  } else {
+    const int32_t* gtop = p.top + ((long)b * p.H + h) * p.n_top;
+    for (int i = tid; i < n_sel; i += NT) { top_list[i] = gtop[i]; sel[gtop[i]] = i; }
+  }
+  __syncthreads();
+  const float* qbase = p.q + (long)b * LQ * p.q_ld + (long)h * E;
+  for (int i = tid; i < n_sel * E; i += NT) {
+    const int si = i / E, e = i - si * E, q = top_list[si];
+    Qsel[si * EP + e] = qbase[(long)q * p.q_ld + e];
+    dCsel[si * EP + e] = p.dctx[ctx_off(p, b, h, q) + e];
+  }
+  __syncthreads();
+
+  // phase 1: per selected query recompute P, then dS = P * (dP - sum(P*dP)) * scale
+  for (int si = wave; si < n_sel; si += NW) {
+    const int q = top_list[si];
+    const int kmax = (p.mode == 2) ? q + 1 : LK;
+    float* Pr = P + (long)si * LK;
+    float* dSr = dS + (long)si * LK;
+    float mx = -INFINITY;
+    for (int s = lane; s < kmax; s += 64) {
+      float d = 0.f;
+      for (int e = 0; e < E; ++e) d = fmaf(Qsel[si * EP + e], Ks[s * EP + e], d);
+      d *= p.scale;
+      Pr[s] = d;
+      mx = fmaxf(mx, d);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int s = lane; s < kmax; s += 64) {
+      const float e_ = expf(Pr[s] - mx);
+      Pr[s] = e_;
+      sum += e_;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    float dot = 0.f;
+    for (int s = lane; s < kmax; s += 64) {
+      const float pr = Pr[s] * inv;
+      float dp = 0.f;
+      for (int e = 0; e < E; ++e) dp = fmaf(dCsel[si * EP + e], Vs[s * EP + e], dp);
+      Pr[s] = pr;
+      dSr[s] = dp;
+      dot += pr * dp;
+    }
+    dot = wave_sum(dot);
+    for (int s = lane; s < LK; s += 64) {
+      if (s < kmax) {
+        dSr[s] = Pr[s] * (dSr[s] - dot) * p.scale;
+      } else {
+        Pr[s] = 0.f;
+        dSr[s] = 0.f;
+      }
+    }
+    // dQ[q] = dS[q,:] K
+    float* dqrow = p.dq + ((long)b * LQ + q) * p.dq_ld + (long)h * E;
+    for (int e = lane; e < E; e += 64) {
+      float a = 0.f;
+      for (int s = 0; s < kmax; ++s) a = fmaf(dSr[s], Ks[s * EP + e], a);
+      dqrow[e] = a;
+    }
+  }
+  // non-selected query rows get zero dQ (the sampling stage is not differentiated)
+  for (int i = tid; i < LQ * E; i += NT) {
+    const int q = i / E, e = i - q * E;
+    if (sel[q] < 0) p.dq[((long)b * LQ + q) * p.dq_ld + (long)h * E + e] = 0.f;
+  }
+  // lazy-row gradient source: column sums of dctx over NON-selected rows (unmasked mode)
+  if (p.mode == 1) {
+    for (int d = tid; d < E; d += NT) {
+      float s = 0.f;
+      for (int ql = 0; ql < LQ; ++ql)
+        if (sel[ql] < 0) s += p.dctx[ctx_off(p, b, h, ql) + d];
+      colsum[d] = s / (float)LK;
+    }
+  }
+  __syncthreads();
+
+  // phase 2: dK[s,e] = sum_q dS[q,s] Q[q,e];  dV[s,d] = sum_q P[q,s] dC[q,d] + lazy-row term
+  if (p.mode == 2) {
+    // masked lazy rows: ctx[q] = sum_{s<=q} V[s]  =>  dV[s] += sum_{q>=s, q not selected} dC[q]
+    for (int d = tid; d < E; d += NT) {
+      float run = 0.f;
+      for (int ql = LQ - 1; ql >= 0; --ql) {
+        if (sel[ql] < 0) run += p.dctx[ctx_off(p, b, h, ql) + d];
+        // stash the running sum in the (no longer needed) V tile
+        Vs[ql * EP + d] = run;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < LK * E; i += NT) {
+    const int s = i / E, e = i - s * E;
+    float ak = 0.f, av = 0.f;
+    for (int si = 0; si < n_sel; ++si) {
+      ak = fmaf(dS[(long)si * LK + s], Qsel[si * EP + e], ak);
+      av = fmaf(P[(long)si * LK + s], dCsel[si * EP + e], av);
+    }
+    if (p.mode == 1) av += colsum[e];
+    if (p.mode == 2) av += Vs[s * EP + e];
+    p.dk[((long)b * LK + s) * p.dk_ld + (long)h * E + e] = ak;
+    p.dv[((long)b * LK + s) * p.dv_ld + (long)h * E + e] = av;
+  }
+}
+
+size_t fwd_lds(int LQ, int LK, int E, int n_top) {
+  const size_t EP = E + 1;
+  return sizeof(float) * (LQ * EP + 2 * LK * EP + NW * (size_t)LK + LQ) + sizeof(int) * ((size_t)LQ + max(n_top, LQ));
+}
+size_t bwd_lds(int LQ, int LK, int E, int n_sel) {
+  const size_t EP = E + 1;
+  return sizeof(float) * (2 * LK * EP + 2 * n_sel * EP + 2 * (size_t)n_sel * LK + E) + sizeof(int) * ((size_t)n_sel + LQ);
+}
+
+}  // namespace
+
+extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
+                           int64_t v_ld, float* ctx, int out_layout, const int32_t* index_sample,
+                           int32_t* top_idx, int force_top, int B, int H, int LQ, int LK, int E,
+                           int sample_k, int n_top, int mode, float scale, void* stream) {
+  RF_REQUIRE(q && k && v && ctx && B > 0 && H > 0 && LQ > 0 && LK > 0 && E > 0);
+  RF_REQUIRE(mode >= 0 && mode <= 2);
+  RF_REQUIRE(mode == 0 || (top_idx && n_top > 0 && n_top <= LQ));
+  RF_REQUIRE(mode == 0 || force_top || (index_sample && sample_k > 0));
+  RF_REQUIRE(mode != 2 || LQ == LK);
+  const size_t lds = fwd_lds(LQ, LK, E, n_top);
+  if (lds > 160 * 1024) { rf_g_last_error = "attention head slice exceeds 160 KB LDS"; return RF_EUNSUPPORTED; }
+  AttnP p{};
+  p.q = q; p.k = k; p.v = v; p.q_ld = q_ld; p.k_ld = k_ld; p.v_ld = v_ld; p.ctx = ctx;
+  p.out_layout = out_layout; p.idx = index_sample; p.top = top_idx; p.force_top = force_top;
+  p.B = B; p.H = H; p.LQ = LQ; p.LK = LK; p.E = E; p.sample_k = sample_k; p.n_top = n_top;
+  p.mode = mode; p.scale = scale;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(NT), lds, static_cast<hipStream_t>(stream), p);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_attn_bwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
+                           int64_t v_ld, const float* dctx, int out_layout, const int32_t* top_idx,
+                           float* dq, float* dk, float* dv, int64_t dq_ld, int64_t dk_ld, int64_t dv_ld,
+                           int B, int H, int LQ, int LK, int E, int n_top, int mode, float scale,
+                           void* stream) {
+  RF_REQUIRE(q && k && v && dctx && dq && dk && dv && B > 0 && H > 0 && LQ > 0 && LK > 0 && E > 0);
+  RF_REQUIRE(mode >= 0 && mode <= 2);
+  RF_REQUIRE(mode == 0 || (top_idx && n_top > 0 && n_top <= LQ));
+  RF_REQUIRE(mode != 2 || LQ == LK);
+  const int n_sel = mode == 0 ? LQ : n_top;
+  const size_t lds = bwd_lds(LQ, LK, E, n_sel);
+  if (lds > 160 * 1024) { rf_g_last_error = "attention backward exceeds 160 KB LDS"; return RF_EUNSUPPORTED; }
+  AttnP p{};
+  p.q = q; p.k = k; p.v = v; p.q_ld = q_ld; p.k_ld = k_ld; p.v_ld = v_ld; p.dctx = dctx;
+  p.out_layout = out_layout; p.top = const_cast<int32_t*>(top_idx); p.dq = dq; p.dk = dk; p.dv = dv;
+  p.dq_ld = dq_ld; p.dk_ld = dk_ld; p.dv_ld = dv_ld; p.B = B; p.H = H; p.LQ = LQ; p.LK = LK;
+  p.E = E; p.n_top = n_top; p.mode = mode; p.scale = scale;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(NT), lds, static_cast<hipStream_t>(stream), p);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}

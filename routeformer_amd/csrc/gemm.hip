@@ -1,0 +1,396 @@
+// Dense contraction on the CDNA4 matrix cores, with the fused epilogues the Routeformer hot path
+// needs, and the implicit-GEMM (im2col-on-the-fly) A-loader used for the frozen NHWC conv trunk.
+//
+//   C[M,N] = epi( A[M,K] * B[K,N] )
+//
+// One workgroup = 4 waves (256 threads).  Operands are staged global -> registers -> LDS with K
+// innermost ([row][k], padded), so both MFMA operands are read as K-contiguous fragments:
+//   prec 0: v_mfma_f32_16x16x4_f32   (exact fp32; lane l holds A[l&15][l>>4], B[l>>4][l&15])
+//   prec 1: v_mfma_f32_16x16x32_bf16 (lane l holds A[l&15][8*(l>>4)+j], j<8; fp32 -> bf16 on the
+//           way into LDS, fp32 accumulate)
+// C/D fragment: col = lane&15, row = 4*(lane>>4)+reg.
+// Tile configs (BM x BN, BK = 32): 0 = 64x64 (2x2 waves, 2x2 tiles), 1 = 128x16 (4x1 waves, 2x1),
+// 2 = 128x32 (4x1 waves, 2x2) -- the narrow ones serve the 16/32-channel HRNet branches.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NT = 256;
+
+struct GemmP {
+  const float* A; long lda_m, lda_k;
+  const float* B; long ldb_k, ldb_n;
+  float* C; long ldc;
+  int M, N, K;
+  const float* bias;
+  const float* res; long ldr; int res_rows; int res_before_act;
+  int act;
+  float* preact; long ldp;
+  const float* dsrc; long ldd; int dact;
+  int kchunk;  // K range per split-K slice (multiple of BK)
+  float* ws;   // split-K partials [splits][M][N] (null: single pass with epilogue)
+  // implicit-GEMM conv (A mode 3): A is the NHWC input, row m = output pixel
+  int cH, cW, cCin, cKs, cStride, cPad, cHo, cWo;
+};
+
+template <int CFG> struct Cfg;
+template <> struct Cfg<0> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; };
+template <> struct Cfg<1> { static constexpr int WM = 4, WN = 1, TM = 2, TN = 1; };
+template <> struct Cfg<2> { static constexpr int WM = 4, WN = 1, TM = 2, TN = 2; };
+
+template <int PREC> struct Lds;
+template <> struct Lds<0> { using T = float; static constexpr int LD = BK + 2; };   // 34: conflict-free b32 reads
+template <> struct Lds<1> { using T = __bf16; static constexpr int LD = BK + 8; };  // 80-B rows, 16-B aligned
+
+template <typename T> __device__ __forceinline__ T cvt(float v);
+template <> __device__ __forceinline__ float cvt<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 cvt<__bf16>(float v) { return (__bf16)v; }
+
+// ---- global -> LDS tile loaders.  Tile is ROWS x BK, stored [row][k]. ----
+// MODE 0: k contiguous in memory (ld_k == 1), 16-B vectorizable.
+// MODE 1: row index contiguous in memory (ld_row == 1), 16-B vectorizable (transposing store).
+// MODE 2: arbitrary strides / alignment, scalar.
+template <int ROWS, int MODE, typename T, int LD>
+__device__ __forceinline__ void load_tile(T* __restrict__ S, const float* __restrict__ G, long ld_row,
+                                          long ld_k, int row0, int nrows, int k0, int kend, int tid) {
+  if constexpr (MODE == 0) {
+    constexpr int VPR = BK / 4;
+#pragma unroll
+    for (int i = tid; i < ROWS * VPR; i += NT) {
+      const int r = i / VPR, kv = (i % VPR) * 4;
+      const int gr = row0 + r, gk = k0 + kv;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < nrows) {
+        const float* p = G + (long)gr * ld_row + gk;
+        if (gk + 3 < kend) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (gk + 0 < kend) v.x = p[0];
+          if (gk + 1 < kend) v.y = p[1];
+          if (gk + 2 < kend) v.z = p[2];
+        }
+      }
+      T* s = S + r * LD + kv;
+      s[0] = cvt<T>(v.x); s[1] = cvt<T>(v.y); s[2] = cvt<T>(v.z); s[3] = cvt<T>(v.w);
+    }
+  } else if constexpr (MODE == 1) {
+    constexpr int VPK = ROWS / 4;  // row-vectors per k
+#pragma unroll
+    for (int i = tid; i < BK * VPK; i += NT) {
+      const int k = i / VPK, rv = (i % VPK) * 4;
+      const int gr = row0 + rv, gk = k0 + k;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gk < kend) {
+        const float* p = G + (long)gk * ld_k + gr;
+        if (gr + 3 < nrows) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (gr + 0 < nrows) v.x = p[0];
+          if (gr + 1 < nrows) v.y = p[1];
+          if (gr + 2 < nrows) v.z = p[2];
+        }
+      }
+      T* s = S + rv * LD + k;
+      s[0] = cvt<T>(v.x); s[LD] = cvt<T>(v.y); s[2 * LD] = cvt<T>(v.z); s[3 * LD] = cvt<T>(v.w);
+    }
+  } else {
+#pragma unroll 4
+    for (int i = tid; i < ROWS * BK; i += NT) {
+      const int r = i / BK, k = i % BK;
+      const int gr = row0 + r, gk = k0 + k;
+      float v = 0.f;
+      if (gr < nrows && gk < kend) v = G[(long)gr * ld_row + (long)gk * ld_k];
+      S[r * LD + k] = cvt<T>(v);
+    }
+  }
+}
+
+template <int PREC, int AM, int BMODE, int CFG>
+__global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
+  using C_ = Cfg<CFG>;
+  using L_ = Lds<PREC>;
+  using T = typename L_::T;
+  constexpr int LD = L_::LD;
+  constexpr int BM = C_::WM * C_::TM * 16, BN = C_::WN * C_::TN * 16;
+  __shared__ __attribute__((aligned(16))) T smem[(BM + BN) * LD];
+  T* As = smem;
+  T* Bs = smem + BM * LD;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C_::WN, wn = wave % C_::WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kbeg = blockIdx.z * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+
+  f32x4 acc[C_::TM][C_::TN];
+#pragma unroll
+  for (int i = 0; i < C_::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < C_::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // implicit-GEMM row decode (thread's rows are the same for every k-tile)
+  constexpr int VPR = BK / 4;
+  constexpr int RPT = (BM * VPR + NT - 1) / NT;  // rows per thread in the vector loader
+  long c_img[RPT]; int c_h[RPT], c_w[RPT];
+  if constexpr (AM == 3) {
+#pragma unroll
+    for (int s = 0; s < RPT; ++s) {
+      const int r = (tid + s * NT) / VPR;
+      const int gm = m0 + r;
+      if (gm < p.M) {
+        const int wo = gm % p.cWo, t = gm / p.cWo, ho = t % p.cHo, n = t / p.cHo;
+        c_img[s] = (long)n * p.cH * p.cW * p.cCin;
+        c_h[s] = ho * p.cStride - p.cPad;
+        c_w[s] = wo * p.cStride - p.cPad;
+      } else {
+        c_img[s] = -1; c_h[s] = 0; c_w[s] = 0;
+      }
+    }
+  }
+
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    if constexpr (AM == 3) {
+#pragma unroll
+      for (int s = 0; s < RPT; ++s) {
+        const int i = tid + s * NT;
+        if (i < BM * VPR) {
+          const int r = i / VPR, kv = (i % VPR) * 4, gk = k0 + kv;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (c_img[s] >= 0 && gk < kend) {
+            const int tap = gk / p.cCin, c = gk - tap * p.cCin;
+            const int kh = tap / p.cKs, kw = tap - kh * p.cKs;
+            const int hi = c_h[s] + kh, wi = c_w[s] + kw;
+            if (hi >= 0 && hi < p.cH && wi >= 0 && wi < p.cW)
+              v = *reinterpret_cast<const float4*>(p.A + c_img[s] + ((long)hi * p.cW + wi) * p.cCin + c);
+          }
+          T* sp = As + r * LD + kv;
+          sp[0] = cvt<T>(v.x); sp[1] = cvt<T>(v.y); sp[2] = cvt<T>(v.z); sp[3] = cvt<T>(v.w);
+        }
+      }
+    } else {
+      load_tile<BM, AM, T, LD>(As, p.A, p.lda_m, p.lda_k, m0, p.M, k0, kend, tid);
+    }
+    load_tile<BN, BMODE, T, LD>(Bs, p.B, p.ldb_n, p.ldb_k, n0, p.N, k0, kend, tid);
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    if constexpr (PREC == 0) {
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        float a[C_::TM], b[C_::TN];
+#pragma unroll
+        for (int i = 0; i < C_::TM; ++i) a[i] = As[((wm * C_::TM + i) * 16 + fr) * LD + kk * 4 + fq];
+#pragma unroll
+        for (int j = 0; j < C_::TN; ++j) b[j] = Bs[((wn * C_::TN + j) * 16 + fr) * LD + kk * 4 + fq];
+#pragma unroll
+        for (int i = 0; i < C_::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < C_::TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      bf16x8 a[C_::TM], b[C_::TN];
+#pragma unroll
+      for (int i = 0; i < C_::TM; ++i)
+        a[i] = *reinterpret_cast<const bf16x8*>(As + ((wm * C_::TM + i) * 16 + fr) * LD + fq * 8);
+#pragma unroll
+      for (int j = 0; j < C_::TN; ++j)
+        b[j] = *reinterpret_cast<const bf16x8*>(Bs + ((wn * C_::TN + j) * 16 + fr) * LD + fq * 8);
+#pragma unroll
+      for (int i = 0; i < C_::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C_::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < C_::TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < C_::TN; ++j) {
+      const int n = n0 + (wn * C_::TN + j) * 16 + fr;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + (wm * C_::TM + i) * 16 + fq * 4 + r;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r];
+        if (p.ws) {
+          p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = v;
+          continue;
+        }
+        if (p.bias) v += p.bias[n];
+        if (p.res && p.res_before_act) v += p.res[(long)(m % p.res_rows) * p.ldr + n];
+        if (p.preact) p.preact[(long)m * p.ldp + n] = v;
+        v = apply_act(v, p.act);
+        if (p.dact) v *= act_grad(p.dsrc[(long)m * p.ldd + n], p.dact);
+        if (p.res && !p.res_before_act) v += p.res[(long)(m % p.res_rows) * p.ldr + n];
+        p.C[(long)m * p.ldc + n] = v;
+      }
+    }
+  }
+}
+
+__global__ void splitk_reduce_kernel(GemmP p, int splits) {
+  const long total = (long)p.M * p.N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / p.N), n = (int)(i % p.N);
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += p.ws[(long)s * total + i];
+    if (p.bias) v += p.bias[n];
+    if (p.res && p.res_before_act) v += p.res[(long)(m % p.res_rows) * p.ldr + n];
+    if (p.preact) p.preact[(long)m * p.ldp + n] = v;
+    v = apply_act(v, p.act);
+    if (p.dact) v *= act_grad(p.dsrc[(long)m * p.ldd + n], p.dact);
+    if (p.res && !p.res_before_act) v += p.res[(long)(m % p.res_rows) * p.ldr + n];
+    p.C[(long)m * p.ldc + n] = v;
+  }
+}
+
+template <int PREC, int AM, int BMODE, int CFG>
+void launch(const GemmP& p, int splits, hipStream_t st) {
+  using C_ = Cfg<CFG>;
+  constexpr int BM = C_::WM * C_::TM * 16, BN = C_::WN * C_::TN * 16;
+  dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, splits);
+  hipLaunchKernelGGL((gemm_kernel<PREC, AM, BMODE, CFG>), grid, dim3(NT), 0, st, p);
+}
+
+template <int PREC, int AM>
+void dispatch_b(const GemmP& p, int bmode, int splits, hipStream_t st) {
+  switch (bmode) {
+    case 0: launch<PREC, AM, 0, 0>(p, splits, st); break;
+    case 1: launch<PREC, AM, 1, 0>(p, splits, st); break;
+    default: launch<PREC, AM, 2, 0>(p, splits, st); break;
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k,
+                       int64_t ldb_n, float* C, int64_t ldc, int M, int N, int K, const float* bias,
+                       const float* residual, int64_t ldr, int res_rows, int res_before_act, int act,
+                       float* preact, int64_t ldp, const float* dact_src, int64_t ldd, int dact_mode,
+                       int prec, int splitk, float* workspace, void* stream) {
+  RF_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0);
+  RF_REQUIRE(prec == 0 || prec == 1);
+  RF_REQUIRE(splitk >= 1 && (splitk == 1 || workspace != nullptr));
+  RF_REQUIRE(!residual || res_rows > 0);
+  RF_REQUIRE(!dact_mode || dact_src);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  GemmP p{};
+  p.A = A; p.lda_m = lda_m; p.lda_k = lda_k; p.B = B; p.ldb_k = ldb_k; p.ldb_n = ldb_n;
+  p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = residual; p.ldr = ldr;
+  p.res_rows = residual ? res_rows : 1; p.res_before_act = res_before_act; p.act = act;
+  p.preact = preact; p.ldp = ldp; p.dsrc = dact_src; p.ldd = ldd; p.dact = dact_mode;
+  const int ktiles = (K + BK - 1) / BK;
+  if (splitk > ktiles) splitk = ktiles;
+  p.kchunk = ((ktiles + splitk - 1) / splitk) * BK;
+  splitk = (K + p.kchunk - 1) / p.kchunk;
+  p.ws = splitk > 1 ? workspace : nullptr;
+
+  int am = 2, bm = 2;
+  if (lda_k == 1 && (lda_m % 4) == 0 && aligned16(A)) am = 0;
+  else if (lda_m == 1 && (lda_k % 4) == 0 && aligned16(A)) am = 1;
+  if (ldb_k == 1 && (ldb_n % 4) == 0 && aligned16(B)) bm = 0;
+  else if (ldb_n == 1 && (ldb_k % 4) == 0 && aligned16(B)) bm = 1;
+
+  if (prec == 0) {
+    if (am == 0) dispatch_b<0, 0>(p, bm, splitk, st);
+    else if (am == 1) dispatch_b<0, 1>(p, bm, splitk, st);
+    else dispatch_b<0, 2>(p, bm, splitk, st);
+  } else {
+    if (am == 0) dispatch_b<1, 0>(p, bm, splitk, st);
+    else if (am == 1) dispatch_b<1, 1>(p, bm, splitk, st);
+    else dispatch_b<1, 2>(p, bm, splitk, st);
+  }
+  RF_CHECK_LAUNCH();
+  if (splitk > 1) {
+    const long total = (long)M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, splitk);
+    RF_CHECK_LAUNCH();
+  }
+  return RF_OK;
+}
+
+extern "C" int rf_conv2d_nhwc(const float* x, const float* w, const float* bias, const float* residual,
+                              float* y, int N, int H, int W, int cin, int cout, int ksize, int stride,
+                              int pad, int Ho, int Wo, int64_t ldy, int64_t ldres, int relu, int prec,
+                              void* stream) {
+  RF_REQUIRE(x && w && y && N > 0 && cin > 0 && cout > 0);
+  RF_REQUIRE(cin % 4 == 0 && aligned16(x) && aligned16(w));
+  RF_REQUIRE(prec == 0 || prec == 1);
+  RF_REQUIRE(Ho == (H + 2 * pad - ksize) / stride + 1 && Wo == (W + 2 * pad - ksize) / stride + 1);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  GemmP p{};
+  const int K = ksize * ksize * cin;
+  p.A = x; p.B = w; p.ldb_k = 1; p.ldb_n = K;  // w: [cout][kh][kw][cin]
+  p.C = y; p.ldc = ldy; p.M = N * Ho * Wo; p.N = cout; p.K = K; p.bias = bias;
+  p.res = residual; p.ldr = ldres; p.res_rows = p.M; p.res_before_act = 1;
+  p.act = relu ? RF_ACT_RELU : RF_ACT_NONE;
+  p.kchunk = ((K + BK - 1) / BK) * BK; p.ws = nullptr;
+  p.cH = H; p.cW = W; p.cCin = cin; p.cKs = ksize; p.cStride = stride; p.cPad = pad; p.cHo = Ho; p.cWo = Wo;
+  const int cfg = cout <= 16 ? 1 : (cout <= 32 ? 2 : 0);
+  if (prec == 0) {
+    if (cfg == 1) launch<0, 3, 0, 1>(p, 1, st);
+    else if (cfg == 2) launch<0, 3, 0, 2>(p, 1, st);
+    else launch<0, 3, 0, 0>(p, 1, st);
+  } else {
+    if (cfg == 1) launch<1, 3, 0, 1>(p, 1, st);
+    else if (cfg == 2) launch<1, 3, 0, 2>(p, 1, st);
+    else launch<1, 3, 0, 0>(p, 1, st);
+  }
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+// ---- column sums (bias gradients): two deterministic passes --------------------------------
+namespace {
+constexpr int CS_ROWS = 256;  // rows per first-pass block
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, long ldx, int M, int N,
+                                                           float* __restrict__ part) {
+  // block = 64 columns x 4 row-lanes; blockIdx.y = row chunk
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  float s = 0.f;
+  if (n < N)
+    for (int r = r0 + ty; r < r1; r += 4) s += X[(long)r * ldx + n];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n < N) part[(long)blockIdx.y * N + n] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int parts, int N, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int i = 0; i < parts; ++i) s += part[(long)i * N + n];
+  out[n] = s;
+}
+}  // namespace
+
+extern "C" int rf_colsum_parts(int M, int N) { (void)N; return (M + CS_ROWS - 1) / CS_ROWS; }
+
+extern "C" int rf_colsum(const float* X, int64_t ldx, int M, int N, float* out, float* workspace,
+                         void* stream) {
+  RF_REQUIRE(X && out && workspace && M > 0 && N > 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int parts = rf_colsum_parts(M, N);
+  hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 63) / 64, parts), dim3(256), 0, st, X, (long)ldx, M, N,
+                     workspace);
+  RF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, workspace, parts, N, out);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}

@@ -1,0 +1,336 @@
+// Row-wise sequence ops of the transformer blocks: LayerNorm (+residual), circular unfold/fold for
+// the k=3 token/distil convolutions, and the Informer distilling tail BatchNorm1d -> ELU -> MaxPool1d.
+// All are HBM/latency-bound streaming kernels: channels innermost, one wave per row where a row
+// reduction is needed (wave-shuffle reductions), coalesced 256-B accesses per wave-instruction.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAXV = 16;  // cols <= 64 * 16
+constexpr int LN_WAVES = 4;
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ xhat, float* __restrict__ rstd_out,
+                                                            int rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * LN_WAVES + wave;
+  if (row >= rows) return;
+  const long off = (long)row * cols;
+  float v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = i * 64 + lane;
+    float t = 0.f;
+    if (c < cols) {
+      t = x[off + c];
+      if (res) t += res[off + c];
+    }
+    v[i] = t;
+    s += t;
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = i * 64 + lane;
+    const float d = (c < cols) ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float var = wave_sum(q) / (float)cols;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < cols) {
+      const float h = (v[i] - mean) * rstd;
+      if (xhat) xhat[off + c] = h;
+      y[off + c] = h * gamma[c] + beta[c];
+    }
+  }
+  if (rstd_out && lane == 0) rstd_out[row] = rstd;
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, float* __restrict__ dx,
+                                                            float* __restrict__ ws, int rows, int cols) {
+  __shared__ float red[LN_WAVES][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dg[LN_MAXV], db[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+  for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
+    const long off = (long)row * cols;
+    float g[LN_MAXV], h[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = i * 64 + lane;
+      float d = 0.f, hh = 0.f, gm = 0.f;
+      if (c < cols) { d = dy[off + c]; hh = xhat[off + c]; gm = gamma[c]; }
+      dg[i] += d * hh;
+      db[i] += d;
+      g[i] = d * gm;
+      h[i] = hh;
+      s1 += g[i];
+      s2 += g[i] * hh;
+    }
+    const float m1 = wave_sum(s1) / (float)cols, m2 = wave_sum(s2) / (float)cols;
+    const float r = rstd[row];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = i * 64 + lane;
+      if (c < cols) dx[off + c] = r * (g[i] - m1 - h[i] * m2);
+    }
+  }
+  // block partials -> ws[block][0][cols] (dgamma), ws[block][1][cols] (dbeta)
+  float* wg = ws + (long)blockIdx.x * 2 * cols;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    if (i * 64 >= cols) break;
+    const int c = i * 64 + lane;
+    red[wave][lane] = dg[i];
+    __syncthreads();
+    if (wave == 0 && c < cols) wg[c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    __syncthreads();
+    red[wave][lane] = db[i];
+    __syncthreads();
+    if (wave == 0 && c < cols) wg[cols + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    __syncthreads();
+  }
+}
+
+__global__ void ln_param_reduce_kernel(const float* __restrict__ ws, int parts, int cols, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float a = 0.f, b = 0.f;
+  for (int i = 0; i < parts; ++i) {
+    a += ws[(long)i * 2 * cols + c];
+    b += ws[(long)i * 2 * cols + cols + c];
+  }
+  dgamma[c] = a;
+  dbeta[c] = b;
+}
+
+__global__ void unfold3_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int L, int C, int pad,
+                               int Lout) {
+  const long total = (long)B * Lout * 3 * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int t = (int)(r % 3); r /= 3;
+    const int l = (int)(r % Lout);
+    const int b = (int)(r / Lout);
+    int src = (l + t - pad) % L;
+    if (src < 0) src += L;
+    cols[i] = x[((long)b * L + src) * C + c];
+  }
+}
+
+__global__ void fold3_kernel(const float* __restrict__ dcols, float* __restrict__ dx, int B, int L, int C, int pad,
+                             int Lout) {
+  const long total = (long)B * L * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const int l = (int)(r % L);
+    const int b = (int)(r / L);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      int lo = (l - t + pad) % L;
+      if (lo < 0) lo += L;
+      for (; lo < Lout; lo += L) s += dcols[(((long)b * Lout + lo) * 3 + t) * C + c];
+    }
+    dx[i] = s;
+  }
+}
+
+// ---- BatchNorm1d statistics over rows (biased variance), block = 64 channels x 4 row lanes ----
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ mean,
+                                                       float* __restrict__ var, int rows, int C) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float s = 0.f;
+  if (c < C) for (int r = ty; r < rows; r += 4) s += x[(long)r * C + c];
+  red[ty][tx] = s;
+  __syncthreads();
+  const float m = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)rows;
+  __syncthreads();
+  float q = 0.f;
+  if (c < C) for (int r = ty; r < rows; r += 4) { const float d = x[(long)r * C + c] - m; q += d * d; }
+  red[ty][tx] = q;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    mean[c] = m;
+    var[c] = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)rows;
+  }
+}
+
+__device__ __forceinline__ float elu(float z) { return z > 0.f ? z : expm1f(z); }
+
+__global__ void bn_elu_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                       const float* __restrict__ var, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ y,
+                                       int32_t* __restrict__ argmax, int B, int L, int C, int Lout, float eps) {
+  const long total = (long)B * Lout * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const int lo = (int)(r % Lout);
+    const int b = (int)(r / Lout);
+    const float sc = gamma[c] / sqrtf(var[c] + eps), sh = beta[c] - mean[c] * sc;
+    float best = -INFINITY;
+    int arg = -1;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int li = 2 * lo - 1 + t;
+      if (li < 0 || li >= L) continue;
+      const float z = elu(fmaf(x[((long)b * L + li) * C + c], sc, sh));
+      if (z > best || arg < 0) { best = z; arg = li; }
+    }
+    y[i] = best;
+    if (argmax) argmax[i] = arg;
+  }
+}
+
+// One block per 64 channels: (A) dgamma/dbeta sums over all rows, (B) dx.  rows = B*L is small here.
+__global__ __launch_bounds__(256) void bn_elu_pool_bwd_kernel(const float* __restrict__ dy,
+                                                              const int32_t* __restrict__ argmax,
+                                                              const float* __restrict__ x,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ var,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ dx,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int B, int L, int C, int Lout, float eps, int training) {
+  __shared__ float red[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int rows = B * L;
+  float g = 0.f, istd = 0.f, mu = 0.f, bt = 0.f;
+  if (c < C) { g = gamma[c]; istd = 1.0f / sqrtf(var[c] + eps); mu = mean[c]; bt = beta[c]; }
+  auto dpre = [&](int r, float& xh) -> float {
+    // gradient w.r.t. the BN output at row r (through ELU and the max-pool routing)
+    const int b = r / L, li = r - b * L;
+    xh = (x[(long)r * C + c] - mu) * istd;
+    const float z = fmaf(xh, g, bt);
+    float dz = 0.f;
+    const int lo_min = li / 2, lo_max = (li + 1) / 2;  // windows [2lo-1, 2lo+1] containing li
+    for (int lo = lo_min; lo <= lo_max; ++lo)
+      if (lo < Lout && argmax[((long)b * Lout + lo) * C + c] == li) dz += dy[((long)b * Lout + lo) * C + c];
+    return dz * (z > 0.f ? 1.f : expf(z));
+  };
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C)
+    for (int r = ty; r < rows; r += 4) {
+      float xh;
+      const float d = dpre(r, xh);
+      s1 += d;
+      s2 += d * xh;
+    }
+  red[0][ty][tx] = s1;
+  red[1][ty][tx] = s2;
+  __syncthreads();
+  const float S1 = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+  const float S2 = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+  if (c >= C) return;
+  if (ty == 0) { dbeta[c] = S1; dgamma[c] = S2; }
+  const float m1 = S1 / (float)rows, m2 = S2 / (float)rows;
+  for (int r = ty; r < rows; r += 4) {
+    float xh;
+    const float d = dpre(r, xh);
+    dx[(long)r * C + c] = training ? g * istd * (d - m1 - xh * m2) : g * istd * d;
+  }
+}
+
+inline int grid_for(long total, int block = 256, int cap = 4096) {
+  long g = (total + block - 1) / block;
+  return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int rf_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                                float* y, float* xhat, float* rstd, int rows, int cols, float eps, void* stream) {
+  RF_REQUIRE(x && gamma && beta && y && rows > 0 && cols > 0 && cols <= 64 * LN_MAXV);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + LN_WAVES - 1) / LN_WAVES), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, residual, gamma, beta, y, xhat, rstd, rows, cols, eps);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_layernorm_bwd_parts(int rows) {
+  const int blocks = (rows + LN_WAVES - 1) / LN_WAVES;
+  return blocks > 256 ? 256 : blocks;
+}
+
+extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,
+                                float* dgamma, float* dbeta, float* workspace, int rows, int cols, void* stream) {
+  RF_REQUIRE(dy && xhat && rstd && gamma && dx && dgamma && dbeta && workspace);
+  RF_REQUIRE(rows > 0 && cols > 0 && cols <= 64 * LN_MAXV);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int parts = rf_layernorm_bwd_parts(rows);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, st, dy, xhat, rstd, gamma, dx, workspace, rows,
+                     cols);
+  RF_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, workspace, parts, cols,
+                     dgamma, dbeta);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_unfold3_circular(const float* x, float* cols, int B, int L, int C, int pad, void* stream) {
+  RF_REQUIRE(x && cols && B > 0 && L > 0 && C > 0 && pad >= 1 && pad <= 2);
+  const int Lout = L + 2 * pad - 2;
+  hipLaunchKernelGGL(unfold3_kernel, dim3(grid_for((long)B * Lout * 3 * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, cols, B, L, C, pad, Lout);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_fold3_circular(const float* dcols, float* dx, int B, int L, int C, int pad, void* stream) {
+  RF_REQUIRE(dcols && dx && B > 0 && L > 0 && C > 0 && pad >= 1 && pad <= 2);
+  const int Lout = L + 2 * pad - 2;
+  hipLaunchKernelGGL(fold3_kernel, dim3(grid_for((long)B * L * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     dcols, dx, B, L, C, pad, Lout);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_bn_stats(const float* x, float* mean, float* var, int rows, int C, void* stream) {
+  RF_REQUIRE(x && mean && var && rows > 0 && C > 0);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), x, mean,
+                     var, rows, C);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_bn_elu_pool_fwd(const float* x, const float* mean, const float* var, const float* gamma,
+                                  const float* beta, float* y, int32_t* argmax, int B, int L, int C, float eps,
+                                  void* stream) {
+  RF_REQUIRE(x && mean && var && gamma && beta && y && B > 0 && L > 0 && C > 0);
+  const int Lout = (L - 1) / 2 + 1;
+  hipLaunchKernelGGL(bn_elu_pool_fwd_kernel, dim3(grid_for((long)B * Lout * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, mean, var, gamma, beta, y, argmax, B, L, C, Lout, eps);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const float* x, const float* mean,
+                                  const float* var, const float* gamma, const float* beta, float* dx, float* dgamma,
+                                  float* dbeta, float* workspace, int B, int L, int C, float eps, int training,
+                                  void* stream) {
+  (void)workspace;
+  RF_REQUIRE(dy && argmax && x && mean && var && gamma && beta && dx && dgamma && dbeta && B > 0 && L > 0 && C > 0);
+  const int Lout = (L - 1) / 2 + 1;
+  hipLaunchKernelGGL(bn_elu_pool_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), dy,
+                     argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, B, L, C, Lout, eps, training);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}

@@ -1,0 +1,204 @@
+// Streaming NHWC helpers around the implicit-GEMM convolutions of the frozen HRNet-16 trunk:
+// stem (frame gather + fp16 -> fp32 + 2x2/s2 conv), bilinear upsample(+add), add+ReLU, and the
+// AdaptiveAvgPool2d((8,8)) -> token layout.  Channels are innermost so consecutive lanes touch
+// consecutive addresses; each kernel is a grid-stride loop (HBM-bound, no reuse to stage).
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace {
+
+inline int grid_for(long total, int block = 256, int cap = 8192) {
+  long g = (total + block - 1) / block;
+  return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+__device__ __forceinline__ float ldf(const __half* p) { return __half2float(*p); }
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+
+template <typename TIn>
+__global__ void stem_conv0_kernel(const TIn* __restrict__ video, const int32_t* __restrict__ fidx,
+                                  const float* __restrict__ w, float* __restrict__ y, int B, int T, int F, int H,
+                                  int W) {
+  __shared__ float ws[36];
+  if (threadIdx.x < 36) ws[threadIdx.x] = w[threadIdx.x];  // [co][ci][kh][kw]
+  __syncthreads();
+  const int Ho = H / 2, Wo = W / 2;
+  const long total = (long)B * F * Ho * Wo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int wo = (int)(i % Wo);
+    long r = i / Wo;
+    const int ho = (int)(r % Ho); r /= Ho;
+    const int f = (int)(r % F);
+    const int b = (int)(r / F);
+    const TIn* img = video + (((long)b * T + fidx[f]) * 3) * H * W;
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        const TIn* row = img + ((long)ci * H + 2 * ho + kh) * W + 2 * wo;
+        const float x0 = ldf(row), x1 = ldf(row + 1);
+#pragma unroll
+        for (int co = 0; co < 3; ++co)
+          acc[co] = fmaf(x1, ws[(co * 3 + ci) * 4 + kh * 2 + 1], fmaf(x0, ws[(co * 3 + ci) * 4 + kh * 2], acc[co]));
+      }
+    *reinterpret_cast<float4*>(y + i * 4) = make_float4(acc[0], acc[1], acc[2], 0.f);
+  }
+}
+
+__global__ void upsample_kernel(const float* __restrict__ x, const float* __restrict__ addend, float* __restrict__ y,
+                                int N, int Hi, int Wi, int C, int Ho, int Wo, long ldy, int accumulate, int relu) {
+  const long total = (long)N * Ho * Wo * C;
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    // align_corners=False source index, clamped at 0 (ATen area_pixel_compute_source_index)
+    float fh = ((float)ho + 0.5f) * sh - 0.5f; if (fh < 0.f) fh = 0.f;
+    float fw = ((float)wo + 0.5f) * sw - 0.5f; if (fw < 0.f) fw = 0.f;
+    const int h0 = (int)fh, w0 = (int)fw;
+    const int h1 = h0 + (h0 < Hi - 1 ? 1 : 0), w1 = w0 + (w0 < Wi - 1 ? 1 : 0);
+    const float lh = fh - (float)h0, lw = fw - (float)w0;
+    const float* xb = x + (long)n * Hi * Wi * C + c;
+    const float v = (1.f - lh) * ((1.f - lw) * xb[((long)h0 * Wi + w0) * C] + lw * xb[((long)h0 * Wi + w1) * C]) +
+                    lh * ((1.f - lw) * xb[((long)h1 * Wi + w0) * C] + lw * xb[((long)h1 * Wi + w1) * C]);
+    float* yp = y + (((long)n * Ho + ho) * Wo + wo) * ldy + c;
+    float o = accumulate ? *yp : 0.f;
+    if (addend) o += addend[i];
+    o += v;
+    if (relu) o = o > 0.f ? o : 0.f;
+    *yp = o;
+  }
+}
+
+__global__ void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                long n, int relu) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = a[i] + b[i];
+    if (relu) v = v > 0.f ? v : 0.f;
+    out[i] = v;
+  }
+}
+
+__global__ void avgpool8_tokens_kernel(const float* __restrict__ x, float* __restrict__ tok, int N, int H, int W,
+                                       int C) {
+  const long total = (long)N * 65 * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const int t = (int)(r % 65);
+    const int n = (int)(r / 65);
+    if (t == 64) { tok[i] = -1.f; continue; }
+    const int bh = t / 8, bw = t % 8;
+    const int h0 = (bh * H) / 8, h1 = ((bh + 1) * H + 7) / 8;
+    const int w0 = (bw * W) / 8, w1 = ((bw + 1) * W + 7) / 8;
+    float s = 0.f;
+    for (int h = h0; h < h1; ++h)
+      for (int w = w0; w < w1; ++w) s += x[(((long)n * H + h) * W + w) * C + c];
+    tok[i] = s / (float)((h1 - h0) * (w1 - w0));
+  }
+}
+
+// ---- optimizer ----
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void adamw_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, long n, const float* __restrict__ sumsq, float max_norm,
+                                  float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                  float grad_scale) {
+  float coef = grad_scale;
+  if (max_norm > 0.f) {
+    const float total = grad_scale * sqrtf(*sumsq);
+    const float c = max_norm / (total + 1e-6f);
+    if (c < 1.f) coef *= c;
+  }
+  const float step = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    pi -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    p[i] = pi;
+  }
+}
+
+}  // namespace
+
+extern "C" int rf_stem_conv0(const void* video, int video_is_f32, const int32_t* frame_idx, const float* w, float* y,
+                             int B, int T, int F, int H, int W, void* stream) {
+  RF_REQUIRE(video && frame_idx && w && y && B > 0 && T > 0 && F > 0 && H > 1 && W > 1);
+  RF_REQUIRE(H % 2 == 0 && W % 2 == 0);
+  const long total = (long)B * F * (H / 2) * (W / 2);
+  if (video_is_f32)
+    hipLaunchKernelGGL(stem_conv0_kernel<float>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(video), frame_idx, w, y, B, T, F, H, W);
+  else
+    hipLaunchKernelGGL(stem_conv0_kernel<__half>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const __half*>(video), frame_idx, w, y, B, T, F, H, W);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_upsample_bilinear_nhwc(const float* x, const float* addend, float* y, int N, int Hi, int Wi, int C,
+                                         int Ho, int Wo, int64_t ldy, int accumulate, int relu, void* stream) {
+  RF_REQUIRE(x && y && N > 0 && Hi > 0 && Wi > 0 && C > 0 && Ho > 0 && Wo > 0 && ldy >= C);
+  hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((long)N * Ho * Wo * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, addend, y, N, Hi, Wi, C, Ho, Wo, (long)ldy, accumulate, relu);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_add_relu(const float* a, const float* b, float* out, int64_t n, int relu, void* stream) {
+  RF_REQUIRE(a && b && out && n > 0);
+  hipLaunchKernelGGL(add_relu_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out,
+                     (long)n, relu);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_avgpool8_tokens(const float* x, float* tokens, int N, int H, int W, int C, void* stream) {
+  RF_REQUIRE(x && tokens && N > 0 && H > 0 && W > 0 && C > 0);
+  hipLaunchKernelGGL(avgpool8_tokens_kernel, dim3(grid_for((long)N * 65 * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, tokens, N, H, W, C);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_sumsq(const float* g, int64_t n, float* sumsq, void* stream) {
+  RF_REQUIRE(g && sumsq && n > 0);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), g,
+                     (long)n, sumsq);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
+                             float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
+                             float grad_scale, void* stream) {
+  RF_REQUIRE(p && g && m && v && n > 0 && step >= 1 && (max_norm <= 0.f || sumsq));
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_clip_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     p, g, m, v, (long)n, sumsq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, grad_scale);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+thread_local const char* rf_g_last_error = "";
+extern "C" int rf_version(void) { return 1; }
+extern "C" const char* rf_last_error(void) { return rf_g_last_error; }

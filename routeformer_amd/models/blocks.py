@@ -1,0 +1,319 @@
+"""Transformer building blocks of the Routeformer hot path, executing on librf_hip.so.
+
+These modules are *parameter containers with the reference's state_dict layout* (so reference
+checkpoints load) whose ``forward`` hands raw weights to the HIP kernels through
+``routeformer_amd.kernels``.  The torch ``nn.Linear`` / ``nn.Conv1d`` / ``nn.LayerNorm`` children are
+never *called*: they only own parameters (and give the reference's default initialisation).
+
+Interface mirrored (file:line in /root/reference):
+  PerceiveEncoder / PerceiveDecoder ............ routeformer/models/cross_modal_transformer.py:372-503
+  AttentionLayer (both variants) ............... cross_modal_transformer.py:169-198,
+                                                 gps_backbone/layers/SelfAttentionFamily.py:168-194
+  EncoderLayer / DecoderLayer (post-LN) ........ cross_modal_transformer.py:201-301
+  distilling ConvLayer ......................... gps_backbone/layers/TransformerEncoderDecoder.py:9-29
+  DataEmbedding (timeF) ........................ gps_backbone/layers/Embedding.py:111-126
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from routeformer_amd import kernels as K
+
+
+# ---------------------------------------------------------------------------------------------
+# host RNG for the ProbSparse key samples (cross_modal_transformer.py:95): drawn on the CPU from the
+# global generator in call order, exactly like the reference, then shipped to the device.
+# ---------------------------------------------------------------------------------------------
+class IndexSampler:
+    """Process-wide source of ``index_sample`` tensors.
+
+    ``draw`` performs the reference's own call ``torch.randint(L_K, (L_Q, sample_k))`` on the host, so a
+    ``torch.manual_seed`` reproduces the reference's samples.  ``replay`` injects recorded samples
+    (tests); ``log`` keeps what was drawn (draw-order tests)."""
+
+    def __init__(self):
+        self.replay: Optional[list] = None
+        self.log: Optional[list] = None
+
+    def draw(self, L_K: int, L_Q: int, sample_k: int, device) -> torch.Tensor:
+        if self.replay is not None:
+            t = self.replay.pop(0)
+            assert tuple(t.shape) == (L_Q, sample_k), (tuple(t.shape), (L_Q, sample_k))
+        else:
+            t = torch.randint(L_K, (L_Q, sample_k))
+        if self.log is not None:
+            self.log.append(t.clone())
+        return t.to(torch.int32).to(device, non_blocking=True)
+
+
+SAMPLER = IndexSampler()
+
+
+def _dropout(x, p: float, training: bool):
+    return F.dropout(x, p, True) if (p > 0.0 and training) else x
+
+
+class PositionalEmbedding(nn.Module):
+    """Fixed sin/cos table kept as the buffer ``pe`` (1, max_len, d)."""
+
+    def __init__(self, d_model: int, max_len: int = 5000):
+        super().__init__()
+        pos = torch.arange(0, max_len).float().unsqueeze(1)
+        freq = (torch.arange(0, d_model, 2).float() * -(math.log(10000.0) / d_model)).exp()
+        pe = torch.zeros(max_len, d_model)
+        pe[:, 0::2] = torch.sin(pos * freq)
+        pe[:, 1::2] = torch.cos(pos * freq)
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+    def forward(self, L: int):
+        return self.pe[:, :L]
+
+
+class TokenEmbedding(nn.Module):
+    """Circular Conv1d(k=3) token embedding; bias only in the cross-modal flavour."""
+
+    def __init__(self, c_in: int, d_model: int, bias: bool):
+        super().__init__()
+        self.tokenConv = nn.Conv1d(c_in, d_model, kernel_size=3, padding=1, padding_mode="circular",
+                                   bias=bias)
+        nn.init.kaiming_normal_(self.tokenConv.weight, mode="fan_in", nonlinearity="leaky_relu")
+
+    def forward(self, x):
+        return K.circular_conv3(x, self.tokenConv.weight, self.tokenConv.bias, pad=1)
+
+
+class _TimeFeature(nn.Module):
+    def __init__(self, d_model: int):
+        super().__init__()
+        self.embed = nn.Linear(1, d_model, bias=False)
+
+
+class DataEmbedding(nn.Module):
+    """token conv (no bias) + Linear(1->d)(position index) + PE, then dropout."""
+
+    def __init__(self, c_in: int, d_model: int, dropout: float):
+        super().__init__()
+        self.value_embedding = TokenEmbedding(c_in, d_model, bias=False)
+        self.position_embedding = PositionalEmbedding(d_model)
+        self.temporal_embedding = _TimeFeature(d_model)
+        self.p = dropout
+
+    def forward(self, x):
+        L = x.shape[1]
+        mark = torch.arange(L, device=x.device, dtype=torch.float32).view(1, L, 1)
+        # rank-1 time feature + table: (1,L,d) host-side plumbing, broadcast over the batch
+        offset = mark * self.temporal_embedding.embed.weight.view(1, 1, -1) + self.position_embedding(L)
+        return _dropout(self.value_embedding(x) + offset, self.p, self.training)
+
+
+class AttentionLayer(nn.Module):
+    """Q/K/V/O projections around the attention kernel.
+
+    kind: "prob" | "prob_masked" | "full".  ``gps_variant`` reproduces the Informer copy whose core
+    returns (B,H,L,D) and is then *viewed* as (B,L,H*D) without a transpose."""
+
+    def __init__(self, kind: str, d_model: int, n_heads: int, factor: int = 5, gps_variant: bool = False,
+                 mix: bool = False, attn_dropout: float = 0.0):
+        super().__init__()
+        d_head = d_model // n_heads
+        self.query_projection = nn.Linear(d_model, d_head * n_heads)
+        self.key_projection = nn.Linear(d_model, d_head * n_heads)
+        self.value_projection = nn.Linear(d_model, d_head * n_heads)
+        self.out_projection = nn.Linear(d_head * n_heads, d_model)
+        self.n_heads, self.kind, self.factor = n_heads, kind, factor
+        self.gps_variant, self.mix, self.attn_dropout = gps_variant, mix, attn_dropout
+
+    def forward(self, x, memory=None):
+        """Self-attention when ``memory is None`` (one packed QKV GEMM), else queries from ``x`` and
+        keys/values from ``memory`` (packed KV GEMM)."""
+        B, L, _ = x.shape
+        H = self.n_heads
+        qp, kp, vp = self.query_projection, self.key_projection, self.value_projection
+        HE = qp.weight.shape[0]
+        E = HE // H
+        if memory is None:
+            S = L
+            w = torch.cat([qp.weight, kp.weight, vp.weight], dim=0)
+            b = torch.cat([qp.bias, kp.bias, vp.bias], dim=0)
+            a = bm = K.linear(x.reshape(B * L, -1), w, b)
+            offs = (0, HE, 2 * HE)
+        else:
+            S = memory.shape[1]
+            a = K.linear(x.reshape(B * L, -1), qp.weight, qp.bias)
+            w = torch.cat([kp.weight, vp.weight], dim=0)
+            b = torch.cat([kp.bias, vp.bias], dim=0)
+            bm = K.linear(memory.reshape(B * S, -1), w, b)
+            offs = (0, 0, HE)
+        dims = (B, H, L, S, E)
+        layout = 1 if self.gps_variant else 0
+        if self.kind == "full":
+            if self.attn_dropout > 0.0 and self.training:
+                raise NotImplementedError("attention-probability dropout (FullAttention) is not implemented "
+                                          "in the HIP kernel; run with feature_dropout=0")
+            ctx = K.attention(a, bm, offs, dims, 0, out_layout=layout)
+        else:
+            sample_k, n_top = K.prob_sizes(L, S, self.factor)
+            idx = SAMPLER.draw(S, L, sample_k, x.device)
+            ctx = K.attention(a, bm, offs, dims, 2 if self.kind == "prob_masked" else 1, index_sample=idx,
+                              n_top=n_top, out_layout=layout)
+        if self.mix and not self.gps_variant:
+            ctx = ctx.transpose(2, 1).contiguous()
+        ctx = ctx.view(B, L, HE)  # GPS variant: (B,H,L,D) memory reinterpreted -- the head scramble
+        return K.linear(ctx, self.out_projection.weight, self.out_projection.bias)
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, attention: AttentionLayer, d_model: int, d_ff: Optional[int], dropout: float,
+                 activation: str):
+        super().__init__()
+        d_ff = d_ff or 4 * d_model
+        self.attention = attention
+        self.conv1 = nn.Conv1d(d_model, d_ff, kernel_size=1)
+        self.conv2 = nn.Conv1d(d_ff, d_model, kernel_size=1)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.p = dropout
+        self.act = "relu" if activation == "relu" else "gelu"
+
+    def _ffn(self, x):
+        if self.p > 0.0 and self.training:
+            raise NotImplementedError("dropout inside the fused FFN is not implemented; use dropout=0")
+        return K.ffn(x, self.conv1.weight.squeeze(-1), self.conv1.bias, self.conv2.weight.squeeze(-1),
+                     self.conv2.bias, self.act)
+
+    def forward(self, x):
+        x = K.add_layer_norm(x, _dropout(self.attention(x), self.p, self.training), self.norm1.weight,
+                             self.norm1.bias)
+        return K.add_layer_norm(x, self._ffn(x), self.norm2.weight, self.norm2.bias)
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, self_attention: AttentionLayer, cross_attention: AttentionLayer, d_model: int,
+                 d_ff: Optional[int], dropout: float, activation: str):
+        super().__init__()
+        d_ff = d_ff or 4 * d_model
+        self.self_attention = self_attention
+        self.cross_attention = cross_attention
+        self.conv1 = nn.Conv1d(d_model, d_ff, kernel_size=1)
+        self.conv2 = nn.Conv1d(d_ff, d_model, kernel_size=1)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.p = dropout
+        self.act = "relu" if activation == "relu" else "gelu"
+
+    _ffn = EncoderLayer._ffn
+
+    def forward(self, x, memory):
+        x = K.add_layer_norm(x, _dropout(self.self_attention(x), self.p, self.training), self.norm1.weight,
+                             self.norm1.bias)
+        x = K.add_layer_norm(x, _dropout(self.cross_attention(x, memory), self.p, self.training),
+                             self.norm2.weight, self.norm2.bias)
+        return K.add_layer_norm(x, self._ffn(x), self.norm3.weight, self.norm3.bias)
+
+
+class DistilConv(nn.Module):
+    """Conv1d(k3, circular pad 2) -> BatchNorm1d -> ELU -> MaxPool1d(3,2,1): halves the sequence."""
+
+    def __init__(self, c: int):
+        super().__init__()
+        self.downConv = nn.Conv1d(c, c, kernel_size=3, padding=2, padding_mode="circular")
+        self.norm = nn.BatchNorm1d(c)
+
+    def forward(self, x):
+        z = K.circular_conv3(x, self.downConv.weight, self.downConv.bias, pad=2)
+        n = self.norm
+        return K.bn_elu_pool(z, n.weight, n.bias, n.running_mean, n.running_var, n.num_batches_tracked,
+                             training=self.training, momentum=n.momentum, eps=n.eps)
+
+
+class Encoder(nn.Module):
+    def __init__(self, attn_layers, conv_layers=None, norm_layer=None):
+        super().__init__()
+        self.attn_layers = nn.ModuleList(attn_layers)
+        self.conv_layers = nn.ModuleList(conv_layers) if conv_layers is not None else None
+        self.norm = norm_layer
+
+    def forward(self, x):
+        if self.conv_layers is not None:
+            for attn, conv in zip(self.attn_layers, self.conv_layers):
+                x = conv(attn(x))
+            x = self.attn_layers[-1](x)
+        else:
+            for attn in self.attn_layers:
+                x = attn(x)
+        if self.norm is not None:
+            x = K.add_layer_norm(x, None, self.norm.weight, self.norm.bias)
+        return x
+
+
+class Decoder(nn.Module):
+    def __init__(self, layers, norm_layer=None, projection=None):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+        self.norm = norm_layer
+        self.projection = projection
+
+    def forward(self, x, memory):
+        for layer in self.layers:
+            x = layer(x, memory)
+        if self.norm is not None:
+            x = K.add_layer_norm(x, None, self.norm.weight, self.norm.bias)
+        if self.projection is not None:
+            x = K.linear(x, self.projection.weight, self.projection.bias)
+        return x
+
+
+class PerceiveEncoder(nn.Module):
+    """ProbSparse encoder used for the frame, gaze and fusion encoders (internal width 128)."""
+
+    def __init__(self, in_channels, out_channels, out_len, factor=5, d_model=128, n_heads=8, layers=3,
+                 d_ff=None, dropout=0.1, activation="gelu", output_attention=False):
+        super().__init__()
+        if output_attention:
+            raise NotImplementedError("output_attention is not produced by the fused attention kernel")
+        self.pred_len = out_len
+        d_ff = d_ff if d_ff is not None else 4 * d_model
+        self.value_embedding = TokenEmbedding(in_channels, d_model, bias=True)
+        self.position_embedding = PositionalEmbedding(d_model)
+        self.encoder = Encoder(
+            [EncoderLayer(AttentionLayer("prob", d_model, n_heads, factor), d_model, d_ff, dropout, activation)
+             for _ in range(layers)],
+            None, norm_layer=nn.LayerNorm(d_model))
+        self.projection = nn.Linear(d_model, out_channels, bias=True)
+
+    def forward(self, x_enc):
+        h = self.value_embedding(x_enc) + self.position_embedding(x_enc.shape[1])
+        h = self.encoder(h)
+        # only the last pred_len tokens are consumed: project just those rows
+        return K.linear(h[:, -self.pred_len:, :], self.projection.weight, self.projection.bias)
+
+
+class PerceiveDecoder(nn.Module):
+    """Masked-ProbSparse self attention + full cross attention (gaze tokens query FoV features)."""
+
+    def __init__(self, query_channels, value_channels, out_channels, out_len, factor=5, n_heads=8, layers=2,
+                 d_ff=None, dropout=0.1, activation="gelu", mix=True):
+        super().__init__()
+        self.pred_len = out_len
+        d_model = value_channels
+        d_ff = d_ff if d_ff is not None else 4 * d_model
+        self.value_embedding = TokenEmbedding(query_channels, d_model, bias=True)
+        self.position_embedding = PositionalEmbedding(d_model)
+        self.decoder = Decoder(
+            [DecoderLayer(AttentionLayer("prob_masked", d_model, n_heads, factor, mix=mix),
+                          AttentionLayer("full", d_model, n_heads, factor, attn_dropout=dropout),
+                          d_model, d_ff, dropout, activation)
+             for _ in range(layers)],
+            norm_layer=nn.LayerNorm(d_model))
+        self.projection = nn.Linear(d_model, out_channels, bias=True)
+
+    def forward(self, x_enc, x_dec):
+        h = self.value_embedding(x_dec) + self.position_embedding(x_dec.shape[1])
+        h = self.decoder(h, x_enc)
+        return K.linear(h[:, -self.pred_len:, :], self.projection.weight, self.projection.bias)

@@ -1,0 +1,50 @@
+"""Informer GPS backbone on the HIP kernels (interface of ``routeformer/models/gps_backbone/
+Informer.py:18-167``): ``Informer(configs: GPSBackboneConfig)``, ``forward(x (B,L,enc_in)) ->
+(B,pred_len,c_out)``, mutable ``.pred_len`` (the autoregressive eval loop patches it,
+``routeformer.py:171-172,191``)."""
+import torch
+from torch import nn
+
+from routeformer_amd.models.blocks import (AttentionLayer, DataEmbedding, Decoder, DecoderLayer,
+                                           DistilConv, Encoder, EncoderLayer)
+
+from .config import GPSBackboneConfig
+
+
+class Informer(nn.Module):
+    def __init__(self, configs: GPSBackboneConfig):
+        super().__init__()
+        c = configs
+        if c.output_attention:
+            raise NotImplementedError("output_attention is not produced by the fused attention kernel")
+        if c.embed != "timeF":
+            raise NotImplementedError("only the timeF embedding used by Routeformer is implemented")
+        self.pred_len = c.pred_len
+        self.output_attention = False
+        self.smart_decoder = c.smart_decoder
+        self.enc_embedding = DataEmbedding(c.enc_in, c.d_model, c.dropout)
+        self.dec_embedding = DataEmbedding(c.dec_in, c.d_model, c.dropout)
+
+        def attn(kind):
+            return AttentionLayer(kind, c.d_model, c.n_heads, c.factor, gps_variant=True)
+
+        self.encoder = Encoder(
+            [EncoderLayer(attn("prob"), c.d_model, c.d_ff, c.dropout, c.activation) for _ in range(c.e_layers)],
+            [DistilConv(c.d_model) for _ in range(c.e_layers - 1)] if c.distil else None,
+            norm_layer=nn.LayerNorm(c.d_model))
+        self.decoder = Decoder(
+            [DecoderLayer(attn("prob_masked"), attn("prob"), c.d_model, c.d_ff, c.dropout, c.activation)
+             for _ in range(c.d_layers)],
+            norm_layer=nn.LayerNorm(c.d_model),
+            projection=nn.Linear(c.d_model, c.c_out, bias=True))
+
+    def forward(self, x):
+        B, L, C = x.shape
+        if self.smart_decoder:  # decoder sees the history followed by its last row repeated
+            tail = x[:, -1:, :].expand(B, self.pred_len, C)
+        else:
+            tail = torch.zeros(B, self.pred_len, C, device=x.device, dtype=torch.float32)
+        x_dec = torch.cat([x, tail], dim=1)
+        memory = self.encoder(self.enc_embedding(x))
+        out = self.decoder(self.dec_embedding(x_dec), memory)
+        return out[:, -self.pred_len:, :]

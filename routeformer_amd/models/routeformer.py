@@ -1,0 +1,235 @@
+"""Routeformer on MI355X: same constructor / ``forward`` / ``preprocess_batch`` /
+``postprocess_batch`` surface as ``routeformer/models/routeformer.py:20-533`` of the reference, with
+every dense op underneath executed by the hand-written HIP kernels of ``librf_hip.so``.
+
+What stays in Python is orchestration and O(B*T)-sized tensor plumbing (diff / pad / cat / cumsum /
+timeline scatter); see DESIGN.md for the op -> kernel map.  Host-RNG call order (ProbSparse key
+samples, view/gaze dropout draws) follows SURVEY.md Appendix D so that a ``torch.manual_seed``
+reproduces the reference's stochastic choices.
+"""
+from __future__ import annotations
+
+from typing import Optional, Type
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from routeformer_amd.models.blocks import PerceiveDecoder, PerceiveEncoder
+from routeformer_amd.models.config import RouteformerConfig
+from routeformer_amd.models.gps_backbone import Informer
+from routeformer_amd.models.video_backbone import VideoBackboneModule
+from routeformer_amd.utils.tensor import estimate_angle_and_norm, median_downsampler, rotate
+
+
+class Routeformer(nn.Module):
+    """Predicts the future ego-trajectory from GPS history, scene video and driver gaze."""
+
+    current_epoch = 0  # Lightning attribute read by reference callers; set by the harness
+
+    def __init__(self, configs: RouteformerConfig, gps_backbone: Optional[Type[nn.Module]] = Informer,
+                 video_backbone: Optional[Type[VideoBackboneModule]] = None):
+        super().__init__()
+        self.configs = configs.copy()
+        c = self.configs
+        self.with_video = c.with_video if c.with_video is not None else video_backbone is not None
+        self.with_scene = c.with_scene
+        self.with_gaze = c.with_gaze
+        if not self.with_video and self.with_gaze:
+            raise ValueError(
+                "Current gaze backbone requires a video backbone, but video backbone is not provided.")
+
+        if self.with_video:
+            E = c.image_embedding_size
+            enc = dict(n_heads=c.encoder_heads, layers=c.encoder_layers, d_ff=c.encoder_d_ff,
+                       dropout=c.feature_dropout)
+            self.video_backbone = video_backbone(configs=c.video_backbone_config)
+            self.frame_encoder = PerceiveEncoder(in_channels=self.video_backbone.output_feature_shape[0],
+                                                 out_len=1, out_channels=E, **enc)
+            # learned per-stream tags added before the fusion encoder
+            self.left_video_embedding = nn.Parameter(torch.randn(1, 1, E))
+            self.right_video_embedding = nn.Parameter(torch.randn(1, 1, E))
+            self.gaze_video_embedding = nn.Parameter(torch.randn(1, 1, E))
+            self.video_output_embedding = nn.Parameter(torch.randn(1, 1, E))
+            seq_len = c.gps_backbone_config.seq_len
+            self.video_encoder = PerceiveEncoder(in_channels=E, out_len=seq_len,
+                                                 out_channels=c.encoder_hidden_size, **enc)
+            if self.with_gaze:
+                self.gaze_encoder = PerceiveEncoder(in_channels=2, out_len=seq_len,
+                                                    out_channels=c.encoder_hidden_size, **enc)
+                self.gaze_video_decoder = PerceiveDecoder(
+                    query_channels=c.encoder_hidden_size, value_channels=c.encoder_hidden_size,
+                    out_channels=c.encoder_hidden_size, out_len=seq_len, dropout=c.feature_dropout,
+                    d_ff=c.encoder_d_ff, n_heads=c.cross_modal_decoder_heads,
+                    layers=c.cross_modal_decoder_layers, mix=False)
+
+        self.gps_backbone = gps_backbone(configs=c.gps_backbone_config)
+        self.view_dropout = c.view_dropout
+        self.motion_noise = c.motion_noise
+        self.gaze_dropout = c.gaze_dropout
+        self.feature_dropout = c.feature_dropout
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, batch, target_batch=None):
+        """batch: dict with ``gps`` (B,T,2) and optionally ``left_video``/``right_video``/
+        ``front_video`` (B,T,3,H,W) and ``gaze`` (B,Tg,2).  Returns future positions (B,P,2), or
+        ``(positions, future visual features (B,P,E))`` when ``dense_prediction``."""
+        motion, visual = self.preprocess_batch(batch)
+        last_gps = batch["gps"][:, -1:, :]
+        c = self.configs
+        if self.training or not c.autoregressive:
+            out, _ = self._forward(motion, visual)
+            _, positions, future_visual = self.postprocess_batch(last_gps, out)
+        else:
+            # eval-time autoregressive roll-out: feed predictions back, `step` steps at a time
+            step, total = c.autoregressive_step_size, self.gps_backbone.pred_len
+            self.gps_backbone.pred_len = step
+            chunks, done = [], 0
+            try:
+                while done < total:
+                    dtype = motion.dtype
+                    out, _ = self._forward(motion, visual)
+                    mv, pos, fvis = self.postprocess_batch(last_gps, out)
+                    chunks.append((pos, fvis))
+                    motion = torch.cat([motion[:, step:], mv], dim=1).to(dtype)
+                    last_gps = pos[:, -1:, :]
+                    visual = torch.cat([visual[:, step:], fvis], dim=1).to(dtype)
+                    done += step
+            finally:
+                self.gps_backbone.pred_len = total
+            positions = torch.cat([p for p, _ in chunks], dim=1)[:, :total]
+            future_visual = None
+            if self.with_video:
+                future_visual = torch.cat([v for _, v in chunks], dim=1)[:, :total]
+        if c.dense_prediction:
+            return positions, future_visual
+        return positions
+
+    def _forward(self, motion, visual):
+        c = self.configs
+        angle, norm = estimate_angle_and_norm(motion)
+        origin = angle[:, -1:, :] if c.rotate_motion else angle[:, :1, :]
+        rel_angle = (angle - origin) / torch.pi
+        accel = F.pad(norm[:, 1:, :] - norm[:, :-1, :], (0, 0, 1, 0))
+        if c.rotate_motion:
+            motion = rotate(motion, -origin)
+        feats = [torch.cat([motion, rel_angle, norm, accel], dim=-1)]
+        if self.with_video:
+            feats.append(visual)
+        if c._only_motion:
+            feats[-1] = torch.zeros_like(feats[-1])
+        x = torch.cat(feats, dim=-1)
+        out = self.gps_backbone(x)
+        if c.decoder_mode == "recursive":
+            out = out + (x[:, -1:, :] if c.dense_prediction else x[:, -1:, :2])
+        if c.rotate_motion:
+            out = torch.cat([rotate(out[:, :, :2], origin), out[:, :, 2:]], dim=-1)
+        return out, None
+
+    # ------------------------------------------------------------------------------------------
+    def preprocess_batch(self, batch, training: bool = None):
+        """-> (motion dynamics (B,T,2), fused visual tokens (B,T,hidden) or [] without video)."""
+        c = self.configs
+        if training is None:
+            training = self.training
+        gps = batch["gps"].to(torch.float32)
+        if self.motion_noise > 0.0 and self.training:
+            gps = gps + torch.randn_like(gps) * self.motion_noise
+        mv = gps[:, 1:, :] - gps[:, :-1, :]
+        if c.normalize_motion:
+            mv = (mv - c.motion_mean) / c.motion_std
+        motion = F.pad(mv, (0, 0, 1, 0))  # zero row in front aligns motion with the frames
+        visual = []
+        if self.with_video and self.with_scene:
+            visual.extend(self._forward_video(batch, training))
+        if self.with_gaze:
+            drop_gaze = False
+            if self.gaze_dropout > 0.0 and training:
+                drop_gaze = bool(torch.rand(1) < self.gaze_dropout)
+            if drop_gaze:
+                fv = batch["front_video"]
+                gaze_feats = torch.zeros(fv.shape[0], fv.shape[1], c.image_embedding_size, dtype=motion.dtype,
+                                         device=motion.device)
+            else:
+                gaze_video = self._forward_gaze_video(batch, training)
+                tokens = median_downsampler(batch["gaze"].to(torch.float32), c.gps_backbone_config.seq_len)
+                tokens = self.gaze_encoder(tokens)
+                gaze_feats = self.gaze_video_decoder(gaze_video, tokens)[:, : gaze_video.shape[1]]
+            visual.append(gaze_feats)
+        if self.with_video:
+            if self.with_scene:
+                visual[0] = visual[0] + self.left_video_embedding
+                visual[1] = visual[1] + self.right_video_embedding
+            if self.with_gaze:
+                visual[-1] = visual[-1] + self.gaze_video_embedding
+            visual.append(torch.zeros_like(visual[-1]) + self.video_output_embedding)
+            visual = self.video_encoder(torch.cat(visual, dim=1))
+        return motion, visual
+
+    def postprocess_batch(self, last_input_gps, output):
+        """Integrate predicted motion into positions; split off the dense visual head."""
+        c = self.configs
+        motion = output[:, :, :2]
+        if c.normalize_motion:
+            motion = motion * c.motion_std + c.motion_mean
+        positions = (last_input_gps + torch.cumsum(motion, dim=1)).to(last_input_gps.dtype)
+        rest = output[:, :, 2:]
+        future_visual = None
+        if self.with_video and c.dense_prediction:
+            assert rest.shape[-1] >= c.image_embedding_size, (
+                f"Output shape for left/right vid. must be at least {c.image_embedding_size}, "
+                f"but is {rest.shape}.")
+            future_visual = rest[:, :, : c.image_embedding_size]
+            rest = rest[:, :, c.image_embedding_size:]
+        assert rest.shape[-1] == 0, f"Output should be empty at this point, but is {rest.shape}."
+        return motion, positions, future_visual
+
+    # ------------------------------------------------------------------------------------------
+    def _frame_indices(self, T: int, fps: int, what: str) -> torch.Tensor:
+        rel = self.configs.output_fps // fps
+        assert rel > 0, f"{what} FPS must be a divisor of the output FPS"
+        return torch.flip(torch.arange(T - 1, 0, -rel), dims=[0])  # last frame always in, frame 0 never
+
+    def _encode_stream(self, video, idx, drop: bool, training: bool):
+        """(B,T,3,H,W) -> per-frame embeddings scattered into a zero (B,T,E) timeline."""
+        B, T = video.shape[:2]
+        E = self.configs.image_embedding_size
+        dev = video.device
+        dtype = next(self.gps_backbone.parameters()).dtype
+        timeline = torch.zeros(B, T, E, device=dev)
+        if drop and training:
+            return timeline  # dropped view: all-zero features (no RNG consumed by the encoder)
+        if hasattr(self.video_backbone, "encode_tokens"):
+            tokens = self.video_backbone.encode_tokens(video, idx)  # fused gather+cast+trunk+pool+(-1 row)
+        else:  # generic plugin backbone
+            frames = video[:, idx].flatten(0, 1)
+            fmap = self.video_backbone(frames).to(dtype)
+            tokens = fmap.permute(0, 2, 3, 1).reshape(fmap.shape[0], -1, fmap.shape[1])
+            tokens = torch.cat([tokens, -torch.ones_like(tokens)[:, :1, :]], dim=1)
+        emb = self.frame_encoder(tokens.to(dtype)).view(B, -1, E)
+        timeline[:, idx.to(dev)] = emb
+        return timeline
+
+    def _forward_video(self, batch, training: bool):
+        if training is None:
+            training = self.training
+        left = batch["left_video"]
+        right = batch.get("right_video", left)
+        drop_left, drop_right = False, "right_video" not in batch
+        if self.view_dropout > 0.0 and training:
+            drop_one = bool(torch.rand(1) < self.view_dropout)
+            drop_left = drop_one and bool(torch.rand(1) < 0.5)
+            drop_right = (drop_one and not drop_left) or "right_video" not in batch
+        idx = self._frame_indices(left.shape[1], self.configs.video_fps, "Video")
+        right_feats = self._encode_stream(right, idx, drop_right, training)  # right first: RNG order
+        left_feats = self._encode_stream(left, idx, drop_left, training)
+        return left_feats, right_feats
+
+    def _forward_gaze_video(self, batch, training: bool):
+        video = batch["front_video"]
+        idx = self._frame_indices(video.shape[1], self.configs.gaze_fps, "Gaze")
+        return self._encode_stream(video, idx, False, training)

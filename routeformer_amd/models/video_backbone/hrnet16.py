@@ -1,0 +1,284 @@
+"""Frozen HRNet-16 conv encoder ("InverseForm" backbone of the reference) on the HIP kernels.
+
+Plugin contract = ``routeformer/models/video_backbone/config.py:45-52`` / ``InverseForm.py:140-176``:
+``HRNet16Backbone(configs)``, ``.output_feature_shape == (240, 8, 8)``,
+``forward(images (N,3,H,W)) -> (N,240,8,8)``.  The state_dict keys are those of the reference trunk
+(``video_backbone._Backbone.*``; architecture: ``inverse_form_layers/hrnetv2.py:282-500`` with
+``config.py:177-206``), so the Qualcomm ``hr16s_4k_slim`` checkpoint the reference downloads maps
+onto it key-for-key (``load_inverseform_checkpoint``).
+
+MI355X design: inference-only, so BatchNorm2d(eval) is folded into the conv weights once; activations
+are NHWC fp32 so each 3x3/1x1 convolution is an implicit GEMM on the matrix cores
+(``rf_conv2d_nhwc``: M = pixels, N = C_out, K = k*k*C_in) with bias / residual / ReLU in the epilogue;
+the trunk output is pooled straight into the (N,65,240) token layout the frame encoder consumes.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from routeformer_amd import _hip
+from routeformer_amd import kernels as K
+from routeformer_amd._hip import check, ptr
+
+from .config import VideoBackboneConfig, VideoBackboneModule
+
+BRANCH_CH = (16, 32, 64, 128)
+STAGES = (("stage2", 2, 1), ("stage3", 3, 3), ("stage4", 4, 2))  # name, branches, modules
+BLOCKS_PER_BRANCH = 2
+
+
+class _Tree(nn.Module):
+    """Nested empty modules so parameters get dotted names identical to the reference's."""
+
+    def put(self, path: str, tensor: torch.Tensor, buffer: bool = False):
+        node = self
+        *parents, leaf = path.split(".")
+        for name in parents:
+            if name not in node._modules:
+                node.add_module(name, _Tree())
+            node = node._modules[name]
+        if buffer:
+            node.register_buffer(leaf, tensor)
+        else:
+            node.register_parameter(leaf, nn.Parameter(tensor, requires_grad=False))
+
+
+def _conv_units() -> List[Tuple[str, Optional[str], int, int, int]]:
+    """(conv key, bn key or None, c_in, c_out, ksize) for every convolution of the HRNet16 trunk."""
+    u: List[Tuple[str, Optional[str], int, int, int]] = [
+        ("conv0", None, 3, 3, 2), ("conv1", "bn1", 3, 64, 3), ("conv2", "bn2", 64, 64, 3)]
+    for b, cin in ((0, 64), (1, 256)):  # layer1: two Bottlenecks (planes 64, expansion 4)
+        p = f"layer1.{b}"
+        u += [(p + ".conv1", p + ".bn1", cin, 64, 1), (p + ".conv2", p + ".bn2", 64, 64, 3),
+              (p + ".conv3", p + ".bn3", 64, 256, 1)]
+        if b == 0:
+            u.append((p + ".downsample.0", p + ".downsample.1", 64, 256, 1))
+    u += [("transition1.0.0", "transition1.0.1", 256, 16, 3),
+          ("transition1.1.0.0", "transition1.1.0.1", 256, 32, 3),
+          ("transition2.2.0.0", "transition2.2.0.1", 32, 64, 3),
+          ("transition3.3.0.0", "transition3.3.0.1", 64, 128, 3)]
+    for stage, nb, nmod in STAGES:
+        for m in range(nmod):
+            p = f"{stage}.{m}"
+            for br in range(nb):
+                c = BRANCH_CH[br]
+                for k in range(BLOCKS_PER_BRANCH):
+                    q = f"{p}.branches.{br}.{k}"
+                    u += [(q + ".conv1", q + ".bn1", c, c, 3), (q + ".conv2", q + ".bn2", c, c, 3)]
+            for i in range(nb):
+                for j in range(nb):
+                    q = f"{p}.fuse_layers.{i}.{j}"
+                    if j > i:
+                        u.append((q + ".0", q + ".1", BRANCH_CH[j], BRANCH_CH[i], 1))
+                    elif j < i:
+                        for k in range(i - j):
+                            cout = BRANCH_CH[i] if k == i - j - 1 else BRANCH_CH[j]
+                            u.append((f"{q}.{k}.0", f"{q}.{k}.1", BRANCH_CH[j], cout, 3))
+    return u
+
+
+UNITS = _conv_units()
+
+
+class HRNet16Backbone(VideoBackboneModule):
+    def __init__(self, configs: Optional[VideoBackboneConfig] = None):
+        super().__init__()
+        self.configs = configs
+        self._Backbone = _Tree()
+        for conv, bn, cin, cout, k in UNITS:
+            # reference init (hrnetv2.py:502-512): conv ~ N(0, 0.001), BN weight 1 / bias 0
+            self._Backbone.put(conv + ".weight", torch.randn(cout, cin, k, k) * 0.001)
+            if bn is not None:
+                self._Backbone.put(bn + ".weight", torch.ones(cout))
+                self._Backbone.put(bn + ".bias", torch.zeros(cout))
+                self._Backbone.put(bn + ".running_mean", torch.zeros(cout), buffer=True)
+                self._Backbone.put(bn + ".running_var", torch.ones(cout), buffer=True)
+                self._Backbone.put(bn + ".num_batches_tracked", torch.tensor(0, dtype=torch.long), buffer=True)
+        self._folded: Optional[Dict[str, tuple]] = None
+        self._folded_key = None
+
+    # ---- plugin contract ---------------------------------------------------------------------
+    @property
+    def output_feature_shape(self) -> tuple:
+        return (240, 8, 8)
+
+    def train(self, mode: bool = True):
+        """Frozen encoder: BatchNorm stays in eval mode (InverseForm.py:69-71)."""
+        super().train(mode)
+        return self
+
+    def forward(self, images: torch.Tensor) -> torch.Tensor:
+        """(N,3,H,W) -> (N,240,8,8).  The result is a channels-last *view* of the pooled NHWC map, so
+        the ``permute(0,2,3,1).reshape`` the caller applies (routeformer.py:478-480) is free."""
+        tok = self.encode_tokens(images.unsqueeze(0), None)
+        return tok[:, :64, :].reshape(images.shape[0], 8, 8, 240).permute(0, 3, 1, 2)
+
+    # ---- checkpoint compatibility --------------------------------------------------------------
+    def load_inverseform_checkpoint(self, path: str):
+        """Load the Qualcomm checkpoint the reference uses (key remapping of InverseForm.py:94-133:
+        strip 'module.'/'model.' and 'backbone.' prefixes, keep shape-matching trunk entries)."""
+        raw = torch.load(path, map_location="cpu")["state_dict"]
+        own = self._Backbone.state_dict()
+        picked = {}
+        for k, v in raw.items():
+            parts = k.split(".")
+            while parts and parts[0] in ("module", "modules", "model", "backbone"):
+                parts = parts[1:]
+            k2 = ".".join(parts)
+            if k2 in own and own[k2].shape == v.shape:
+                picked[k2] = v
+        own.update(picked)
+        self._Backbone.load_state_dict(own)
+        self._folded = None
+        return len(picked)
+
+    # ---- weight preparation (BN folding, NHWC filter layout) ------------------------------------
+    def _prepare(self, device):
+        key = (str(device), tuple(p._version for p in self._Backbone.parameters()),
+               tuple(b._version for b in self._Backbone.buffers()), id(next(self._Backbone.parameters())))
+        if self._folded is not None and self._folded_key == key:
+            return self._folded
+        sd = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in self._Backbone.state_dict().items()}
+        folded = {}
+        with torch.no_grad():
+            for conv, bn, cin, cout, k in UNITS:
+                w = sd[conv + ".weight"]
+                if bn is not None:
+                    scale = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + 1e-5)
+                    bias = (sd[bn + ".bias"] - sd[bn + ".running_mean"] * scale).contiguous()
+                    w = w * scale.view(-1, 1, 1, 1)
+                else:
+                    bias = None
+                if conv == "conv0":
+                    folded[conv] = (w.contiguous(), None, cin, cout, k)
+                    continue
+                cin_p = (cin + 3) // 4 * 4  # conv1 reads the 4-channel (zero-padded) stem output
+                wk = torch.zeros(cout, k, k, cin_p, device=device, dtype=torch.float32)
+                wk[..., :cin] = w.permute(0, 2, 3, 1)
+                folded[conv] = (wk.contiguous(), bias, cin_p, cout, k)
+        self._folded, self._folded_key = folded, key
+        return folded
+
+    # ---- execution --------------------------------------------------------------------------------
+    def _conv(self, W, unit, x, stride=1, relu=False, residual=None):
+        w, b, cin, cout, k = W[unit]
+        N, H, Wd, C = x.shape
+        assert C == cin, (unit, C, cin)
+        pad = 1 if k == 3 else 0
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
+        y = torch.empty(N, Ho, Wo, cout, device=x.device, dtype=torch.float32)
+        check(_hip.lib().rf_conv2d_nhwc(ptr(x), ptr(w), ptr(b), ptr(residual), ptr(y), N, H, Wd, cin, cout, k,
+                                        stride, pad, Ho, Wo, cout, cout, 1 if relu else 0, K._PRECISION,
+                                        K._stream()), "rf_conv2d_nhwc")
+        return y
+
+    @staticmethod
+    def _upsample(x, size, *, addend=None, out=None, ldy=None, accumulate=False, relu=False):
+        N, Hi, Wi, C = x.shape
+        Ho, Wo = size
+        if out is None:
+            out = torch.empty(N, Ho, Wo, C, device=x.device, dtype=torch.float32)
+            ldy = C
+        check(_hip.lib().rf_upsample_bilinear_nhwc(ptr(x), ptr(addend), out.data_ptr() if isinstance(out, torch.Tensor)
+                                                   else out, N, Hi, Wi, C, Ho, Wo, ldy, 1 if accumulate else 0,
+                                                   1 if relu else 0, K._stream()), "rf_upsample_bilinear_nhwc")
+        return out
+
+    @staticmethod
+    def _add(a, b, relu):
+        out = torch.empty_like(a)
+        check(_hip.lib().rf_add_relu(ptr(a), ptr(b), ptr(out), a.numel(), 1 if relu else 0, K._stream()),
+              "rf_add_relu")
+        return out
+
+    def _basic(self, W, p, x):
+        y = self._conv(W, p + ".conv1", x, relu=True)
+        return self._conv(W, p + ".conv2", y, relu=True, residual=x)
+
+    def _bottleneck(self, W, p, x):
+        y = self._conv(W, p + ".conv1", x, relu=True)
+        y = self._conv(W, p + ".conv2", y, relu=True)
+        res = self._conv(W, p + ".downsample.0", x) if (p + ".downsample.0") in W else x
+        return self._conv(W, p + ".conv3", y, relu=True, residual=res)
+
+    def _module(self, W, p, xs):
+        """One HighResolutionModule: per-branch BasicBlocks, then the cross-resolution fuse
+        (hrnetv2.py:250-277), summing terms in the reference's order j = 0..nb-1, ReLU on the last."""
+        nb = len(xs)
+        xs = list(xs)
+        for b in range(nb):
+            for k in range(BLOCKS_PER_BRANCH):
+                xs[b] = self._basic(W, f"{p}.branches.{b}.{k}", xs[b])
+        outs = []
+        for i in range(nb):
+            size = tuple(xs[i].shape[1:3])
+            acc, owned = None, False  # owned: acc is a private buffer that may be updated in place
+            for j in range(nb):
+                last = j == nb - 1
+                q = f"{p}.fuse_layers.{i}.{j}"
+                if j < i:  # stride-2 3x3 chain; the running sum rides in the last conv's epilogue
+                    t = xs[j]
+                    for k in range(i - j):
+                        final = k == i - j - 1
+                        t = self._conv(W, f"{q}.{k}.0", t, stride=2, relu=not final,
+                                       residual=acc if final else None)
+                    acc, owned = t, True
+                elif j == i:
+                    if acc is None:
+                        acc, owned = xs[j], False
+                    else:
+                        acc, owned = self._add(acc, xs[j], relu=last), True
+                else:  # 1x1 conv + BN at low resolution, bilinear up-sample into the sum
+                    t = self._conv(W, q + ".0", xs[j])
+                    if owned:
+                        self._upsample(t, size, out=acc, ldy=acc.shape[-1], accumulate=True, relu=last)
+                    else:
+                        acc, owned = self._upsample(t, size, addend=acc, relu=last), True
+            outs.append(acc)
+        return outs
+
+    def encode_tokens(self, video: torch.Tensor, frame_idx: Optional[torch.Tensor]) -> torch.Tensor:
+        """video (B,T,3,H,W) fp16/fp32 + frame indices (F,) -> tokens (B*F, 65, 240) with the trailing
+        constant -1 row (routeformer.py:478-487).  Frame gather, dtype cast and conv0 are one kernel."""
+        if not video.is_cuda:
+            raise _hip.HipLibraryError("HRNet16Backbone runs on the GPU only; there is no CPU path")
+        if video.dtype not in (torch.float16, torch.float32):
+            video = video.float()
+        video = video.contiguous()
+        B, T, C3, H, Wd = video.shape
+        assert C3 == 3 and H % 2 == 0 and Wd % 2 == 0
+        dev = video.device
+        if frame_idx is None:
+            frame_idx = torch.arange(T, device=dev, dtype=torch.int32)
+        frame_idx = frame_idx.to(device=dev, dtype=torch.int32)
+        F_ = frame_idx.numel()
+        N = B * F_
+        W = self._prepare(dev)
+        x = torch.empty(N, H // 2, Wd // 2, 4, device=dev, dtype=torch.float32)
+        check(_hip.lib().rf_stem_conv0(ptr(video), 1 if video.dtype == torch.float32 else 0, ptr(frame_idx),
+                                       ptr(W["conv0"][0]), ptr(x), B, T, F_, H, Wd, K._stream()), "rf_stem_conv0")
+        x = self._conv(W, "conv1", x, stride=2, relu=True)
+        x = self._conv(W, "conv2", x, stride=2, relu=True)
+        x = self._bottleneck(W, "layer1.0", x)
+        x = self._bottleneck(W, "layer1.1", x)
+        xs = [self._conv(W, "transition1.0.0", x, relu=True),
+              self._conv(W, "transition1.1.0.0", x, stride=2, relu=True)]
+        for stage, nb, nmod in STAGES:
+            if len(xs) < nb:
+                xs.append(self._conv(W, f"transition{nb - 1}.{nb - 1}.0.0", xs[-1], stride=2, relu=True))
+            for m in range(nmod):
+                xs = self._module(W, f"{stage}.{m}", xs)
+        Hf, Wf = xs[0].shape[1:3]
+        feats = torch.empty(N, Hf, Wf, 240, device=dev, dtype=torch.float32)
+        off = 0
+        for t in xs:  # concat along channels; identity-scale "upsample" copies branch 0
+            c = t.shape[-1]
+            self._upsample(t, (Hf, Wf), out=feats.data_ptr() + 4 * off, ldy=240)
+            off += c
+        tokens = torch.empty(N, 65, 240, device=dev, dtype=torch.float32)
+        check(_hip.lib().rf_avgpool8_tokens(ptr(feats), ptr(tokens), N, Hf, Wf, 240, K._stream()),
+              "rf_avgpool8_tokens")
+        return tokens
