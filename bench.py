@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- samples/s of one full Routeformer train step on synthetic GEM-shaped batches.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = forward(input) + target-side feature forward + trajectory/dense losses + backward
+(+ bucketed RCCL gradient all-reduce overlapped with backward when N > 1) + global-norm clip + AdamW,
+i.e. the reference's ``training_step`` + optimizer step (experiments/full_comparison.py:470-532,
+681-711, 829-830) for ONE Routeformer.  Workload = BASELINE.json configs[1] ("C2"): full model
+(GPS + left/right scene video + front video + gaze), 224x224, 8 s history -> 6 s future, paper
+hyper-parameters, batch 8 PER GPU (weak scaling: configs[2] is the same at N=8).
+Inputs are resident in HBM before the timed region starts.
+
+Prints ONE JSON line on rank 0 (metric/value/... + "roofline" for the dominant kernel class +
+"cpu_baseline" = the CPU oracle timed on this box's host cores at N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense peaks, same guide
+
+
+def build(case_name, device, precision):
+    from routeformer_amd import kernels as K, presets, synthetic
+    from routeformer_amd.models import Routeformer, RouteformerConfig
+    from routeformer_amd.models.gps_backbone import GPSBackboneConfig, Informer
+    from routeformer_amd.models.video_backbone import HRNet16Backbone, VideoBackboneConfig
+
+    K.set_precision(precision)
+    c = presets.case(case_name)
+    _, cfg = presets.build_configs(c, GPSBackboneConfig, RouteformerConfig, VideoBackboneConfig)
+    torch.manual_seed(0)
+    model = Routeformer(cfg, gps_backbone=Informer, video_backbone=HRNet16Backbone if cfg.with_video else None)
+    sd = synthetic.synth_state_dict(model.state_dict(), 7)  # random-init weights of that architecture
+    model.load_state_dict(sd)
+    return model.to(device), cfg, sd, c
+
+
+def make_item(c, rank, device=None, case_id=2):
+    from routeformer_amd import synthetic
+    item = synthetic.synth_item(c["B"], c["T"], c["P"], 1000 * case_id + rank, c["H"], c["W"], streams=c["streams"],
+                                gaze=c["gaze"])
+    if device is not None:
+        item = {k: {n: v.to(device) for n, v in d.items()} for k, d in item.items()}
+    return item
+
+
+def cpu_baseline(cfg, sd, c, steps=2):
+    """The CPU oracle (kind "port": our restatement of the reference, pinned to the reference's golden
+    vectors) doing the SAME full train step on the host cores.  Bounded sample: `steps` steps of the B=8
+    workload after one warm-up step is skipped (first step is included in no average)."""
+    from oracle import routeformer_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    item = make_item(c, 0)
+    params = {k: v.clone().requires_grad_(v.is_floating_point() and "video_backbone" not in k and "running" not in k
+                                          and not k.endswith(".pe")) for k, v in sd.items()}
+    train = [p for p in params.values() if p.requires_grad]
+    opt = torch.optim.AdamW(train, lr=cfg.lr, weight_decay=cfg.wd)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        torch.manual_seed(i)
+        orc = O.OracleRouteformer(cfg, params, training=True)
+        res = orc.train_step(item, epoch=10)
+        opt.zero_grad(set_to_none=True)
+        res["loss"].backward()
+        torch.nn.utils.clip_grad_norm_(train, 2.5)
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:]) / steps
+    return {"value": c["B"] / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} full train steps (after 1 warm-up) of the same C2 batch-{c['B']} workload, "
+                      f"fp32, torch CPU oracle, {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--case", default="C2")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from routeformer_amd import kernels as K
+    from routeformer_amd.engine import TrainEngine
+
+    model, cfg, sd, c = build(args.case, device, args.precision)
+    item = make_item(c, rank, device)
+    engine = TrainEngine(model)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        engine.step(item, epoch=10)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if i == args.steps - 1:
+            K.PROFILE.enable()  # HIP events around every kernel-class launch of the last timed step
+        res = engine.step(item, epoch=10)
+    sync()
+    elapsed = time.perf_counter() - t0
+    K.PROFILE.disable()
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+    assert torch.isfinite(res["loss"]).item(), "loss is not finite"
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        total_samples = c["B"] * world * args.steps
+        prof = K.PROFILE.summary()
+        roof = None
+        if prof:
+            name, st = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+            avg_s = st["total_ms"] / st["launches"] * 1e-3
+            gbs = st["bytes"] / st["launches"] / avg_s / 1e9
+            tfl = st["flops"] / st["launches"] / avg_s / 1e12
+            peak_tf = MFMA_PEAK_TFLOPS[args.precision]
+            # regime: arithmetic intensity vs the ridge point
+            mfma_bound = (st["flops"] / max(st["bytes"], 1)) > (peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9))
+            roof = {"kernel": name, "bound": "mfma" if mfma_bound else "hbm",
+                    "achieved": tfl if mfma_bound else gbs, "peak": peak_tf if mfma_bound else HBM_PEAK_GBS,
+                    "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                    "frac": (tfl / peak_tf) if mfma_bound else (gbs / HBM_PEAK_GBS), "traffic": None,
+                    "launches_per_step": st["launches"], "avg_us": avg_s * 1e6,
+                    "share_of_step": st["total_ms"] / ms, "alt_tflops": tfl, "alt_gbs": gbs,
+                    "classes": {k: round(v["total_ms"], 3) for k, v in sorted(prof.items(),
+                                                                             key=lambda kv: -kv[1]["total_ms"])}}
+        out = {
+            "metric": "samples/sec (train step) on synthetic GEM batch",
+            "value": total_samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"{args.case}: full Routeformer (GPS+left/right/front video+gaze), "
+                                   f"{c['H']}x{c['W']}, T={c['T']}->P={c['P']}, paper hyper-params, "
+                                   f"batch {c['B']}/GPU, random-init weights, frozen HRNet-16 encoder",
+                       "global_batch": c["B"] * world, "parallelism": f"dp{world}",
+                       "step": "fwd + target-feature fwd + losses + bwd + grad all-reduce + clip + AdamW"},
+            "loss": float(res["loss"]), "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, c, args.cpu_steps)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,6 +21,13 @@ import torch
 import torch.nn.functional as F
 
 SD = Dict[str, torch.Tensor]
+TAPS: Optional[dict] = None  # debug: name -> list of intermediate activations (tools/debug_taps.py)
+
+
+def _tap(name: str, x):
+    if TAPS is not None:
+        TAPS.setdefault(name, []).append(x.detach().clone())
+    return x
 
 
 # ---------------------------------------------------------------------------------------------
@@ -37,6 +44,13 @@ class IndexSource:
     def __init__(self, replay: Optional[Sequence[torch.Tensor]] = None):
         self.replay = list(replay) if replay is not None else None
         self.log: List[torch.Tensor] = []
+        # top-u selections made by each ProbSparse call, (B,H,u) ascending, in call order; tests use
+        # them to teacher-force the HIP kernels (the selection is discontinuous in the inputs) and to
+        # count selection flips.  ``margins`` = gap between the last selected and the first rejected
+        # sparsity measure per (b,h), relative to the largest sampled |q.k| it was computed from (M is a
+        # difference of such dot products, so their rounding error is what can flip a selection).
+        self.tops: List[torch.Tensor] = []
+        self.margins: List[torch.Tensor] = []
 
     def randint(self, high: int, size) -> torch.Tensor:
         if self.replay is not None:
@@ -68,7 +82,7 @@ def full_attention(q, k, v, scale=None):
 
 
 def prob_attention(q, k, v, index_sample, factor: int, masked: bool, scale=None,
-                   gps_variant: bool = False, return_top: bool = False):
+                   gps_variant: bool = False, return_top: bool = False, trace: Optional[IndexSource] = None):
     """Informer ProbSparse attention -- cross_modal_transformer.py:88-166 (A.3 of SURVEY).
 
     q,k,v: (B, L, H, D).  Returns (B, L_Q, H, D) for the cross-modal variant, or the
@@ -83,6 +97,11 @@ def prob_attention(q, k, v, index_sample, factor: int, masked: bool, scale=None,
     qk_s = torch.einsum("bhqd,bhqjd->bhqj", Q, K_s)
     M = qk_s.max(-1).values - qk_s.sum(-1) / L_K  # sparsity measure (:100)
     top = M.topk(n_top, sorted=False).indices  # (B,H,u)  (:101)
+    if trace is not None:
+        trace.tops.append(top.sort(dim=-1).values)
+        srt = M.detach().sort(dim=-1, descending=True).values
+        gap = (srt[..., n_top - 1] - srt[..., n_top]) if n_top < L_Q else torch.full(srt.shape[:-1], float("inf"))
+        trace.margins.append(gap / qk_s.detach().abs().amax(dim=(-1, -2)).clamp_min(1e-12))
     Q_red = torch.gather(Q, 2, top.unsqueeze(-1).expand(-1, -1, -1, D))
     scores = torch.matmul(Q_red, K.transpose(-2, -1)) * (scale or 1.0 / math.sqrt(D))  # (:107,158-160)
     if masked:  # ProbMask: key s visible to selected query i iff s <= top[i]  (:22-29)
@@ -118,7 +137,7 @@ def attention_layer(sd: SD, p: str, xq, xk, xv, n_heads: int, kind: str, idx: In
         sample_k, _ = prob_sizes(L, S, factor)
         index_sample = idx.randint(S, (L, sample_k))
         out = prob_attention(q, k, v, index_sample, factor, kind == "prob_masked",
-                             gps_variant=gps_variant)
+                             gps_variant=gps_variant, trace=idx)
     if mix and not gps_variant:
         out = out.transpose(2, 1).contiguous()
     # GPS variant: (B,H,L,D) memory reinterpreted as (B,L,H*D) -- the "head scramble" (:192)
@@ -146,7 +165,7 @@ def encoder_layer(sd: SD, p: str, x, n_heads, idx, factor, activation, gps_varia
     x = x + attention_layer(sd, p + ".attention", x, x, x, n_heads, "prob", idx, factor,
                             gps_variant)
     x = _ln(sd, p + ".norm1", x)
-    return _ln(sd, p + ".norm2", x + _ffn(sd, p, x, activation))
+    return _tap(p, _ln(sd, p + ".norm2", x + _ffn(sd, p, x, activation)))
 
 
 def decoder_layer(sd: SD, p: str, x, cross, n_heads, idx, factor, activation, gps_variant,
@@ -158,7 +177,7 @@ def decoder_layer(sd: SD, p: str, x, cross, n_heads, idx, factor, activation, gp
     x = x + attention_layer(sd, p + ".cross_attention", x, cross, cross, n_heads, cross_kind, idx,
                             factor, gps_variant)
     x = _ln(sd, p + ".norm2", x)
-    return _ln(sd, p + ".norm3", x + _ffn(sd, p, x, activation))
+    return _tap(p, _ln(sd, p + ".norm3", x + _ffn(sd, p, x, activation)))
 
 
 def _count(sd: SD, prefix: str) -> int:
@@ -192,7 +211,7 @@ def perceive_encoder(sd: SD, p: str, x, n_heads: int, out_len: int, idx: IndexSo
         h = encoder_layer(sd, f"{p}.encoder.attn_layers.{i}", h, n_heads, idx, factor, activation,
                           gps_variant=False)
     h = _ln(sd, p + ".encoder.norm", h)
-    return _linear(sd, p + ".projection", h)[:, -out_len:, :]
+    return _tap(p, _linear(sd, p + ".projection", h)[:, -out_len:, :])
 
 
 def perceive_decoder(sd: SD, p: str, x_enc, x_dec, n_heads: int, out_len: int, idx: IndexSource,
@@ -206,7 +225,7 @@ def perceive_decoder(sd: SD, p: str, x_enc, x_dec, n_heads: int, out_len: int, i
         h = decoder_layer(sd, f"{p}.decoder.layers.{i}", h, x_enc, n_heads, idx, factor, activation,
                           gps_variant=False, cross_kind="full", mix=mix)
     h = _ln(sd, p + ".decoder.norm", h)
-    return _linear(sd, p + ".projection", h)[:, -out_len:, :]
+    return _tap(p, _linear(sd, p + ".projection", h)[:, -out_len:, :])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -239,7 +258,7 @@ def distil_conv(sd: SD, p: str, x, training: bool, bn_state: Optional[dict] = No
         mean, var = sd[p + ".norm.running_mean"], sd[p + ".norm.running_var"]
     y = (y - mean) / torch.sqrt(var + 1e-5) * sd[p + ".norm.weight"] + sd[p + ".norm.bias"]
     y = F.elu(y)
-    return F.max_pool1d(y.transpose(1, 2), kernel_size=3, stride=2, padding=1).transpose(1, 2)
+    return _tap(p, F.max_pool1d(y.transpose(1, 2), kernel_size=3, stride=2, padding=1).transpose(1, 2))
 
 
 def informer(sd: SD, p: str, x, *, pred_len: int, n_heads: int, factor: int, activation: str,
@@ -269,7 +288,7 @@ def informer(sd: SD, p: str, x, *, pred_len: int, n_heads: int, factor: int, act
         d = decoder_layer(sd, f"{p}.decoder.layers.{i}", d, enc, n_heads, idx, factor, activation,
                           gps_variant=True, cross_kind="prob")
     d = _ln(sd, p + ".decoder.norm", d)
-    return _linear(sd, p + ".decoder.projection", d)[:, -pred_len:, :]
+    return _tap(p, _linear(sd, p + ".decoder.projection", d)[:, -pred_len:, :])
 
 
 # ---------------------------------------------------------------------------------------------

@@ -46,7 +46,7 @@ __device__ __forceinline__ void load_head(float* S, const float* G, long ld, int
 }
 
 // Select the n_top rows of M (size LQ): sel[q] = position among the selected (ascending q) or -1.
-__device__ void select_top(const float* Ms, int* sel, int* top_list, int LQ, int n_top, int tid) {
+__device__ void select_top(float* Ms, int* sel, int* top_list, int LQ, int n_top, int tid) {
   for (int q = tid; q < LQ; q += NT) {
     const float mq = Ms[q];
     int rank = 0;
@@ -57,23 +57,19 @@ __device__ void select_top(const float* Ms, int* sel, int* top_list, int LQ, int
     sel[q] = rank < n_top ? 1 : 0;
   }
   __syncthreads();
+  // positions go to a scratch array (Ms is dead now) so no thread reads a flag another one rewrites
+  int* posbuf = reinterpret_cast<int*>(Ms);
   for (int q = tid; q < LQ; q += NT) {
+    int pos = -1;
     if (sel[q]) {
-      int pos = 0;
+      pos = 0;
       for (int o = 0; o < q; ++o) pos += sel[o];
       top_list[pos] = q;
     }
+    posbuf[q] = pos;
   }
   __syncthreads();
-  for (int q = tid; q < LQ; q += NT) {
-    if (sel[q]) {
-      int pos = 0;
-      for (int o = 0; o < q; ++o) pos += sel[o];
-      sel[q] = pos;
-    } else {
-      sel[q] = -1;
-    }
-  }
+  for (int q = tid; q < LQ; q += NT) sel[q] = posbuf[q];
   __syncthreads();
 }
 

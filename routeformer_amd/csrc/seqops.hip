@@ -103,17 +103,25 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
-__global__ void ln_param_reduce_kernel(const float* __restrict__ ws, int parts, int cols, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// block = 64 columns x 4 part-lanes: sums the per-block partials of layernorm_bwd_kernel
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ ws, int parts, int cols,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
   float a = 0.f, b = 0.f;
-  for (int i = 0; i < parts; ++i) {
-    a += ws[(long)i * 2 * cols + c];
-    b += ws[(long)i * 2 * cols + cols + c];
+  if (c < cols)
+    for (int i = ty; i < parts; i += 4) {
+      a += ws[(long)i * 2 * cols + c];
+      b += ws[(long)i * 2 * cols + cols + c];
+    }
+  red[0][ty][tx] = a;
+  red[1][ty][tx] = b;
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    dgamma[c] = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+    dbeta[c] = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
   }
-  dgamma[c] = a;
-  dbeta[c] = b;
 }
 
 __global__ void unfold3_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int L, int C, int pad,
@@ -267,7 +275,7 @@ extern "C" int rf_layernorm_fwd(const float* x, const float* residual, const flo
 
 extern "C" int rf_layernorm_bwd_parts(int rows) {
   const int blocks = (rows + LN_WAVES - 1) / LN_WAVES;
-  return blocks > 256 ? 256 : blocks;
+  return blocks > 128 ? 128 : blocks;
 }
 
 extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,
@@ -279,7 +287,7 @@ extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float*
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, st, dy, xhat, rstd, gamma, dx, workspace, rows,
                      cols);
   RF_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, workspace, parts, cols,
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, workspace, parts, cols,
                      dgamma, dbeta);
   RF_CHECK_LAUNCH();
   return RF_OK;

@@ -31,7 +31,9 @@ __global__ void stem_conv0_kernel(const TIn* __restrict__ video, const int32_t* 
     const int ho = (int)(r % Ho); r /= Ho;
     const int f = (int)(r % F);
     const int b = (int)(r / F);
-    const TIn* img = video + (((long)b * T + fidx[f]) * 3) * H * W;
+    int fi = fidx[f];
+    fi = fi < 0 ? 0 : (fi >= T ? T - 1 : fi);  // never read outside the clip, whatever the host passed
+    const TIn* img = video + (((long)b * T + fi) * 3) * H * W;
     float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int ci = 0; ci < 3; ++ci)

@@ -1,0 +1,193 @@
+"""Training-step engine: the reference's step recipe + MI355X-native data parallelism.
+
+* ``train_step_losses``  -- the Routeformer branch of ``ParallelTrainer.training_step``
+  (``experiments/full_comparison.py:476-521``): forward, target-side feature pass, trajectory /
+  dense SmoothL1 losses with the epoch-gated dense weight, ADE / FDE.
+* ``GradReducer``        -- one process per GPU; all trainable gradients live in ONE flat fp32 buffer,
+  cut into buckets in reverse-forward order; each bucket is all-reduced (RCCL over xGMI through
+  ``torch.distributed``) as soon as autograd has produced its last gradient, on the communicator's own
+  HIP stream, overlapping the rest of backward.  Replaces Lightning's ``DDPStrategy(nccl)``
+  (``full_comparison.py:794,832``).  No data-path collective other than this one exchange.
+* ``FusedAdamW``         -- global-norm clip (2.5) + AdamW over the flat buffers in two launches
+  (``full_comparison.py:694-702,829-830``).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from routeformer_amd.losses import FutureDiscountedLoss
+from routeformer_amd.score import ade, fde
+
+
+def train_step_losses(model, item, epoch: int = 0, trajectory_loss: Optional[FutureDiscountedLoss] = None,
+                      dense_loss: Optional[FutureDiscountedLoss] = None) -> Dict[str, torch.Tensor]:
+    """item = {"train": Data, "target": Data}.  Returns loss terms, metrics and predictions."""
+    cfg = model.configs
+    tl = trajectory_loss or FutureDiscountedLoss(cfg.discount_factor, cfg.epsilon, loss_function="smooth_l1")
+    dl = dense_loss or FutureDiscountedLoss(cfg.discount_factor, cfg.visual_epsilon, loss_function="smooth_l1")
+    tl.current_epoch = dl.current_epoch = epoch
+    target_gps = item["target"]["gps"].to(torch.float32)
+    res: Dict[str, torch.Tensor] = {}
+    if cfg.dense_prediction:
+        future_gps, future_vis = model(item["train"])
+        with torch.no_grad():  # the reference detaches this branch (full_comparison.py:495)
+            _, target_vis = model.preprocess_batch(item["target"], training=False)
+        target_vis = target_vis[:, : future_vis.shape[1]]
+        step = cfg.autoregressive_step_size
+        if cfg.autoregressive:
+            future_gps, target_gps = future_gps[:, :step], target_gps[:, :step]
+        traj = tl(future_gps, target_gps)
+        if cfg.autoregressive:
+            traj = traj * (cfg.gps_backbone_config.pred_len / step)
+            future_vis, target_vis = future_vis[:, :step], target_vis[:, :step]
+        dense = dl(future_vis, target_vis)
+        if epoch < 10:  # dense loss switched on after 10 epochs
+            weight = 0
+        else:
+            weight = (cfg.dense_loss_ratio * traj / torch.clamp(dense, min=1e-6)).detach()
+        loss = traj + weight * dense
+        res.update(dense_loss=dense, future_vis=future_vis, target_vis=target_vis)
+    else:
+        future_gps = model(item["train"])
+        traj = tl(future_gps, target_gps)
+        loss = traj
+    res.update(loss=loss, traj_loss=traj, future_gps=future_gps, ade=ade(future_gps, target_gps),
+               fde=fde(future_gps, target_gps))
+    return res
+
+
+def trainable_parameters(model) -> List[torch.nn.Parameter]:
+    """Everything but the frozen video backbone (full_comparison.py:689-691), registration order."""
+    return [p for n, p in model.named_parameters() if "video_backbone" not in n and p.requires_grad]
+
+
+class GradReducer:
+    """Flat gradient buffer + bucketed, overlapped all-reduce (mean over ranks).
+
+    Device-agnostic (the 2-rank gloo test drives it on the CPU); on the GPU the process group is RCCL.
+    Parameters are laid out in REVERSE registration order so buckets fill in roughly the order
+    backward produces gradients (GPS backbone first, frame encoder last)."""
+
+    def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 32.0, group=None):
+        self.params = list(reversed(params))
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        dev = self.params[0].device
+        ALIGN = 64  # floats: every parameter starts on a 256-B boundary (16-B vector loads in the GEMMs)
+        total = sum(-(-p.numel() // ALIGN) * ALIGN for p in self.params)
+        self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat_param = torch.zeros(total, device=dev, dtype=torch.float32)
+        cap = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.buckets: List[tuple] = []  # (start, end)
+        self._bucket_of: Dict[int, int] = {}
+        off, b_start = 0, 0
+        for p in self.params:
+            n = p.numel()
+            self.flat_param[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = self.flat_param[off:off + n].view_as(p)
+            p.grad = self.flat_grad[off:off + n].view_as(p)
+            self._bucket_of[id(p)] = len(self.buckets)
+            off += -(-n // ALIGN) * ALIGN
+            if off - b_start >= cap:
+                self.buckets.append((b_start, off))
+                b_start = off
+        if off > b_start:
+            self.buckets.append((b_start, off))
+        self._members = [0] * len(self.buckets)
+        for p in self.params:
+            self._members[self._bucket_of[id(p)]] += 1
+        self._pending = list(self._members)
+        self._launched = [False] * len(self.buckets)
+        self._works: List = []
+        if self.world > 1:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    # -- per-step protocol: zero() -> backward -> finish() -----------------------------------------
+    def zero(self):
+        self.flat_grad.zero_()
+        self._pending = list(self._members)
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+
+    def _launch(self, b: int):
+        s, e = self.buckets[b]
+        # async: RCCL runs on the process group's own stream, ordered after everything enqueued so far
+        self._works.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                           async_op=True))
+        self._launched[b] = True
+
+    def _on_grad(self, p):
+        b = self._bucket_of[id(p)]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and not self._launched[b]:
+            self._launch(b)
+
+    def finish(self):
+        """Flush buckets whose parameters got no gradient this step (e.g. gaze branch dropped), then
+        make the compute stream wait for all reductions.  Gradients hold the SUM over ranks; the
+        1/world factor is folded into the optimizer kernel (``grad_scale``)."""
+        if self.world > 1:
+            for b in range(len(self.buckets)):
+                if not self._launched[b]:
+                    self._launch(b)
+            for w in self._works:
+                w.wait()
+        return 1.0 / self.world
+
+    def broadcast_parameters(self, src: int = 0):
+        if self.world > 1:
+            dist.broadcast(self.flat_param, src=src, group=self.group)
+
+
+class FusedAdamW:
+    """AdamW + global-norm clipping over flat buffers; two kernel launches per step."""
+
+    def __init__(self, flat_param: torch.Tensor, flat_grad: torch.Tensor, lr=1e-5, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=1e-4, max_grad_norm: float = 2.5):
+        self.p, self.g = flat_param, flat_grad
+        self.m = torch.zeros_like(flat_param)
+        self.v = torch.zeros_like(flat_param)
+        self.sumsq = torch.zeros(1, device=flat_param.device, dtype=torch.float32)
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.t = 0
+
+    def step(self, grad_scale: float = 1.0):
+        from routeformer_amd import _hip, kernels as K
+        self.t += 1
+        n = self.p.numel()
+        self.sumsq.zero_()
+        _hip.check(_hip.lib().rf_sumsq(self.g.data_ptr(), n, self.sumsq.data_ptr(), K._stream()), "rf_sumsq")
+        _hip.check(_hip.lib().rf_adamw_clip(self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                            n, self.sumsq.data_ptr(), self.max_norm, self.lr, self.betas[0],
+                                            self.betas[1], self.eps, self.wd, self.t, grad_scale, K._stream()),
+                   "rf_adamw_clip")
+
+
+class TrainEngine:
+    """One full train step = forward(input) + target-feature forward + losses + backward (+ overlapped
+    gradient all-reduce) + clip + AdamW -- the unit ``bench.py`` times."""
+
+    def __init__(self, model, lr=None, weight_decay=None, max_grad_norm: float = 2.5, bucket_mb: float = 32.0):
+        self.model = model
+        cfg = model.configs
+        self.reducer = GradReducer(trainable_parameters(model), bucket_mb)
+        self.reducer.broadcast_parameters(0)
+        self.opt = FusedAdamW(self.reducer.flat_param, self.reducer.flat_grad,
+                              lr=cfg.lr if lr is None else lr,
+                              weight_decay=cfg.wd if weight_decay is None else weight_decay,
+                              max_grad_norm=max_grad_norm)
+        self.tl = FutureDiscountedLoss(cfg.discount_factor, cfg.epsilon, loss_function="smooth_l1")
+        self.dl = FutureDiscountedLoss(cfg.discount_factor, cfg.visual_epsilon, loss_function="smooth_l1")
+
+    def step(self, item, epoch: int = 0):
+        self.model.train()
+        self.reducer.zero()
+        res = train_step_losses(self.model, item, epoch, self.tl, self.dl)
+        res["loss"].backward()
+        scale = self.reducer.finish()
+        self.opt.step(scale)
+        return res

@@ -33,6 +33,48 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _Profiler:
+    """HIP-event timing of kernel classes on the launch stream (bench.py's live roofline numbers).
+    Off by default: a single attribute test per launch."""
+
+    def __init__(self):
+        self.on = False
+        self.events = []
+
+    def enable(self):
+        self.on, self.events = True, []
+
+    def disable(self):
+        self.on = False
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, tag, start, flops, nbytes):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.events.append((tag, start, e, flops, nbytes))
+
+    def summary(self):
+        """tag -> {launches, total_ms, flops, bytes} (algorithmic flops / bytes summed over launches)."""
+        if not self.events:
+            return {}
+        torch.cuda.synchronize()
+        out = {}
+        for tag, s, e, fl, by in self.events:
+            d = out.setdefault(tag, {"launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["total_ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+PROFILE = _Profiler()
+
+
 def _req(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise _hip.HipLibraryError(
@@ -53,10 +95,13 @@ def gemm(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, *, bias=None, residu
     ws = None
     if splitk > 1:
         ws = torch.empty(splitk * M * N, device=C.device, dtype=torch.float32)
+    ev = PROFILE.begin() if PROFILE.on else None
     check(_hip.lib().rf_gemm(ptr(A), lda_m, lda_k, ptr(B), ldb_k, ldb_n, ptr(C), ldc, M, N, K,
                              ptr(bias), ptr(residual), ldr, res_rows, res_before_act, act,
                              ptr(preact), ldp, ptr(dact_src), ldd, dact, _PRECISION, splitk, ptr(ws),
                              _stream()), "rf_gemm")
+    if ev is not None:
+        PROFILE.end("gemm", ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N))
 
 
 def colsum(X2d: torch.Tensor) -> torch.Tensor:
@@ -184,8 +229,11 @@ class _AddLayerNorm(torch.autograd.Function):
         y = torch.empty_like(x2)
         xhat = torch.empty_like(x2)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        ev = PROFILE.begin() if PROFILE.on else None
         check(_hip.lib().rf_layernorm_fwd(ptr(x2), ptr(r2), ptr(gamma), ptr(beta), ptr(y), ptr(xhat),
                                           ptr(rstd), rows, cols, eps, _stream()), "rf_layernorm_fwd")
+        if ev is not None:
+            PROFILE.end("layernorm_fwd", ev, 8.0 * rows * cols, 4.0 * rows * cols * (4 if r2 is not None else 3))
         ctx.save_for_backward(xhat, rstd, gamma)
         ctx.has_res = residual is not None
         ctx.xshape = x.shape
@@ -201,8 +249,11 @@ class _AddLayerNorm(torch.autograd.Function):
         db = torch.empty(cols, device=dy.device, dtype=torch.float32)
         parts = _hip.lib().rf_layernorm_bwd_parts(rows)
         ws = torch.empty(parts * 2 * cols, device=dy.device, dtype=torch.float32)
+        ev = PROFILE.begin() if PROFILE.on else None
         check(_hip.lib().rf_layernorm_bwd(ptr(dy2), ptr(xhat), ptr(rstd), ptr(gamma), ptr(dx), ptr(dg),
                                           ptr(db), ptr(ws), rows, cols, _stream()), "rf_layernorm_bwd")
+        if ev is not None:
+            PROFILE.end("layernorm_bwd", ev, 12.0 * rows * cols, 4.0 * rows * cols * 3)
         dx = dx.view(ctx.xshape)
         return dx, (dx if ctx.has_res else None), dg, db, None
 
@@ -294,6 +345,17 @@ def bn_elu_pool(x, gamma, beta, running_mean, running_var, num_batches_tracked, 
     return _BnEluPool.apply(x, gamma, beta, mean, var, eps, training)
 
 
+class TopSelection:
+    """Debug / test hook around the ProbSparse top-u selection (discontinuous in its inputs).
+    ``record``: list collecting the (B,H,u) ascending selections each call made.
+    ``forced``: list of selections to impose, consumed in call order (teacher forcing)."""
+    record: Optional[list] = None
+    forced: Optional[list] = None
+
+
+TOPS = TopSelection()
+
+
 def prob_sizes(L_Q: int, L_K: int, factor: int):
     """(sample_k, n_top) = (min(c*ceil(ln L_K), L_K), min(c*ceil(ln L_Q), L_Q))."""
     U = factor * int(math.ceil(math.log(L_K)))
@@ -319,17 +381,26 @@ class _Attention(torch.autograd.Function):
         out = torch.empty(shape, device=a.device, dtype=torch.float32)
         top, sample_k = None, 0
         if mode != 0:
+            if forced_top is None and TOPS.forced is not None:
+                forced_top = TOPS.forced.pop(0).to(device=a.device, dtype=torch.int32).contiguous()
+                assert tuple(forced_top.shape) == (B, H, n_top), (tuple(forced_top.shape), (B, H, n_top))
             top = forced_top if forced_top is not None else \
                 torch.empty(B, H, n_top, device=a.device, dtype=torch.int32)
             sample_k = index_sample.shape[1] if index_sample is not None else 0
+        ev = PROFILE.begin() if PROFILE.on else None
         check(_hip.lib().rf_attn_fwd(a.data_ptr() + 4 * q_off, b.data_ptr() + 4 * k_off,
                                      b.data_ptr() + 4 * v_off, a.stride(0), b.stride(0), b.stride(0),
                                      ptr(out), out_layout, ptr(index_sample), ptr(top),
                                      1 if forced_top is not None else 0, B, H, LQ, LK, E, sample_k, n_top,
                                      mode, scale, _stream()), "rf_attn_fwd")
+        if ev is not None:
+            u = LQ if mode == 0 else n_top  # sample stage + active rows (QK^T and AV)
+            PROFILE.end("attn_fwd", ev, B * H * (2.0 * LQ * sample_k * E + 4.0 * u * LK * E),
+                        4.0 * B * H * E * (2 * LQ + 2 * LK) + 4.0 * LQ * sample_k)
+        if top is not None and TOPS.record is not None:
+            TOPS.record.append(top.clone())
         ctx.save_for_backward(a, b, top if top is not None else a)
         ctx.cfg = (dims, offs, mode, n_top, out_layout, scale, a.data_ptr() == b.data_ptr())
-        ctx.last_top = top
         return out
 
     @staticmethod
@@ -339,12 +410,16 @@ class _Attention(torch.autograd.Function):
         dout = dout.contiguous()
         da = torch.empty(a.shape, device=dout.device, dtype=torch.float32)
         db = da if same else torch.empty(b.shape, device=dout.device, dtype=torch.float32)
+        ev = PROFILE.begin() if PROFILE.on else None
         check(_hip.lib().rf_attn_bwd(a.data_ptr() + 4 * q_off, b.data_ptr() + 4 * k_off,
                                      b.data_ptr() + 4 * v_off, a.stride(0), b.stride(0), b.stride(0),
                                      ptr(dout), out_layout, ptr(top) if mode != 0 else None,
                                      da.data_ptr() + 4 * q_off, db.data_ptr() + 4 * k_off,
                                      db.data_ptr() + 4 * v_off, da.stride(0), db.stride(0), db.stride(0),
                                      B, H, LQ, LK, E, n_top, mode, scale, _stream()), "rf_attn_bwd")
+        if ev is not None:
+            u = LQ if mode == 0 else n_top
+            PROFILE.end("attn_bwd", ev, B * H * 10.0 * u * LK * E, 4.0 * B * H * E * (4 * LQ + 4 * LK))
         return da, (None if same else db), None, None, None, None, None, None, None, None
 
 

@@ -170,9 +170,15 @@ class HRNet16Backbone(VideoBackboneModule):
         pad = 1 if k == 3 else 0
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
         y = torch.empty(N, Ho, Wo, cout, device=x.device, dtype=torch.float32)
+        ev = K.PROFILE.begin() if K.PROFILE.on else None
         check(_hip.lib().rf_conv2d_nhwc(ptr(x), ptr(w), ptr(b), ptr(residual), ptr(y), N, H, Wd, cin, cout, k,
                                         stride, pad, Ho, Wo, cout, cout, 1 if relu else 0, K._PRECISION,
                                         K._stream()), "rf_conv2d_nhwc")
+        if ev is not None:  # algorithmic work: one read of x / w (/ residual), one write of y
+            M = N * Ho * Wo
+            tag = "conv2d_n16" if cout <= 16 else ("conv2d_n32" if cout <= 32 else "conv2d_n64")
+            K.PROFILE.end(tag, ev, 2.0 * M * cout * k * k * cin,
+                          4.0 * (x.numel() + w.numel() + M * cout * (2 if residual is not None else 1)))
         return y
 
     @staticmethod

@@ -66,3 +66,9 @@ def case_item(c):
 def rel_err(a, b):
     a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
     return float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+
+
+def fro_err(a, b):
+    """Relative Frobenius error: robust to a handful of ReLU-mask / top-u flips in bf16 mode."""
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / max(1e-12, float(b.norm())))

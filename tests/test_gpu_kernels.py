@@ -1,0 +1,404 @@
+"""GPU parity tests, kernel by kernel: the HIP path (through the C ABI / ctypes binding) against
+CPU torch math and the CPU oracle on the same seeded inputs, plus the reference golden vectors for
+attention.  fp32 mode is held to ~1e-5 relative; bf16-MFMA mode to 2e-2."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import fro_err, golden, rel_err, t
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import routeformer_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(autouse=True)
+def _f32_mode():
+    from routeformer_amd import kernels as K
+    K.set_precision("f32")
+    yield
+    K.set_precision("f32")
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (520, 128, 128), (37, 66, 207), (12480, 64, 128),
+                                   (560, 3328, 832), (5, 3, 6), (130, 17, 33)])
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_gemm_linear_layouts(M, N, K, prec):
+    """All three operand layouts used by linear fwd / dX / dW, odd sizes, split-K."""
+    from routeformer_amd import kernels as Kn
+    Kn.set_precision(prec)
+    tol = 2e-5 if prec == "f32" else 2e-2
+    g = _g(M * 7 + N)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    xd, wd, bd, dyd = (a.to(DEV) for a in (x, w, b, dy))
+    y = torch.empty(M, N, device=DEV)
+    Kn.gemm(xd, K, 1, wd, 1, K, y, N, M, N, K, bias=bd)
+    ref = x.double() @ w.double().t() + b.double()
+    assert rel_err(y, ref) < tol
+    dx = Kn._input_grad(dyd, wd)
+    assert rel_err(dx, dy.double() @ w.double()) < tol
+    dw = Kn._weight_grad(dyd, xd)
+    assert rel_err(dw, dy.double().t() @ x.double()) < tol
+    # explicit split-K on the forward product
+    y2 = torch.empty(M, N, device=DEV)
+    Kn.gemm(xd, K, 1, wd, 1, K, y2, N, M, N, K, bias=bd, splitk=3)
+    assert rel_err(y2, ref) < tol
+    assert rel_err(Kn.colsum(dyd), dy.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("act", ["relu", "gelu"])
+def test_gemm_epilogues(act):
+    from routeformer_amd import kernels as Kn
+    g = _g(3)
+    M, N, K = 200, 96, 64
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    res = torch.randn(40, N, generator=g)
+    xd, wd, bd, rd = (a.to(DEV) for a in (x, w, b, res))
+    y, z = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    Kn.gemm(xd, K, 1, wd, 1, K, y, N, M, N, K, bias=bd, act=Kn.ACT[act], preact=z, ldp=N, residual=rd, ldr=N,
+            res_rows=40)
+    zr = x @ w.t() + b
+    a = F.relu(zr) if act == "relu" else F.gelu(zr)
+    assert rel_err(z, zr) < 2e-5
+    assert rel_err(y, a + res.repeat(5, 1)) < 2e-5
+    # derivative epilogue: C = (X W^T) * act'(src)
+    src = torch.randn(M, N, generator=g)
+    y2 = torch.empty(M, N, device=DEV)
+    src_d = src.to(DEV)
+    Kn.gemm(xd, K, 1, wd, 1, K, y2, N, M, N, K, dact_src=src_d, ldd=N, dact=Kn.ACT[act])
+    s = src.clone().requires_grad_()
+    (F.relu(s) if act == "relu" else F.gelu(s)).sum().backward()
+    assert rel_err(y2, (x @ w.t()) * s.grad) < 2e-5
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 5e-2)])
+def test_linear_ffn_autograd(prec, tol):
+    from routeformer_amd import kernels as Kn
+    Kn.set_precision(prec)
+    rel_err = globals()["rel_err"] if prec == "f32" else fro_err  # bf16 rounding flips a few ReLU masks
+    g = _g(11)
+    for act in ("relu", "gelu"):
+        x = torch.randn(3, 65, 128, generator=g)
+        w1, b1 = torch.randn(256, 128, generator=g) / 11, torch.randn(256, generator=g) * 0.1
+        w2, b2 = torch.randn(128, 256, generator=g) / 16, torch.randn(128, generator=g) * 0.1
+        cpu = [a.clone().requires_grad_() for a in (x, w1, b1, w2, b2)]
+        dev = [a.clone().to(DEV).requires_grad_() for a in (x, w1, b1, w2, b2)]
+        yc = F.linear((F.relu if act == "relu" else F.gelu)(F.linear(cpu[0], cpu[1], cpu[2])), cpu[3], cpu[4])
+        yd = Kn.ffn(dev[0], dev[1], dev[2], dev[3], dev[4], act)
+        wgt = torch.randn(yc.shape, generator=g)
+        (yc * wgt).sum().backward()
+        (yd * wgt.to(DEV)).sum().backward()
+        assert rel_err(yd, yc) < tol
+        for c, d in zip(cpu, dev):
+            assert rel_err(d.grad, c.grad) < tol
+    x = torch.randn(4, 40, 69, generator=g)
+    w, b = torch.randn(832, 69, generator=g) / 8, torch.randn(832, generator=g)
+    cpu = [a.clone().requires_grad_() for a in (x, w, b)]
+    dev = [a.clone().to(DEV).requires_grad_() for a in (x, w, b)]
+    yc, yd = F.linear(*cpu), Kn.linear(*dev)
+    yc.square().sum().backward()
+    yd.square().sum().backward()
+    assert rel_err(yd, yc) < tol
+    for c, d in zip(cpu, dev):
+        assert rel_err(d.grad, c.grad) < tol
+
+
+@pytest.mark.parametrize("rows,cols", [(7, 64), (520, 128), (12480, 128), (560, 832), (3, 1024)])
+def test_layernorm(rows, cols):
+    from routeformer_amd import kernels as Kn
+    g = _g(rows + cols)
+    x, r = torch.randn(rows, cols, generator=g) * 2 + 0.3, torch.randn(rows, cols, generator=g)
+    w, b = torch.randn(cols, generator=g), torch.randn(cols, generator=g)
+    cpu = [a.clone().requires_grad_() for a in (x, r, w, b)]
+    dev = [a.clone().to(DEV).requires_grad_() for a in (x, r, w, b)]
+    yc = F.layer_norm(cpu[0] + cpu[1], (cols,), cpu[2], cpu[3], 1e-5)
+    yd = Kn.add_layer_norm(dev[0], dev[1], dev[2], dev[3])
+    wt = torch.randn(rows, cols, generator=g)
+    (yc * wt).sum().backward()
+    (yd * wt.to(DEV)).sum().backward()
+    assert rel_err(yd, yc) < 1e-5
+    for c, d in zip(cpu, dev):
+        assert rel_err(d.grad, c.grad) < 3e-5
+    y1 = Kn.add_layer_norm(dev[0].detach(), None, dev[2].detach(), dev[3].detach())
+    assert rel_err(y1, F.layer_norm(x, (cols,), w, b, 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("B,L,C,D,pad", [(3, 65, 240, 128, 1), (2, 40, 2, 128, 1), (4, 40, 69, 64, 1),
+                                         (2, 21, 64, 64, 2), (3, 4, 32, 32, 2), (2, 5, 16, 16, 2)])
+def test_circular_conv3(B, L, C, D, pad):
+    from routeformer_amd import kernels as Kn
+    g = _g(B * L + C)
+    x, w, b = torch.randn(B, L, C, generator=g), torch.randn(D, C, 3, generator=g) / 4, torch.randn(D, generator=g)
+    cpu = [a.clone().requires_grad_() for a in (x, w, b)]
+    dev = [a.clone().to(DEV).requires_grad_() for a in (x, w, b)]
+    yc = F.conv1d(F.pad(cpu[0].transpose(1, 2), (pad, pad), mode="circular"), cpu[1], cpu[2]).transpose(1, 2)
+    yd = Kn.circular_conv3(dev[0], dev[1], dev[2], pad=pad)
+    assert yd.shape == yc.shape
+    wt = torch.randn(yc.shape, generator=g)
+    (yc * wt).sum().backward()
+    (yd * wt.to(DEV)).sum().backward()
+    assert rel_err(yd, yc) < 2e-5
+    assert rel_err(yd, O.circular_conv3(x, w, b, padding=pad)) < 2e-5
+    for c, d in zip(cpu, dev):
+        assert rel_err(d.grad, c.grad) < 3e-5
+
+
+@pytest.mark.parametrize("B,L,C", [(4, 42, 64), (8, 23, 832), (2, 7, 16), (3, 6, 128)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_elu_pool(B, L, C, training):
+    from routeformer_amd import kernels as Kn
+    g = _g(B + L + C)
+    x = torch.randn(B, L, C, generator=g) * 1.5
+    gam, bet = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    rm, rv = 0.1 * torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.copy_(gam); bn.bias.copy_(bet); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    bn.train(training)
+    xc = x.clone().requires_grad_()
+    yc = F.max_pool1d(F.elu(bn(xc.transpose(1, 2))), 3, 2, 1).transpose(1, 2)
+    dev = [a.clone().to(DEV).requires_grad_() for a in (x, gam, bet)]
+    rmd, rvd, nbt = rm.clone().to(DEV), rv.clone().to(DEV), torch.zeros((), dtype=torch.long, device=DEV)
+    yd = Kn.bn_elu_pool(dev[0], dev[1], dev[2], rmd, rvd, nbt, training)
+    wt = torch.randn(yc.shape, generator=g)
+    (yc * wt).sum().backward()
+    (yd * wt.to(DEV)).sum().backward()
+    assert rel_err(yd, yc) < 2e-5
+    assert rel_err(dev[0].grad, xc.grad) < 5e-5
+    assert rel_err(dev[1].grad, bn.weight.grad) < 5e-5 and rel_err(dev[2].grad, bn.bias.grad) < 5e-5
+    if training:
+        assert rel_err(rmd, bn.running_mean) < 1e-5 and rel_err(rvd, bn.running_var) < 1e-5 and int(nbt) == 1
+
+
+# ------------------------------------------------------------------------------------------------
+def _run_attn(q, k, v, mode, idx, factor, layout, forced_top=None):
+    """q,k,v (B,L,H,E) CPU leaf tensors -> (ctx, dq, dk, dv, top) from the HIP kernels."""
+    from routeformer_amd import kernels as Kn
+    B, LQ, H, E = q.shape
+    LK = k.shape[1]
+    qd = q.detach().reshape(B * LQ, H * E).to(DEV).requires_grad_()
+    kv = torch.cat([k.detach().reshape(B * LK, H * E), v.detach().reshape(B * LK, H * E)], dim=1).to(DEV).requires_grad_()
+    n_top = 0
+    if mode != 0:
+        _, n_top = Kn.prob_sizes(LQ, LK, factor)
+    idx_d = None if idx is None else idx.to(torch.int32).to(DEV)
+    ctx = Kn.attention(qd, kv, (0, 0, H * E), (B, H, LQ, LK, E), mode, index_sample=idx_d, n_top=n_top,
+                       out_layout=layout, forced_top=forced_top)
+    return ctx, qd, kv
+
+
+ATTN_TAGS = ["frame", "fusion", "decself", "gps_enc", "gps_enc5", "gps_decself", "gps_deccross", "gps_def_cross"]
+
+
+@pytest.mark.parametrize("tag", ATTN_TAGS)
+def test_prob_attention_golden(tag):
+    """Against the REFERENCE's outputs and input gradients (tests/golden/attention.npz)."""
+    G = golden("attention")
+    LQ, LK, H, E, masked, factor, gps = (int(x) for x in G[tag + ".meta"])
+    g = _g(100 + LQ * 7 + LK)
+    q, k, v = (torch.randn(2, L, H, E, generator=g) for L in (LQ, LK, LK))
+    ctx, qd, kv = _run_attn(q, k, v, 2 if masked else 1, t(G[tag + ".idx"]), factor, gps)
+    w = torch.randn(ctx.shape, generator=g)
+    (ctx * w.to(DEV)).sum().backward()
+    assert rel_err(ctx, G[tag + ".ctx"]) < 2e-5
+    HE = H * E
+    assert rel_err(qd.grad.view(2, LQ, H, E), G[tag + ".dq"]) < 3e-5
+    assert rel_err(kv.grad[:, :HE].reshape(2, LK, H, E), G[tag + ".dk"]) < 3e-5
+    assert rel_err(kv.grad[:, HE:].reshape(2, LK, H, E), G[tag + ".dv"]) < 3e-5
+
+
+def test_full_attention_golden():
+    G = golden("attention")
+    g = _g(55)
+    q, k, v = (torch.randn(2, 40, 8, 8, generator=g) for _ in range(3))
+    ctx, qd, kv = _run_attn(q, k, v, 0, None, 5, 0)
+    w = torch.randn(ctx.shape, generator=g)
+    (ctx * w.to(DEV)).sum().backward()
+    assert rel_err(ctx, G["full.ctx"]) < 2e-5
+    assert rel_err(qd.grad.view(2, 40, 8, 8), G["full.dq"]) < 3e-5
+    assert rel_err(kv.grad[:, :64].reshape(2, 40, 8, 8), G["full.dk"]) < 3e-5
+    assert rel_err(kv.grad[:, 64:].reshape(2, 40, 8, 8), G["full.dv"]) < 3e-5
+
+
+@pytest.mark.parametrize("LQ,LK,H,E,masked,factor,gps", [
+    (320, 320, 8, 16, False, 5, 0), (80, 80, 8, 8, True, 5, 0), (105, 105, 8, 104, True, 4, 1),
+    (105, 5, 8, 104, False, 4, 1), (2, 2, 2, 8, False, 5, 0),
+    (40, 30, 8, 8, None, 5, 0), (80, 25, 8, 8, None, 5, 0), (10, 10, 8, 16, False, 1, 1), (6, 6, 8, 16, True, 1, 1)])
+def test_attention_vs_oracle(LQ, LK, H, E, masked, factor, gps):
+    """Long-horizon (C5) and edge shapes against the CPU oracle; masked=None means full attention."""
+    B = 3
+    g = _g(LQ * 3 + LK + E)
+    q, k, v = (torch.randn(B, L, H, E, generator=g).requires_grad_() for L in (LQ, LK, LK))
+    if masked is None:
+        ref = O.full_attention(q, k, v)
+        idx, mode = None, 0
+    else:
+        sample_k, _ = O.prob_sizes(LQ, LK, factor)
+        idx = torch.randint(LK, (LQ, sample_k), generator=g)
+        ref, top_ref = O.prob_attention(q, k, v, idx, factor, masked, gps_variant=bool(gps), return_top=True)
+        mode = 2 if masked else 1
+    ctx, qd, kv = _run_attn(q, k, v, mode, idx, factor, gps)
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    (ctx * w.to(DEV)).sum().backward()
+    assert rel_err(ctx, ref) < 3e-5
+    HE = H * E
+    assert rel_err(qd.grad.view(B, LQ, H, E), q.grad) < 5e-5
+    assert rel_err(kv.grad[:, :HE].reshape(B, LK, H, E), k.grad) < 5e-5
+    assert rel_err(kv.grad[:, HE:].reshape(B, LK, H, E), v.grad) < 5e-5
+
+
+def test_attention_packed_self_and_forced_top():
+    """Packed QKV buffer (one projection GEMM) + injected selection (forced_top)."""
+    from routeformer_amd import kernels as Kn
+    B, L, H, E, factor = 2, 65, 8, 16, 5
+    g = _g(9)
+    qkv = torch.randn(B * L, 3 * H * E, generator=g)
+    q, k, v = (qkv[:, i * H * E:(i + 1) * H * E].reshape(B, L, H, E).clone().requires_grad_() for i in range(3))
+    sample_k, n_top = O.prob_sizes(L, L, factor)
+    idx = torch.randint(L, (L, sample_k), generator=g)
+    ref, top = O.prob_attention(q, k, v, idx, factor, False, return_top=True)
+    qd = qkv.clone().to(DEV).requires_grad_()
+    idx_d = idx.to(torch.int32).to(DEV)
+    ctx = Kn.attention(qd, qd, (0, H * E, 2 * H * E), (B, H, L, L, E), 1, index_sample=idx_d, n_top=n_top)
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    (ctx * w.to(DEV)).sum().backward()
+    assert rel_err(ctx, ref) < 3e-5
+    packed_ref = torch.cat([a.grad.reshape(B * L, H * E) for a in (q, k, v)], dim=1)
+    assert rel_err(qd.grad, packed_ref) < 5e-5
+    # forced selection: give the kernel a *different* (sorted) top set and compare with the oracle run on it
+    forced = torch.stack([torch.randperm(L, generator=g)[:n_top].sort().values for _ in range(B * H)]).view(B, H, n_top)
+    forced_d, qdd = forced.to(torch.int32).to(DEV), qd.detach()
+    ctx2 = Kn.attention(qdd, qdd, (0, H * E, 2 * H * E), (B, H, L, L, E), 1, n_top=n_top, forced_top=forced_d)
+    Q, Km, V = (a.detach().transpose(1, 2) for a in (q, k, v))
+    exp = V.mean(2, keepdim=True).expand(B, H, L, E).clone()
+    qs = torch.gather(Q, 2, forced.unsqueeze(-1).expand(-1, -1, -1, E))
+    upd = torch.softmax(qs @ Km.transpose(-1, -2) / math.sqrt(E), -1) @ V
+    exp = exp.scatter(2, forced.unsqueeze(-1).expand(-1, -1, -1, E), upd).transpose(1, 2)
+    assert rel_err(ctx2, exp) < 3e-5
+
+
+# ------------------------------------------------------------------------------------------------
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,k,s", [(3, 28, 28, 16, 16, 3, 1), (2, 28, 28, 256, 32, 3, 2),
+                                                (2, 28, 28, 64, 256, 1, 1), (2, 56, 56, 4, 64, 3, 2),
+                                                (5, 7, 7, 64, 64, 3, 1), (3, 4, 4, 128, 128, 3, 1),
+                                                (2, 14, 14, 32, 64, 3, 2), (2, 4, 4, 128, 16, 1, 1),
+                                                (1, 1, 1, 128, 128, 3, 1), (2, 2, 2, 64, 128, 3, 2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+def test_conv2d_nhwc(N, H, W, cin, cout, k, s, prec, tol):
+    from routeformer_amd import _hip, kernels as Kn
+    Kn.set_precision(prec)
+    g = _g(H + cin + cout)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    pad = 1 if k == 3 else 0
+    ref = F.conv2d(x, w, b, stride=s, padding=pad)
+    res = torch.randn(ref.shape, generator=g)
+    ref = F.relu(ref + res)
+    Ho, Wo = ref.shape[-2:]
+    xd, rd, bd = _nhwc(x).to(DEV), _nhwc(res).to(DEV), b.to(DEV)  # keep every operand alive across the launch
+    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = torch.empty(N, Ho, Wo, cout, device=DEV)
+    _hip.check(_hip.lib().rf_conv2d_nhwc(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr(),
+                                         y.data_ptr(), N, H, W, cin, cout, k, s, pad, Ho, Wo, cout, cout, 1,
+                                         Kn._PRECISION, Kn._stream()), "conv")
+    assert rel_err(y, _nhwc(ref)) < tol
+
+
+def test_vision_helpers():
+    from routeformer_amd import _hip, kernels as Kn
+    from routeformer_amd.models.video_backbone.hrnet16 import HRNet16Backbone
+    g = _g(21)
+    # upsample (+addend, accumulate, relu) for the resolution pairs HRNet uses
+    for (hi, ho) in ((14, 28), (4, 28), (7, 14), (1, 8), (2, 3), (28, 28)):
+        x = torch.randn(2, 16, hi, hi, generator=g)
+        add = torch.randn(2, 16, ho, ho, generator=g)
+        ref = F.relu(add + F.interpolate(x, size=(ho, ho), mode="bilinear", align_corners=False))
+        xd, ad = _nhwc(x).to(DEV), _nhwc(add).to(DEV)
+        y = HRNet16Backbone._upsample(xd, (ho, ho), addend=ad, relu=True)
+        assert rel_err(y, _nhwc(ref)) < 1e-5, (hi, ho)
+        y2 = ad.clone()
+        HRNet16Backbone._upsample(xd, (ho, ho), out=y2, ldy=16, accumulate=True)
+        assert rel_err(y2, _nhwc(add + F.interpolate(x, size=(ho, ho), mode="bilinear", align_corners=False))) < 1e-5
+    # adaptive avg pool -> tokens with the -1 row, for 28x28 / 8x8 / 12x12 / 56x56 / 3x5 maps
+    for (h, w) in ((28, 28), (8, 8), (12, 12), (56, 56), (3, 5)):
+        x = torch.randn(2, 24, h, w, generator=g)
+        tok, xd = torch.empty(2, 65, 24, device=DEV), _nhwc(x).to(DEV)
+        _hip.check(_hip.lib().rf_avgpool8_tokens(xd.data_ptr(), tok.data_ptr(), 2, h, w, 24, Kn._stream()), "pool")
+        ref = F.adaptive_avg_pool2d(x, (8, 8)).permute(0, 2, 3, 1).reshape(2, 64, 24)
+        assert rel_err(tok[:, :64], ref) < 1e-5 and torch.all(tok[:, 64] == -1)
+    # stem: frame gather + fp16 cast + conv0
+    video = torch.rand(2, 5, 3, 16, 20, generator=g).half()
+    w0 = torch.randn(3, 3, 2, 2, generator=g)
+    idx = torch.tensor([4, 1, 3])
+    ref = F.conv2d(video[:, idx].flatten(0, 1).float(), w0, stride=2)
+    y, idx_d, w0_d = torch.empty(6, 8, 10, 4, device=DEV), idx.int().to(DEV), w0.to(DEV)
+    for vid, is32 in ((video.to(DEV), 0), (video.float().to(DEV), 1)):
+        _hip.check(_hip.lib().rf_stem_conv0(vid.data_ptr(), is32, idx_d.data_ptr(), w0_d.data_ptr(), y.data_ptr(),
+                                            2, 5, 3, 16, 20, Kn._stream()), "stem")
+        assert rel_err(y[..., :3], _nhwc(ref)) < 1e-5 and torch.all(y[..., 3] == 0)
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16", 5e-2)])
+def test_hrnet16_golden(prec, tol):
+    """Whole frozen conv encoder against the reference's outputs (tests/golden/hrnet.npz)."""
+    from routeformer_amd import kernels as Kn, synthetic
+    from routeformer_amd.models.video_backbone import HRNet16Backbone
+    Kn.set_precision(prec)
+    G = golden("hrnet")
+    net = HRNet16Backbone()
+    net.load_state_dict(synthetic.synth_state_dict(net.state_dict(), 7))
+    net = net.to(DEV)
+    for tag, n, hw in (("s64", 2, 64), ("s96", 1, 96), ("s224", 2, 224)):
+        x = synthetic.synth_video(1, n, hw, hw, 11, "hrnet." + tag)[0].to(DEV)
+        y = net(x)
+        assert y.shape == (n, 240, 8, 8)
+        assert rel_err(y, G[tag + ".y"]) < tol, tag
+
+
+def test_adamw_clip():
+    from routeformer_amd import _hip, kernels as Kn
+    g = _g(5)
+    n = 100003
+    p0, g0 = torch.randn(n, generator=g), torch.randn(n, generator=g) * 3
+    pc = p0.clone().requires_grad_()
+    opt = torch.optim.AdamW([pc], lr=1e-3, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    pd, m, v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in (1, 2, 3):
+        gs = g0 * step
+        pc.grad = gs.clone()
+        torch.nn.utils.clip_grad_norm_([pc], 2.5)
+        opt.step()
+        gd = gs.to(DEV)
+        ss = torch.zeros(1, device=DEV)
+        _hip.check(_hip.lib().rf_sumsq(gd.data_ptr(), n, ss.data_ptr(), Kn._stream()), "sumsq")
+        assert abs(float(ss) - float(gs.double().square().sum())) < 1e-3 * float(gs.double().square().sum())
+        _hip.check(_hip.lib().rf_adamw_clip(pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, ss.data_ptr(),
+                                            2.5, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, 1.0, Kn._stream()), "adamw")
+        assert rel_err(pd, pc) < 1e-5, step
+
+
+def test_cpu_tensor_is_refused():
+    """No CPU fallback: handing the product a CPU tensor must fail loudly."""
+    from routeformer_amd import _hip, kernels as Kn
+    with pytest.raises(_hip.HipLibraryError):
+        Kn.linear(torch.randn(4, 8), torch.randn(8, 8).to(DEV), None)

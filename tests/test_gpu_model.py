@@ -1,0 +1,266 @@
+"""GPU parity tests at block and whole-model level: the HIP-backed product modules against
+(i) the reference's golden vectors and (ii) the CPU oracle on the same seeded inputs.
+
+Tolerance (stated per BASELINE.json north_star): trajectories within 1e-3 (fp32 mode) / 1e-2
+(bf16-MFMA mode) of the reference, measured as max|err| / max(1, max|ref|)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import RSEED, build_product_model, case_item, draws, golden, rel_err, t
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import routeformer_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL_F32, TOL_BF16 = 1e-3, 1e-2
+
+
+@pytest.fixture(autouse=True)
+def _reset():
+    from routeformer_amd import kernels as K
+    from routeformer_amd.models.blocks import SAMPLER
+    K.set_precision("f32")
+    SAMPLER.replay, SAMPLER.log = None, None
+    K.TOPS.record, K.TOPS.forced = None, None
+    yield
+    K.set_precision("f32")
+    SAMPLER.replay, SAMPLER.log = None, None
+    K.TOPS.record, K.TOPS.forced = None, None
+
+
+def _to_dev(batch):
+    return {k: v.to(DEV) for k, v in batch.items()}
+
+
+def _load(module, seed=7):
+    from routeformer_amd import synthetic
+    module.load_state_dict(synthetic.synth_state_dict(module.state_dict(), seed))
+    return module.to(DEV)
+
+
+def _check_grads(G, key, named_params, tol):
+    names = [str(s) for s in G[key + "grad_names"]]
+    stats = G[key + "grad_stats"]
+    bad = []
+    floor = 1e-3 * float(stats[:, 0].max())  # e.g. key-projection biases have an exactly-zero true gradient
+    for n, (nrm, _) in zip(names, stats):
+        g = named_params[n].grad
+        got = 0.0 if g is None else float(g.double().norm())
+        if abs(got - nrm) > tol * max(floor, nrm):
+            bad.append((n, got, nrm))
+    assert not bad, bad[:8]
+    for f in G.files:
+        if f.startswith(key + "grad::"):
+            n = f[len(key + "grad::"):]
+            assert rel_err(named_params[n].grad, G[f]) < tol, n
+
+
+def test_perceive_blocks_golden():
+    from routeformer_amd.models.blocks import SAMPLER, PerceiveDecoder, PerceiveEncoder
+    G = golden("blocks")
+    enc = _load(PerceiveEncoder(in_channels=240, out_channels=64, out_len=1, n_heads=8, layers=2, d_ff=64, dropout=0.0))
+    SAMPLER.replay = draws(G, "enc.")
+    y = enc(t(G["enc.x"]).to(DEV))
+    assert rel_err(y, G["enc.y"]) < 1e-4
+    y.square().sum().backward()
+    _check_grads(G, "enc.", dict(enc.named_parameters()), 1e-3)
+
+    enc2 = _load(PerceiveEncoder(in_channels=2, out_channels=64, out_len=40, n_heads=8, layers=2, d_ff=256, dropout=0.0))
+    SAMPLER.replay = None
+    torch.manual_seed(RSEED)  # host RNG reproduces the reference's draws
+    assert rel_err(enc2(t(G["enc2.x"]).to(DEV)), G["enc2.y"]) < 1e-4
+
+    dec = _load(PerceiveDecoder(query_channels=64, value_channels=64, out_channels=64, out_len=40, dropout=0.0,
+                                d_ff=256, n_heads=8, layers=2, mix=False))
+    SAMPLER.replay = draws(G, "dec.")
+    mem, qry = t(G["dec.mem"]).to(DEV).requires_grad_(), t(G["dec.qry"]).to(DEV).requires_grad_()
+    yd = dec(mem, qry)
+    assert rel_err(yd, G["dec.y"]) < 1e-4
+    yd.square().sum().backward()
+    assert rel_err(mem.grad, G["dec.dmem"]) < 1e-3 and rel_err(qry.grad, G["dec.dqry"]) < 1e-3
+    _check_grads(G, "dec.", dict(dec.named_parameters()), 1e-3)
+
+
+@pytest.mark.parametrize("tag,preset,B,T,P,cin", [("tiny", "GPS_TINY", 3, 20, 10, 69), ("default", "GPS_DEFAULT", 4, 10, 15, 5),
+                                                   ("paper", "GPS_PAPER", 2, 40, 30, 69)])
+def test_informer_golden(tag, preset, B, T, P, cin):
+    from routeformer_amd import presets
+    from routeformer_amd.models.blocks import SAMPLER
+    from routeformer_amd.models.gps_backbone import GPSBackboneConfig, Informer
+    G = golden("informer")
+    x = t(G[tag + ".x"]).to(DEV)
+    for smart in (False, True):
+        gcfg = GPSBackboneConfig(seq_len=T, label_len=T, pred_len=P, **getattr(presets, preset))
+        gcfg.output_attention, gcfg.smart_decoder, gcfg._enc_in, gcfg._c_out = False, smart, cin, cin - 3
+        for mode in ("eval", "train"):
+            key = f"{tag}.{'smart' if smart else 'vanilla'}.{mode}."
+            if key + "y" not in G.files:
+                continue
+            net = _load(Informer(gcfg))
+            net.train(mode == "train")
+            SAMPLER.replay = draws(G, key)
+            y = net(x)
+            assert rel_err(y, G[key + "y"]) < 2e-4, key
+            if mode == "train":
+                y.square().mean().backward()
+                _check_grads(G, key, dict(net.named_parameters()), 2e-3)
+                sd = net.state_dict()
+                assert rel_err(sd["encoder.conv_layers.0.norm.running_mean"], G[key + "bn0_running_mean"]) < 1e-4
+                assert rel_err(sd["encoder.conv_layers.0.norm.running_var"], G[key + "bn0_running_var"]) < 1e-4
+
+
+CASES = ["c1_default", "c1_paper", "c1_recursive", "c2_small", "c4_small", "c5_small", "ar_small", "c2_paper"]
+
+
+def _first_flip(tops_gpu, src):
+    """Compare the top-u selections call by call.  Returns None when all agree, else
+    (call index, #differing (b,h) rows, largest oracle margin among the differing rows of that call)."""
+    for i, (a, b) in enumerate(zip(tops_gpu, src.tops)):
+        diff = (a.cpu().long() != b).any(dim=-1)  # (B,H)
+        if diff.any():
+            return i, int(diff.sum()), float(src.margins[i][diff].max())
+    return None
+
+
+def _oracle_eval(cfg, sd, batch, replay):
+    src = O.IndexSource(replay)
+    with torch.no_grad():
+        out = O.OracleRouteformer(cfg, sd, training=False, idx=src).forward(batch)
+    return (out if isinstance(out, tuple) else (out, None)), src
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_model_eval_forward_golden(name):
+    """Whole Routeformer forward (eval) vs the reference's trajectories.
+
+    ProbSparse's top-u query selection is discontinuous: a near-tie in the sparsity measure can resolve
+    differently under a different fp32 summation order and move the output by O(1e-2) ("hard
+    parts").  So: (a) free-running run -- host RNG draws must equal the reference's, and if any
+    selection differs from the oracle's, the FIRST difference must be a near-tie (relative margin
+    < 1e-4); (b) run with the oracle's selections imposed -- trajectories within 1e-3 of the reference."""
+    from routeformer_amd import kernels as K
+    from routeformer_amd.models.blocks import SAMPLER
+    model, cfg, sd, c = build_product_model(name, DEV)
+    G = golden(name)
+    item = case_item(c)
+    batch = _to_dev(item["train"])
+    rec = draws(G, "eval.")
+    (pos_o, vis_o), src = _oracle_eval(cfg, sd, item["train"], list(rec))
+    model.eval()
+    # (b) oracle selections imposed: strict parity
+    K.TOPS.forced = [t_.clone() for t_ in src.tops]
+    torch.manual_seed(RSEED)
+    with torch.no_grad():
+        out = model(batch)
+    assert not K.TOPS.forced, "not all forced selections were consumed"
+    K.TOPS.forced = None
+    pos, vis = out if isinstance(out, tuple) else (out, None)
+    assert pos.shape == G["eval.future_gps"].shape and pos.dtype == torch.float32
+    assert rel_err(pos, pos_o) < 3e-4 and rel_err(pos, G["eval.future_gps"]) < TOL_F32, name
+    if vis is not None:
+        assert rel_err(vis, G["eval.future_vis"]) < TOL_F32
+    # (a) free running
+    SAMPLER.log, K.TOPS.record = [], []
+    torch.manual_seed(RSEED)
+    with torch.no_grad():
+        out = model(batch)
+    pos = out[0] if isinstance(out, tuple) else out
+    assert len(SAMPLER.log) == len(rec), "host RNG call count differs from the reference"
+    for a, b in zip(SAMPLER.log, rec):
+        assert torch.equal(a, b), "host RNG draw order differs from the reference (SURVEY Appendix D)"
+    flip = _first_flip(K.TOPS.record, src)
+    SAMPLER.log, K.TOPS.record = None, None
+    if flip is None:
+        assert rel_err(pos, G["eval.future_gps"]) < TOL_F32, name
+    else:
+        print(f"[{name}] selection flip at ProbSparse call {flip[0]}: {flip[1]} rows, margin/|qk| {flip[2]:.2e}; "
+              f"free-running rel err {rel_err(pos, G['eval.future_gps']):.2e}")
+        assert flip[2] < 2e-4, f"selection differs from the oracle away from a rounding-level tie: {flip}"
+        assert rel_err(pos, G["eval.future_gps"]) < 0.1
+
+
+@pytest.mark.parametrize("name", ["c2_small", "c4_small", "c2_paper"])
+def test_model_eval_forward_bf16(name):
+    """bf16 matrix-core mode: trajectories within 1e-2 of the reference with the oracle's top-u
+    selections imposed (the selection is discontinuous -- see above); free-running error is reported."""
+    from routeformer_amd import kernels as K
+    model, cfg, sd, c = build_product_model(name, DEV)
+    G = golden(name)
+    item = case_item(c)
+    (pos_o, _), src = _oracle_eval(cfg, sd, item["train"], draws(G, "eval."))
+    K.set_precision("bf16")
+    model.eval()
+    K.TOPS.forced = [t_.clone() for t_ in src.tops]
+    torch.manual_seed(RSEED)
+    with torch.no_grad():
+        out = model(_to_dev(item["train"]))
+    K.TOPS.forced = None
+    pos = out[0] if isinstance(out, tuple) else out
+    assert rel_err(pos, G["eval.future_gps"]) < TOL_BF16, name
+    torch.manual_seed(RSEED)
+    with torch.no_grad():
+        out = model(_to_dev(item["train"]))
+    free = rel_err(out[0] if isinstance(out, tuple) else out, G["eval.future_gps"])
+    print(f"[{name}] bf16 free-running rel err {free:.2e}")
+    assert free < 0.2
+
+
+@pytest.mark.parametrize("name", ["c1_default", "c1_recursive", "c2_small", "c4_small", "c2_paper"])
+def test_model_train_step_golden(name):
+    """The train-step recipe (loss, ADE, FDE, gradients) vs the reference, epochs 0 and 10, with the
+    oracle's top-u selections imposed (train-mode oracle run with the same seed)."""
+    from routeformer_amd import kernels as K
+    from routeformer_amd.engine import train_step_losses
+    model, cfg, sd, c = build_product_model(name, DEV)
+    G = golden(name)
+    item = case_item(c)
+    item_d = {"train": _to_dev(item["train"]), "target": _to_dev(item["target"])}
+    for epoch in (0, 10):
+        key = f"train{epoch}."
+        if key + "loss" not in G.files:
+            continue
+        if name == "c2_paper" and epoch == 0:
+            continue  # keep the suite short: the dense-loss epoch covers a superset of the graph
+        torch.manual_seed(RSEED)
+        orc = O.OracleRouteformer(cfg, sd, training=True)
+        with torch.no_grad():
+            orc.train_step(item, epoch)
+        model.load_state_dict(sd)
+        model.train()
+        model.zero_grad(set_to_none=True)
+        K.TOPS.forced = [t_.clone() for t_ in orc.idx.tops]
+        torch.manual_seed(RSEED)
+        res = train_step_losses(model, item_d, epoch)
+        assert not K.TOPS.forced
+        K.TOPS.forced = None
+        assert rel_err(res["future_gps"], G[key + "future_gps"]) < TOL_F32
+        for k in ("loss", "traj_loss", "ade", "fde"):
+            ref = float(G[key + k])
+            assert abs(float(res[k]) - ref) < 1e-3 * max(1.0, abs(ref)), (k, float(res[k]), ref)
+        if "dense_loss" in res:
+            assert abs(float(res["dense_loss"]) - float(G[key + "dense_loss"])) < 1e-3
+            assert rel_err(res["target_vis"], G[key + "target_vis"]) < TOL_F32
+        res["loss"].backward()
+        _check_grads(G, key, dict(model.named_parameters()), 5e-3)
+
+
+def test_model_vs_oracle_seeded():
+    """Same seed, no recorded indices: product (HIP) vs CPU oracle on c2_small in train mode."""
+    from routeformer_amd import kernels as K
+    model, cfg, sd, c = build_product_model("c2_small", DEV)
+    item = case_item(c)
+    torch.manual_seed(4321)
+    src = O.IndexSource()
+    with torch.no_grad():
+        pos_o, vis_o = O.OracleRouteformer(cfg, sd, training=True, idx=src).forward(item["train"])
+    model.train()
+    K.TOPS.forced = [t_.clone() for t_ in src.tops]
+    torch.manual_seed(4321)
+    pos_d, vis_d = model(_to_dev(item["train"]))
+    K.TOPS.forced = None
+    assert rel_err(pos_d, pos_o) < TOL_F32 and rel_err(vis_d, vis_o) < TOL_F32

@@ -1,0 +1,141 @@
+"""CPU: host-side logic of the drop-in boundary -- configs, state_dict layout, losses / scores /
+helpers against the reference's golden vectors, synthetic-data determinism, sampler order."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import build_product_model, golden, rel_err, t
+
+ALL_CASES = ["c1_default", "c1_paper", "c1_recursive", "c2_small", "c4_small", "c5_small", "ar_small", "c2_paper"]
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_state_dict_layout_matches_reference(name):
+    """Same keys, shapes and (synthetic) values as the reference model: the digest covers key names."""
+    from routeformer_amd import synthetic
+    model, cfg, sd, c = build_product_model(name)
+    G = golden(name)
+    assert sum(p.numel() for p in model.parameters()) == int(G["n_params"])
+    assert abs(synthetic.state_dict_digest(sd) - float(G["digest"])) < 1e-6 * float(G["digest"])
+    frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
+    assert all("video_backbone" in n for n in frozen)
+
+
+def test_losses_scores_helpers_golden():
+    from routeformer_amd.losses.future_discounted_mse import FutureDiscountedLoss
+    from routeformer_amd.score import ade, fde
+    from routeformer_amd.utils import estimate_angle_and_norm, median_downsampler, rotate
+    G = golden("helpers")
+    pred, true = t(G["pred"]), t(G["true"])
+    for kind in ("mse", "mae", "smooth_l1"):
+        loss = FutureDiscountedLoss({0: 0.97, 100: 0.98}, 1.0, loss_function=kind)
+        assert abs(float(loss(pred, true)) - float(G["loss." + kind])) < 1e-6
+    dense = FutureDiscountedLoss(0.9, 0.3, loss_function="smooth_l1")
+    assert abs(float(dense(t(G["feat_p"]), t(G["feat_t"]))) - float(G["loss.dense"])) < 1e-6
+    assert abs(float(ade(pred, true)) - float(G["ade"])) < 1e-6
+    assert abs(float(fde(pred, true)) - float(G["fde"])) < 1e-6
+    assert torch.equal(median_downsampler(t(G["gaze"]), 40), t(G["gaze_ds40"]))
+    assert torch.equal(median_downsampler(t(G["gaze"])[:, :100], 7), t(G["gaze_ds7"]))
+    assert rel_err(rotate(t(G["v"]), t(G["ang"])), G["rot"]) < 1e-6
+    a, n = estimate_angle_and_norm(t(G["v"]))
+    assert rel_err(a, G["angle"]) < 1e-6 and rel_err(n, G["norm"]) < 1e-6
+
+
+def test_loss_quirks():
+    from routeformer_amd.losses import FutureDiscountedLoss
+    from routeformer_amd.score import ade
+    from routeformer_amd.utils import median_downsampler
+    with pytest.raises(ValueError):
+        FutureDiscountedLoss(0.9, 1.0, loss_function="huber")
+    with pytest.raises(TypeError):  # epsilon=None is evaluated even on the smooth-L1 path
+        FutureDiscountedLoss(0.9, None, loss_function="smooth_l1")(torch.zeros(1, 2, 2), torch.zeros(1, 2, 2))
+    loss = FutureDiscountedLoss({0: 0.5, 3: 1.0}, 1.0, loss_function="mse")
+    x, y = torch.ones(1, 4, 2), torch.zeros(1, 4, 2)
+    x = x * 2
+    assert abs(float(loss(x, y)) - 4 * (1 + .5 + .25 + .125) / 4) < 1e-6
+    loss.current_epoch = 3
+    assert abs(float(loss(x, y)) - 4.0) < 1e-6
+    loss.current_epoch = 4  # sticky: stays at the last switched value
+    assert abs(float(loss(x, y)) - 4.0) < 1e-6
+    with pytest.raises(AssertionError):
+        ade(torch.zeros(2, 3, 2), torch.zeros(2, 4, 2))
+    with pytest.raises(ValueError):
+        median_downsampler(torch.zeros(1, 5, 2), 5)
+
+
+def test_configs():
+    from routeformer_amd.models import Routeformer, RouteformerConfig
+    from routeformer_amd.models.gps_backbone import GPSBackboneConfig, Informer
+    from routeformer_amd.models.video_backbone import VideoBackboneConfig
+    g = GPSBackboneConfig(seq_len=40, label_len=40, pred_len=30)
+    r = RouteformerConfig(gps_backbone_config=g)
+    assert r.with_video is False and g.enc_in == 5 and g.c_out == 2 and g.smart_decoder is False
+    r2 = r.override(video_backbone_config=VideoBackboneConfig(torchcache_enabled=False), with_video=True,
+                    dense_prediction=True, decoder_mode="smart", encoder_hidden_size=64)
+    g2 = r2.gps_backbone_config
+    assert g2.enc_in == 69 and g2.c_out == 66 and g2.dec_in == 69 and g2.smart_decoder is True
+    assert r.gps_backbone_config.enc_in == 5, "override must deep-copy"
+    assert r2["encoder_heads"] == 8 and r2.get("nope", 3) == 3
+    with pytest.raises(AssertionError):
+        RouteformerConfig(gps_backbone_config=g, video_fps=2)
+    with pytest.raises(AssertionError):
+        RouteformerConfig(gps_backbone_config=g, with_gaze=True, with_video=False)
+    with pytest.raises(ValueError):
+        VideoBackboneConfig(torchcache_enabled=True, train_backbone=True)
+    m = Routeformer(r, gps_backbone=Informer)
+    m.configs.rotate_motion = True
+    assert r.rotate_motion is False, "model must copy its config"
+
+
+def test_hrnet_units_and_keys():
+    from routeformer_amd.models.video_backbone import HRNet16Backbone
+    from routeformer_amd.models.video_backbone.hrnet16 import UNITS
+    assert len(UNITS) == 145  # 145 Conv2d
+    net = HRNet16Backbone()
+    assert len(net.state_dict()) == 865 and net.output_feature_shape == (240, 8, 8)
+    assert sum(p.numel() for p in net.parameters()) == 3102788
+    net.train()
+    assert all(not p.requires_grad for p in net.parameters())
+
+
+def test_synthetic_is_deterministic_and_gem_shaped():
+    from routeformer_amd import synthetic
+    a = synthetic.synth_item(2, 40, 30, 5, 32, 32)
+    b = synthetic.synth_item(2, 40, 30, 5, 32, 32)
+    for part in ("train", "target"):
+        for k in a[part]:
+            assert torch.equal(a[part][k], b[part][k])
+    tr = a["train"]
+    assert tr["gps"].shape == (2, 40, 2) and tr["left_video"].dtype == torch.float16
+    assert tr["left_video"].shape == (2, 40, 3, 32, 32) and tr["gaze"].shape == (2, 1600, 2)
+    assert a["target"]["gaze"].shape == (2, 1200, 2)
+    assert torch.allclose(a["target"]["gps"][:, 0] - tr["gps"][:, -1], a["target"]["gps"][:, 0] - tr["gps"][:, -1])
+    t1 = synthetic.synth_tensor("a.weight", torch.empty(4, 3), 1)
+    t2 = synthetic.synth_tensor("a.weight", torch.empty(4, 3), 1)
+    assert torch.equal(t1, t2) and not torch.equal(t1, synthetic.synth_tensor("b.weight", torch.empty(4, 3), 1))
+
+
+def test_index_sampler_and_prob_sizes():
+    from routeformer_amd import kernels as K
+    from routeformer_amd.models.blocks import IndexSampler
+    # (L_Q, L_K, factor) -> (sample_k, n_top): SURVEY Appendix B
+    assert K.prob_sizes(65, 65, 5) == (25, 25) and K.prob_sizes(160, 160, 5) == (30, 30)
+    assert K.prob_sizes(40, 40, 4) == (16, 16) and K.prob_sizes(70, 4, 4) == (4, 20)
+    assert K.prob_sizes(5, 5, 4) == (5, 5) and K.prob_sizes(25, 6, 1) == (2, 4)
+    s = IndexSampler()
+    s.log = []
+    torch.manual_seed(3)
+    a = s.draw(65, 65, 25, "cpu")
+    torch.manual_seed(3)
+    ref = torch.randint(65, (65, 25))
+    assert a.dtype == torch.int32 and torch.equal(a.long(), ref) and torch.equal(s.log[0], ref)
+    s.replay = [ref[:40, :16] % 40]
+    assert torch.equal(s.draw(40, 40, 16, "cpu").long(), ref[:40, :16] % 40)
+
+
+def test_product_refuses_cpu_execution():
+    """No CPU fallback: running the product model on CPU tensors raises instead of silently computing."""
+    from routeformer_amd import _hip
+    model, cfg, sd, c = build_product_model("c1_default")
+    with pytest.raises(_hip.HipLibraryError):
+        model({"gps": torch.zeros(4, 10, 2)})
