@@ -27,7 +27,7 @@ struct AttnP {
   int force_top;
   float *dq, *dk, *dv;
   long dq_ld, dk_ld, dv_ld;
-  int B, H, LQ, LK, E, sample_k, n_top, mode;
+  int B, H, LQ, LK, E, sample_k, n_top, mode, idx_group;
   float scale;
 };
 
@@ -73,18 +73,45 @@ __device__ void select_top(float* Ms, int* sel, int* top_list, int LQ, int n_top
   __syncthreads();
 }
 
-// LDS carve (floats): Qs[LQ*EP] Ks[LK*EP] Vs[LK*EP] Ps[NW*LK] Ms[LQ] | ints: sel[LQ] top[n_top]
+// Flattened work decomposition: every phase spreads (row, column) pairs over all 256 threads, so the
+// serial depth per thread is ~(rows*cols/256) short dot products instead of whole rows.
+//
+// LDS carve (floats): Qs[LQ*EP] Ks[LK*EP] Vs[LK*EP] S[max(LQ*sample_k, n_sel*LK)] Ms[LQ] vmean[E]
+//            | ints: sel[LQ] top[n_sel]
+__device__ __forceinline__ void softmax_rows(float* S, int n_rows, int LK, const int* top_list, int masked,
+                                             int lane, int wave) {
+  for (int si = wave; si < n_rows; si += NW) {
+    float* row = S + (long)si * LK;
+    const int kmax = masked ? top_list[si] + 1 : LK;
+    float mx = -INFINITY;
+    for (int s = lane; s < kmax; s += 64) mx = fmaxf(mx, row[s]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int s = lane; s < kmax; s += 64) {
+      const float e_ = expf(row[s] - mx);
+      row[s] = e_;
+      sum += e_;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int s = lane; s < LK; s += 64) row[s] = s < kmax ? row[s] * inv : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int LQ = p.LQ, LK = p.LK, E = p.E, EP = E + 1;
+  const int n_sel = (p.mode == 0) ? LQ : p.n_top;
+  const int s_elems = max(LQ * p.sample_k, n_sel * LK);
   float* Qs = smem;
   float* Ks = Qs + LQ * EP;
   float* Vs = Ks + LK * EP;
-  float* Ps = Vs + LK * EP;
-  float* Ms = Ps + NW * LK;
-  int* sel = reinterpret_cast<int*>(Ms + LQ);
+  float* S = Vs + LK * EP;
+  float* Ms = S + s_elems;
+  float* vmean = Ms + LQ;
+  int* sel = reinterpret_cast<int*>(vmean + E);
   int* top_list = sel + LQ;
 
   load_head(Qs, p.q, p.q_ld, b, h, LQ, E, EP, tid);
@@ -92,13 +119,10 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
   load_head(Vs, p.v, p.v_ld, b, h, LK, E, EP, tid);
   __syncthreads();
 
-  int n_sel;
   if (p.mode == 0) {
-    n_sel = LQ;
     for (int q = tid; q < LQ; q += NT) { sel[q] = q; top_list[q] = q; }
     __syncthreads();
   } else {
-    n_sel = p.n_top;
     int32_t* gtop = p.top + ((long)b * p.H + h) * p.n_top;
     if (p.force_top) {
       for (int q = tid; q < LQ; q += NT) sel[q] = -1;
@@ -106,14 +130,20 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
       for (int i = tid; i < n_sel; i += NT) { top_list[i] = gtop[i]; sel[gtop[i]] = i; }
       __syncthreads();
     } else {
-      // (1) sparsity measure from the sampled keys
+      // (1) sampled scores Q[q].K[idx[q,j]] (one table per group of `idx_group` consecutive batch rows)
+      const int32_t* idx = p.idx + (long)(b / p.idx_group) * LQ * p.sample_k;
+      for (int i = tid; i < LQ * p.sample_k; i += NT) {
+        const int q = i / p.sample_k;
+        const int kk = idx[i];
+        float d = 0.f;
+        for (int e = 0; e < E; ++e) d = fmaf(Qs[q * EP + e], Ks[kk * EP + e], d);
+        S[i] = d;
+      }
+      __syncthreads();
       for (int q = tid; q < LQ; q += NT) {
-        const int32_t* iq = p.idx + (long)q * p.sample_k;
         float mx = -INFINITY, sm = 0.f;
         for (int j = 0; j < p.sample_k; ++j) {
-          const int kk = iq[j];
-          float d = 0.f;
-          for (int e = 0; e < E; ++e) d = fmaf(Qs[q * EP + e], Ks[kk * EP + e], d);
+          const float d = S[q * p.sample_k + j];
           mx = fmaxf(mx, d);
           sm += d;
         }
@@ -125,14 +155,19 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
       for (int i = tid; i < n_sel; i += NT) gtop[i] = top_list[i];
     }
     // (4) lazy rows: mean(V) or cumsum(V)
-    for (int d = tid; d < E; d += NT) {
-      if (p.mode == 1) {
+    if (p.mode == 1) {
+      for (int d = tid; d < E; d += NT) {
         float s = 0.f;
         for (int l = 0; l < LK; ++l) s += Vs[l * EP + d];
-        s /= (float)LK;
-        for (int ql = 0; ql < LQ; ++ql)
-          if (sel[ql] < 0) p.ctx[ctx_off(p, b, h, ql) + d] = s;
-      } else {
+        vmean[d] = s / (float)LK;
+      }
+      __syncthreads();
+      for (int i = tid; i < LQ * E; i += NT) {
+        const int ql = i / E, d = i - ql * E;
+        if (sel[ql] < 0) p.ctx[ctx_off(p, b, h, ql) + d] = vmean[d];
+      }
+    } else {
+      for (int d = tid; d < E; d += NT) {
         float s = 0.f;
         for (int ql = 0; ql < LQ; ++ql) {
           s += Vs[ql * EP + d];
@@ -140,36 +175,32 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
         }
       }
     }
+    __syncthreads();  // S is re-used below
   }
 
-  // (3) active rows: one wave per selected query, keys spread over lanes
-  float* Pw = Ps + wave * LK;
-  for (int si = wave; si < n_sel; si += NW) {
+  // (3) active rows.  A: scores, B: row softmax, C: P.V
+  for (int i = tid; i < n_sel * LK; i += NT) {
+    const int si = i / LK, s = i - si * LK;
     const int q = top_list[si];
-    const int kmax = (p.mode == 2) ? q + 1 : LK;  // masked: keys s <= q
-    float mx = -INFINITY;
-    for (int s = lane; s < kmax; s += 64) {
-      float d = 0.f;
+    float d = -INFINITY;
+    if (p.mode != 2 || s <= q) {
+      d = 0.f;
       for (int e = 0; e < E; ++e) d = fmaf(Qs[q * EP + e], Ks[s * EP + e], d);
       d *= p.scale;
-      Pw[s] = d;
-      mx = fmaxf(mx, d);
     }
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int s = lane; s < kmax; s += 64) {
-      const float e_ = expf(Pw[s] - mx);
-      Pw[s] = e_;
-      sum += e_;
-    }
-    sum = wave_sum(sum);
-    const float inv = 1.f / sum;
-    // Pw is written and read by the same wave only; LDS ops of one wave are ordered.
-    for (int d = lane; d < E; d += 64) {
-      float a = 0.f;
-      for (int s = 0; s < kmax; ++s) a = fmaf(Pw[s], Vs[s * EP + d], a);
-      p.ctx[ctx_off(p, b, h, q) + d] = a * inv;
-    }
+    S[i] = d;
+  }
+  __syncthreads();
+  softmax_rows(S, n_sel, LK, top_list, p.mode == 2, lane, wave);
+  __syncthreads();
+  for (int i = tid; i < n_sel * E; i += NT) {
+    const int si = i / E, d = i - si * E;
+    const int q = top_list[si];
+    const int kmax = (p.mode == 2) ? q + 1 : LK;
+    const float* row = S + (long)si * LK;
+    float a = 0.f;
+    for (int s = 0; s < kmax; ++s) a = fmaf(row[s], Vs[s * EP + d], a);
+    p.ctx[ctx_off(p, b, h, q) + d] = a;
   }
 }
 
@@ -210,54 +241,42 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
   }
   __syncthreads();
 
-  // phase 1: per selected query recompute P, then dS = P * (dP - sum(P*dP)) * scale
-  for (int si = wave; si < n_sel; si += NW) {
+  // phase 1: recompute P; dP = dC V^T; dS = P * (dP - rowsum(P*dP)) * scale; dQ = dS K
+  for (int i = tid; i < n_sel * LK; i += NT) {
+    const int si = i / LK, s = i - si * LK;
     const int q = top_list[si];
-    const int kmax = (p.mode == 2) ? q + 1 : LK;
+    float d = -INFINITY, dp = 0.f;
+    if (p.mode != 2 || s <= q) {
+      d = 0.f;
+      for (int e = 0; e < E; ++e) {
+        d = fmaf(Qsel[si * EP + e], Ks[s * EP + e], d);
+        dp = fmaf(dCsel[si * EP + e], Vs[s * EP + e], dp);
+      }
+      d *= p.scale;
+    }
+    P[i] = d;
+    dS[i] = dp;
+  }
+  __syncthreads();
+  softmax_rows(P, n_sel, LK, top_list, p.mode == 2, lane, wave);
+  // same wave owns the same rows in softmax_rows and here: no barrier needed in between
+  for (int si = wave; si < n_sel; si += NW) {
     float* Pr = P + (long)si * LK;
     float* dSr = dS + (long)si * LK;
-    float mx = -INFINITY;
-    for (int s = lane; s < kmax; s += 64) {
-      float d = 0.f;
-      for (int e = 0; e < E; ++e) d = fmaf(Qsel[si * EP + e], Ks[s * EP + e], d);
-      d *= p.scale;
-      Pr[s] = d;
-      mx = fmaxf(mx, d);
-    }
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int s = lane; s < kmax; s += 64) {
-      const float e_ = expf(Pr[s] - mx);
-      Pr[s] = e_;
-      sum += e_;
-    }
-    sum = wave_sum(sum);
-    const float inv = 1.f / sum;
     float dot = 0.f;
-    for (int s = lane; s < kmax; s += 64) {
-      const float pr = Pr[s] * inv;
-      float dp = 0.f;
-      for (int e = 0; e < E; ++e) dp = fmaf(dCsel[si * EP + e], Vs[s * EP + e], dp);
-      Pr[s] = pr;
-      dSr[s] = dp;
-      dot += pr * dp;
-    }
+    for (int s = lane; s < LK; s += 64) dot += Pr[s] * dSr[s];
     dot = wave_sum(dot);
-    for (int s = lane; s < LK; s += 64) {
-      if (s < kmax) {
-        dSr[s] = Pr[s] * (dSr[s] - dot) * p.scale;
-      } else {
-        Pr[s] = 0.f;
-        dSr[s] = 0.f;
-      }
-    }
-    // dQ[q] = dS[q,:] K
-    float* dqrow = p.dq + ((long)b * LQ + q) * p.dq_ld + (long)h * E;
-    for (int e = lane; e < E; e += 64) {
-      float a = 0.f;
-      for (int s = 0; s < kmax; ++s) a = fmaf(dSr[s], Ks[s * EP + e], a);
-      dqrow[e] = a;
-    }
+    for (int s = lane; s < LK; s += 64) dSr[s] = Pr[s] * (dSr[s] - dot) * p.scale;
+  }
+  __syncthreads();
+  for (int i = tid; i < n_sel * E; i += NT) {
+    const int si = i / E, e = i - si * E;
+    const int q = top_list[si];
+    const int kmax = (p.mode == 2) ? q + 1 : LK;
+    const float* dSr = dS + (long)si * LK;
+    float a = 0.f;
+    for (int s = 0; s < kmax; ++s) a = fmaf(dSr[s], Ks[s * EP + e], a);
+    p.dq[((long)b * LQ + q) * p.dq_ld + (long)h * E + e] = a;
   }
   // non-selected query rows get zero dQ (the sampling stage is not differentiated)
   for (int i = tid; i < LQ * E; i += NT) {
@@ -302,9 +321,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
   }
 }
 
-size_t fwd_lds(int LQ, int LK, int E, int n_top) {
+size_t fwd_lds(int LQ, int LK, int E, int n_sel, int sample_k) {
   const size_t EP = E + 1;
-  return sizeof(float) * (LQ * EP + 2 * LK * EP + NW * (size_t)LK + LQ) + sizeof(int) * ((size_t)LQ + max(n_top, LQ));
+  const size_t s_elems = max((size_t)LQ * sample_k, (size_t)n_sel * LK);
+  return sizeof(float) * (LQ * EP + 2 * LK * EP + s_elems + LQ + E) + sizeof(int) * ((size_t)LQ + n_sel);
 }
 size_t bwd_lds(int LQ, int LK, int E, int n_sel) {
   const size_t EP = E + 1;
@@ -315,20 +335,21 @@ size_t bwd_lds(int LQ, int LK, int E, int n_sel) {
 
 extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
                            int64_t v_ld, float* ctx, int out_layout, const int32_t* index_sample,
-                           int32_t* top_idx, int force_top, int B, int H, int LQ, int LK, int E,
-                           int sample_k, int n_top, int mode, float scale, void* stream) {
+                           int idx_group, int32_t* top_idx, int force_top, int B, int H, int LQ, int LK,
+                           int E, int sample_k, int n_top, int mode, float scale, void* stream) {
   RF_REQUIRE(q && k && v && ctx && B > 0 && H > 0 && LQ > 0 && LK > 0 && E > 0);
   RF_REQUIRE(mode >= 0 && mode <= 2);
   RF_REQUIRE(mode == 0 || (top_idx && n_top > 0 && n_top <= LQ));
   RF_REQUIRE(mode == 0 || force_top || (index_sample && sample_k > 0));
   RF_REQUIRE(mode != 2 || LQ == LK);
-  const size_t lds = fwd_lds(LQ, LK, E, n_top);
+  const size_t lds = fwd_lds(LQ, LK, E, mode == 0 ? LQ : n_top, mode == 0 ? 0 : sample_k);
   if (lds > 160 * 1024) { rf_g_last_error = "attention head slice exceeds 160 KB LDS"; return RF_EUNSUPPORTED; }
   AttnP p{};
   p.q = q; p.k = k; p.v = v; p.q_ld = q_ld; p.k_ld = k_ld; p.v_ld = v_ld; p.ctx = ctx;
   p.out_layout = out_layout; p.idx = index_sample; p.top = top_idx; p.force_top = force_top;
   p.B = B; p.H = H; p.LQ = LQ; p.LK = LK; p.E = E; p.sample_k = sample_k; p.n_top = n_top;
   p.mode = mode; p.scale = scale;
+  p.idx_group = (idx_group <= 0 || idx_group > B) ? B : idx_group;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

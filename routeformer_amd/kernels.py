@@ -352,6 +352,25 @@ class TopSelection:
     record: Optional[list] = None
     forced: Optional[list] = None
 
+    def merge_forced(self, n_calls: int, n_layers: int):
+        """``n_calls`` reference encoder calls (each ``n_layers`` selections) run as one batched call:
+        turn their queued selections [call][layer] into per-layer batch-concatenated ones."""
+        if self.forced is None or n_calls == 1:
+            return
+        head, rest = self.forced[: n_calls * n_layers], self.forced[n_calls * n_layers:]
+        self.forced = [torch.cat([head[c * n_layers + l] for c in range(n_calls)], dim=0)
+                       for l in range(n_layers)] + rest
+
+    def split_record(self, n_calls: int, n_layers: int):
+        """Inverse bookkeeping for ``record``: re-emit a batched call's selections in reference order."""
+        if self.record is None or n_calls == 1:
+            return
+        tail = self.record[-n_layers:]
+        del self.record[-n_layers:]
+        for c in range(n_calls):
+            for l in range(n_layers):
+                self.record.append(tail[l].chunk(n_calls, dim=0)[c])
+
 
 TOPS = TopSelection()
 
@@ -370,7 +389,7 @@ class _Attention(torch.autograd.Function):
     mode 0 full, 1 ProbSparse, 2 ProbSparse masked."""
 
     @staticmethod
-    def forward(ctx, a, b, offs, index_sample, dims, mode, n_top, out_layout, scale, forced_top):
+    def forward(ctx, a, b, offs, index_sample, dims, mode, n_top, out_layout, scale, forced_top, idx_group=0):
         B, H, LQ, LK, E = dims
         q_off, k_off, v_off = offs
         _req(a, "attention.q")
@@ -386,11 +405,11 @@ class _Attention(torch.autograd.Function):
                 assert tuple(forced_top.shape) == (B, H, n_top), (tuple(forced_top.shape), (B, H, n_top))
             top = forced_top if forced_top is not None else \
                 torch.empty(B, H, n_top, device=a.device, dtype=torch.int32)
-            sample_k = index_sample.shape[1] if index_sample is not None else 0
+            sample_k = index_sample.shape[-1] if index_sample is not None else 0
         ev = PROFILE.begin() if PROFILE.on else None
         check(_hip.lib().rf_attn_fwd(a.data_ptr() + 4 * q_off, b.data_ptr() + 4 * k_off,
                                      b.data_ptr() + 4 * v_off, a.stride(0), b.stride(0), b.stride(0),
-                                     ptr(out), out_layout, ptr(index_sample), ptr(top),
+                                     ptr(out), out_layout, ptr(index_sample), idx_group, ptr(top),
                                      1 if forced_top is not None else 0, B, H, LQ, LK, E, sample_k, n_top,
                                      mode, scale, _stream()), "rf_attn_fwd")
         if ev is not None:
@@ -420,11 +439,11 @@ class _Attention(torch.autograd.Function):
         if ev is not None:
             u = LQ if mode == 0 else n_top
             PROFILE.end("attn_bwd", ev, B * H * 10.0 * u * LK * E, 4.0 * B * H * E * (4 * LQ + 4 * LK))
-        return da, (None if same else db), None, None, None, None, None, None, None, None
+        return da, (None if same else db), None, None, None, None, None, None, None, None, None
 
 
 def attention(a, b, offs, dims, mode: int, *, index_sample=None, n_top: int = 0, out_layout: int = 0,
-              scale: Optional[float] = None, forced_top=None):
+              scale: Optional[float] = None, forced_top=None, idx_group: int = 0):
     """Returns ctx in (B,LQ,H,E) [out_layout 0] or (B,H,LQ,E) [out_layout 1: Informer's un-transposed
     layout, layers/SelfAttentionFamily.py:165].  Every column of ``a`` / ``b`` must be one of Q/K/V."""
     B, H, LQ, LK, E = dims
@@ -433,4 +452,6 @@ def attention(a, b, offs, dims, mode: int, *, index_sample=None, n_top: int = 0,
         assert a.shape[1] == 3 * H * E
     else:
         assert a.shape[1] == H * E and b.shape[1] == 2 * H * E
-    return _Attention.apply(a, b, offs, index_sample, dims, mode, n_top, out_layout, scale, forced_top)
+    if index_sample is not None and index_sample.dim() == 3:
+        assert idx_group > 0 and index_sample.shape[0] * idx_group == B, (index_sample.shape, idx_group, B)
+    return _Attention.apply(a, b, offs, index_sample, dims, mode, n_top, out_layout, scale, forced_top, idx_group)

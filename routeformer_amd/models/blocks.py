@@ -40,7 +40,8 @@ class IndexSampler:
         self.replay: Optional[list] = None
         self.log: Optional[list] = None
 
-    def draw(self, L_K: int, L_Q: int, sample_k: int, device) -> torch.Tensor:
+    def draw_host(self, L_K: int, L_Q: int, sample_k: int) -> torch.Tensor:
+        """One host draw (int64, CPU) -- consumes the global CPU generator exactly like the reference."""
         if self.replay is not None:
             t = self.replay.pop(0)
             assert tuple(t.shape) == (L_Q, sample_k), (tuple(t.shape), (L_Q, sample_k))
@@ -48,7 +49,10 @@ class IndexSampler:
             t = torch.randint(L_K, (L_Q, sample_k))
         if self.log is not None:
             self.log.append(t.clone())
-        return t.to(torch.int32).to(device, non_blocking=True)
+        return t
+
+    def draw(self, L_K: int, L_Q: int, sample_k: int, device) -> torch.Tensor:
+        return self.draw_host(L_K, L_Q, sample_k).to(torch.int32).to(device, non_blocking=True)
 
 
 SAMPLER = IndexSampler()
@@ -128,9 +132,10 @@ class AttentionLayer(nn.Module):
         self.n_heads, self.kind, self.factor = n_heads, kind, factor
         self.gps_variant, self.mix, self.attn_dropout = gps_variant, mix, attn_dropout
 
-    def forward(self, x, memory=None):
+    def forward(self, x, memory=None, idx=None, idx_group: int = 0):
         """Self-attention when ``memory is None`` (one packed QKV GEMM), else queries from ``x`` and
-        keys/values from ``memory`` (packed KV GEMM)."""
+        keys/values from ``memory`` (packed KV GEMM).  ``idx`` (G,L,k) int32 on the device = pre-drawn
+        key samples, one table per ``idx_group`` consecutive sequences (stream-batched encoders)."""
         B, L, _ = x.shape
         H = self.n_heads
         qp, kp, vp = self.query_projection, self.key_projection, self.value_projection
@@ -158,9 +163,10 @@ class AttentionLayer(nn.Module):
             ctx = K.attention(a, bm, offs, dims, 0, out_layout=layout)
         else:
             sample_k, n_top = K.prob_sizes(L, S, self.factor)
-            idx = SAMPLER.draw(S, L, sample_k, x.device)
+            if idx is None:
+                idx = SAMPLER.draw(S, L, sample_k, x.device)
             ctx = K.attention(a, bm, offs, dims, 2 if self.kind == "prob_masked" else 1, index_sample=idx,
-                              n_top=n_top, out_layout=layout)
+                              n_top=n_top, out_layout=layout, idx_group=idx_group)
         if self.mix and not self.gps_variant:
             ctx = ctx.transpose(2, 1).contiguous()
         ctx = ctx.view(B, L, HE)  # GPS variant: (B,H,L,D) memory reinterpreted -- the head scramble
@@ -186,9 +192,9 @@ class EncoderLayer(nn.Module):
         return K.ffn(x, self.conv1.weight.squeeze(-1), self.conv1.bias, self.conv2.weight.squeeze(-1),
                      self.conv2.bias, self.act)
 
-    def forward(self, x):
-        x = K.add_layer_norm(x, _dropout(self.attention(x), self.p, self.training), self.norm1.weight,
-                             self.norm1.bias)
+    def forward(self, x, idx=None, idx_group: int = 0):
+        x = K.add_layer_norm(x, _dropout(self.attention(x, idx=idx, idx_group=idx_group), self.p, self.training),
+                             self.norm1.weight, self.norm1.bias)
         return K.add_layer_norm(x, self._ffn(x), self.norm2.weight, self.norm2.bias)
 
 
@@ -239,14 +245,14 @@ class Encoder(nn.Module):
         self.conv_layers = nn.ModuleList(conv_layers) if conv_layers is not None else None
         self.norm = norm_layer
 
-    def forward(self, x):
+    def forward(self, x, idx_list=None, idx_group: int = 0):
         if self.conv_layers is not None:
             for attn, conv in zip(self.attn_layers, self.conv_layers):
                 x = conv(attn(x))
             x = self.attn_layers[-1](x)
         else:
-            for attn in self.attn_layers:
-                x = attn(x)
+            for i, attn in enumerate(self.attn_layers):
+                x = attn(x, None if idx_list is None else idx_list[i], idx_group)
         if self.norm is not None:
             x = K.add_layer_norm(x, None, self.norm.weight, self.norm.bias)
         return x
@@ -287,9 +293,19 @@ class PerceiveEncoder(nn.Module):
             None, norm_layer=nn.LayerNorm(d_model))
         self.projection = nn.Linear(d_model, out_channels, bias=True)
 
-    def forward(self, x_enc):
+    def predraw(self, L: int):
+        """The host draws one forward over length-L sequences makes, in layer order (CPU int64)."""
+        out = []
+        for layer in self.encoder.attn_layers:
+            sample_k, _ = K.prob_sizes(L, L, layer.attention.factor)
+            out.append(SAMPLER.draw_host(L, L, sample_k))
+        return out
+
+    def forward(self, x_enc, idx_list=None, idx_group: int = 0):
+        """``idx_list``: per layer a (G,L,k) int32 device tensor of pre-drawn key samples (several
+        reference calls batched into one: rows [g*idx_group, (g+1)*idx_group) use table g)."""
         h = self.value_embedding(x_enc) + self.position_embedding(x_enc.shape[1])
-        h = self.encoder(h)
+        h = self.encoder(h, idx_list, idx_group)
         # only the last pred_len tokens are consumed: project just those rows
         return K.linear(h[:, -self.pred_len:, :], self.projection.weight, self.projection.bias)
 

@@ -246,26 +246,31 @@ class HRNet16Backbone(VideoBackboneModule):
             outs.append(acc)
         return outs
 
-    def encode_tokens(self, video: torch.Tensor, frame_idx: Optional[torch.Tensor]) -> torch.Tensor:
-        """video (B,T,3,H,W) fp16/fp32 + frame indices (F,) -> tokens (B*F, 65, 240) with the trailing
-        constant -1 row (routeformer.py:478-487).  Frame gather, dtype cast and conv0 are one kernel."""
-        if not video.is_cuda:
-            raise _hip.HipLibraryError("HRNet16Backbone runs on the GPU only; there is no CPU path")
-        if video.dtype not in (torch.float16, torch.float32):
-            video = video.float()
-        video = video.contiguous()
-        B, T, C3, H, Wd = video.shape
+    def encode_tokens(self, video, frame_idx: Optional[torch.Tensor]) -> torch.Tensor:
+        """video (B,T,3,H,W) fp16/fp32 -- or a LIST of such clips (several camera streams batched through
+        the trunk at once) -- + frame indices (F,) -> tokens (S*B*F, 65, 240), stream-major, each with the
+        trailing constant -1 row (routeformer.py:478-487).  Frame gather, dtype cast and conv0 are one kernel."""
+        videos = list(video) if isinstance(video, (list, tuple)) else [video]
+        for v in videos:
+            if not v.is_cuda:
+                raise _hip.HipLibraryError("HRNet16Backbone runs on the GPU only; there is no CPU path")
+        videos = [(v if v.dtype in (torch.float16, torch.float32) else v.float()).contiguous() for v in videos]
+        B, T, C3, H, Wd = videos[0].shape
         assert C3 == 3 and H % 2 == 0 and Wd % 2 == 0
-        dev = video.device
+        assert all(v.shape == videos[0].shape for v in videos)
+        dev = videos[0].device
         if frame_idx is None:
             frame_idx = torch.arange(T, device=dev, dtype=torch.int32)
         frame_idx = frame_idx.to(device=dev, dtype=torch.int32)
         F_ = frame_idx.numel()
-        N = B * F_
+        n_each = B * F_
+        N = n_each * len(videos)
         W = self._prepare(dev)
         x = torch.empty(N, H // 2, Wd // 2, 4, device=dev, dtype=torch.float32)
-        check(_hip.lib().rf_stem_conv0(ptr(video), 1 if video.dtype == torch.float32 else 0, ptr(frame_idx),
-                                       ptr(W["conv0"][0]), ptr(x), B, T, F_, H, Wd, K._stream()), "rf_stem_conv0")
+        for s_i, v in enumerate(videos):
+            check(_hip.lib().rf_stem_conv0(ptr(v), 1 if v.dtype == torch.float32 else 0, ptr(frame_idx),
+                                           ptr(W["conv0"][0]), x.data_ptr() + 4 * s_i * n_each * (H // 2) * (Wd // 2) * 4,
+                                           B, T, F_, H, Wd, K._stream()), "rf_stem_conv0")
         x = self._conv(W, "conv1", x, stride=2, relu=True)
         x = self._conv(W, "conv2", x, stride=2, relu=True)
         x = self._bottleneck(W, "layer1.0", x)
