@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--case", default="C2")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (N=1)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     args = ap.parse_args()
 
@@ -107,11 +108,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from routeformer_amd import kernels as K
-    from routeformer_amd.engine import TrainEngine
+    from routeformer_amd.engine import GraphedTrainEngine, TrainEngine
 
     model, cfg, sd, c = build(args.case, device, args.precision)
     item = make_item(c, rank, device)
-    engine = TrainEngine(model)
+    use_graph = world == 1 and not args.no_graph
+    engine = GraphedTrainEngine(model) if use_graph else TrainEngine(model)
 
     def sync():
         if world > 1:
@@ -123,12 +125,20 @@ def main():
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i == args.steps - 1:
+        if i == args.steps - 1 and not use_graph:
             K.PROFILE.enable()  # HIP events around every kernel-class launch of the last timed step
         res = engine.step(item, epoch=10)
     sync()
     elapsed = time.perf_counter() - t0
     K.PROFILE.disable()
+    if use_graph:
+        # Graph replay has no per-launch host hook: time the kernel classes live on the same stream in one
+        # extra eager pass right after the timed region (same shapes, same data, HIP events per launch).
+        from routeformer_amd.models.blocks import SAMPLER
+        SAMPLER.rewind_static()
+        K.PROFILE.enable()
+        engine._eager_fwd_bwd(item, 10)
+        K.PROFILE.disable()
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -165,7 +175,8 @@ def main():
                                    f"{c['H']}x{c['W']}, T={c['T']}->P={c['P']}, paper hyper-params, "
                                    f"batch {c['B']}/GPU, random-init weights, frozen HRNet-16 encoder",
                        "global_batch": c["B"] * world, "parallelism": f"dp{world}",
-                       "step": "fwd + target-feature fwd + losses + bwd + grad all-reduce + clip + AdamW"},
+                       "step": "fwd + target-feature fwd + losses + bwd + grad all-reduce + clip + AdamW",
+                       "launch": "hipGraph replay of fwd+bwd" if use_graph else "eager launches"},
             "loss": float(res["loss"]), "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

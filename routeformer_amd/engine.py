@@ -191,3 +191,75 @@ class TrainEngine:
         scale = self.reducer.finish()
         self.opt.step(scale)
         return res
+
+
+class GraphedTrainEngine(TrainEngine):
+    """The same step with forward + backward captured once in a HIP graph and replayed.
+
+    A step of this model is ~4k small launches; replaying them from a graph removes the Python /
+    launch-path cost between kernels.  What stays outside the graph: (i) the host-RNG draws of the
+    ProbSparse key samples -- made before every replay in the reference's order, one async copy
+    (``IndexSampler`` static mode); (ii) the gradient all-reduce (N > 1) and the clip + AdamW launches,
+    whose scalar arguments (bias correction) change every step.  Requires a step whose control flow does
+    not depend on random draws (view / gaze dropout 0) and fixed batch shapes; inputs are copied into
+    static buffers."""
+
+    def __init__(self, model, **kw):
+        super().__init__(model, **kw)
+        self.graph = None
+        self._static_item = None
+        self._out = None
+        c = model.configs
+        if c.view_dropout > 0 or c.gaze_dropout > 0 or c.motion_noise > 0 or c.feature_dropout > 0:
+            raise ValueError("GraphedTrainEngine needs a draw-independent step (all dropouts / noise 0)")
+
+    def _eager_fwd_bwd(self, item, epoch):
+        self.reducer.zero()
+        res = train_step_losses(self.model, item, epoch, self.tl, self.dl)
+        res["loss"].backward()
+        return res
+
+    def capture(self, item, epoch: int = 0, warmup: int = 2):
+        from routeformer_amd.models.blocks import SAMPLER
+        if self.reducer.world > 1:
+            raise NotImplementedError("graph capture with in-backward all-reduce hooks is not supported; "
+                                      "use TrainEngine for N > 1")
+        self.model.train()
+        dev = self.reducer.flat_param.device
+        # the caller's tensors become the graph's static inputs (later batches are copied into them)
+        self._static_item = {k: dict(d) for k, d in item.items()}
+        # plan: which draws does one step make?
+        plan = None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(max(1, warmup)):
+                SAMPLER.plan = [] if i == 0 else None
+                self._eager_fwd_bwd(self._static_item, epoch)
+                if i == 0:
+                    plan = SAMPLER.plan
+        torch.cuda.current_stream().wait_stream(side)
+        SAMPLER.plan = None
+        SAMPLER.make_static(plan, dev)
+        SAMPLER.refill_static()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._out = self._eager_fwd_bwd(self._static_item, epoch)
+        self._epoch = epoch
+        return self
+
+    def step(self, item, epoch: int = 0):
+        from routeformer_amd.models.blocks import SAMPLER
+        if self.graph is None:
+            self.capture(item, epoch)
+        assert epoch == self._epoch or (epoch >= 10) == (self._epoch >= 10), "re-capture when the loss recipe changes"
+        for part in ("train", "target"):
+            for n, v in item[part].items():
+                if v.data_ptr() != self._static_item[part][n].data_ptr():
+                    self._static_item[part][n].copy_(v, non_blocking=True)
+        SAMPLER.refill_static()
+        self.graph.replay()
+        scale = self.reducer.finish()
+        self.opt.step(scale)
+        return self._out

@@ -32,13 +32,21 @@ from routeformer_amd import kernels as K
 class IndexSampler:
     """Process-wide source of ``index_sample`` tensors.
 
-    ``draw`` performs the reference's own call ``torch.randint(L_K, (L_Q, sample_k))`` on the host, so a
-    ``torch.manual_seed`` reproduces the reference's samples.  ``replay`` injects recorded samples
-    (tests); ``log`` keeps what was drawn (draw-order tests)."""
+    ``draw_host`` performs the reference's own call ``torch.randint(L_K, (L_Q, sample_k))`` on the host, so
+    a ``torch.manual_seed`` reproduces the reference's samples.  ``replay`` injects recorded samples
+    (tests); ``log`` keeps what was drawn (draw-order tests).
+
+    Static mode (HIP-graph replay, ``engine.GraphedTrainEngine``): the sequence of draws of one step is
+    fixed by the shapes, so all of them are made on the host BEFORE the replay -- same calls, same order --
+    into one pinned buffer, shipped with a single async copy, and ``draw`` hands out views of the static
+    device buffer in call order (no host work and no copies inside the captured region)."""
 
     def __init__(self):
         self.replay: Optional[list] = None
         self.log: Optional[list] = None
+        self.plan: Optional[list] = None      # recording: [(L_K, L_Q, sample_k)] of one step
+        self._static = None                   # (device buffer, pinned buffer, [(offset, L_K, L_Q, k)])
+        self._cursor = 0
 
     def draw_host(self, L_K: int, L_Q: int, sample_k: int) -> torch.Tensor:
         """One host draw (int64, CPU) -- consumes the global CPU generator exactly like the reference."""
@@ -52,7 +60,40 @@ class IndexSampler:
         return t
 
     def draw(self, L_K: int, L_Q: int, sample_k: int, device) -> torch.Tensor:
+        """(L_Q, sample_k) int32 on ``device``."""
+        if self._static is not None:
+            dev_buf, _, slots = self._static
+            off, lk, lq, k = slots[self._cursor]
+            assert (lk, lq, k) == (L_K, L_Q, sample_k), "draw sequence changed since the graph was planned"
+            self._cursor += 1
+            return dev_buf[off:off + lq * k].view(lq, k)
+        if self.plan is not None:
+            self.plan.append((L_K, L_Q, sample_k))
         return self.draw_host(L_K, L_Q, sample_k).to(torch.int32).to(device, non_blocking=True)
+
+    # -- static mode ------------------------------------------------------------------------------
+    def make_static(self, plan, device):
+        slots, off = [], 0
+        for lk, lq, k in plan:
+            slots.append((off, lk, lq, k))
+            off += lq * k
+        self._static = (torch.zeros(off, dtype=torch.int32, device=device),
+                        torch.zeros(off, dtype=torch.int32).pin_memory(), slots)
+        self._cursor = 0
+
+    def refill_static(self):
+        """Host side of one step: the reference's draws in order, then ONE async H2D copy."""
+        dev_buf, pinned, slots = self._static
+        for off, lk, lq, k in slots:
+            pinned[off:off + lq * k].copy_(self.draw_host(lk, lq, k).view(-1))
+        dev_buf.copy_(pinned, non_blocking=True)
+        self._cursor = 0
+
+    def rewind_static(self):
+        self._cursor = 0
+
+    def drop_static(self):
+        self._static, self._cursor = None, 0
 
 
 SAMPLER = IndexSampler()
@@ -293,12 +334,12 @@ class PerceiveEncoder(nn.Module):
             None, norm_layer=nn.LayerNorm(d_model))
         self.projection = nn.Linear(d_model, out_channels, bias=True)
 
-    def predraw(self, L: int):
-        """The host draws one forward over length-L sequences makes, in layer order (CPU int64)."""
+    def predraw(self, L: int, device):
+        """The draws one forward over length-L sequences makes, in layer order ((L,k) int32 on device)."""
         out = []
         for layer in self.encoder.attn_layers:
             sample_k, _ = K.prob_sizes(L, L, layer.attention.factor)
-            out.append(SAMPLER.draw_host(L, L, sample_k))
+            out.append(SAMPLER.draw(L, L, sample_k, device))
         return out
 
     def forward(self, x_enc, idx_list=None, idx_group: int = 0):

@@ -167,7 +167,7 @@ class Routeformer(nn.Module):
                         visual[slot] = torch.zeros(video.shape[0], video.shape[1], c.image_embedding_size,
                                                    device=video.device)
                     else:
-                        jobs.append((slot, video, idx, self.frame_encoder.predraw(self._tokens_per_frame)))
+                        jobs.append((slot, video, idx, self.frame_encoder.predraw(self._tokens_per_frame, video.device)))
             drop_gaze = False
             if self.with_gaze:
                 if self.gaze_dropout > 0.0 and training:
@@ -180,7 +180,7 @@ class Routeformer(nn.Module):
                 else:
                     fv = batch["front_video"]
                     jobs.append((len(visual) - 1, fv, self._frame_indices(fv.shape[1], c.gaze_fps, "Gaze"),
-                                 self.frame_encoder.predraw(self._tokens_per_frame)))
+                                 self.frame_encoder.predraw(self._tokens_per_frame, fv.device)))
             for slot, timeline in self._encode_streams(jobs):
                 visual[slot] = timeline
             if self.with_gaze and not drop_gaze:
@@ -222,6 +222,14 @@ class Routeformer(nn.Module):
         assert rel > 0, f"{what} FPS must be a divisor of the output FPS"
         return torch.flip(torch.arange(T - 1, 0, -rel), dims=[0])  # last frame always in, frame 0 never
 
+    def _device_index(self, idx: torch.Tensor, dev) -> torch.Tensor:
+        """Frame indices on the device, cached (no host->device copy inside a captured step)."""
+        key = (tuple(idx.tolist()), str(dev))
+        cache = self.__dict__.setdefault("_idx_cache", {})
+        if key not in cache:
+            cache[key] = idx.to(dev)
+        return cache[key]
+
     def _encode_streams(self, jobs):
         """jobs: [(slot, video (B,T,3,H,W), frame idx, per-layer key samples)] -> [(slot, (B,T,E) timeline)].
 
@@ -249,13 +257,13 @@ class Routeformer(nn.Module):
                     toks.append(torch.cat([t, -torch.ones_like(t)[:, :1, :]], dim=1))
                 tokens = torch.cat(toks, dim=0)
             n_per = tokens.shape[0] // len(members)
-            idx_list = [torch.stack([m[3][layer] for m in members]).to(torch.int32).to(dev, non_blocking=True)
-                        for layer in range(len(members[0][3]))]
+            idx_list = [torch.stack([m[3][layer] for m in members]) for layer in range(len(members[0][3]))]
             K.TOPS.merge_forced(len(members), len(idx_list))  # test hooks only (no-ops in production)
             emb = self.frame_encoder(tokens.to(dtype), idx_list, n_per).view(len(members), B, -1, E)
             K.TOPS.split_record(len(members), len(idx_list))
+            idx_dev = self._device_index(idx, dev)
             for s_i, m in enumerate(members):
                 timeline = torch.zeros(B, T, E, device=dev)
-                timeline[:, idx.to(dev)] = emb[s_i]
+                timeline[:, idx_dev] = emb[s_i]
                 out.append((m[0], timeline))
         return out

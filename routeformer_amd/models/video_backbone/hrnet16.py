@@ -99,6 +99,7 @@ class HRNet16Backbone(VideoBackboneModule):
                 self._Backbone.put(bn + ".num_batches_tracked", torch.tensor(0, dtype=torch.long), buffer=True)
         self._folded: Optional[Dict[str, tuple]] = None
         self._folded_key = None
+        self._fidx_cache: Dict[tuple, torch.Tensor] = {}
 
     # ---- plugin contract ---------------------------------------------------------------------
     @property
@@ -260,8 +261,11 @@ class HRNet16Backbone(VideoBackboneModule):
         assert all(v.shape == videos[0].shape for v in videos)
         dev = videos[0].device
         if frame_idx is None:
-            frame_idx = torch.arange(T, device=dev, dtype=torch.int32)
-        frame_idx = frame_idx.to(device=dev, dtype=torch.int32)
+            frame_idx = torch.arange(T, dtype=torch.int32)
+        key = (tuple(frame_idx.tolist()), str(dev))
+        if key not in self._fidx_cache:  # cached: no host->device copy inside a captured step
+            self._fidx_cache[key] = frame_idx.to(device=dev, dtype=torch.int32)
+        frame_idx = self._fidx_cache[key]
         F_ = frame_idx.numel()
         n_each = B * F_
         N = n_each * len(videos)
