@@ -48,9 +48,11 @@ int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_
             float* preact, int64_t ldp, const float* dact_src, int64_t ldd, int dact_mode,
             int prec, int splitk, float* workspace, void* stream);
 
-/* out[n] = sum_m X[m*ldx + n] (bias gradients).  workspace: parts*N floats, parts = rf_colsum_parts(M,N). */
+/* out[n] (+)= sum_m X[m*ldx + n] (bias gradients; accumulate=1 adds into out, e.g. a slot of the flat
+ * gradient buffer).  workspace: parts*N floats, parts = rf_colsum_parts(M,N). */
 int rf_colsum_parts(int M, int N);
-int rf_colsum(const float* X, int64_t ldx, int M, int N, float* out, float* workspace, void* stream);
+int rf_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, float* workspace,
+              void* stream);
 
 /* ---- conv2d as implicit GEMM over NHWC (frozen HRNet-16 trunk, inference only) -------------
  * y[n,ho,wo,co] = act( sum_{kh,kw,ci} x[n,ho*s-p+kh,wo*s-p+kw,ci] * w[co,kh,kw,ci] + bias[co]
@@ -84,7 +86,9 @@ int rf_avgpool8_tokens(const float* x, float* tokens, int N, int H, int W, int C
 
 /* ---- sequence ops ---------------------------------------------------------------------------
  * Circular unfold for Conv1d(k=3, padding_mode="circular"): x (B,L,C) -> cols (B,Lout,3C),
- * Lout = L + 2*pad - 2, cols[b,l,t*C+c] = x[b,(l+t-pad) mod L,c]; fold is its adjoint (gradient).
+ * Lout = L + 2*pad - 2, cols[b,l,c*3+t] = x[b,(l+t-pad) mod L,c] -- (c,t) order = the memory order of a
+ * Conv1d weight (d,c,3), so the weight is used (and its gradient written) in place as a (d,3c) matrix;
+ * fold is the adjoint (gradient).
  * cross_modal_transformer.py:352-369; layers/Embedding.py:28-46; TransformerEncoderDecoder.py:12-18. */
 int rf_unfold3_circular(const float* x, float* cols, int B, int L, int C, int pad, void* stream);
 int rf_fold3_circular(const float* dcols, float* dx, int B, int L, int C, int pad, void* stream);
@@ -94,11 +98,11 @@ int rf_fold3_circular(const float* dcols, float* dx, int B, int L, int C, int pa
 int rf_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
                      float* y, float* xhat, float* rstd, int rows, int cols, float eps, void* stream);
 /* dx = d(loss)/d(s); dgamma/dbeta reduced deterministically through `workspace`
- * (rf_layernorm_bwd_parts(rows)*2*cols floats). */
+ * (rf_layernorm_bwd_parts(rows)*2*cols floats); accumulate=1 adds them into dgamma/dbeta. */
 int rf_layernorm_bwd_parts(int rows);
 int rf_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma,
-                     float* dx, float* dgamma, float* dbeta, float* workspace, int rows, int cols,
-                     void* stream);
+                     float* dx, float* dgamma, float* dbeta, int accumulate, float* workspace, int rows,
+                     int cols, void* stream);
 
 /* Informer distilling layer tail: BatchNorm1d (train: batch stats, eval: running stats) -> ELU ->
  * MaxPool1d(3,2,1) on (B,L,C), C innermost.  layers/TransformerEncoderDecoder.py:19-28.

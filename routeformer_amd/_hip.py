@@ -19,7 +19,7 @@ SIGNATURES = {
     "rf_gemm": [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _I, _P, _L, _P, _L,
                 _I, _I, _I, _P, _P],
     "rf_colsum_parts": [_I, _I],
-    "rf_colsum": [_P, _L, _I, _I, _P, _P, _P],
+    "rf_colsum": [_P, _L, _I, _I, _P, _I, _P, _P],
     "rf_conv2d_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _I, _I, _P],
     "rf_stem_conv0": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "rf_upsample_bilinear_nhwc": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _I, _I, _P],
@@ -29,7 +29,7 @@ SIGNATURES = {
     "rf_fold3_circular": [_P, _P, _I, _I, _I, _I, _P],
     "rf_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "rf_layernorm_bwd_parts": [_I],
-    "rf_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "rf_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P],
     "rf_bn_stats": [_P, _P, _P, _I, _I, _P],
     "rf_bn_elu_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
     "rf_bn_elu_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],

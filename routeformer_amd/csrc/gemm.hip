@@ -371,18 +371,19 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
   __syncthreads();
   if (ty == 0 && n < N) part[(long)blockIdx.y * N + n] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int parts, int N, float* __restrict__ out) {
+__global__ void colsum_final_kernel(const float* __restrict__ part, int parts, int N, float* __restrict__ out,
+                                    int accumulate) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float s = 0.f;
   for (int i = 0; i < parts; ++i) s += part[(long)i * N + n];
-  out[n] = s;
+  out[n] = accumulate ? out[n] + s : s;
 }
 }  // namespace
 
 extern "C" int rf_colsum_parts(int M, int N) { (void)N; return (M + CS_ROWS - 1) / CS_ROWS; }
 
-extern "C" int rf_colsum(const float* X, int64_t ldx, int M, int N, float* out, float* workspace,
+extern "C" int rf_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, float* workspace,
                          void* stream) {
   RF_REQUIRE(X && out && workspace && M > 0 && N > 0);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -390,7 +391,7 @@ extern "C" int rf_colsum(const float* X, int64_t ldx, int M, int N, float* out, 
   hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 63) / 64, parts), dim3(256), 0, st, X, (long)ldx, M, N,
                      workspace);
   RF_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, workspace, parts, N, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, workspace, parts, N, out, accumulate);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 // block = 64 columns x 4 part-lanes: sums the per-block partials of layernorm_bwd_kernel
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ ws, int parts, int cols,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int accumulate) {
   __shared__ float red[2][4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -119,8 +120,10 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
   red[1][ty][tx] = b;
   __syncthreads();
   if (ty == 0 && c < cols) {
-    dgamma[c] = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
-    dbeta[c] = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+    const float g = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+    const float bt = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+    dgamma[c] = accumulate ? dgamma[c] + g : g;
+    dbeta[c] = accumulate ? dbeta[c] + bt : bt;
   }
 }
 
@@ -128,9 +131,9 @@ __global__ void unfold3_kernel(const float* __restrict__ x, float* __restrict__ 
                                int Lout) {
   const long total = (long)B * Lout * 3 * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    long r = i / C;
-    const int t = (int)(r % 3); r /= 3;
+    const int t = (int)(i % 3);
+    long r = i / 3;
+    const int c = (int)(r % C); r /= C;
     const int l = (int)(r % Lout);
     const int b = (int)(r / Lout);
     int src = (l + t - pad) % L;
@@ -152,7 +155,7 @@ __global__ void fold3_kernel(const float* __restrict__ dcols, float* __restrict_
     for (int t = 0; t < 3; ++t) {
       int lo = (l - t + pad) % L;
       if (lo < 0) lo += L;
-      for (; lo < Lout; lo += L) s += dcols[(((long)b * Lout + lo) * 3 + t) * C + c];
+      for (; lo < Lout; lo += L) s += dcols[(((long)b * Lout + lo) * C + c) * 3 + t];
     }
     dx[i] = s;
   }
@@ -279,7 +282,8 @@ extern "C" int rf_layernorm_bwd_parts(int rows) {
 }
 
 extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,
-                                float* dgamma, float* dbeta, float* workspace, int rows, int cols, void* stream) {
+                                float* dgamma, float* dbeta, int accumulate, float* workspace, int rows, int cols,
+                                void* stream) {
   RF_REQUIRE(dy && xhat && rstd && gamma && dx && dgamma && dbeta && workspace);
   RF_REQUIRE(rows > 0 && cols > 0 && cols <= 64 * LN_MAXV);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -288,7 +292,7 @@ extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float*
                      cols);
   RF_CHECK_LAUNCH();
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, workspace, parts, cols,
-                     dgamma, dbeta);
+                     dgamma, dbeta, accumulate);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

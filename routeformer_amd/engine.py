@@ -71,8 +71,19 @@ class GradReducer:
     Parameters are laid out in REVERSE registration order so buckets fill in roughly the order
     backward produces gradients (GPS backbone first, frame encoder last)."""
 
-    def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 32.0, group=None):
-        self.params = list(reversed(params))
+    def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 32.0, group=None, groups=()):
+        """``groups``: lists of parameters that must sit back to back, in the given order (e.g. the Q, K, V
+        projection weights of one attention layer, so they can be used as ONE packed matrix)."""
+        order = list(reversed(params))
+        member = {id(p): g for g in groups for p in g}
+        seen, laid = set(), []
+        for p in order:  # keep reverse-registration order, but emit a whole group at its first member
+            if id(p) in seen:
+                continue
+            for q in member.get(id(p), [p]):
+                seen.add(id(q))
+                laid.append(q)
+        self.params = laid
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         dev = self.params[0].device
@@ -83,12 +94,15 @@ class GradReducer:
         cap = max(1, int(bucket_mb * (1 << 20) / 4))
         self.buckets: List[tuple] = []  # (start, end)
         self._bucket_of: Dict[int, int] = {}
+        self.offset: Dict[int, int] = {}
         off, b_start = 0, 0
         for p in self.params:
             n = p.numel()
             self.flat_param[off:off + n].copy_(p.detach().reshape(-1))
             p.data = self.flat_param[off:off + n].view_as(p)
             p.grad = self.flat_grad[off:off + n].view_as(p)
+            p._rf_grad = p.grad  # gradient sink picked up by routeformer_amd.kernels
+            self.offset[id(p)] = off
             self._bucket_of[id(p)] = len(self.buckets)
             off += -(-n // ALIGN) * ALIGN
             if off - b_start >= cap:
@@ -102,9 +116,35 @@ class GradReducer:
         self._pending = list(self._members)
         self._launched = [False] * len(self.buckets)
         self._works: List = []
+        self._starts = sorted((self.offset[id(p)], id(p)) for p in self.params)
         if self.world > 1:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def on_sink_write(self, view):
+        """A kernel accumulated straight into ``view`` (a slice of flat_grad): same bookkeeping as the
+        autograd hook, for every parameter slot the view covers (packed Q/K/V views cover three)."""
+        import bisect
+        lo = (view.data_ptr() - self.flat_grad.data_ptr()) // 4
+        hi = lo + view.numel()
+        i = bisect.bisect_left(self._starts, (lo, 0))
+        while i < len(self._starts) and self._starts[i][0] < hi:
+            b = self._bucket_of[self._starts[i][1]]
+            self._pending[b] -= 1
+            if self._pending[b] == 0 and not self._launched[b]:
+                self._launch(b)
+            i += 1
+
+    def packed_view(self, group):
+        """(param view, grad view) spanning a contiguous group, or None if padding separates its members."""
+        start = self.offset[id(group[0])]
+        off = start
+        for p in group:
+            if self.offset[id(p)] != off:
+                return None
+            off += p.numel()
+        shape = (sum(p.shape[0] for p in group),) + tuple(group[0].shape[1:])
+        return self.flat_param[start:off].view(shape), self.flat_grad[start:off].view(shape)
 
     # -- per-step protocol: zero() -> backward -> finish() -----------------------------------------
     def zero(self):
@@ -174,7 +214,14 @@ class TrainEngine:
     def __init__(self, model, lr=None, weight_decay=None, max_grad_norm: float = 2.5, bucket_mb: float = 32.0):
         self.model = model
         cfg = model.configs
-        self.reducer = GradReducer(trainable_parameters(model), bucket_mb)
+        layers = [m for m in model.modules() if hasattr(m, "packing_groups")]
+        groups = [g for m in layers for g in m.packing_groups()]
+        self.reducer = GradReducer(trainable_parameters(model), bucket_mb, groups=groups)
+        for m in layers:  # hand each attention layer its packed [Wq;Wk;Wv] / [bq;bk;bv] views
+            gw, gb = m.packing_groups()
+            vw, vb = self.reducer.packed_view(gw), self.reducer.packed_view(gb)
+            if vw is not None and vb is not None:
+                m._packed = {"w": vw[0], "gw": vw[1], "b": vb[0], "gb": vb[1]}
         self.reducer.broadcast_parameters(0)
         self.opt = FusedAdamW(self.reducer.flat_param, self.reducer.flat_grad,
                               lr=cfg.lr if lr is None else lr,
@@ -183,11 +230,21 @@ class TrainEngine:
         self.tl = FutureDiscountedLoss(cfg.discount_factor, cfg.epsilon, loss_function="smooth_l1")
         self.dl = FutureDiscountedLoss(cfg.discount_factor, cfg.visual_epsilon, loss_function="smooth_l1")
 
+    def _fwd_bwd(self, item, epoch):
+        from routeformer_amd import kernels as K
+        self.reducer.zero()
+        K.SINK.active = True  # kernels accumulate parameter gradients straight into the flat buffer
+        K.SINK.on_write = self.reducer.on_sink_write if self.reducer.world > 1 else None
+        try:
+            res = train_step_losses(self.model, item, epoch, self.tl, self.dl)
+            res["loss"].backward()
+        finally:
+            K.SINK.active, K.SINK.on_write = False, None
+        return res
+
     def step(self, item, epoch: int = 0):
         self.model.train()
-        self.reducer.zero()
-        res = train_step_losses(self.model, item, epoch, self.tl, self.dl)
-        res["loss"].backward()
+        res = self._fwd_bwd(item, epoch)
         scale = self.reducer.finish()
         self.opt.step(scale)
         return res
@@ -214,10 +271,7 @@ class GraphedTrainEngine(TrainEngine):
             raise ValueError("GraphedTrainEngine needs a draw-independent step (all dropouts / noise 0)")
 
     def _eager_fwd_bwd(self, item, epoch):
-        self.reducer.zero()
-        res = train_step_losses(self.model, item, epoch, self.tl, self.dl)
-        res["loss"].backward()
-        return res
+        return self._fwd_bwd(item, epoch)
 
     def capture(self, item, epoch: int = 0, warmup: int = 2):
         from routeformer_amd.models.blocks import SAMPLER

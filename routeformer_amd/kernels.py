@@ -104,23 +104,59 @@ def gemm(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, *, bias=None, residu
         PROFILE.end("gemm", ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N))
 
 
-def colsum(X2d: torch.Tensor) -> torch.Tensor:
+def colsum(X2d: torch.Tensor, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Column sums; ``into`` = slot of the flat gradient buffer to ACCUMULATE into (returns None then)."""
     M, N = X2d.shape
-    out = torch.empty(N, device=X2d.device, dtype=torch.float32)
+    out = into if into is not None else torch.empty(N, device=X2d.device, dtype=torch.float32)
     parts = _hip.lib().rf_colsum_parts(M, N)
     ws = torch.empty(parts * N, device=X2d.device, dtype=torch.float32)
-    check(_hip.lib().rf_colsum(ptr(X2d), X2d.stride(0), M, N, ptr(out), ptr(ws), _stream()), "rf_colsum")
-    return out
+    check(_hip.lib().rf_colsum(ptr(X2d), X2d.stride(0), M, N, ptr(out), 1 if into is not None else 0, ptr(ws),
+                               _stream()), "rf_colsum")
+    return None if into is not None else out
 
 
-def _weight_grad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
-    """dW[N,K] = dY[M,N]^T X[M,K]  (split-K over the row dimension M)."""
+def _weight_grad(dy2: torch.Tensor, x2: torch.Tensor, into: Optional[torch.Tensor] = None):
+    """dW[N,K] = dY[M,N]^T X[M,K]  (split-K over the row dimension M).  ``into``: accumulate straight into
+    that (N,K)-shaped slot of the flat gradient buffer (epilogue residual = the slot itself)."""
     M, N = dy2.shape
     K = x2.shape[1]
-    dw = torch.empty(N, K, device=dy2.device, dtype=torch.float32)
     tiles = -(-N // 64) * -(-K // 64)
+    if into is not None:
+        gemm(dy2, 1, dy2.stride(0), x2, x2.stride(0), 1, into, K, N, K, M, residual=into, ldr=K, res_rows=N,
+             splitk=_splits(tiles, M))
+        return None
+    dw = torch.empty(N, K, device=dy2.device, dtype=torch.float32)
     gemm(dy2, 1, dy2.stride(0), x2, x2.stride(0), 1, dw, K, N, K, M, splitk=_splits(tiles, M))
     return dw
+
+
+class _Sink:
+    """Gradient sinks: when the training engine owns a flat gradient buffer it tags every trainable
+    parameter with ``_rf_grad`` (its slot).  Kernels then ACCUMULATE weight / bias / gain gradients
+    straight into the slot (the buffer is zeroed once per step) instead of materialising a temporary that
+    autograd adds in -- one launch and one round trip less per parameter per step."""
+    active = False
+    on_write = None  # callback(view) after a slot has been written (DP: bucket-ready bookkeeping)
+
+
+SINK = _Sink()
+
+
+def _wrote(*views):
+    if SINK.on_write is not None:
+        for v in views:
+            if v is not None:
+                SINK.on_write(v)
+
+
+def _slot(t, shape=None):
+    """The flat-buffer slot of parameter ``t`` (viewed as ``shape``) or None."""
+    if not SINK.active or t is None:
+        return None
+    g = getattr(t, "_rf_grad", None)
+    if g is None:
+        return None
+    return g if shape is None else g.view(shape)
 
 
 def _input_grad(dy2: torch.Tensor, w: torch.Tensor, **epi) -> torch.Tensor:
@@ -133,10 +169,10 @@ def _input_grad(dy2: torch.Tensor, w: torch.Tensor, **epi) -> torch.Tensor:
 
 
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b (+ residual broadcast over row blocks)."""
+    """y = x W^T + b (+ residual rows broadcast over the batch: y[m] += residual[m % R])."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, residual, gw, gb):
         _req(x, "linear.x"); _req(w, "linear.w")
         K = x.shape[-1]
         N = w.shape[0]
@@ -146,8 +182,14 @@ class _Linear(torch.autograd.Function):
         w = w.contiguous()
         M = x2.shape[0]
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
-        gemm(x2, x2.stride(0), 1, w, 1, K, y, N, M, N, K, bias=b)
+        if residual is not None:
+            r2 = residual.reshape(-1, N).contiguous()
+            gemm(x2, x2.stride(0), 1, w, 1, K, y, N, M, N, K, bias=b, residual=r2, ldr=N, res_rows=r2.shape[0])
+            ctx.res_rows, ctx.res_shape = r2.shape[0], residual.shape
+        else:
+            gemm(x2, x2.stride(0), 1, w, 1, K, y, N, M, N, K, bias=b)
         ctx.save_for_backward(x2, w)
+        ctx.sinks = (gw, gb)  # plain attributes: slots of a buffer other kernels also write (no version check)
         ctx.has_bias = b is not None
         ctx.xshape = x.shape
         return y.view(*x.shape[:-1], N)
@@ -155,21 +197,32 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
+        gw, gb = ctx.sinks
         dy2 = dy.reshape(-1, dy.shape[-1])
         if dy2.stride(1) != 1 or dy2.stride(0) != dy2.shape[1]:
             dy2 = dy2.contiguous()
-        dx = dw = db = None
+        dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = _input_grad(dy2, w).view(ctx.xshape)
-        if ctx.needs_input_grad[1]:
-            dw = _weight_grad(dy2, x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy2)
-        return dx, dw, db
+        if gw is not None or ctx.needs_input_grad[1]:
+            dw = _weight_grad(dy2, x2, into=gw)
+        if ctx.has_bias and (gb is not None or ctx.needs_input_grad[2]):
+            db = colsum(dy2, into=gb)
+        _wrote(gw, gb)
+        if ctx.needs_input_grad[3]:  # residual rows are shared by M / R row blocks
+            dres = colsum(dy2.view(-1, ctx.res_rows * dy2.shape[1])).view(ctx.res_shape)
+        return dx, dw, db, dres, None, None
 
 
-def linear(x, w, b=None):
-    return _Linear.apply(x, w, b)
+def linear(x, w, b=None, residual=None):
+    """``w`` / ``b`` may be parameters (gradient sinks are picked up from them) or plain views."""
+    return _Linear.apply(x, w, b, residual, _slot(w), _slot(b))
+
+
+def linear_packed(x, w, b, gw, gb):
+    """Linear over a packed (non-parameter) weight view, e.g. [Wq;Wk;Wv] in the flat buffer; gradients go
+    to the matching packed gradient views."""
+    return _Linear.apply(x, w, b, None, gw, gb)
 
 
 class _FFN(torch.autograd.Function):
@@ -177,13 +230,13 @@ class _FFN(torch.autograd.Function):
     The activation and its derivative ride in GEMM epilogues."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act: str):
+    def forward(ctx, x, w1, b1, w2, b2, act: str, g1, gb1, g2, gb2):
         _req(x, "ffn.x")
-        D, F = w1.shape[1], w1.shape[0]
+        F, D = w1.shape[0], w1.shape[1]
+        w1, w2 = w1.reshape(F, D), w2.reshape(D, F)  # Conv1d(k=1) weights (out,in,1) viewed as matrices
         x2 = x.reshape(-1, D)
         if x2.stride(1) != 1:
             x2 = x2.contiguous()
-        w1, w2 = w1.contiguous(), w2.contiguous()
         M = x2.shape[0]
         h = torch.empty(M, F, device=x.device, dtype=torch.float32)
         z = torch.empty_like(h) if act == "gelu" else None
@@ -191,36 +244,45 @@ class _FFN(torch.autograd.Function):
         y = torch.empty(M, D, device=x.device, dtype=torch.float32)
         gemm(h, F, 1, w2, 1, F, y, D, M, D, F, bias=b2)
         ctx.save_for_backward(x2, w1, w2, h, z if z is not None else h)
+        ctx.sinks = (g1, gb1, g2, gb2)
         ctx.act = act
         ctx.xshape = x.shape
+        ctx.wshapes = (F, D)
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
         x2, w1, w2, h, zsrc = ctx.saved_tensors
-        D = w1.shape[1]
+        g1, gb1, g2, gb2 = ctx.sinks
+        F, D = ctx.wshapes
         dy2 = dy.reshape(-1, D)
         if dy2.stride(1) != 1 or dy2.stride(0) != D:
             dy2 = dy2.contiguous()
         # dZ = (dY W2) * act'(Z)   (relu: mask from H > 0; gelu: from the saved pre-activation)
         dz = _input_grad(dy2, w2, dact_src=zsrc, ldd=zsrc.stride(0), dact=ACT[ctx.act])
-        dw2 = _weight_grad(dy2, h)
-        db2 = colsum(dy2)
-        dw1 = _weight_grad(dz, x2)
-        db1 = colsum(dz)
+        dw2 = _weight_grad(dy2, h, into=None if g2 is None else g2.view(D, F))
+        db2 = colsum(dy2, into=gb2)
+        dw1 = _weight_grad(dz, x2, into=None if g1 is None else g1.view(F, D))
+        db1 = colsum(dz, into=gb1)
         dx = _input_grad(dz, w1).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        return dx, dw1, db1, dw2, db2, None
+        _wrote(g1, gb1, g2, gb2)
+        if dw1 is not None:
+            dw1, dw2 = dw1.view(F, D, 1), dw2.view(D, F, 1)
+        return dx, dw1, db1, dw2, db2, None, None, None, None, None
 
 
-def ffn(x, w1, b1, w2, b2, act: str):
-    return _FFN.apply(x, w1, b1, w2, b2, act)
+def ffn(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str):
+    """conv*_w: the Conv1d(k=1) weight parameters, shape (out, in, 1)."""
+    assert conv1_w.dim() == 3 and conv2_w.dim() == 3
+    return _FFN.apply(x, conv1_w, conv1_b, conv2_w, conv2_b, act, _slot(conv1_w), _slot(conv1_b),
+                      _slot(conv2_w), _slot(conv2_b))
 
 
 class _AddLayerNorm(torch.autograd.Function):
     """y = LayerNorm(x + residual) (eps 1e-5); residual optional."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps):
+    def forward(ctx, x, residual, gamma, beta, eps, gg, gb):
         _req(x, "layernorm.x")
         cols = x.shape[-1]
         x2 = x.reshape(-1, cols).contiguous()
@@ -235,6 +297,7 @@ class _AddLayerNorm(torch.autograd.Function):
         if ev is not None:
             PROFILE.end("layernorm_fwd", ev, 8.0 * rows * cols, 4.0 * rows * cols * (4 if r2 is not None else 3))
         ctx.save_for_backward(xhat, rstd, gamma)
+        ctx.sinks = (gg, gb)
         ctx.has_res = residual is not None
         ctx.xshape = x.shape
         return y.view(x.shape)
@@ -242,24 +305,30 @@ class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         xhat, rstd, gamma = ctx.saved_tensors
+        gg, gb = ctx.sinks
         rows, cols = xhat.shape
         dy2 = dy.reshape(rows, cols).contiguous()
         dx = torch.empty_like(xhat)
-        dg = torch.empty(cols, device=dy.device, dtype=torch.float32)
-        db = torch.empty(cols, device=dy.device, dtype=torch.float32)
+        sink = gg is not None and gb is not None
+        dg = gg if sink else torch.empty(cols, device=dy.device, dtype=torch.float32)
+        db = gb if sink else torch.empty(cols, device=dy.device, dtype=torch.float32)
         parts = _hip.lib().rf_layernorm_bwd_parts(rows)
         ws = torch.empty(parts * 2 * cols, device=dy.device, dtype=torch.float32)
         ev = PROFILE.begin() if PROFILE.on else None
         check(_hip.lib().rf_layernorm_bwd(ptr(dy2), ptr(xhat), ptr(rstd), ptr(gamma), ptr(dx), ptr(dg),
-                                          ptr(db), ptr(ws), rows, cols, _stream()), "rf_layernorm_bwd")
+                                          ptr(db), 1 if sink else 0, ptr(ws), rows, cols, _stream()),
+              "rf_layernorm_bwd")
         if ev is not None:
             PROFILE.end("layernorm_bwd", ev, 12.0 * rows * cols, 4.0 * rows * cols * 3)
         dx = dx.view(ctx.xshape)
-        return dx, (dx if ctx.has_res else None), dg, db, None
+        if sink:
+            _wrote(gg, gb)
+            dg = db = None
+        return dx, (dx if ctx.has_res else None), dg, db, None, None, None
 
 
 def add_layer_norm(x, residual, gamma, beta, eps: float = 1e-5):
-    return _AddLayerNorm.apply(x, residual, gamma, beta, eps)
+    return _AddLayerNorm.apply(x, residual, gamma, beta, eps, _slot(gamma), _slot(beta))
 
 
 class _Unfold3(torch.autograd.Function):
@@ -284,11 +353,14 @@ class _Unfold3(torch.autograd.Function):
         return dx, None
 
 
-def circular_conv3(x, weight, bias=None, pad: int = 1):
-    """Conv1d(k=3, padding_mode='circular') on channels-last sequences: weight (d, c, 3)."""
+def circular_conv3(x, weight, bias=None, pad: int = 1, residual=None):
+    """Conv1d(k=3, padding_mode='circular') on channels-last sequences: weight (d, c, 3), used in place as
+    a (d, 3c) matrix (the unfold emits columns in the weight's own (c, t) memory order).
+    ``residual`` (L_out, d): added to every sequence (positional / time-feature table)."""
     cols = _Unfold3.apply(x, pad)
-    w2 = weight.permute(0, 2, 1).reshape(weight.shape[0], -1)  # [d][t*C + c]
-    return linear(cols, w2, bias)
+    d = weight.shape[0]
+    return _Linear.apply(cols, weight.view(d, -1), bias, residual, _slot(weight, (d, weight.shape[1] * 3)),
+                         _slot(bias))
 
 
 class _BnEluPool(torch.autograd.Function):

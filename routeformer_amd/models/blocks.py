@@ -128,8 +128,8 @@ class TokenEmbedding(nn.Module):
                                    bias=bias)
         nn.init.kaiming_normal_(self.tokenConv.weight, mode="fan_in", nonlinearity="leaky_relu")
 
-    def forward(self, x):
-        return K.circular_conv3(x, self.tokenConv.weight, self.tokenConv.bias, pad=1)
+    def forward(self, x, residual=None):
+        return K.circular_conv3(x, self.tokenConv.weight, self.tokenConv.bias, pad=1, residual=residual)
 
 
 class _TimeFeature(nn.Module):
@@ -153,7 +153,7 @@ class DataEmbedding(nn.Module):
         mark = torch.arange(L, device=x.device, dtype=torch.float32).view(1, L, 1)
         # rank-1 time feature + table: (1,L,d) host-side plumbing, broadcast over the batch
         offset = mark * self.temporal_embedding.embed.weight.view(1, 1, -1) + self.position_embedding(L)
-        return _dropout(self.value_embedding(x) + offset, self.p, self.training)
+        return _dropout(self.value_embedding(x, residual=offset[0]), self.p, self.training)
 
 
 class AttentionLayer(nn.Module):
@@ -173,6 +173,11 @@ class AttentionLayer(nn.Module):
         self.n_heads, self.kind, self.factor = n_heads, kind, factor
         self.gps_variant, self.mix, self.attn_dropout = gps_variant, mix, attn_dropout
 
+    def packing_groups(self):
+        """Parameters the training engine should lay out back to back (in this order) in its flat buffers."""
+        q, k, v = self.query_projection, self.key_projection, self.value_projection
+        return [[q.weight, k.weight, v.weight], [q.bias, k.bias, v.bias]]
+
     def forward(self, x, memory=None, idx=None, idx_group: int = 0):
         """Self-attention when ``memory is None`` (one packed QKV GEMM), else queries from ``x`` and
         keys/values from ``memory`` (packed KV GEMM).  ``idx`` (G,L,k) int32 on the device = pre-drawn
@@ -182,18 +187,25 @@ class AttentionLayer(nn.Module):
         qp, kp, vp = self.query_projection, self.key_projection, self.value_projection
         HE = qp.weight.shape[0]
         E = HE // H
+        pk = self.__dict__.get("_packed") if K.SINK.active else None
         if memory is None:
             S = L
-            w = torch.cat([qp.weight, kp.weight, vp.weight], dim=0)
-            b = torch.cat([qp.bias, kp.bias, vp.bias], dim=0)
-            a = bm = K.linear(x.reshape(B * L, -1), w, b)
+            if pk is not None:  # [Wq;Wk;Wv] are adjacent in the engine's flat buffers: no cat, one dW GEMM
+                a = bm = K.linear_packed(x.reshape(B * L, -1), pk["w"], pk["b"], pk["gw"], pk["gb"])
+            else:
+                w = torch.cat([qp.weight, kp.weight, vp.weight], dim=0)
+                b = torch.cat([qp.bias, kp.bias, vp.bias], dim=0)
+                a = bm = K.linear(x.reshape(B * L, -1), w, b)
             offs = (0, HE, 2 * HE)
         else:
             S = memory.shape[1]
             a = K.linear(x.reshape(B * L, -1), qp.weight, qp.bias)
-            w = torch.cat([kp.weight, vp.weight], dim=0)
-            b = torch.cat([kp.bias, vp.bias], dim=0)
-            bm = K.linear(memory.reshape(B * S, -1), w, b)
+            if pk is not None:
+                bm = K.linear_packed(memory.reshape(B * S, -1), pk["w"][HE:], pk["b"][HE:], pk["gw"][HE:], pk["gb"][HE:])
+            else:
+                w = torch.cat([kp.weight, vp.weight], dim=0)
+                b = torch.cat([kp.bias, vp.bias], dim=0)
+                bm = K.linear(memory.reshape(B * S, -1), w, b)
             offs = (0, 0, HE)
         dims = (B, H, L, S, E)
         layout = 1 if self.gps_variant else 0
@@ -230,8 +242,7 @@ class EncoderLayer(nn.Module):
     def _ffn(self, x):
         if self.p > 0.0 and self.training:
             raise NotImplementedError("dropout inside the fused FFN is not implemented; use dropout=0")
-        return K.ffn(x, self.conv1.weight.squeeze(-1), self.conv1.bias, self.conv2.weight.squeeze(-1),
-                     self.conv2.bias, self.act)
+        return K.ffn(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.act)
 
     def forward(self, x, idx=None, idx_group: int = 0):
         x = K.add_layer_norm(x, _dropout(self.attention(x, idx=idx, idx_group=idx_group), self.p, self.training),
@@ -345,7 +356,7 @@ class PerceiveEncoder(nn.Module):
     def forward(self, x_enc, idx_list=None, idx_group: int = 0):
         """``idx_list``: per layer a (G,L,k) int32 device tensor of pre-drawn key samples (several
         reference calls batched into one: rows [g*idx_group, (g+1)*idx_group) use table g)."""
-        h = self.value_embedding(x_enc) + self.position_embedding(x_enc.shape[1])
+        h = self.value_embedding(x_enc, residual=self.position_embedding(x_enc.shape[1])[0])
         h = self.encoder(h, idx_list, idx_group)
         # only the last pred_len tokens are consumed: project just those rows
         return K.linear(h[:, -self.pred_len:, :], self.projection.weight, self.projection.bias)
@@ -371,6 +382,6 @@ class PerceiveDecoder(nn.Module):
         self.projection = nn.Linear(d_model, out_channels, bias=True)
 
     def forward(self, x_enc, x_dec):
-        h = self.value_embedding(x_dec) + self.position_embedding(x_dec.shape[1])
+        h = self.value_embedding(x_dec, residual=self.position_embedding(x_dec.shape[1])[0])
         h = self.decoder(h, x_enc)
         return K.linear(h[:, -self.pred_len:, :], self.projection.weight, self.projection.bias)

@@ -92,11 +92,12 @@ def test_linear_ffn_autograd(prec, tol):
     g = _g(11)
     for act in ("relu", "gelu"):
         x = torch.randn(3, 65, 128, generator=g)
-        w1, b1 = torch.randn(256, 128, generator=g) / 11, torch.randn(256, generator=g) * 0.1
-        w2, b2 = torch.randn(128, 256, generator=g) / 16, torch.randn(128, generator=g) * 0.1
+        w1, b1 = torch.randn(256, 128, 1, generator=g) / 11, torch.randn(256, generator=g) * 0.1  # Conv1d(k=1)
+        w2, b2 = torch.randn(128, 256, 1, generator=g) / 16, torch.randn(128, generator=g) * 0.1
         cpu = [a.clone().requires_grad_() for a in (x, w1, b1, w2, b2)]
         dev = [a.clone().to(DEV).requires_grad_() for a in (x, w1, b1, w2, b2)]
-        yc = F.linear((F.relu if act == "relu" else F.gelu)(F.linear(cpu[0], cpu[1], cpu[2])), cpu[3], cpu[4])
+        yc = F.linear((F.relu if act == "relu" else F.gelu)(F.linear(cpu[0], cpu[1].squeeze(-1), cpu[2])),
+                      cpu[3].squeeze(-1), cpu[4])
         yd = Kn.ffn(dev[0], dev[1], dev[2], dev[3], dev[4], act)
         wgt = torch.randn(yc.shape, generator=g)
         (yc * wgt).sum().backward()

@@ -295,3 +295,25 @@ def test_graphed_step_matches_eager():
     assert rel_err(gg, ge) < 1e-4
     # AdamW turns rounding-level noise on near-zero gradients into +-lr steps, hence the looser bound here
     assert rel_err(pg, pe) < 3 * 3 * 1e-3
+
+
+def test_engine_sinks_match_autograd():
+    """Gradient sinks (kernels accumulate straight into the flat buffer, packed QKV) give the same
+    gradients as plain autograd accumulation on the same model and batch."""
+    from routeformer_amd.engine import TrainEngine, train_step_losses, trainable_parameters
+    model, cfg, sd, c = build_product_model("c2_small", DEV)
+    item = case_item(c)
+    item_d = {"train": _to_dev(item["train"]), "target": _to_dev(item["target"])}
+    model.train()
+    torch.manual_seed(5)
+    train_step_losses(model, item_d, 10)["loss"].backward()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    eng = TrainEngine(model)
+    assert any("_packed" in m.__dict__ for m in model.modules()), "no attention layer got packed QKV views"
+    torch.manual_seed(5)
+    eng._fwd_bwd(item_d, 10)
+    for n, p in model.named_parameters():
+        if n in ref:
+            assert rel_err(p.grad, ref[n]) < 2e-5, n
+    assert set(ref) == {n for n, p in model.named_parameters() if "video_backbone" not in n}
