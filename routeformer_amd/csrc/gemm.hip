@@ -254,6 +254,266 @@ __global__ void splitk_reduce_kernel(GemmP p, int splits) {
   }
 }
 
+// =============================================================================================
+// v2: software-pipelined variant.  Same tiles / fragments / epilogue, but
+//   * BK = 64 (bf16) / 32 (f32) per stage, two LDS stages;
+//   * the global loads of stage t+1 are issued into registers BEFORE the MFMAs of stage t and
+//     written to the other LDS stage after them -> one barrier per K-step, HBM/L2 latency hidden
+//     behind the matrix work of the same workgroup (these GEMMs run at ~1-2 workgroups per CU, so
+//     there is little thread-level parallelism to hide it otherwise);
+//   * extra tile config 3 = 128x64 (4x1 waves, 2x4 tiles) for the tall activations (M >= 4096).
+// Used whenever both operands are 16-B vectorizable (modes 0/1) and for the implicit-GEMM convs.
+// =============================================================================================
+template <> struct Cfg<3> { static constexpr int WM = 4, WN = 1, TM = 2, TN = 4; };
+
+template <int PREC> struct Lds2;
+template <> struct Lds2<0> { using T = float; static constexpr int BKV = 32, LD = 34; };
+template <> struct Lds2<1> { using T = __bf16; static constexpr int BKV = 64, LD = 72; };
+
+template <typename T> __device__ __forceinline__ void st4(T* s, const float4& v);
+template <> __device__ __forceinline__ void st4<float>(float* s, const float4& v) {
+  *reinterpret_cast<float2*>(s) = make_float2(v.x, v.y);
+  *reinterpret_cast<float2*>(s + 2) = make_float2(v.z, v.w);
+}
+template <> __device__ __forceinline__ void st4<__bf16>(__bf16* s, const float4& v) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  *reinterpret_cast<bf16x4*>(s) = o;
+}
+
+// global -> registers (NV float4 per thread) for a ROWS x BKV tile; MODE 0: k contiguous, 1: row contiguous
+template <int ROWS, int BKV, int MODE, int NV>
+__device__ __forceinline__ void gload(float4 (&r)[NV], const float* __restrict__ G, long ld_row, long ld_k,
+                                      int row0, int nrows, int k0, int kend, int tid) {
+#pragma unroll
+  for (int s = 0; s < NV; ++s) {
+    const int i = tid + s * NT;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (MODE == 0) {
+      constexpr int VPR = BKV / 4;
+      const int rr = i / VPR, kv = (i % VPR) * 4;
+      const int gr = row0 + rr, gk = k0 + kv;
+      if (i < ROWS * VPR && gr < nrows && gk < kend) {
+        const float* p = G + (long)gr * ld_row + gk;
+        if (gk + 3 < kend) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          v.x = p[0];
+          if (gk + 1 < kend) v.y = p[1];
+          if (gk + 2 < kend) v.z = p[2];
+        }
+      }
+    } else {
+      constexpr int VPK = ROWS / 4;
+      const int k = i / VPK, rv = (i % VPK) * 4;
+      const int gr = row0 + rv, gk = k0 + k;
+      if (i < BKV * VPK && gk < kend && gr < nrows) {
+        const float* p = G + (long)gk * ld_k + gr;
+        if (gr + 3 < nrows) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          v.x = p[0];
+          if (gr + 1 < nrows) v.y = p[1];
+          if (gr + 2 < nrows) v.z = p[2];
+        }
+      }
+    }
+    r[s] = v;
+  }
+}
+
+// registers -> LDS stage ([row][k], pitch LD)
+template <int ROWS, int BKV, int MODE, int NV, typename T, int LD>
+__device__ __forceinline__ void lstore(T* __restrict__ S, const float4 (&r)[NV], int tid) {
+#pragma unroll
+  for (int s = 0; s < NV; ++s) {
+    const int i = tid + s * NT;
+    if constexpr (MODE == 0) {
+      constexpr int VPR = BKV / 4;
+      if (i < ROWS * VPR) st4<T>(S + (i / VPR) * LD + (i % VPR) * 4, r[s]);
+    } else {
+      constexpr int VPK = ROWS / 4;
+      if (i < BKV * VPK) {
+        T* sp = S + ((i % VPK) * 4) * LD + i / VPK;
+        sp[0] = cvt<T>(r[s].x); sp[LD] = cvt<T>(r[s].y); sp[2 * LD] = cvt<T>(r[s].z); sp[3 * LD] = cvt<T>(r[s].w);
+      }
+    }
+  }
+}
+
+template <int PREC, int AM, int BMODE, int CFG>
+__global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
+  using C_ = Cfg<CFG>;
+  using L_ = Lds2<PREC>;
+  using T = typename L_::T;
+  constexpr int LD = L_::LD, BKV = L_::BKV;
+  constexpr int BM = C_::WM * C_::TM * 16, BN = C_::WN * C_::TN * 16;
+  constexpr int NA = (BM * BKV / 4 + NT - 1) / NT, NB = (BN * BKV / 4 + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LD];
+  T* As0 = smem;
+  T* Bs0 = smem + 2 * BM * LD;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C_::WN, wn = wave % C_::WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kbeg = blockIdx.z * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int fr = lane & 15, fq = lane >> 4;
+
+  f32x4 acc[C_::TM][C_::TN];
+#pragma unroll
+  for (int i = 0; i < C_::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < C_::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // implicit-GEMM (AM == 3): decode this thread's output pixels once
+  constexpr int VPR = BKV / 4;
+  long c_img[NA]; int c_h[NA], c_w[NA];
+  if constexpr (AM == 3) {
+#pragma unroll
+    for (int s = 0; s < NA; ++s) {
+      const int gm = m0 + (tid + s * NT) / VPR;
+      if (gm < p.M && (tid + s * NT) < BM * VPR) {
+        const int wo = gm % p.cWo, t = gm / p.cWo, ho = t % p.cHo, n = t / p.cHo;
+        c_img[s] = (long)n * p.cH * p.cW * p.cCin;
+        c_h[s] = ho * p.cStride - p.cPad;
+        c_w[s] = wo * p.cStride - p.cPad;
+      } else {
+        c_img[s] = -1; c_h[s] = 0; c_w[s] = 0;
+      }
+    }
+  }
+
+  float4 ra[NA], rb[NB];
+  auto load_a = [&](int k0) {
+    if constexpr (AM == 3) {
+#pragma unroll
+      for (int s = 0; s < NA; ++s) {
+        const int gk = k0 + ((tid + s * NT) % VPR) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c_img[s] >= 0 && gk < kend) {
+          const int tap = gk / p.cCin, c = gk - tap * p.cCin;
+          const int kh = tap / p.cKs, kw = tap - kh * p.cKs;
+          const int hi = c_h[s] + kh, wi = c_w[s] + kw;
+          if (hi >= 0 && hi < p.cH && wi >= 0 && wi < p.cW)
+            v = *reinterpret_cast<const float4*>(p.A + c_img[s] + ((long)hi * p.cW + wi) * p.cCin + c);
+        }
+        ra[s] = v;
+      }
+    } else {
+      gload<BM, BKV, AM, NA>(ra, p.A, p.lda_m, p.lda_k, m0, p.M, k0, kend, tid);
+    }
+  };
+  auto store_a = [&](T* As) {
+    if constexpr (AM == 3) lstore<BM, BKV, 0, NA, T, LD>(As, ra, tid);
+    else lstore<BM, BKV, AM, NA, T, LD>(As, ra, tid);
+  };
+
+  load_a(kbeg);
+  gload<BN, BKV, BMODE, NB>(rb, p.B, p.ldb_n, p.ldb_k, n0, p.N, kbeg, kend, tid);
+  store_a(As0);
+  lstore<BN, BKV, BMODE, NB, T, LD>(Bs0, rb, tid);
+  __syncthreads();
+
+  int cur = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BKV) {
+    const bool more = k0 + BKV < kend;
+    if (more) {  // next stage's global loads go out before this stage's matrix work
+      load_a(k0 + BKV);
+      gload<BN, BKV, BMODE, NB>(rb, p.B, p.ldb_n, p.ldb_k, n0, p.N, k0 + BKV, kend, tid);
+    }
+    const T* As = As0 + cur * BM * LD;
+    const T* Bs = Bs0 + cur * BN * LD;
+    if constexpr (PREC == 0) {
+#pragma unroll
+      for (int kk = 0; kk < BKV / 4; ++kk) {
+        float a[C_::TM], b[C_::TN];
+#pragma unroll
+        for (int i = 0; i < C_::TM; ++i) a[i] = As[((wm * C_::TM + i) * 16 + fr) * LD + kk * 4 + fq];
+#pragma unroll
+        for (int j = 0; j < C_::TN; ++j) b[j] = Bs[((wn * C_::TN + j) * 16 + fr) * LD + kk * 4 + fq];
+#pragma unroll
+        for (int i = 0; i < C_::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < C_::TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BKV / 32; ++ks) {
+        bf16x8 a[C_::TM], b[C_::TN];
+#pragma unroll
+        for (int i = 0; i < C_::TM; ++i)
+          a[i] = *reinterpret_cast<const bf16x8*>(As + ((wm * C_::TM + i) * 16 + fr) * LD + ks * 32 + fq * 8);
+#pragma unroll
+        for (int j = 0; j < C_::TN; ++j)
+          b[j] = *reinterpret_cast<const bf16x8*>(Bs + ((wn * C_::TN + j) * 16 + fr) * LD + ks * 32 + fq * 8);
+#pragma unroll
+        for (int i = 0; i < C_::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < C_::TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) {
+      store_a(As0 + (cur ^ 1) * BM * LD);
+      lstore<BN, BKV, BMODE, NB, T, LD>(Bs0 + (cur ^ 1) * BN * LD, rb, tid);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue (identical to v1) ----
+#pragma unroll
+  for (int i = 0; i < C_::TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < C_::TN; ++j) {
+      const int n = n0 + (wn * C_::TN + j) * 16 + fr;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + (wm * C_::TM + i) * 16 + fq * 4 + r;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r];
+        if (p.ws) {
+          p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = v;
+          continue;
+        }
+        if (p.bias) v += p.bias[n];
+        if (p.res && p.res_before_act) v += p.res[(long)(m % p.res_rows) * p.ldr + n];
+        if (p.preact) p.preact[(long)m * p.ldp + n] = v;
+        v = apply_act(v, p.act);
+        if (p.dact) v *= act_grad(p.dsrc[(long)m * p.ldd + n], p.dact);
+        if (p.res && !p.res_before_act) v += p.res[(long)(m % p.res_rows) * p.ldr + n];
+        p.C[(long)m * p.ldc + n] = v;
+      }
+    }
+  }
+}
+
+template <int PREC, int AM, int BMODE, int CFG>
+void launch2(const GemmP& p, int splits, hipStream_t st) {
+  using C_ = Cfg<CFG>;
+  constexpr int BM = C_::WM * C_::TM * 16, BN = C_::WN * C_::TN * 16;
+  dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, splits);
+  hipLaunchKernelGGL((gemm2_kernel<PREC, AM, BMODE, CFG>), grid, dim3(NT), 0, st, p);
+}
+
+template <int PREC>
+void dispatch2(const GemmP& p, int am, int bm, bool tall, int splits, hipStream_t st) {
+  if (tall) {
+    if (am == 0 && bm == 0) launch2<PREC, 0, 0, 3>(p, splits, st);
+    else if (am == 0) launch2<PREC, 0, 1, 3>(p, splits, st);
+    else if (bm == 0) launch2<PREC, 1, 0, 3>(p, splits, st);
+    else launch2<PREC, 1, 1, 3>(p, splits, st);
+  } else {
+    if (am == 0 && bm == 0) launch2<PREC, 0, 0, 0>(p, splits, st);
+    else if (am == 0) launch2<PREC, 0, 1, 0>(p, splits, st);
+    else if (bm == 0) launch2<PREC, 1, 0, 0>(p, splits, st);
+    else launch2<PREC, 1, 1, 0>(p, splits, st);
+  }
+}
+
 template <int PREC, int AM, int BMODE, int CFG>
 void launch(const GemmP& p, int splits, hipStream_t st) {
   using C_ = Cfg<CFG>;
@@ -291,9 +551,10 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
   p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = residual; p.ldr = ldr;
   p.res_rows = residual ? res_rows : 1; p.res_before_act = res_before_act; p.act = act;
   p.preact = preact; p.ldp = ldp; p.dsrc = dact_src; p.ldd = ldd; p.dact = dact_mode;
-  const int ktiles = (K + BK - 1) / BK;
+  constexpr int KQ = 64;  // K-slice granularity (covers BK of both kernel generations)
+  const int ktiles = (K + KQ - 1) / KQ;
   if (splitk > ktiles) splitk = ktiles;
-  p.kchunk = ((ktiles + splitk - 1) / splitk) * BK;
+  p.kchunk = ((ktiles + splitk - 1) / splitk) * KQ;
   splitk = (K + p.kchunk - 1) / p.kchunk;
   p.ws = splitk > 1 ? workspace : nullptr;
 
@@ -303,7 +564,11 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
   if (ldb_k == 1 && (ldb_n % 4) == 0 && aligned16(B)) bm = 0;
   else if (ldb_n == 1 && (ldb_k % 4) == 0 && aligned16(B)) bm = 1;
 
-  if (prec == 0) {
+  if (am <= 1 && bm <= 1) {  // both operands vectorizable: pipelined kernel
+    const bool tall = M >= 4096 && N >= 64;
+    if (prec == 0) dispatch2<0>(p, am, bm, tall, splitk, st);
+    else dispatch2<1>(p, am, bm, tall, splitk, st);
+  } else if (prec == 0) {
     if (am == 0) dispatch_b<0, 0>(p, bm, splitk, st);
     else if (am == 1) dispatch_b<0, 1>(p, bm, splitk, st);
     else dispatch_b<0, 2>(p, bm, splitk, st);
@@ -338,17 +603,17 @@ extern "C" int rf_conv2d_nhwc(const float* x, const float* w, const float* bias,
   p.C = y; p.ldc = ldy; p.M = N * Ho * Wo; p.N = cout; p.K = K; p.bias = bias;
   p.res = residual; p.ldr = ldres; p.res_rows = p.M; p.res_before_act = 1;
   p.act = relu ? RF_ACT_RELU : RF_ACT_NONE;
-  p.kchunk = ((K + BK - 1) / BK) * BK; p.ws = nullptr;
+  p.kchunk = ((K + 63) / 64) * 64; p.ws = nullptr;
   p.cH = H; p.cW = W; p.cCin = cin; p.cKs = ksize; p.cStride = stride; p.cPad = pad; p.cHo = Ho; p.cWo = Wo;
   const int cfg = cout <= 16 ? 1 : (cout <= 32 ? 2 : 0);
   if (prec == 0) {
-    if (cfg == 1) launch<0, 3, 0, 1>(p, 1, st);
-    else if (cfg == 2) launch<0, 3, 0, 2>(p, 1, st);
-    else launch<0, 3, 0, 0>(p, 1, st);
+    if (cfg == 1) launch2<0, 3, 0, 1>(p, 1, st);
+    else if (cfg == 2) launch2<0, 3, 0, 2>(p, 1, st);
+    else launch2<0, 3, 0, 0>(p, 1, st);
   } else {
-    if (cfg == 1) launch<1, 3, 0, 1>(p, 1, st);
-    else if (cfg == 2) launch<1, 3, 0, 2>(p, 1, st);
-    else launch<1, 3, 0, 0>(p, 1, st);
+    if (cfg == 1) launch2<1, 3, 0, 1>(p, 1, st);
+    else if (cfg == 2) launch2<1, 3, 0, 2>(p, 1, st);
+    else launch2<1, 3, 0, 0>(p, 1, st);
   }
   RF_CHECK_LAUNCH();
   return RF_OK;
