@@ -355,7 +355,9 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C_::WN, wn = wave % C_::WN;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // blockIdx.x walks the N tiles: the column tiles that share one A row-panel are dispatched together,
+  // so the panel is fetched from HBM once and re-read from L2
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kbeg = blockIdx.z * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int fr = lane & 15, fq = lane >> 4;
@@ -495,7 +497,7 @@ template <int PREC, int AM, int BMODE, int CFG>
 void launch2(const GemmP& p, int splits, hipStream_t st) {
   using C_ = Cfg<CFG>;
   constexpr int BM = C_::WM * C_::TM * 16, BN = C_::WN * C_::TN * 16;
-  dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, splits);
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, splits);
   hipLaunchKernelGGL((gemm2_kernel<PREC, AM, BMODE, CFG>), grid, dim3(NT), 0, st, p);
 }
 

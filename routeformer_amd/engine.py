@@ -32,9 +32,21 @@ def train_step_losses(model, item, epoch: int = 0, trajectory_loss: Optional[Fut
     target_gps = item["target"]["gps"].to(torch.float32)
     res: Dict[str, torch.Tensor] = {}
     if cfg.dense_prediction:
+        from routeformer_amd import kernels as K
+        overlap = K.OVERLAP and (K.OVERLAP_MASK & 1) and target_gps.is_cuda
+        if overlap:  # fork point: the target-side pass must not wait for the input forward
+            side = K.side_stream("target")
+            side.wait_stream(torch.cuda.current_stream())
         future_gps, future_vis = model(item["train"])
+        # host order stays "input forward, then target pass" (reference draw order, full_comparison.py:481-482);
+        # on the device the two are independent, so the target pass gets its own stream
         with torch.no_grad():  # the reference detaches this branch (full_comparison.py:495)
-            _, target_vis = model.preprocess_batch(item["target"], training=False)
+            if overlap:
+                with torch.cuda.stream(side):
+                    _, target_vis = model.preprocess_batch(item["target"], training=False)
+                torch.cuda.current_stream().wait_stream(side)
+            else:
+                _, target_vis = model.preprocess_batch(item["target"], training=False)
         target_vis = target_vis[:, : future_vis.shape[1]]
         step = cfg.autoregressive_step_size
         if cfg.autoregressive:
@@ -211,8 +223,10 @@ class TrainEngine:
     """One full train step = forward(input) + target-feature forward + losses + backward (+ overlapped
     gradient all-reduce) + clip + AdamW -- the unit ``bench.py`` times."""
 
-    def __init__(self, model, lr=None, weight_decay=None, max_grad_norm: float = 2.5, bucket_mb: float = 32.0):
+    def __init__(self, model, lr=None, weight_decay=None, max_grad_norm: float = 2.5, bucket_mb: float = 32.0,
+                 overlap: bool = True):
         self.model = model
+        self.overlap = overlap  # independent sub-graphs of the step on separate HIP streams
         cfg = model.configs
         layers = [m for m in model.modules() if hasattr(m, "packing_groups")]
         groups = [g for m in layers for g in m.packing_groups()]
@@ -233,13 +247,16 @@ class TrainEngine:
     def _fwd_bwd(self, item, epoch):
         from routeformer_amd import kernels as K
         self.reducer.zero()
+        K.OVERLAP = self.overlap
         K.SINK.active = True  # kernels accumulate parameter gradients straight into the flat buffer
         K.SINK.on_write = self.reducer.on_sink_write if self.reducer.world > 1 else None
         try:
             res = train_step_losses(self.model, item, epoch, self.tl, self.dl)
             res["loss"].backward()
+            if self.overlap:
+                K.join_side_streams()
         finally:
-            K.SINK.active, K.SINK.on_write = False, None
+            K.SINK.active, K.SINK.on_write, K.OVERLAP = False, None, False
         return res
 
     def step(self, item, epoch: int = 0):

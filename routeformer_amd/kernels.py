@@ -33,6 +33,40 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Independent sub-graphs of one step (the gaze-token encoder vs the video frame encoders; the target-side
+# feature pass vs the input forward) are latency-bound chains of small kernels: running them on separate
+# HIP streams lets the otherwise idle CUs overlap them.  Off by default (strict reference call order for
+# the test hooks); the training engine switches it on.  Host-RNG draw order is unaffected.
+OVERLAP = False
+OVERLAP_MASK = int(__import__("os").environ.get("RF_OVERLAP", "3"))  # bit0: target pass, bit1: gaze encoder
+_SIDE_STREAMS = {}
+
+
+def side_stream(key: str):
+    dev = torch.cuda.current_device()
+    st = _SIDE_STREAMS.get((key, dev))
+    if st is None:
+        st = _SIDE_STREAMS[(key, dev)] = torch.cuda.Stream()
+    return st
+
+
+def on_side_stream() -> bool:
+    """True when the current stream is itself one of the side streams (no nested forks: a fork from a
+    forked stream crashes hipStreamEndCapture on ROCm 7.2)."""
+    cur = torch.cuda.current_stream()
+    return any(cur == st for st in _SIDE_STREAMS.values())
+
+
+def join_side_streams():
+    """Make the current stream wait for everything queued on the side streams.  Needed after backward:
+    gradient sinks written by side-stream kernels bypass autograd's own leaf-stream synchronisation."""
+    cur = torch.cuda.current_stream()
+    dev = torch.cuda.current_device()
+    for (_, d), st in _SIDE_STREAMS.items():
+        if d == dev:
+            cur.wait_stream(st)
+
+
 class _Profiler:
     """HIP-event timing of kernel classes on the launch stream (bench.py's live roofline numbers).
     Off by default: a single attribute test per launch."""
@@ -89,9 +123,21 @@ def _splits(tiles: int, depth: int) -> int:
     return max(1, min(64, depth // 128, -(-512 // max(tiles, 1))))
 
 
+def _auto_split(M: int, N: int, K: int) -> int:
+    """Split-K for launches that would leave most of the 256 CUs idle (small-M Informer GEMMs): aim for
+    ~512 workgroups with >= 128 of reduction depth each."""
+    tm = -(-M // (128 if M >= 4096 and N >= 64 else 64))
+    tiles = tm * -(-N // 64)
+    if tiles >= 256 or K < 256:
+        return 1
+    return max(1, min(16, K // 128, -(-512 // tiles)))
+
+
 def gemm(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, *, bias=None, residual=None, ldr=0,
          res_rows=0, res_before_act=0, act=0, preact=None, ldp=0, dact_src=None, ldd=0, dact=0,
-         splitk=1):
+         splitk=0):
+    if splitk == 0:
+        splitk = _auto_split(M, N, K)
     ws = None
     if splitk > 1:
         ws = torch.empty(splitk * M * N, device=C.device, dtype=torch.float32)

@@ -181,12 +181,25 @@ class Routeformer(nn.Module):
                     fv = batch["front_video"]
                     jobs.append((len(visual) - 1, fv, self._frame_indices(fv.shape[1], c.gaze_fps, "Gaze"),
                                  self.frame_encoder.predraw(self._tokens_per_frame, fv.device)))
+            use_gaze = self.with_gaze and not drop_gaze
+            tokens, fork = None, None
+            if use_gaze and K.OVERLAP and (K.OVERLAP_MASK & 2) and motion.is_cuda and not K.on_side_stream():
+                # the gaze-token encoder depends only on the gaze track: run it on a side stream while the
+                # main stream encodes the video frames (its host draws still come after the frame draws)
+                fork = K.side_stream("gaze")
+                fork.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(fork):
+                    tokens = median_downsampler(batch["gaze"].to(torch.float32), c.gps_backbone_config.seq_len)
+                    tokens = self.gaze_encoder(tokens)
             for slot, timeline in self._encode_streams(jobs):
                 visual[slot] = timeline
-            if self.with_gaze and not drop_gaze:
+            if use_gaze:
                 gaze_video = visual[-1]
-                tokens = median_downsampler(batch["gaze"].to(torch.float32), c.gps_backbone_config.seq_len)
-                tokens = self.gaze_encoder(tokens)
+                if fork is None:
+                    tokens = median_downsampler(batch["gaze"].to(torch.float32), c.gps_backbone_config.seq_len)
+                    tokens = self.gaze_encoder(tokens)
+                else:
+                    torch.cuda.current_stream().wait_stream(fork)
                 visual[-1] = self.gaze_video_decoder(gaze_video, tokens)[:, : gaze_video.shape[1]]
         if self.with_video:
             if self.with_scene:
