@@ -41,12 +41,19 @@ const char* rf_last_error(void);
  * Replaces nn.Linear / Conv1d(k=1) forward+backward GEMMs: cross_modal_transformer.py:177-180,
  * 189-198,215-216,281-282,423,496; gps_backbone/layers/SelfAttentionFamily.py:176-192;
  * layers/TransformerEncoderDecoder.py:36-37,50-51,98-99; Informer.py:102.
- * splitk > 1 needs workspace of splitk*M*N floats (deterministic two-pass reduction). */
+ * splitk > 1 needs workspace of splitk*M*N floats (deterministic two-pass reduction), unless
+ * atomic_accumulate = 1: then every K-slice adds its partial product into C with fp32 atomics
+ * (C += A*B; C must hold the running sum, e.g. a zeroed slot of the flat gradient buffer; no epilogue
+ * other than that is allowed; summation order, hence the last bits, vary run to run).
+ * a_rowsum (optional, needs atomic_accumulate and a row-contiguous A, i.e. lda_m == 1):
+ * a_rowsum[m] += sum_k A[m,k] -- the bias gradient rides along with the weight-gradient GEMM
+ * (dW = dY^T X, db = dY^T 1) instead of a second pass over dY. */
 int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k,
             int64_t ldb_n, float* C, int64_t ldc, int M, int N, int K, const float* bias,
             const float* residual, int64_t ldr, int res_rows, int res_before_act, int act,
             float* preact, int64_t ldp, const float* dact_src, int64_t ldd, int dact_mode,
-            int prec, int splitk, float* workspace, void* stream);
+            int prec, int splitk, float* workspace, int atomic_accumulate, float* a_rowsum,
+            void* stream);
 
 /* out[n] (+)= sum_m X[m*ldx + n] (bias gradients; accumulate=1 adds into out, e.g. a slot of the flat
  * gradient buffer).  workspace: parts*N floats, parts = rf_colsum_parts(M,N). */

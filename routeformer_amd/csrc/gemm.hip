@@ -33,6 +33,8 @@ struct GemmP {
   const float* dsrc; long ldd; int dact;
   int kchunk;  // K range per split-K slice (multiple of BK)
   float* ws;   // split-K partials [splits][M][N] (null: single pass with epilogue)
+  int atomic;  // 1: C += partial via fp32 atomics (no other epilogue)
+  float* a_rowsum;  // optional: a_rowsum[m] += sum_k A[m,k] (A row-contiguous)
   // implicit-GEMM conv (A mode 3): A is the NHWC input, row m = output pixel
   int cH, cW, cCin, cKs, cStride, cPad, cHo, cWo;
 };
@@ -387,6 +389,11 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
   }
 
   float4 ra[NA], rb[NB];
+  float4 rsum[NA];  // per-thread partial row sums of A (bias-gradient side product, AM == 1 only)
+  if constexpr (AM == 1) {
+#pragma unroll
+    for (int s = 0; s < NA; ++s) rsum[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   auto load_a = [&](int k0) {
     if constexpr (AM == 3) {
 #pragma unroll
@@ -404,6 +411,14 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
       }
     } else {
       gload<BM, BKV, AM, NA>(ra, p.A, p.lda_m, p.lda_k, m0, p.M, k0, kend, tid);
+      if constexpr (AM == 1) {
+        if (p.a_rowsum) {
+#pragma unroll
+          for (int s = 0; s < NA; ++s) {
+            rsum[s].x += ra[s].x; rsum[s].y += ra[s].y; rsum[s].z += ra[s].z; rsum[s].w += ra[s].w;
+          }
+        }
+      }
     }
   };
   auto store_a = [&](T* As) {
@@ -465,6 +480,27 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
     cur ^= 1;
   }
 
+  if constexpr (AM == 1) {
+    // bias-gradient side product: only the first column tile of each row panel contributes (the other
+    // column tiles stage the same A panel); rows of a thread: 4*(tid % (BM/4)) .. +3 in every slot
+    if (p.a_rowsum && blockIdx.x == 0) {
+      constexpr int VPK = BM / 4;
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int s = 0; s < NA; ++s) {
+        if (tid + s * NT < BKV * VPK) { t.x += rsum[s].x; t.y += rsum[s].y; t.z += rsum[s].z; t.w += rsum[s].w; }
+      }
+      float* red = reinterpret_cast<float*>(smem);  // all stages are dead after the last barrier
+      if (tid < BM) red[tid] = 0.f;
+      __syncthreads();
+      const int rv = (tid % VPK) * 4;
+      atomicAdd(&red[rv + 0], t.x); atomicAdd(&red[rv + 1], t.y);
+      atomicAdd(&red[rv + 2], t.z); atomicAdd(&red[rv + 3], t.w);
+      __syncthreads();
+      if (tid < BM && m0 + tid < p.M) atomicAdd(&p.a_rowsum[m0 + tid], red[tid]);
+    }
+  }
+
   // ---- epilogue (identical to v1) ----
 #pragma unroll
   for (int i = 0; i < C_::TM; ++i) {
@@ -477,6 +513,10 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
         const int m = m0 + (wm * C_::TM + i) * 16 + fq * 4 + r;
         if (m >= p.M) continue;
         float v = acc[i][j][r];
+        if (p.atomic) {
+          atomicAdd(&p.C[(long)m * p.ldc + n], v);
+          continue;
+        }
         if (p.ws) {
           p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = v;
           continue;
@@ -541,10 +581,13 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
                        int64_t ldb_n, float* C, int64_t ldc, int M, int N, int K, const float* bias,
                        const float* residual, int64_t ldr, int res_rows, int res_before_act, int act,
                        float* preact, int64_t ldp, const float* dact_src, int64_t ldd, int dact_mode,
-                       int prec, int splitk, float* workspace, void* stream) {
+                       int prec, int splitk, float* workspace, int atomic_accumulate, float* a_rowsum,
+                       void* stream) {
   RF_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0);
   RF_REQUIRE(prec == 0 || prec == 1);
-  RF_REQUIRE(splitk >= 1 && (splitk == 1 || workspace != nullptr));
+  RF_REQUIRE(splitk >= 1 && (splitk == 1 || workspace != nullptr || atomic_accumulate));
+  RF_REQUIRE(!atomic_accumulate || (!bias && !residual && !act && !preact && !dact_mode));
+  RF_REQUIRE(!a_rowsum || (atomic_accumulate && lda_m == 1));
   RF_REQUIRE(!residual || res_rows > 0);
   RF_REQUIRE(!dact_mode || dact_src);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -558,7 +601,8 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
   if (splitk > ktiles) splitk = ktiles;
   p.kchunk = ((ktiles + splitk - 1) / splitk) * KQ;
   splitk = (K + p.kchunk - 1) / p.kchunk;
-  p.ws = splitk > 1 ? workspace : nullptr;
+  p.ws = (splitk > 1 && !atomic_accumulate) ? workspace : nullptr;
+  p.atomic = atomic_accumulate; p.a_rowsum = a_rowsum;
 
   int am = 2, bm = 2;
   if (lda_k == 1 && (lda_m % 4) == 0 && aligned16(A)) am = 0;
@@ -566,6 +610,11 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
   if (ldb_k == 1 && (ldb_n % 4) == 0 && aligned16(B)) bm = 0;
   else if (ldb_n == 1 && (ldb_k % 4) == 0 && aligned16(B)) bm = 1;
 
+  if (atomic_accumulate && !(am <= 1 && bm <= 1)) {
+    rf_g_last_error = "atomic_accumulate needs 16-B vectorizable operands";
+    return RF_EUNSUPPORTED;
+  }
+  if (a_rowsum && am != 1) { rf_g_last_error = "a_rowsum needs a row-contiguous, aligned A"; return RF_EUNSUPPORTED; }
   if (am <= 1 && bm <= 1) {  // both operands vectorizable: pipelined kernel
     const bool tall = M >= 4096 && N >= 64;
     if (prec == 0) dispatch2<0>(p, am, bm, tall, splitk, st);
@@ -580,7 +629,7 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
     else dispatch_b<1, 2>(p, bm, splitk, st);
   }
   RF_CHECK_LAUNCH();
-  if (splitk > 1) {
+  if (splitk > 1 && !atomic_accumulate) {
     const long total = (long)M * N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;

@@ -38,7 +38,7 @@ def _stream():
 # HIP streams lets the otherwise idle CUs overlap them.  Off by default (strict reference call order for
 # the test hooks); the training engine switches it on.  Host-RNG draw order is unaffected.
 OVERLAP = False
-OVERLAP_MASK = int(__import__("os").environ.get("RF_OVERLAP", "3"))  # bit0: target pass, bit1: gaze encoder
+OVERLAP_MASK = int(__import__("os").environ.get("RF_OVERLAP", "3"))  # bit0 target pass, bit1 gaze encoder, bit2 wgrad (no gain measured)
 _SIDE_STREAMS = {}
 
 
@@ -57,6 +57,9 @@ def on_side_stream() -> bool:
     return any(cur == st for st in _SIDE_STREAMS.values())
 
 
+_KEEPALIVE = []  # tensors read by side-stream kernels: kept referenced until the join (no early reuse)
+
+
 def join_side_streams():
     """Make the current stream wait for everything queued on the side streams.  Needed after backward:
     gradient sinks written by side-stream kernels bypass autograd's own leaf-stream synchronisation."""
@@ -65,6 +68,30 @@ def join_side_streams():
     for (_, d), st in _SIDE_STREAMS.items():
         if d == dev:
             cur.wait_stream(st)
+    _KEEPALIVE.clear()
+
+
+class _WgradStream:
+    """Weight / bias gradients only feed the optimizer, not the backward chain: with gradient sinks active
+    they are launched on a side stream so the dX chain (the critical path) is not serialised behind them."""
+
+    def __init__(self, *tensors):
+        self.st = None
+        if OVERLAP and (OVERLAP_MASK & 4) and SINK.active and not on_side_stream():
+            self.st = side_stream("wgrad")
+            self.st.wait_stream(torch.cuda.current_stream())
+            _KEEPALIVE.append(tensors)
+            self.ctx = torch.cuda.stream(self.st)
+
+    def __enter__(self):
+        if self.st is not None:
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.st is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 class _Profiler:
@@ -135,17 +162,17 @@ def _auto_split(M: int, N: int, K: int) -> int:
 
 def gemm(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, *, bias=None, residual=None, ldr=0,
          res_rows=0, res_before_act=0, act=0, preact=None, ldp=0, dact_src=None, ldd=0, dact=0,
-         splitk=0):
+         splitk=0, atomic=False, a_rowsum=None):
     if splitk == 0:
         splitk = _auto_split(M, N, K)
     ws = None
-    if splitk > 1:
+    if splitk > 1 and not atomic:
         ws = torch.empty(splitk * M * N, device=C.device, dtype=torch.float32)
     ev = PROFILE.begin() if PROFILE.on else None
     check(_hip.lib().rf_gemm(ptr(A), lda_m, lda_k, ptr(B), ldb_k, ldb_n, ptr(C), ldc, M, N, K,
                              ptr(bias), ptr(residual), ldr, res_rows, res_before_act, act,
                              ptr(preact), ldp, ptr(dact_src), ldd, dact, _PRECISION, splitk, ptr(ws),
-                             _stream()), "rf_gemm")
+                             1 if atomic else 0, ptr(a_rowsum), _stream()), "rf_gemm")
     if ev is not None:
         PROFILE.end("gemm", ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N))
 
@@ -161,12 +188,24 @@ def colsum(X2d: torch.Tensor, into: Optional[torch.Tensor] = None) -> Optional[t
     return None if into is not None else out
 
 
-def _weight_grad(dy2: torch.Tensor, x2: torch.Tensor, into: Optional[torch.Tensor] = None):
+DETERMINISTIC = False  # True: split-K through a workspace + ordered reduction instead of fp32 atomics
+
+
+def _vec_ok(t: torch.Tensor) -> bool:
+    return t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1
+
+
+def _weight_grad(dy2: torch.Tensor, x2: torch.Tensor, into: Optional[torch.Tensor] = None, bias_into=None):
     """dW[N,K] = dY[M,N]^T X[M,K]  (split-K over the row dimension M).  ``into``: accumulate straight into
-    that (N,K)-shaped slot of the flat gradient buffer (epilogue residual = the slot itself)."""
+    that (N,K)-shaped slot of the flat gradient buffer.  With ``bias_into`` the bias gradient (column sums
+    of dY) is produced by the same launch; returns True when it was (else the caller runs ``colsum``)."""
     M, N = dy2.shape
     K = x2.shape[1]
     tiles = -(-N // 64) * -(-K // 64)
+    if into is not None and not DETERMINISTIC and _vec_ok(dy2) and _vec_ok(x2) and into.data_ptr() % 16 == 0:
+        gemm(dy2, 1, dy2.stride(0), x2, x2.stride(0), 1, into, K, N, K, M, splitk=_splits(tiles, M), atomic=True,
+             a_rowsum=bias_into)
+        return bias_into is not None
     if into is not None:
         gemm(dy2, 1, dy2.stride(0), x2, x2.stride(0), 1, into, K, N, K, M, residual=into, ldr=K, res_rows=N,
              splitk=_splits(tiles, M))
@@ -248,12 +287,16 @@ class _Linear(torch.autograd.Function):
         if dy2.stride(1) != 1 or dy2.stride(0) != dy2.shape[1]:
             dy2 = dy2.contiguous()
         dx = dw = db = dres = None
+        with _WgradStream(dy2, x2):
+            fused_bias = False
+            if gw is not None:
+                fused_bias = _weight_grad(dy2, x2, into=gw, bias_into=gb if ctx.has_bias else None) is True
+            elif ctx.needs_input_grad[1]:
+                dw = _weight_grad(dy2, x2)
+            if ctx.has_bias and not fused_bias and (gb is not None or ctx.needs_input_grad[2]):
+                db = colsum(dy2, into=gb)
         if ctx.needs_input_grad[0]:
             dx = _input_grad(dy2, w).view(ctx.xshape)
-        if gw is not None or ctx.needs_input_grad[1]:
-            dw = _weight_grad(dy2, x2, into=gw)
-        if ctx.has_bias and (gb is not None or ctx.needs_input_grad[2]):
-            db = colsum(dy2, into=gb)
         _wrote(gw, gb)
         if ctx.needs_input_grad[3]:  # residual rows are shared by M / R row blocks
             dres = colsum(dy2.view(-1, ctx.res_rows * dy2.shape[1])).view(ctx.res_shape)
@@ -305,11 +348,17 @@ class _FFN(torch.autograd.Function):
         if dy2.stride(1) != 1 or dy2.stride(0) != D:
             dy2 = dy2.contiguous()
         # dZ = (dY W2) * act'(Z)   (relu: mask from H > 0; gelu: from the saved pre-activation)
+        with _WgradStream(dy2, h):
+            dw2 = _weight_grad(dy2, h, into=None if g2 is None else g2.view(D, F), bias_into=gb2)
+            db2 = None if dw2 is True else colsum(dy2, into=gb2)
         dz = _input_grad(dy2, w2, dact_src=zsrc, ldd=zsrc.stride(0), dact=ACT[ctx.act])
-        dw2 = _weight_grad(dy2, h, into=None if g2 is None else g2.view(D, F))
-        db2 = colsum(dy2, into=gb2)
-        dw1 = _weight_grad(dz, x2, into=None if g1 is None else g1.view(F, D))
-        db1 = colsum(dz, into=gb1)
+        with _WgradStream(dz, x2):
+            dw1 = _weight_grad(dz, x2, into=None if g1 is None else g1.view(F, D), bias_into=gb1)
+            db1 = None if dw1 is True else colsum(dz, into=gb1)
+        if dw1 is True or dw1 is False:
+            dw1 = None
+        if dw2 is True or dw2 is False:
+            dw2 = None
         dx = _input_grad(dz, w1).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         _wrote(g1, gb1, g2, gb2)
         if dw1 is not None:

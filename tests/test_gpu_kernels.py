@@ -57,6 +57,13 @@ def test_gemm_linear_layouts(M, N, K, prec):
     Kn.gemm(xd, K, 1, wd, 1, K, y2, N, M, N, K, bias=bd, splitk=3)
     assert rel_err(y2, ref) < tol
     assert rel_err(Kn.colsum(dyd), dy.double().sum(0)) < 1e-5
+    # gradient-sink form: dW and db accumulated with fp32 atomics into pre-filled slots, one launch
+    if N % 4 == 0 and K % 4 == 0:
+        slot_w = torch.full((N, K), 0.5, device=DEV)
+        slot_b = torch.full((N,), -0.25, device=DEV)
+        assert Kn._weight_grad(dyd, xd, into=slot_w, bias_into=slot_b) is True
+        assert rel_err(slot_w, 0.5 + dy.double().t() @ x.double()) < tol
+        assert rel_err(slot_b, -0.25 + dy.double().sum(0)) < 1e-4
 
 
 @pytest.mark.parametrize("act", ["relu", "gelu"])
