@@ -34,6 +34,9 @@ def train_step_losses(model, item, epoch: int = 0, trajectory_loss: Optional[Fut
     if cfg.dense_prediction:
         from routeformer_amd import kernels as K
         overlap = K.OVERLAP and (K.OVERLAP_MASK & 1) and target_gps.is_cuda
+        if K.OVERLAP and hasattr(model, "prefetch_video_tokens"):
+            # frozen conv trunk: one pass over the history AND target frames (336 images at B=8)
+            model.prefetch_video_tokens([item["train"], item["target"]])
         if overlap:  # fork point: the target-side pass must not wait for the input forward
             side = K.side_stream("target")
             side.wait_stream(torch.cuda.current_stream())
@@ -68,6 +71,8 @@ def train_step_losses(model, item, epoch: int = 0, trajectory_loss: Optional[Fut
         loss = traj
     res.update(loss=loss, traj_loss=traj, future_gps=future_gps, ade=ade(future_gps, target_gps),
                fde=fde(future_gps, target_gps))
+    if hasattr(model, "clear_video_tokens"):
+        model.clear_video_tokens()
     return res
 
 

@@ -235,6 +235,60 @@ class Routeformer(nn.Module):
         assert rel > 0, f"{what} FPS must be a divisor of the output FPS"
         return torch.flip(torch.arange(T - 1, 0, -rel), dims=[0])  # last frame always in, frame 0 never
 
+    # -- one trunk pass for several batches (history + target windows of a training item) --------------
+    def _stream_plan(self, batch):
+        """(video, frame idx) of every camera stream ``preprocess_batch`` may encode, in job order."""
+        c, plan = self.configs, []
+        if not self.with_video:
+            return plan
+        if self.with_scene:
+            left = batch["left_video"]
+            idx = self._frame_indices(left.shape[1], c.video_fps, "Video")
+            plan += [(batch.get("right_video", left), idx), (left, idx)]
+        if self.with_gaze:
+            fv = batch["front_video"]
+            plan.append((fv, self._frame_indices(fv.shape[1], c.gaze_fps, "Gaze")))
+        return plan
+
+    def prefetch_video_tokens(self, batches):
+        """Run the frozen conv trunk ONCE over the frames of all given batches (it has no randomness and
+        no gradient, so the history and target windows of a step can share one pass); the per-stream
+        encoders then pick their tokens up from this cache.  Call ``clear_video_tokens`` after the step."""
+        if not (self.with_video and hasattr(self.video_backbone, "encode_clips")):
+            return
+        clips, keys = [], []
+        for batch in batches:
+            for video, idx in self._stream_plan(batch):
+                clips.append((video, idx))
+                keys.append((video.data_ptr(), tuple(video.shape), tuple(idx.tolist())))
+        if not clips:
+            return
+        tokens = self.video_backbone.encode_clips(clips)
+        cache, off = {}, 0
+        for key, (video, idx) in zip(keys, clips):
+            n = video.shape[0] * idx.numel()
+            cache.setdefault(key, []).append((off, n))
+            off += n
+        self.__dict__["_token_cache"] = (tokens, cache)
+
+    def clear_video_tokens(self):
+        self.__dict__.pop("_token_cache", None)
+
+    def _cached_tokens(self, videos, idx):
+        entry = self.__dict__.get("_token_cache")
+        if entry is None:
+            return None
+        tokens, cache = entry
+        spans = []
+        for v in videos:
+            lst = cache.get((v.data_ptr(), tuple(v.shape), tuple(idx.tolist())))
+            if not lst:
+                return None
+            spans.append(lst[0] if len(lst) == 1 else lst.pop(0))
+        if all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1)):
+            return tokens[spans[0][0]: spans[-1][0] + spans[-1][1]]  # contiguous: a view, no copy
+        return torch.cat([tokens[o:o + n] for o, n in spans], dim=0)
+
     def _device_index(self, idx: torch.Tensor, dev) -> torch.Tensor:
         """Frame indices on the device, cached (no host->device copy inside a captured step)."""
         key = (tuple(idx.tolist()), str(dev))
@@ -260,7 +314,10 @@ class Routeformer(nn.Module):
             idx = members[0][2]
             B, T = videos[0].shape[:2]
             dev = videos[0].device
-            if hasattr(self.video_backbone, "encode_tokens"):
+            cached = self._cached_tokens(videos, idx)
+            if cached is not None:
+                tokens = cached
+            elif hasattr(self.video_backbone, "encode_tokens"):
                 tokens = self.video_backbone.encode_tokens(videos, idx)  # (S*B*F, 65, C), stream-major
             else:  # generic plugin backbone: (N,3,H,W) -> (N,C,Hf,Wf), token layout built here
                 toks = []

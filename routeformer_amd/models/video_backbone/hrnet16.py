@@ -252,29 +252,39 @@ class HRNet16Backbone(VideoBackboneModule):
         the trunk at once) -- + frame indices (F,) -> tokens (S*B*F, 65, 240), stream-major, each with the
         trailing constant -1 row (routeformer.py:478-487).  Frame gather, dtype cast and conv0 are one kernel."""
         videos = list(video) if isinstance(video, (list, tuple)) else [video]
-        for v in videos:
+        return self.encode_clips([(v, frame_idx) for v in videos])
+
+    def encode_clips(self, clips) -> torch.Tensor:
+        """clips: [(video (B,T,3,H,W), frame_idx (F,) or None)] -- clips may differ in B, T and frame
+        indices (e.g. the history and the target window of one training item) but share H x W.
+        One trunk pass over ALL selected frames -> tokens (sum_i B_i*F_i, 65, 240), clip-major."""
+        vids, fidx, counts = [], [], []
+        for v, fi in clips:
             if not v.is_cuda:
                 raise _hip.HipLibraryError("HRNet16Backbone runs on the GPU only; there is no CPU path")
-        videos = [(v if v.dtype in (torch.float16, torch.float32) else v.float()).contiguous() for v in videos]
-        B, T, C3, H, Wd = videos[0].shape
-        assert C3 == 3 and H % 2 == 0 and Wd % 2 == 0
-        assert all(v.shape == videos[0].shape for v in videos)
-        dev = videos[0].device
-        if frame_idx is None:
-            frame_idx = torch.arange(T, dtype=torch.int32)
-        key = (tuple(frame_idx.tolist()), str(dev))
-        if key not in self._fidx_cache:  # cached: no host->device copy inside a captured step
-            self._fidx_cache[key] = frame_idx.to(device=dev, dtype=torch.int32)
-        frame_idx = self._fidx_cache[key]
-        F_ = frame_idx.numel()
-        n_each = B * F_
-        N = n_each * len(videos)
+            v = (v if v.dtype in (torch.float16, torch.float32) else v.float()).contiguous()
+            B, T, C3, H, Wd = v.shape
+            assert C3 == 3 and H % 2 == 0 and Wd % 2 == 0 and v.shape[3:] == clips[0][0].shape[3:]
+            dev = v.device
+            if fi is None:
+                fi = torch.arange(T, dtype=torch.int32)
+            key = (tuple(fi.tolist()), str(dev))
+            if key not in self._fidx_cache:  # cached: no host->device copy inside a captured step
+                self._fidx_cache[key] = fi.to(device=dev, dtype=torch.int32)
+            vids.append(v)
+            fidx.append(self._fidx_cache[key])
+            counts.append(B * fidx[-1].numel())
+        H, Wd = vids[0].shape[3:]
+        dev = vids[0].device
+        N = sum(counts)
         W = self._prepare(dev)
         x = torch.empty(N, H // 2, Wd // 2, 4, device=dev, dtype=torch.float32)
-        for s_i, v in enumerate(videos):
-            check(_hip.lib().rf_stem_conv0(ptr(v), 1 if v.dtype == torch.float32 else 0, ptr(frame_idx),
-                                           ptr(W["conv0"][0]), x.data_ptr() + 4 * s_i * n_each * (H // 2) * (Wd // 2) * 4,
-                                           B, T, F_, H, Wd, K._stream()), "rf_stem_conv0")
+        off = 0
+        for v, fi, n in zip(vids, fidx, counts):
+            check(_hip.lib().rf_stem_conv0(ptr(v), 1 if v.dtype == torch.float32 else 0, ptr(fi), ptr(W["conv0"][0]),
+                                           x.data_ptr() + 4 * off * (H // 2) * (Wd // 2) * 4, v.shape[0], v.shape[1],
+                                           fi.numel(), H, Wd, K._stream()), "rf_stem_conv0")
+            off += n
         x = self._conv(W, "conv1", x, stride=2, relu=True)
         x = self._conv(W, "conv2", x, stride=2, relu=True)
         x = self._bottleneck(W, "layer1.0", x)
