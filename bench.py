@@ -62,7 +62,8 @@ def cpu_baseline(cfg, sd, c, steps=2):
     vectors) doing the SAME full train step on the host cores.  Bounded sample: `steps` steps of the B=8
     workload after one warm-up step is skipped (first step is included in no average)."""
     from oracle import routeformer_oracle as O
-    cores = os.cpu_count() or 1
+    # the GPU box gives a 16-core share per GPU (cpu_count() reports the whole host): oversubscribing stalls
+    cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
     torch.set_num_threads(cores)
     item = make_item(c, 0)
     params = {k: v.clone().requires_grad_(v.is_floating_point() and "video_backbone" not in k and "running" not in k
@@ -80,6 +81,7 @@ def cpu_baseline(cfg, sd, c, steps=2):
         torch.nn.utils.clip_grad_norm_(train, 2.5)
         opt.step()
         times.append(time.perf_counter() - t0)
+        print(f"[cpu_baseline] step {i}: {times[-1]:.2f} s on {cores} threads", file=sys.stderr, flush=True)
     dt = sum(times[1:]) / steps
     return {"value": c["B"] / dt, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{steps} full train steps (after 1 warm-up) of the same C2 batch-{c['B']} workload, "
@@ -112,8 +114,18 @@ def main():
 
     model, cfg, sd, c = build(args.case, device, args.precision)
     item = make_item(c, rank, device)
-    use_graph = world == 1 and not args.no_graph
+    use_graph = not args.no_graph
     engine = GraphedTrainEngine(model) if use_graph else TrainEngine(model)
+    if use_graph:
+        try:  # capture once up front; any failure falls back to eager launches (same arithmetic)
+            engine.capture(item, epoch=10)
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] HIP-graph capture failed ({type(exc).__name__}: {exc}); using eager launches",
+                  file=sys.stderr, flush=True)
+            from routeformer_amd.models.blocks import SAMPLER
+            SAMPLER.drop_static()
+            use_graph = False
+            engine = TrainEngine(model)
 
     def sync():
         if world > 1:

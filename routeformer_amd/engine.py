@@ -134,6 +134,7 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._works: List = []
         self._starts = sorted((self.offset[id(p)], id(p)) for p in self.params)
+        self.hooks_enabled = True  # False: no in-backward launches (HIP-graph capture); finish() sends all
         if self.world > 1:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
@@ -142,6 +143,8 @@ class GradReducer:
         """A kernel accumulated straight into ``view`` (a slice of flat_grad): same bookkeeping as the
         autograd hook, for every parameter slot the view covers (packed Q/K/V views cover three)."""
         import bisect
+        if not self.hooks_enabled:
+            return
         lo = (view.data_ptr() - self.flat_grad.data_ptr()) // 4
         hi = lo + view.numel()
         i = bisect.bisect_left(self._starts, (lo, 0))
@@ -178,6 +181,8 @@ class GradReducer:
         self._launched[b] = True
 
     def _on_grad(self, p):
+        if not self.hooks_enabled:
+            return
         b = self._bucket_of[id(p)]
         self._pending[b] -= 1
         if self._pending[b] == 0 and not self._launched[b]:
@@ -278,8 +283,10 @@ class GraphedTrainEngine(TrainEngine):
     A step of this model is ~4k small launches; replaying them from a graph removes the Python /
     launch-path cost between kernels.  What stays outside the graph: (i) the host-RNG draws of the
     ProbSparse key samples -- made before every replay in the reference's order, one async copy
-    (``IndexSampler`` static mode); (ii) the gradient all-reduce (N > 1) and the clip + AdamW launches,
-    whose scalar arguments (bias correction) change every step.  Requires a step whose control flow does
+    (``IndexSampler`` static mode); (ii) for N > 1 the bucketed gradient all-reduce, issued back to back
+    on the communicator's stream right after the replay (the replayed backward cannot call hooks; at
+    301 MB over 7 xGMI links this is a few % of the step); (iii) the clip + AdamW launches, whose scalar
+    arguments (bias correction) change every step.  Requires a step whose control flow does
     not depend on random draws (view / gaze dropout 0) and fixed batch shapes; inputs are copied into
     static buffers."""
 
@@ -297,9 +304,7 @@ class GraphedTrainEngine(TrainEngine):
 
     def capture(self, item, epoch: int = 0, warmup: int = 2):
         from routeformer_amd.models.blocks import SAMPLER
-        if self.reducer.world > 1:
-            raise NotImplementedError("graph capture with in-backward all-reduce hooks is not supported; "
-                                      "use TrainEngine for N > 1")
+        self.reducer.hooks_enabled = False  # no collective inside the captured region
         self.model.train()
         dev = self.reducer.flat_param.device
         # the caller's tensors become the graph's static inputs (later batches are copied into them)
