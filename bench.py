@@ -104,16 +104,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    backend = os.environ.get("RF_DIST_BACKEND", "nccl")  # "gloo": single-GPU rehearsal of the N>1 path
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from routeformer_amd import kernels as K
     from routeformer_amd.engine import GraphedTrainEngine, TrainEngine
 
+    def note(msg):
+        print(f"[bench r{rank}] {msg}", file=sys.stderr, flush=True)
+
     model, cfg, sd, c = build(args.case, device, args.precision)
     item = make_item(c, rank, device)
+    note("model + synthetic batch resident in HBM")
     use_graph = not args.no_graph
     engine = GraphedTrainEngine(model) if use_graph else TrainEngine(model)
     if use_graph:
@@ -128,13 +137,16 @@ def main():
             engine = TrainEngine(model)
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    note(f"engine ready ({'hipGraph' if use_graph else 'eager'}), warm-up")
     for _ in range(args.warmup):
         engine.step(item, epoch=10)
     sync()
+    note("timed region")
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - 1 and not use_graph:
