@@ -71,6 +71,15 @@ int rf_conv2d_nhwc(const float* x, const float* w, const float* bias, const floa
                    float* y, int N, int H, int W, int cin, int cout, int ksize, int stride, int pad,
                    int Ho, int Wo, int64_t ldy, int64_t ldres, int relu, int prec, void* stream);
 
+/* 3x3 / stride 1 / pad 1 fast path on the bf16 matrix cores ("raster window": the contiguous NHWC span a
+ * 128-pixel tile needs is staged into LDS once; no im2col).  w_bf16: [cout][9][cin] bf16 (cin == 16:
+ * [cout][10][16] with a zero 10th tap), BatchNorm folded.  Supported (cin,cout): (16,16) (32,32) (64,64)
+ * (128,128) (256,16) -- the BasicBlock / Bottleneck / transition convs of hrnetv2.py:45-61,79-99,310-330.
+ * Same arithmetic contract as rf_conv2d_nhwc(prec = 1). */
+int rf_conv3x3_bf16_supported(int cin, int cout);
+int rf_conv3x3_bf16(const float* x, const void* w_bf16, const float* bias, const float* residual, float* y,
+                    int N, int H, int W, int cin, int cout, int relu, void* stream);
+
 /* Stem: frame gather + fp16->fp32 + conv0 (3->3, k2 s2, no BN; hrnetv2.py:292-293,432-433).
  * video: (B,T,3,H,W) fp16 (video_is_f32=0) or fp32 (=1); frame_idx[F] picks frames (routeformer.py:418-421);
  * y: (B*F, H/2, W/2, 4) fp32 NHWC with a zero 4th channel. w: (3,3,2,2) as in the state dict. */

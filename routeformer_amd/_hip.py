@@ -21,6 +21,8 @@ SIGNATURES = {
     "rf_colsum_parts": [_I, _I],
     "rf_colsum": [_P, _L, _I, _I, _P, _I, _P, _P],
     "rf_conv2d_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _I, _I, _P],
+    "rf_conv3x3_bf16_supported": [_I, _I],
+    "rf_conv3x3_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "rf_stem_conv0": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "rf_upsample_bilinear_nhwc": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _I, _I, _P],
     "rf_add_relu": [_P, _P, _P, _L, _I, _P],

@@ -154,30 +154,42 @@ class HRNet16Backbone(VideoBackboneModule):
                 else:
                     bias = None
                 if conv == "conv0":
-                    folded[conv] = (w.contiguous(), None, cin, cout, k)
+                    folded[conv] = (w.contiguous(), None, cin, cout, k, None)
                     continue
                 cin_p = (cin + 3) // 4 * 4  # conv1 reads the 4-channel (zero-padded) stem output
                 wk = torch.zeros(cout, k, k, cin_p, device=device, dtype=torch.float32)
                 wk[..., :cin] = w.permute(0, 2, 3, 1)
-                folded[conv] = (wk.contiguous(), bias, cin_p, cout, k)
+                wb = None  # bf16 [cout][taps][cin] copy for the raster-window 3x3 kernel
+                if k == 3 and bias is not None and _hip.lib().rf_conv3x3_bf16_supported(cin_p, cout):
+                    taps = wk.view(cout, 9, cin_p)
+                    if cin_p == 16:  # one k-step spans two taps: zero 10th tap
+                        taps = torch.cat([taps, torch.zeros(cout, 1, cin_p, device=device)], dim=1)
+                    wb = taps.to(torch.bfloat16).contiguous()
+                folded[conv] = (wk.contiguous(), bias, cin_p, cout, k, wb)
         self._folded, self._folded_key = folded, key
         return folded
 
     # ---- execution --------------------------------------------------------------------------------
     def _conv(self, W, unit, x, stride=1, relu=False, residual=None):
-        w, b, cin, cout, k = W[unit]
+        w, b, cin, cout, k, wb = W[unit]
         N, H, Wd, C = x.shape
         assert C == cin, (unit, C, cin)
         pad = 1 if k == 3 else 0
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
         y = torch.empty(N, Ho, Wo, cout, device=x.device, dtype=torch.float32)
         ev = K.PROFILE.begin() if K.PROFILE.on else None
-        check(_hip.lib().rf_conv2d_nhwc(ptr(x), ptr(w), ptr(b), ptr(residual), ptr(y), N, H, Wd, cin, cout, k,
-                                        stride, pad, Ho, Wo, cout, cout, 1 if relu else 0, K._PRECISION,
-                                        K._stream()), "rf_conv2d_nhwc")
+        fast = wb is not None and stride == 1 and K._PRECISION == 1
+        if fast:  # 3x3/s1 on the bf16 matrix cores straight out of an LDS raster window
+            check(_hip.lib().rf_conv3x3_bf16(ptr(x), ptr(wb), ptr(b), ptr(residual), ptr(y), N, H, Wd, cin, cout,
+                                             1 if relu else 0, K._stream()), "rf_conv3x3_bf16")
+        else:
+            check(_hip.lib().rf_conv2d_nhwc(ptr(x), ptr(w), ptr(b), ptr(residual), ptr(y), N, H, Wd, cin, cout, k,
+                                            stride, pad, Ho, Wo, cout, cout, 1 if relu else 0, K._PRECISION,
+                                            K._stream()), "rf_conv2d_nhwc")
         if ev is not None:  # algorithmic work: one read of x / w (/ residual), one write of y
             M = N * Ho * Wo
-            tag = "conv2d_n16" if cout <= 16 else ("conv2d_n32" if cout <= 32 else "conv2d_n64")
+            tag = f"conv3x3_c{cin}" if fast else (
+                "conv2d_n16" if cout <= 16 else ("conv2d_n32" if cout <= 32 else "conv2d_n64"))
             K.PROFILE.end(tag, ev, 2.0 * M * cout * k * k * cin,
                           4.0 * (x.numel() + w.numel() + M * cout * (2 if residual is not None else 1)))
         return y

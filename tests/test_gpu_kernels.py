@@ -332,6 +332,34 @@ def test_conv2d_nhwc(N, H, W, cin, cout, k, s, prec, tol):
     assert rel_err(y, _nhwc(ref)) < tol
 
 
+@pytest.mark.parametrize("N,H,W,cin,cout", [(3, 28, 28, 16, 16), (5, 14, 14, 32, 32), (7, 7, 7, 64, 64), (9, 4, 4, 128, 128),
+                                            (2, 28, 28, 256, 16), (1, 1, 1, 128, 128), (3, 2, 3, 64, 64), (2, 56, 56, 64, 64),
+                                            (11, 5, 9, 16, 16)])
+def test_conv3x3_raster_window(N, H, W, cin, cout):
+    """The LDS raster-window 3x3 kernel (bf16 MFMA) against F.conv2d on bf16-rounded operands."""
+    from routeformer_amd import _hip, kernels as Kn
+    g = _g(N * 31 + H + cin)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(N, cout, H, W, generator=g)
+    xb, wb_ = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.relu(F.conv2d(xb, wb_, b, padding=1) + res)
+    xd, rd, bd = _nhwc(x).to(DEV), _nhwc(res).to(DEV), b.to(DEV)
+    taps = w.permute(0, 2, 3, 1).reshape(cout, 9, cin)
+    if cin == 16:
+        taps = torch.cat([taps, torch.zeros(cout, 1, cin)], dim=1)
+    wd = taps.bfloat16().contiguous().to(DEV)
+    y = torch.empty(N, H, W, cout, device=DEV)
+    assert _hip.lib().rf_conv3x3_bf16_supported(cin, cout) == 1
+    _hip.check(_hip.lib().rf_conv3x3_bf16(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr(), y.data_ptr(),
+                                          N, H, W, cin, cout, 1, Kn._stream()), "conv3x3")
+    assert rel_err(y, _nhwc(ref)) < 2e-5  # identical operands (bf16-rounded), fp32 accumulate
+    _hip.check(_hip.lib().rf_conv3x3_bf16(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, y.data_ptr(),
+                                          N, H, W, cin, cout, 0, Kn._stream()), "conv3x3")
+    assert rel_err(y, _nhwc(F.conv2d(xb, wb_, b, padding=1))) < 2e-5
+
+
 def test_vision_helpers():
     from routeformer_amd import _hip, kernels as Kn
     from routeformer_amd.models.video_backbone.hrnet16 import HRNet16Backbone
