@@ -182,7 +182,7 @@ def main():
             peak_tf = MFMA_PEAK_TFLOPS[args.precision]
             # regime: arithmetic intensity vs the ridge point
             mfma_bound = (st["flops"] / max(st["bytes"], 1)) > (peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9))
-            roof = {"kernel": name, "bound": "mfma" if mfma_bound else "hbm",
+            roof = {"kernel": name + " (librf_hip.so symbol, anonymous namespace)", "bound": "mfma" if mfma_bound else "hbm",
                     "achieved": tfl if mfma_bound else gbs, "peak": peak_tf if mfma_bound else HBM_PEAK_GBS,
                     "unit": "TFLOP/s" if mfma_bound else "GB/s",
                     "frac": (tfl / peak_tf) if mfma_bound else (gbs / HBM_PEAK_GBS), "traffic": None,

@@ -35,13 +35,41 @@ __device__ __forceinline__ long ctx_off(const AttnP& p, int b, int h, int l) {
   return p.out_layout == 0 ? (((long)b * p.LQ + l) * p.H + h) * p.E : (((long)b * p.H + h) * p.LQ + l) * p.E;
 }
 
-// Load an (L x E) head slice into LDS with row pitch EP (= E + 1, odd-ish -> conflict-free columns).
+// V4 = every head row is 16-B addressable (E % 4 == 0, aligned pointers / pitches): LDS rows get pitch E+4
+// and all row traffic is 128-bit (4x fewer LDS instructions, the limiter of these kernels); else pitch E+1
+// and scalar accesses.  Dot products keep the same ascending-e fmaf chain in both forms.
+template <bool V4> __device__ __forceinline__ int pitch(int E) { return V4 ? E + 4 : E + 1; }
+
+template <bool V4>
+__device__ __forceinline__ float dot_rows(const float* __restrict__ a, const float* __restrict__ b, int E) {
+  float d = 0.f;
+  if constexpr (V4) {
+    for (int e = 0; e < E; e += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(a + e), y = *reinterpret_cast<const float4*>(b + e);
+      d = fmaf(x.x, y.x, d); d = fmaf(x.y, y.y, d); d = fmaf(x.z, y.z, d); d = fmaf(x.w, y.w, d);
+    }
+  } else {
+    for (int e = 0; e < E; ++e) d = fmaf(a[e], b[e], d);
+  }
+  return d;
+}
+
+// Load an (L x E) head slice into LDS with row pitch EP.
+template <bool V4>
 __device__ __forceinline__ void load_head(float* S, const float* G, long ld, int b, int h, int L, int E,
                                           int EP, int tid) {
   const float* base = G + (long)b * L * ld + (long)h * E;
-  for (int i = tid; i < L * E; i += NT) {
-    const int l = i / E, e = i - l * E;
-    S[l * EP + e] = base[(long)l * ld + e];
+  if constexpr (V4) {
+    const int E4 = E >> 2;
+    for (int i = tid; i < L * E4; i += NT) {
+      const int l = i / E4, e = (i - l * E4) << 2;
+      *reinterpret_cast<float4*>(S + l * EP + e) = *reinterpret_cast<const float4*>(base + (long)l * ld + e);
+    }
+  } else {
+    for (int i = tid; i < L * E; i += NT) {
+      const int l = i / E, e = i - l * E;
+      S[l * EP + e] = base[(long)l * ld + e];
+    }
   }
 }
 
@@ -98,13 +126,14 @@ __device__ __forceinline__ void softmax_rows(float* S, int n_rows, int LK, const
   }
 }
 
+template <bool V4>
 __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
-  const int LQ = p.LQ, LK = p.LK, E = p.E, EP = E + 1;
+  const int LQ = p.LQ, LK = p.LK, E = p.E, EP = pitch<V4>(E);
   const int n_sel = (p.mode == 0) ? LQ : p.n_top;
-  const int s_elems = max(LQ * p.sample_k, n_sel * LK);
+  const int s_elems = (max(LQ * p.sample_k, n_sel * LK) + 3) & ~3;
   float* Qs = smem;
   float* Ks = Qs + LQ * EP;
   float* Vs = Ks + LK * EP;
@@ -114,9 +143,9 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
   int* sel = reinterpret_cast<int*>(vmean + E);
   int* top_list = sel + LQ;
 
-  load_head(Qs, p.q, p.q_ld, b, h, LQ, E, EP, tid);
-  load_head(Ks, p.k, p.k_ld, b, h, LK, E, EP, tid);
-  load_head(Vs, p.v, p.v_ld, b, h, LK, E, EP, tid);
+  load_head<V4>(Qs, p.q, p.q_ld, b, h, LQ, E, EP, tid);
+  load_head<V4>(Ks, p.k, p.k_ld, b, h, LK, E, EP, tid);
+  load_head<V4>(Vs, p.v, p.v_ld, b, h, LK, E, EP, tid);
   __syncthreads();
 
   if (p.mode == 0) {
@@ -134,10 +163,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
       const int32_t* idx = p.idx + (long)(b / p.idx_group) * LQ * p.sample_k;
       for (int i = tid; i < LQ * p.sample_k; i += NT) {
         const int q = i / p.sample_k;
-        const int kk = idx[i];
-        float d = 0.f;
-        for (int e = 0; e < E; ++e) d = fmaf(Qs[q * EP + e], Ks[kk * EP + e], d);
-        S[i] = d;
+        S[i] = dot_rows<V4>(Qs + q * EP, Ks + idx[i] * EP, E);
       }
       __syncthreads();
       for (int q = tid; q < LQ; q += NT) {
@@ -183,47 +209,62 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
     const int si = i / LK, s = i - si * LK;
     const int q = top_list[si];
     float d = -INFINITY;
-    if (p.mode != 2 || s <= q) {
-      d = 0.f;
-      for (int e = 0; e < E; ++e) d = fmaf(Qs[q * EP + e], Ks[s * EP + e], d);
-      d *= p.scale;
-    }
+    if (p.mode != 2 || s <= q) d = dot_rows<V4>(Qs + q * EP, Ks + s * EP, E) * p.scale;
     S[i] = d;
   }
   __syncthreads();
   softmax_rows(S, n_sel, LK, top_list, p.mode == 2, lane, wave);
   __syncthreads();
-  for (int i = tid; i < n_sel * E; i += NT) {
-    const int si = i / E, d = i - si * E;
-    const int q = top_list[si];
-    const int kmax = (p.mode == 2) ? q + 1 : LK;
-    const float* row = S + (long)si * LK;
-    float a = 0.f;
-    for (int s = 0; s < kmax; ++s) a = fmaf(row[s], Vs[s * EP + d], a);
-    p.ctx[ctx_off(p, b, h, q) + d] = a;
+  if constexpr (V4) {  // each thread: 4 consecutive output channels of one active row
+    const int E4 = E >> 2;
+    for (int i = tid; i < n_sel * E4; i += NT) {
+      const int si = i / E4, d = (i - si * E4) << 2;
+      const int q = top_list[si];
+      const int kmax = (p.mode == 2) ? q + 1 : LK;
+      const float* row = S + (long)si * LK;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = 0; s < kmax; ++s) {
+        const float pv = row[s];
+        const float4 v = *reinterpret_cast<const float4*>(Vs + s * EP + d);
+        a.x = fmaf(pv, v.x, a.x); a.y = fmaf(pv, v.y, a.y); a.z = fmaf(pv, v.z, a.z); a.w = fmaf(pv, v.w, a.w);
+      }
+      *reinterpret_cast<float4*>(p.ctx + ctx_off(p, b, h, q) + d) = a;
+    }
+  } else {
+    for (int i = tid; i < n_sel * E; i += NT) {
+      const int si = i / E, d = i - si * E;
+      const int q = top_list[si];
+      const int kmax = (p.mode == 2) ? q + 1 : LK;
+      const float* row = S + (long)si * LK;
+      float a = 0.f;
+      for (int s = 0; s < kmax; ++s) a = fmaf(row[s], Vs[s * EP + d], a);
+      p.ctx[ctx_off(p, b, h, q) + d] = a;
+    }
   }
 }
 
 // Backward.  LDS carve (floats): Ks[LK*EP] Vs[LK*EP] Qsel[n*EP] dCsel[n*EP] P[n*LK] dS[n*LK]
 //            colsum[E] | ints: top[n] sel[LQ]
+template <bool V4>
 __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
-  const int LQ = p.LQ, LK = p.LK, E = p.E, EP = E + 1;
+  const int LQ = p.LQ, LK = p.LK, E = p.E, EP = pitch<V4>(E);
   const int n_sel = (p.mode == 0) ? LQ : p.n_top;
+  const int pl_elems = (n_sel * LK + 3) & ~3;
   float* Ks = smem;
   float* Vs = Ks + LK * EP;
   float* Qsel = Vs + LK * EP;
   float* dCsel = Qsel + n_sel * EP;
   float* P = dCsel + n_sel * EP;
-  float* dS = P + (long)n_sel * LK;
-  float* colsum = dS + (long)n_sel * LK;
-  int* top_list = reinterpret_cast<int*>(colsum + E);
+  float* dS = P + pl_elems;
+  float* colsum = dS + pl_elems;
+  int* top_list = reinterpret_cast<int*>(colsum + ((E + 3) & ~3));
   int* sel = top_list + n_sel;
 
-  load_head(Ks, p.k, p.k_ld, b, h, LK, E, EP, tid);
-  load_head(Vs, p.v, p.v_ld, b, h, LK, E, EP, tid);
+  load_head<V4>(Ks, p.k, p.k_ld, b, h, LK, E, EP, tid);
+  load_head<V4>(Vs, p.v, p.v_ld, b, h, LK, E, EP, tid);
   for (int q = tid; q < LQ; q += NT) sel[q] = (p.mode == 0) ? q : -1;
   __syncthreads();
   if (p.mode == 0) {
@@ -247,12 +288,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
     const int q = top_list[si];
     float d = -INFINITY, dp = 0.f;
     if (p.mode != 2 || s <= q) {
-      d = 0.f;
-      for (int e = 0; e < E; ++e) {
-        d = fmaf(Qsel[si * EP + e], Ks[s * EP + e], d);
-        dp = fmaf(dCsel[si * EP + e], Vs[s * EP + e], dp);
-      }
-      d *= p.scale;
+      d = dot_rows<V4>(Qsel + si * EP, Ks + s * EP, E) * p.scale;
+      dp = dot_rows<V4>(dCsel + si * EP, Vs + s * EP, E);
     }
     P[i] = d;
     dS[i] = dp;
@@ -269,14 +306,31 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
     for (int s = lane; s < LK; s += 64) dSr[s] = Pr[s] * (dSr[s] - dot) * p.scale;
   }
   __syncthreads();
-  for (int i = tid; i < n_sel * E; i += NT) {
-    const int si = i / E, e = i - si * E;
-    const int q = top_list[si];
-    const int kmax = (p.mode == 2) ? q + 1 : LK;
-    const float* dSr = dS + (long)si * LK;
-    float a = 0.f;
-    for (int s = 0; s < kmax; ++s) a = fmaf(dSr[s], Ks[s * EP + e], a);
-    p.dq[((long)b * LQ + q) * p.dq_ld + (long)h * E + e] = a;
+  if constexpr (V4) {
+    const int E4 = E >> 2;
+    for (int i = tid; i < n_sel * E4; i += NT) {
+      const int si = i / E4, e = (i - si * E4) << 2;
+      const int q = top_list[si];
+      const int kmax = (p.mode == 2) ? q + 1 : LK;
+      const float* dSr = dS + (long)si * LK;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = 0; s < kmax; ++s) {
+        const float g = dSr[s];
+        const float4 kv = *reinterpret_cast<const float4*>(Ks + s * EP + e);
+        a.x = fmaf(g, kv.x, a.x); a.y = fmaf(g, kv.y, a.y); a.z = fmaf(g, kv.z, a.z); a.w = fmaf(g, kv.w, a.w);
+      }
+      *reinterpret_cast<float4*>(p.dq + ((long)b * LQ + q) * p.dq_ld + (long)h * E + e) = a;
+    }
+  } else {
+    for (int i = tid; i < n_sel * E; i += NT) {
+      const int si = i / E, e = i - si * E;
+      const int q = top_list[si];
+      const int kmax = (p.mode == 2) ? q + 1 : LK;
+      const float* dSr = dS + (long)si * LK;
+      float a = 0.f;
+      for (int s = 0; s < kmax; ++s) a = fmaf(dSr[s], Ks[s * EP + e], a);
+      p.dq[((long)b * LQ + q) * p.dq_ld + (long)h * E + e] = a;
+    }
   }
   // non-selected query rows get zero dQ (the sampling stage is not differentiated)
   for (int i = tid; i < LQ * E; i += NT) {
@@ -307,29 +361,53 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
     }
     __syncthreads();
   }
-  for (int i = tid; i < LK * E; i += NT) {
-    const int s = i / E, e = i - s * E;
-    float ak = 0.f, av = 0.f;
-    for (int si = 0; si < n_sel; ++si) {
-      ak = fmaf(dS[(long)si * LK + s], Qsel[si * EP + e], ak);
-      av = fmaf(P[(long)si * LK + s], dCsel[si * EP + e], av);
+  if constexpr (V4) {
+    const int E4 = E >> 2;
+    for (int i = tid; i < LK * E4; i += NT) {
+      const int s = i / E4, e = (i - s * E4) << 2;
+      float4 ak = make_float4(0.f, 0.f, 0.f, 0.f), av = ak;
+      for (int si = 0; si < n_sel; ++si) {
+        const float g = dS[(long)si * LK + s], pr = P[(long)si * LK + s];
+        const float4 qv = *reinterpret_cast<const float4*>(Qsel + si * EP + e);
+        const float4 cv = *reinterpret_cast<const float4*>(dCsel + si * EP + e);
+        ak.x = fmaf(g, qv.x, ak.x); ak.y = fmaf(g, qv.y, ak.y); ak.z = fmaf(g, qv.z, ak.z); ak.w = fmaf(g, qv.w, ak.w);
+        av.x = fmaf(pr, cv.x, av.x); av.y = fmaf(pr, cv.y, av.y); av.z = fmaf(pr, cv.z, av.z); av.w = fmaf(pr, cv.w, av.w);
+      }
+      if (p.mode == 1) { av.x += colsum[e]; av.y += colsum[e + 1]; av.z += colsum[e + 2]; av.w += colsum[e + 3]; }
+      if (p.mode == 2) {
+        const float4 r = *reinterpret_cast<const float4*>(Vs + s * EP + e);
+        av.x += r.x; av.y += r.y; av.z += r.z; av.w += r.w;
+      }
+      *reinterpret_cast<float4*>(p.dk + ((long)b * LK + s) * p.dk_ld + (long)h * E + e) = ak;
+      *reinterpret_cast<float4*>(p.dv + ((long)b * LK + s) * p.dv_ld + (long)h * E + e) = av;
     }
-    if (p.mode == 1) av += colsum[e];
-    if (p.mode == 2) av += Vs[s * EP + e];
-    p.dk[((long)b * LK + s) * p.dk_ld + (long)h * E + e] = ak;
-    p.dv[((long)b * LK + s) * p.dv_ld + (long)h * E + e] = av;
+  } else {
+    for (int i = tid; i < LK * E; i += NT) {
+      const int s = i / E, e = i - s * E;
+      float ak = 0.f, av = 0.f;
+      for (int si = 0; si < n_sel; ++si) {
+        ak = fmaf(dS[(long)si * LK + s], Qsel[si * EP + e], ak);
+        av = fmaf(P[(long)si * LK + s], dCsel[si * EP + e], av);
+      }
+      if (p.mode == 1) av += colsum[e];
+      if (p.mode == 2) av += Vs[s * EP + e];
+      p.dk[((long)b * LK + s) * p.dk_ld + (long)h * E + e] = ak;
+      p.dv[((long)b * LK + s) * p.dv_ld + (long)h * E + e] = av;
+    }
   }
 }
 
-size_t fwd_lds(int LQ, int LK, int E, int n_sel, int sample_k) {
-  const size_t EP = E + 1;
-  const size_t s_elems = max((size_t)LQ * sample_k, (size_t)n_sel * LK);
-  return sizeof(float) * (LQ * EP + 2 * LK * EP + s_elems + LQ + E) + sizeof(int) * ((size_t)LQ + n_sel);
+size_t fwd_lds(int LQ, int LK, int E, int n_sel, int sample_k, bool v4) {
+  const size_t EP = v4 ? E + 4 : E + 1;
+  const size_t s_elems = (max((size_t)LQ * sample_k, (size_t)n_sel * LK) + 3) & ~(size_t)3;
+  return sizeof(float) * (LQ * EP + 2 * LK * EP + s_elems + LQ + E) + sizeof(int) * ((size_t)LQ + n_sel) + 16;
 }
-size_t bwd_lds(int LQ, int LK, int E, int n_sel) {
-  const size_t EP = E + 1;
-  return sizeof(float) * (2 * LK * EP + 2 * n_sel * EP + 2 * (size_t)n_sel * LK + E) + sizeof(int) * ((size_t)n_sel + LQ);
+size_t bwd_lds(int LQ, int LK, int E, int n_sel, bool v4) {
+  const size_t EP = v4 ? E + 4 : E + 1;
+  const size_t pl = ((size_t)n_sel * LK + 3) & ~(size_t)3;
+  return sizeof(float) * (2 * LK * EP + 2 * n_sel * EP + 2 * pl + ((E + 3) & ~3)) + sizeof(int) * ((size_t)n_sel + LQ) + 16;
 }
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
@@ -342,7 +420,9 @@ extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64
   RF_REQUIRE(mode == 0 || (top_idx && n_top > 0 && n_top <= LQ));
   RF_REQUIRE(mode == 0 || force_top || (index_sample && sample_k > 0));
   RF_REQUIRE(mode != 2 || LQ == LK);
-  const size_t lds = fwd_lds(LQ, LK, E, mode == 0 ? LQ : n_top, mode == 0 ? 0 : sample_k);
+  const bool v4 = (E % 4 == 0) && al16(q) && al16(k) && al16(v) && al16(ctx) && q_ld % 4 == 0 && k_ld % 4 == 0 &&
+                  v_ld % 4 == 0;
+  const size_t lds = fwd_lds(LQ, LK, E, mode == 0 ? LQ : n_top, mode == 0 ? 0 : sample_k, v4);
   if (lds > 160 * 1024) { rf_g_last_error = "attention head slice exceeds 160 KB LDS"; return RF_EUNSUPPORTED; }
   AttnP p{};
   p.q = q; p.k = k; p.v = v; p.q_ld = q_ld; p.k_ld = k_ld; p.v_ld = v_ld; p.ctx = ctx;
@@ -352,11 +432,12 @@ extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64
   p.idx_group = (idx_group <= 0 || idx_group > B) ? B : idx_group;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(NT), lds, static_cast<hipStream_t>(stream), p);
+  if (v4) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(B * H), dim3(NT), lds, static_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(B * H), dim3(NT), lds, static_cast<hipStream_t>(stream), p);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
@@ -371,7 +452,9 @@ extern "C" int rf_attn_bwd(const float* q, const float* k, const float* v, int64
   RF_REQUIRE(mode == 0 || (top_idx && n_top > 0 && n_top <= LQ));
   RF_REQUIRE(mode != 2 || LQ == LK);
   const int n_sel = mode == 0 ? LQ : n_top;
-  const size_t lds = bwd_lds(LQ, LK, E, n_sel);
+  const bool v4 = (E % 4 == 0) && al16(q) && al16(k) && al16(v) && al16(dq) && al16(dk) && al16(dv) &&
+                  q_ld % 4 == 0 && k_ld % 4 == 0 && v_ld % 4 == 0 && dq_ld % 4 == 0 && dk_ld % 4 == 0 && dv_ld % 4 == 0;
+  const size_t lds = bwd_lds(LQ, LK, E, n_sel, v4);
   if (lds > 160 * 1024) { rf_g_last_error = "attention backward exceeds 160 KB LDS"; return RF_EUNSUPPORTED; }
   AttnP p{};
   p.q = q; p.k = k; p.v = v; p.q_ld = q_ld; p.k_ld = k_ld; p.v_ld = v_ld; p.dctx = dctx;
@@ -380,10 +463,12 @@ extern "C" int rf_attn_bwd(const float* q, const float* k, const float* v, int64
   p.E = E; p.n_top = n_top; p.mode = mode; p.scale = scale;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(NT), lds, static_cast<hipStream_t>(stream), p);
+  if (v4) hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(B * H), dim3(NT), lds, static_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(B * H), dim3(NT), lds, static_cast<hipStream_t>(stream), p);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

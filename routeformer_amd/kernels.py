@@ -173,8 +173,16 @@ def gemm(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, *, bias=None, residu
                              ptr(bias), ptr(residual), ldr, res_rows, res_before_act, act,
                              ptr(preact), ldp, ptr(dact_src), ldd, dact, _PRECISION, splitk, ptr(ws),
                              1 if atomic else 0, ptr(a_rowsum), _stream()), "rf_gemm")
-    if ev is not None:
-        PROFILE.end("gemm", ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N))
+    if ev is not None:  # tag = the kernel symbol rf_gemm dispatches to (same rules as csrc/gemm.hip)
+        def mode(t, ld_k, ld_row):
+            al = t.data_ptr() % 16 == 0
+            return 0 if (ld_k == 1 and ld_row % 4 == 0 and al) else (1 if (ld_row == 1 and ld_k % 4 == 0 and al) else 2)
+        am, bm = mode(A, lda_k, lda_m), mode(B, ldb_k, ldb_n)
+        if am <= 1 and bm <= 1:
+            tag = f"gemm2_kernel<{_PRECISION}, {am}, {bm}, {3 if (M >= 4096 and N >= 64) else 0}>"
+        else:
+            tag = f"gemm_kernel<{_PRECISION}, {am}, {bm}, 0>"
+        PROFILE.end(tag, ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N))
 
 
 def colsum(X2d: torch.Tensor, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -390,7 +398,7 @@ class _AddLayerNorm(torch.autograd.Function):
         check(_hip.lib().rf_layernorm_fwd(ptr(x2), ptr(r2), ptr(gamma), ptr(beta), ptr(y), ptr(xhat),
                                           ptr(rstd), rows, cols, eps, _stream()), "rf_layernorm_fwd")
         if ev is not None:
-            PROFILE.end("layernorm_fwd", ev, 8.0 * rows * cols, 4.0 * rows * cols * (4 if r2 is not None else 3))
+            PROFILE.end("layernorm_fwd_kernel", ev, 8.0 * rows * cols, 4.0 * rows * cols * (4 if r2 is not None else 3))
         ctx.save_for_backward(xhat, rstd, gamma)
         ctx.sinks = (gg, gb)
         ctx.has_res = residual is not None
@@ -414,7 +422,7 @@ class _AddLayerNorm(torch.autograd.Function):
                                           ptr(db), 1 if sink else 0, ptr(ws), rows, cols, _stream()),
               "rf_layernorm_bwd")
         if ev is not None:
-            PROFILE.end("layernorm_bwd", ev, 12.0 * rows * cols, 4.0 * rows * cols * 3)
+            PROFILE.end("layernorm_bwd_kernel(+ln_param_reduce)", ev, 12.0 * rows * cols, 4.0 * rows * cols * 3)
         dx = dx.view(ctx.xshape)
         if sink:
             _wrote(gg, gb)
@@ -581,7 +589,7 @@ class _Attention(torch.autograd.Function):
                                      mode, scale, _stream()), "rf_attn_fwd")
         if ev is not None:
             u = LQ if mode == 0 else n_top  # sample stage + active rows (QK^T and AV)
-            PROFILE.end("attn_fwd", ev, B * H * (2.0 * LQ * sample_k * E + 4.0 * u * LK * E),
+            PROFILE.end("attn_fwd_kernel", ev, B * H * (2.0 * LQ * sample_k * E + 4.0 * u * LK * E),
                         4.0 * B * H * E * (2 * LQ + 2 * LK) + 4.0 * LQ * sample_k)
         if top is not None and TOPS.record is not None:
             TOPS.record.append(top.clone())
@@ -605,7 +613,7 @@ class _Attention(torch.autograd.Function):
                                      B, H, LQ, LK, E, n_top, mode, scale, _stream()), "rf_attn_bwd")
         if ev is not None:
             u = LQ if mode == 0 else n_top
-            PROFILE.end("attn_bwd", ev, B * H * 10.0 * u * LK * E, 4.0 * B * H * E * (4 * LQ + 4 * LK))
+            PROFILE.end("attn_bwd_kernel", ev, B * H * 10.0 * u * LK * E, 4.0 * B * H * E * (4 * LQ + 4 * LK))
         return da, (None if same else db), None, None, None, None, None, None, None, None, None
 
 

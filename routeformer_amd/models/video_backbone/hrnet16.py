@@ -188,8 +188,8 @@ class HRNet16Backbone(VideoBackboneModule):
                                             K._stream()), "rf_conv2d_nhwc")
         if ev is not None:  # algorithmic work: one read of x / w (/ residual), one write of y
             M = N * Ho * Wo
-            tag = f"conv3x3_c{cin}" if fast else (
-                "conv2d_n16" if cout <= 16 else ("conv2d_n32" if cout <= 32 else "conv2d_n64"))
+            tag = f"conv3x3_kernel<{cin}, {cout}>" if fast else \
+                f"gemm2_kernel<{K._PRECISION}, 3, 0, {1 if cout <= 16 else (2 if cout <= 32 else 0)}>"
             K.PROFILE.end(tag, ev, 2.0 * M * cout * k * k * cin,
                           4.0 * (x.numel() + w.numel() + M * cout * (2 if residual is not None else 1)))
         return y
