@@ -113,10 +113,31 @@ class _Profiler:
         e.record()
         return e
 
-    def end(self, tag, start, flops, nbytes):
+    def end(self, tag, start, flops, nbytes, replay=None):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        self.events.append((tag, start, e, flops, nbytes))
+        self.events.append((tag, start, e, flops, nbytes, replay))
+
+    def refine(self, tag, reps: int = 10):
+        """Per-launch duration of kernel ``tag`` without the eager launch gaps: every recorded launch of it
+        is re-issued ``reps`` times back to back between two HIP events on the launch stream (same
+        operands, same shapes).  Returns (launches, total_us_per_step, flops, bytes) or None."""
+        todo = [(fl, by, rp) for t, _, _, fl, by, rp in self.events if t == tag and rp is not None]
+        if not todo:
+            return None
+        total_us = fl_sum = by_sum = 0.0
+        for fl, by, rp in todo:
+            rp()  # warm
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(reps):
+                rp()
+            e.record()
+            e.synchronize()
+            total_us += s.elapsed_time(e) * 1e3 / reps
+            fl_sum += fl
+            by_sum += by
+        return len(todo), total_us, fl_sum, by_sum
 
     def summary(self):
         """tag -> {launches, total_ms, flops, bytes} (algorithmic flops / bytes summed over launches)."""
@@ -124,7 +145,7 @@ class _Profiler:
             return {}
         torch.cuda.synchronize()
         out = {}
-        for tag, s, e, fl, by in self.events:
+        for tag, s, e, fl, by, _ in self.events:
             d = out.setdefault(tag, {"launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["total_ms"] += s.elapsed_time(e)
@@ -169,10 +190,10 @@ def gemm(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, *, bias=None, residu
     if splitk > 1 and not atomic:
         ws = torch.empty(splitk * M * N, device=C.device, dtype=torch.float32)
     ev = PROFILE.begin() if PROFILE.on else None
-    check(_hip.lib().rf_gemm(ptr(A), lda_m, lda_k, ptr(B), ldb_k, ldb_n, ptr(C), ldc, M, N, K,
-                             ptr(bias), ptr(residual), ldr, res_rows, res_before_act, act,
-                             ptr(preact), ldp, ptr(dact_src), ldd, dact, _PRECISION, splitk, ptr(ws),
-                             1 if atomic else 0, ptr(a_rowsum), _stream()), "rf_gemm")
+    args = (ptr(A), lda_m, lda_k, ptr(B), ldb_k, ldb_n, ptr(C), ldc, M, N, K, ptr(bias), ptr(residual), ldr, res_rows,
+            res_before_act, act, ptr(preact), ldp, ptr(dact_src), ldd, dact, _PRECISION, splitk, ptr(ws),
+            1 if atomic else 0, ptr(a_rowsum))
+    check(_hip.lib().rf_gemm(*args, _stream()), "rf_gemm")
     if ev is not None:  # tag = the kernel symbol rf_gemm dispatches to (same rules as csrc/gemm.hip)
         def mode(t, ld_k, ld_row):
             al = t.data_ptr() % 16 == 0
@@ -182,7 +203,9 @@ def gemm(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, *, bias=None, residu
             tag = f"gemm2_kernel<{_PRECISION}, {am}, {bm}, {3 if (M >= 4096 and N >= 64) else 0}>"
         else:
             tag = f"gemm_kernel<{_PRECISION}, {am}, {bm}, 0>"
-        PROFILE.end(tag, ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N))
+        keep = (A, B, C, bias, residual, preact, dact_src, ws, a_rowsum)  # operands stay alive for the replay
+        PROFILE.end(tag, ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N),
+                    replay=lambda a=args, k=keep: _hip.lib().rf_gemm(*a, _stream()))
 
 
 def colsum(X2d: torch.Tensor, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -582,15 +605,16 @@ class _Attention(torch.autograd.Function):
                 torch.empty(B, H, n_top, device=a.device, dtype=torch.int32)
             sample_k = index_sample.shape[-1] if index_sample is not None else 0
         ev = PROFILE.begin() if PROFILE.on else None
-        check(_hip.lib().rf_attn_fwd(a.data_ptr() + 4 * q_off, b.data_ptr() + 4 * k_off,
-                                     b.data_ptr() + 4 * v_off, a.stride(0), b.stride(0), b.stride(0),
-                                     ptr(out), out_layout, ptr(index_sample), idx_group, ptr(top),
-                                     1 if forced_top is not None else 0, B, H, LQ, LK, E, sample_k, n_top,
-                                     mode, scale, _stream()), "rf_attn_fwd")
+        fargs = (a.data_ptr() + 4 * q_off, b.data_ptr() + 4 * k_off, b.data_ptr() + 4 * v_off, a.stride(0),
+                 b.stride(0), b.stride(0), ptr(out), out_layout, ptr(index_sample), idx_group, ptr(top),
+                 1 if forced_top is not None else 0, B, H, LQ, LK, E, sample_k, n_top, mode, scale)
+        check(_hip.lib().rf_attn_fwd(*fargs, _stream()), "rf_attn_fwd")
         if ev is not None:
             u = LQ if mode == 0 else n_top  # sample stage + active rows (QK^T and AV)
-            PROFILE.end("attn_fwd_kernel", ev, B * H * (2.0 * LQ * sample_k * E + 4.0 * u * LK * E),
-                        4.0 * B * H * E * (2 * LQ + 2 * LK) + 4.0 * LQ * sample_k)
+            keep = (a, b, out, index_sample, top)
+            PROFILE.end("attn_fwd_kernel<true>", ev, B * H * (2.0 * LQ * sample_k * E + 4.0 * u * LK * E),
+                        4.0 * B * H * E * (2 * LQ + 2 * LK) + 4.0 * LQ * sample_k,
+                        replay=lambda fa=fargs, k=keep: _hip.lib().rf_attn_fwd(*fa, _stream()))
         if top is not None and TOPS.record is not None:
             TOPS.record.append(top.clone())
         ctx.save_for_backward(a, b, top if top is not None else a)
@@ -613,7 +637,7 @@ class _Attention(torch.autograd.Function):
                                      B, H, LQ, LK, E, n_top, mode, scale, _stream()), "rf_attn_bwd")
         if ev is not None:
             u = LQ if mode == 0 else n_top
-            PROFILE.end("attn_bwd_kernel", ev, B * H * 10.0 * u * LK * E, 4.0 * B * H * E * (4 * LQ + 4 * LK))
+            PROFILE.end("attn_bwd_kernel<true>", ev, B * H * 10.0 * u * LK * E, 4.0 * B * H * E * (4 * LQ + 4 * LK))
         return da, (None if same else db), None, None, None, None, None, None, None, None, None
 
 
