@@ -121,8 +121,11 @@ def main():
         print(f"[bench r{rank}] {msg}", file=sys.stderr, flush=True)
 
     model, cfg, sd, c = build(args.case, device, args.precision)
-    item = make_item(c, rank, device)
-    note("model + synthetic batch resident in HBM")
+    # two different synthetic batches, used alternately: the engine's look-ahead (conv trunk of the NEXT
+    # batch under the current step) then always works on data it has not seen in this step
+    items = [make_item(c, rank, device), make_item(c, rank + 500, device)]
+    item = items[0]
+    note("model + 2 synthetic batches resident in HBM")
     use_graph = not args.no_graph
     engine = GraphedTrainEngine(model) if use_graph else TrainEngine(model)
     if use_graph:
@@ -143,15 +146,16 @@ def main():
         torch.cuda.synchronize()
 
     note(f"engine ready ({'hipGraph' if use_graph else 'eager'}), warm-up")
-    for _ in range(args.warmup):
-        engine.step(item, epoch=10)
+    for i in range(args.warmup):
+        engine.step(items[i % 2], epoch=10, next_item=items[(i + 1) % 2])
     sync()
     note("timed region")
+    w0 = args.warmup
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == args.steps - 1 and not use_graph:
             K.PROFILE.enable()  # HIP events around every kernel-class launch of the last timed step
-        res = engine.step(item, epoch=10)
+        res = engine.step(items[(w0 + i) % 2], epoch=10, next_item=items[(w0 + i + 1) % 2])
     sync()
     elapsed = time.perf_counter() - t0
     K.PROFILE.disable()

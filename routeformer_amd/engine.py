@@ -23,8 +23,10 @@ from routeformer_amd.score import ade, fde
 
 
 def train_step_losses(model, item, epoch: int = 0, trajectory_loss: Optional[FutureDiscountedLoss] = None,
-                      dense_loss: Optional[FutureDiscountedLoss] = None) -> Dict[str, torch.Tensor]:
-    """item = {"train": Data, "target": Data}.  Returns loss terms, metrics and predictions."""
+                      dense_loss: Optional[FutureDiscountedLoss] = None,
+                      tokens_ready: bool = False) -> Dict[str, torch.Tensor]:
+    """item = {"train": Data, "target": Data}.  Returns loss terms, metrics and predictions.
+    ``tokens_ready``: the conv-trunk tokens of this item were installed already (pipelined engine)."""
     cfg = model.configs
     tl = trajectory_loss or FutureDiscountedLoss(cfg.discount_factor, cfg.epsilon, loss_function="smooth_l1")
     dl = dense_loss or FutureDiscountedLoss(cfg.discount_factor, cfg.visual_epsilon, loss_function="smooth_l1")
@@ -34,7 +36,7 @@ def train_step_losses(model, item, epoch: int = 0, trajectory_loss: Optional[Fut
     if cfg.dense_prediction:
         from routeformer_amd import kernels as K
         overlap = K.OVERLAP and (K.OVERLAP_MASK & 1) and target_gps.is_cuda
-        if K.OVERLAP and hasattr(model, "prefetch_video_tokens"):
+        if K.OVERLAP and not tokens_ready and hasattr(model, "prefetch_video_tokens"):
             # frozen conv trunk: one pass over the history AND target frames (336 images at B=8)
             model.prefetch_video_tokens([item["train"], item["target"]])
         if overlap:  # fork point: the target-side pass must not wait for the input forward
@@ -71,7 +73,7 @@ def train_step_losses(model, item, epoch: int = 0, trajectory_loss: Optional[Fut
         loss = traj
     res.update(loss=loss, traj_loss=traj, future_gps=future_gps, ade=ade(future_gps, target_gps),
                fde=fde(future_gps, target_gps))
-    if hasattr(model, "clear_video_tokens"):
+    if hasattr(model, "clear_video_tokens") and not tokens_ready:
         model.clear_video_tokens()
     return res
 
@@ -254,14 +256,14 @@ class TrainEngine:
         self.tl = FutureDiscountedLoss(cfg.discount_factor, cfg.epsilon, loss_function="smooth_l1")
         self.dl = FutureDiscountedLoss(cfg.discount_factor, cfg.visual_epsilon, loss_function="smooth_l1")
 
-    def _fwd_bwd(self, item, epoch):
+    def _fwd_bwd(self, item, epoch, tokens_ready: bool = False):
         from routeformer_amd import kernels as K
         self.reducer.zero()
         K.OVERLAP = self.overlap
         K.SINK.active = True  # kernels accumulate parameter gradients straight into the flat buffer
         K.SINK.on_write = self.reducer.on_sink_write if self.reducer.world > 1 else None
         try:
-            res = train_step_losses(self.model, item, epoch, self.tl, self.dl)
+            res = train_step_losses(self.model, item, epoch, self.tl, self.dl, tokens_ready=tokens_ready)
             res["loss"].backward()
             if self.overlap:
                 K.join_side_streams()
@@ -269,7 +271,7 @@ class TrainEngine:
             K.SINK.active, K.SINK.on_write, K.OVERLAP = False, None, False
         return res
 
-    def step(self, item, epoch: int = 0):
+    def step(self, item, epoch: int = 0, next_item=None):
         self.model.train()
         res = self._fwd_bwd(item, epoch)
         scale = self.reducer.finish()
@@ -280,21 +282,31 @@ class TrainEngine:
 class GraphedTrainEngine(TrainEngine):
     """The same step with forward + backward captured once in a HIP graph and replayed.
 
-    A step of this model is ~4k small launches; replaying them from a graph removes the Python /
+    A step of this model is ~2-4k small launches; replaying them from a graph removes the Python /
     launch-path cost between kernels.  What stays outside the graph: (i) the host-RNG draws of the
     ProbSparse key samples -- made before every replay in the reference's order, one async copy
     (``IndexSampler`` static mode); (ii) for N > 1 the bucketed gradient all-reduce, issued back to back
     on the communicator's stream right after the replay (the replayed backward cannot call hooks; at
     301 MB over 7 xGMI links this is a few % of the step); (iii) the clip + AdamW launches, whose scalar
-    arguments (bias correction) change every step.  Requires a step whose control flow does
-    not depend on random draws (view / gaze dropout 0) and fixed batch shapes; inputs are copied into
-    static buffers."""
+    arguments (bias correction) change every step.
+
+    Software pipelining across steps: the frozen conv trunk has no gradient and does not depend on the
+    weights being trained, so ``step(item, next_item=...)`` runs the trunk pass of the NEXT batch (its own
+    small graph, on a side stream) underneath this batch's transformer forward / backward / optimizer --
+    large, chip-filling conv launches next to latency-bound small ones.  Every step still executes exactly
+    one trunk pass and one full forward/backward/update.
+
+    Requires a step whose control flow does not depend on random draws (view / gaze dropout 0) and fixed
+    batch shapes."""
 
     def __init__(self, model, **kw):
         super().__init__(model, **kw)
         self.graph = None
         self._static_item = None
         self._out = None
+        self._trunk_graphs = {}
+        self._ready_key = None
+        self._tstream = None
         c = model.configs
         if c.view_dropout > 0 or c.gaze_dropout > 0 or c.motion_noise > 0 or c.feature_dropout > 0:
             raise ValueError("GraphedTrainEngine needs a draw-independent step (all dropouts / noise 0)")
@@ -302,13 +314,38 @@ class GraphedTrainEngine(TrainEngine):
     def _eager_fwd_bwd(self, item, epoch):
         return self._fwd_bwd(item, epoch)
 
+    # -- conv-trunk side ---------------------------------------------------------------------------
+    def _vkey(self, item):
+        clips, _ = self.model.video_clips([item["train"], item["target"]])
+        return tuple(v.data_ptr() for v, _ in clips)
+
+    def _trunk_graph(self, item):
+        """Graph of one trunk pass over ``item``'s frames into ``self._tok_next`` (captured once per set of
+        input buffers: a data pipeline that rotates a few pinned device buffers hits the cache)."""
+        key = self._vkey(item)
+        g = self._trunk_graphs.get(key)
+        if g is None:
+            clips, _ = self.model.video_clips([item["train"], item["target"]])
+            self.model.video_backbone.encode_clips(clips, out=self._tok_next)  # warm (weight folding, caches)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.model.video_backbone.encode_clips(clips, out=self._tok_next)
+            self._trunk_graphs[key] = (g, clips)  # keep the clip tensors alive: the graph reads them
+            g = self._trunk_graphs[key]
+        return g[0]
+
     def capture(self, item, epoch: int = 0, warmup: int = 2):
+        from routeformer_amd import kernels as K
         from routeformer_amd.models.blocks import SAMPLER
         self.reducer.hooks_enabled = False  # no collective inside the captured region
         self.model.train()
         dev = self.reducer.flat_param.device
-        # the caller's tensors become the graph's static inputs (later batches are copied into them)
-        self._static_item = {k: dict(d) for k, d in item.items()}
+        # static inputs of the main graph: private copies of the small tensors (gps, gaze); the video
+        # tensors are only consulted for shapes / cache keys while capturing (the trunk has its own graphs)
+        self._static_item = {part: {n: (v if v.dim() == 5 else v.clone()) for n, v in d.items()}
+                             for part, d in item.items()}
+        self._pipelined = self.overlap and bool(self.model.video_clips([item["train"], item["target"]])[0])
         # plan: which draws does one step make?
         plan = None
         side = torch.cuda.Stream()
@@ -324,23 +361,77 @@ class GraphedTrainEngine(TrainEngine):
         SAMPLER.make_static(plan, dev)
         SAMPLER.refill_static()
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._out = self._eager_fwd_bwd(self._static_item, epoch)
+        if self._pipelined:
+            clips, keys = self.model.video_clips([self._static_item["train"], self._static_item["target"]])
+            n = sum(v.shape[0] * idx.numel() for v, idx in clips)
+            self._tok_cur = torch.empty(n, 65, 240, device=dev, dtype=torch.float32)
+            self._tok_next = torch.empty_like(self._tok_cur)
+            self._tstream = torch.cuda.Stream()
+            self._trunk_graph(item).replay()
+            self._tok_cur.copy_(self._tok_next)
+            self.model.set_video_tokens(self._tok_cur, clips, keys)
+            torch.cuda.synchronize()
         self._epoch = epoch
+        self._graphs = {}
+        self.graph, self._out = self._main_graph(None)
+        self._ready_key = None
         return self
 
-    def step(self, item, epoch: int = 0):
+    def _main_graph(self, next_item):
+        """Graph of forward + backward on the static inputs.  With ``next_item`` the conv-trunk pass of that
+        batch is a parallel branch of the SAME graph (forked stream, writes ``_tok_next``): two separate
+        graphs launched on two streams do not overlap on ROCm 7.2 (measured: 14.2 + 5.4 = 19.5 ms), branches
+        of one graph do."""
+        key = None if (next_item is None or not self._pipelined) else self._vkey(next_item)
+        hit = self._graphs.get(key)
+        if hit is not None:
+            return hit[0], hit[1]
+        clips = None
+        if key is not None:
+            clips, _ = self.model.video_clips([next_item["train"], next_item["target"]])
+            self.model.video_backbone.encode_clips(clips)  # warm caches outside capture (scratch output)
+        if self._pipelined:
+            c0, k0 = self.model.video_clips([self._static_item["train"], self._static_item["target"]])
+            self.model.set_video_tokens(self._tok_cur, c0, k0)
+        torch.cuda.synchronize()
+        from routeformer_amd.models.blocks import SAMPLER
+        SAMPLER.rewind_static()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            cur = torch.cuda.current_stream()
+            if key is not None:
+                self._tstream.wait_stream(cur)
+                with torch.cuda.stream(self._tstream):
+                    self.model.video_backbone.encode_clips(clips, out=self._tok_next)
+            out = self._fwd_bwd(self._static_item, self._epoch, tokens_ready=self._pipelined)
+            if key is not None:
+                cur.wait_stream(self._tstream)
+        self.model.clear_video_tokens()
+        self._graphs[key] = (g, out, clips)
+        return g, out
+
+    def step(self, item, epoch: int = 0, next_item=None):
+        """One train step on ``item``; ``next_item`` (optional) = the batch of the following step, whose
+        conv-trunk pass runs underneath this step (a parallel branch of the replayed graph)."""
         from routeformer_amd.models.blocks import SAMPLER
         if self.graph is None:
             self.capture(item, epoch)
         assert epoch == self._epoch or (epoch >= 10) == (self._epoch >= 10), "re-capture when the loss recipe changes"
+        g, out = self._main_graph(next_item)  # (captures on first use of a new look-ahead buffer set)
+        if self._pipelined:
+            if not (self._ready_key is not None and self._ready_key == self._vkey(item)):
+                self._trunk_graph(item).replay()         # cold start / no look-ahead: run this batch's trunk now
+            self._tok_cur.copy_(self._tok_next)
+            self._ready_key = None
         for part in ("train", "target"):
             for n, v in item[part].items():
-                if v.data_ptr() != self._static_item[part][n].data_ptr():
-                    self._static_item[part][n].copy_(v, non_blocking=True)
+                dst = self._static_item[part][n]
+                if v.dim() != 5 and v.data_ptr() != dst.data_ptr():
+                    dst.copy_(v, non_blocking=True)
         SAMPLER.refill_static()
-        self.graph.replay()
+        g.replay()
+        if self._pipelined and next_item is not None:
+            self._ready_key = self._vkey(next_item)
         scale = self.reducer.finish()
         self.opt.step(scale)
-        return self._out
+        return out

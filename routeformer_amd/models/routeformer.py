@@ -250,26 +250,35 @@ class Routeformer(nn.Module):
             plan.append((fv, self._frame_indices(fv.shape[1], c.gaze_fps, "Gaze")))
         return plan
 
-    def prefetch_video_tokens(self, batches):
-        """Run the frozen conv trunk ONCE over the frames of all given batches (it has no randomness and
-        no gradient, so the history and target windows of a step can share one pass); the per-stream
-        encoders then pick their tokens up from this cache.  Call ``clear_video_tokens`` after the step."""
-        if not (self.with_video and hasattr(self.video_backbone, "encode_clips")):
-            return
+    def video_clips(self, batches):
+        """[(video, frame idx)] of every camera stream the given batches will encode (+ their cache keys)."""
         clips, keys = [], []
-        for batch in batches:
-            for video, idx in self._stream_plan(batch):
-                clips.append((video, idx))
-                keys.append((video.data_ptr(), tuple(video.shape), tuple(idx.tolist())))
-        if not clips:
-            return
-        tokens = self.video_backbone.encode_clips(clips)
+        if self.with_video and hasattr(self.video_backbone, "encode_clips"):
+            for batch in batches:
+                for video, idx in self._stream_plan(batch):
+                    clips.append((video, idx))
+                    keys.append((video.data_ptr(), tuple(video.shape), tuple(idx.tolist())))
+        return clips, keys
+
+    def set_video_tokens(self, tokens, clips, keys):
+        """Install trunk outputs (clip-major, as ``encode_clips`` returns them) for the per-stream encoders."""
         cache, off = {}, 0
         for key, (video, idx) in zip(keys, clips):
             n = video.shape[0] * idx.numel()
             cache.setdefault(key, []).append((off, n))
             off += n
         self.__dict__["_token_cache"] = (tokens, cache)
+
+    def prefetch_video_tokens(self, batches, out=None):
+        """Run the frozen conv trunk ONCE over the frames of all given batches (it has no randomness and
+        no gradient, so the history and target windows of a step can share one pass); the per-stream
+        encoders then pick their tokens up from this cache.  Call ``clear_video_tokens`` after the step."""
+        clips, keys = self.video_clips(batches)
+        if not clips:
+            return None
+        tokens = self.video_backbone.encode_clips(clips, out=out)
+        self.set_video_tokens(tokens, clips, keys)
+        return tokens
 
     def clear_video_tokens(self):
         self.__dict__.pop("_token_cache", None)

@@ -266,7 +266,7 @@ class HRNet16Backbone(VideoBackboneModule):
         videos = list(video) if isinstance(video, (list, tuple)) else [video]
         return self.encode_clips([(v, frame_idx) for v in videos])
 
-    def encode_clips(self, clips) -> torch.Tensor:
+    def encode_clips(self, clips, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """clips: [(video (B,T,3,H,W), frame_idx (F,) or None)] -- clips may differ in B, T and frame
         indices (e.g. the history and the target window of one training item) but share H x W.
         One trunk pass over ALL selected frames -> tokens (sum_i B_i*F_i, 65, 240), clip-major."""
@@ -315,7 +315,8 @@ class HRNet16Backbone(VideoBackboneModule):
             c = t.shape[-1]
             self._upsample(t, (Hf, Wf), out=feats.data_ptr() + 4 * off, ldy=240)
             off += c
-        tokens = torch.empty(N, 65, 240, device=dev, dtype=torch.float32)
+        tokens = out if out is not None else torch.empty(N, 65, 240, device=dev, dtype=torch.float32)
+        assert tuple(tokens.shape) == (N, 65, 240) and tokens.is_contiguous()
         check(_hip.lib().rf_avgpool8_tokens(ptr(feats), ptr(tokens), N, Hf, Wf, 240, K._stream()),
               "rf_avgpool8_tokens")
         return tokens

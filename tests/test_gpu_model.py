@@ -267,34 +267,43 @@ def test_model_vs_oracle_seeded():
 
 
 def test_graphed_step_matches_eager():
-    """HIP-graph replay of forward+backward == eager launches: same losses, same updated weights, and the
+    """HIP-graph replay of forward+backward, with the conv trunk of the NEXT batch pipelined under the
+    current step, == eager launches: same losses on an alternating two-batch stream, same gradients, and the
     host RNG is consumed identically (reference draw order) in both modes."""
+    from routeformer_amd import synthetic
     from routeformer_amd.engine import GraphedTrainEngine, TrainEngine
     from routeformer_amd.models.blocks import SAMPLER
     results = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "graph_nolookahead"):
         model, cfg, sd, c = build_product_model("c2_small", DEV)
-        item = case_item(c)
-        item_d = {"train": _to_dev(item["train"]), "target": _to_dev(item["target"])}
-        eng = (GraphedTrainEngine if mode == "graph" else TrainEngine)(model, lr=1e-3)
-        if mode == "graph":
-            eng.capture(item_d, epoch=10)
+        items = []
+        for seed in (11, 12):
+            it = synthetic.synth_item(c["B"], c["T"], c["P"], seed, c["H"], c["W"], streams=c["streams"], gaze=c["gaze"])
+            items.append({"train": _to_dev(it["train"]), "target": _to_dev(it["target"])})
+        eng = (TrainEngine if mode == "eager" else GraphedTrainEngine)(model, lr=1e-3)
+        if mode != "eager":
+            eng.capture(items[0], epoch=10)
         torch.manual_seed(99)
         SAMPLER.log = []
         losses = []
-        for _ in range(3):
-            losses.append(float(eng.step(item_d, epoch=10)["loss"]))
+        for i in range(4):
+            nxt = items[(i + 1) % 2] if mode == "graph" else None
+            losses.append(float(eng.step(items[i % 2], epoch=10, next_item=nxt)["loss"]))
+        torch.cuda.synchronize()
         results[mode] = (losses, eng.reducer.flat_param.clone(), [t_.clone() for t_ in SAMPLER.log],
                          torch.get_rng_state(), eng.reducer.flat_grad.clone())
         SAMPLER.log = None
         SAMPLER.drop_static()
-    (le, pe, de, re_, ge), (lg, pg, dg, rg, gg) = results["eager"], results["graph"]
-    assert len(de) == len(dg) and all(torch.equal(a, b) for a, b in zip(de, dg))
-    assert torch.equal(re_, rg), "host RNG state diverged between eager and graph mode"
-    assert all(abs(a - b) < 1e-5 * max(1.0, abs(a)) for a, b in zip(le, lg)), (le, lg)
-    assert rel_err(gg, ge) < 1e-4
-    # AdamW turns rounding-level noise on near-zero gradients into +-lr steps, hence the looser bound here
-    assert rel_err(pg, pe) < 3 * 3 * 1e-3
+    le, pe, de, re_, ge = results["eager"]
+    assert abs(le[0] - le[1]) > 1e-6, "the two batches should differ"
+    for mode in ("graph", "graph_nolookahead"):
+        lg, pg, dg, rg, gg = results[mode]
+        assert len(de) == len(dg) and all(torch.equal(a, b) for a, b in zip(de, dg)), mode
+        assert torch.equal(re_, rg), "host RNG state diverged between eager and graph mode"
+        assert all(abs(a - b) < 2e-4 * max(1.0, abs(a)) for a, b in zip(le, lg)), (mode, le, lg)
+        assert rel_err(gg, ge) < 2e-3, mode
+        # AdamW turns rounding-level noise on near-zero gradients into +-lr steps, hence the looser bound here
+        assert rel_err(pg, pe) < 4 * 3 * 1e-3, mode
 
 
 def test_engine_sinks_match_autograd():
