@@ -106,10 +106,35 @@ __device__ void select_top(float* Ms, int* sel, int* top_list, int LQ, int n_top
 //
 // LDS carve (floats): Qs[LQ*EP] Ks[LK*EP] Vs[LK*EP] S[max(LQ*sample_k, n_sel*LK)] Ms[LQ] vmean[E]
 //            | ints: sel[LQ] top[n_sel]
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// C(row, col) = sum_k A(row, k) * B(k, col) on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: an exact,
+// k-ordered fmaf chain, so results equal the scalar loops bit for bit).  16x16 output tiles go round-robin
+// over the 4 waves.  pa(row) / pb(col) return the LDS address of element k = 0 of that row / column and
+// ask / bsk the k strides; every address touched must be readable and finite (callers pad with zeros or
+// clamp indices), rows / columns beyond the real extent are dropped by the store functor.
+template <class PA, class PB, class FS>
+__device__ __forceinline__ void mm_tiles(int TI, int TJ, int KS, int lane, int wave, PA pa, int ask, PB pb, int bsk,
+                                         FS fs) {
+  const int lr = lane & 15, lq = lane >> 4;
+  for (int t = wave; t < TI * TJ; t += NW) {
+    const int ti = t / TJ, tj = t - ti * TJ;
+    const float* ap = pa(16 * ti + lr) + lq * ask;
+    const float* bp = pb(16 * tj + lr) + lq * bsk;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < KS; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * kk * ask], bp[4 * kk * bsk], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fs(16 * ti + 4 * lq + r, 16 * tj + lr, acc[r]);
+  }
+}
+
+// Row softmax over S (row pitch ld >= LK; columns [kmax, ld) are set to 0).
 __device__ __forceinline__ void softmax_rows(float* S, int n_rows, int LK, const int* top_list, int masked,
-                                             int lane, int wave) {
+                                             int lane, int wave, int ld = 0) {
+  if (ld == 0) ld = LK;
   for (int si = wave; si < n_rows; si += NW) {
-    float* row = S + (long)si * LK;
+    float* row = S + (long)si * ld;
     const int kmax = masked ? top_list[si] + 1 : LK;
     float mx = -INFINITY;
     for (int s = lane; s < kmax; s += 64) mx = fmaxf(mx, row[s]);
@@ -122,7 +147,7 @@ __device__ __forceinline__ void softmax_rows(float* S, int n_rows, int LK, const
     }
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
-    for (int s = lane; s < LK; s += 64) row[s] = s < kmax ? row[s] * inv : 0.f;
+    for (int s = lane; s < ld; s += 64) row[s] = s < kmax ? row[s] * inv : 0.f;
   }
 }
 
@@ -133,11 +158,12 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int LQ = p.LQ, LK = p.LK, E = p.E, EP = pitch<V4>(E);
   const int n_sel = (p.mode == 0) ? LQ : p.n_top;
-  const int s_elems = (max(LQ * p.sample_k, n_sel * LK) + 3) & ~3;
+  const int LKP = V4 ? ((LK + 3) & ~3) : LK;  // key rows / score columns padded to the MFMA k granule
+  const int s_elems = (max(LQ * p.sample_k, n_sel * LKP) + 3) & ~3;
   float* Qs = smem;
   float* Ks = Qs + LQ * EP;
-  float* Vs = Ks + LK * EP;
-  float* S = Vs + LK * EP;
+  float* Vs = Ks + LKP * EP;
+  float* S = Vs + LKP * EP;
   float* Ms = S + s_elems;
   float* vmean = Ms + LQ;
   int* sel = reinterpret_cast<int*>(vmean + E);
@@ -146,6 +172,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
   load_head<V4>(Qs, p.q, p.q_ld, b, h, LQ, E, EP, tid);
   load_head<V4>(Ks, p.k, p.k_ld, b, h, LK, E, EP, tid);
   load_head<V4>(Vs, p.v, p.v_ld, b, h, LK, E, EP, tid);
+  for (int i = tid; i < (LKP - LK) * EP; i += NT) { Ks[LK * EP + i] = 0.f; Vs[LK * EP + i] = 0.f; }
   __syncthreads();
 
   if (p.mode == 0) {
@@ -204,40 +231,43 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
     __syncthreads();  // S is re-used below
   }
 
-  // (3) active rows.  A: scores, B: row softmax, C: P.V
-  for (int i = tid; i < n_sel * LK; i += NT) {
-    const int si = i / LK, s = i - si * LK;
-    const int q = top_list[si];
-    float d = -INFINITY;
-    if (p.mode != 2 || s <= q) d = dot_rows<V4>(Qs + q * EP, Ks + s * EP, E) * p.scale;
-    S[i] = d;
-  }
-  __syncthreads();
-  softmax_rows(S, n_sel, LK, top_list, p.mode == 2, lane, wave);
-  __syncthreads();
-  if constexpr (V4) {  // each thread: 4 consecutive output channels of one active row
-    const int E4 = E >> 2;
-    for (int i = tid; i < n_sel * E4; i += NT) {
-      const int si = i / E4, d = (i - si * E4) << 2;
-      const int q = top_list[si];
-      const int kmax = (p.mode == 2) ? q + 1 : LK;
-      const float* row = S + (long)si * LK;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s = 0; s < kmax; ++s) {
-        const float pv = row[s];
-        const float4 v = *reinterpret_cast<const float4*>(Vs + s * EP + d);
-        a.x = fmaf(pv, v.x, a.x); a.y = fmaf(pv, v.y, a.y); a.z = fmaf(pv, v.z, a.z); a.w = fmaf(pv, v.w, a.w);
-      }
-      *reinterpret_cast<float4*>(p.ctx + ctx_off(p, b, h, q) + d) = a;
-    }
+  // (3) active rows.  A: scores = scale * Qsel K^T, B: row softmax, C: P V
+  if constexpr (V4) {
+    const int TI = (n_sel + 15) >> 4;
+    mm_tiles(TI, (LK + 15) >> 4, E >> 2, lane, wave,
+             [&](int si) { return Qs + top_list[min(si, n_sel - 1)] * EP; }, 1,
+             [&](int s_) { return Ks + min(s_, LK - 1) * EP; }, 1,
+             [&](int si, int s_, float v) {
+               if (si < n_sel && s_ < LK)
+                 S[si * LKP + s_] = (p.mode == 2 && s_ > top_list[si]) ? -INFINITY : v * p.scale;
+             });
+    __syncthreads();
+    softmax_rows(S, n_sel, LK, top_list, p.mode == 2, lane, wave, LKP);
+    __syncthreads();
+    mm_tiles(TI, (E + 15) >> 4, LKP >> 2, lane, wave,
+             [&](int si) { return S + min(si, n_sel - 1) * LKP; }, 1,
+             [&](int d) { return Vs + min(d, E - 1); }, EP,
+             [&](int si, int d, float v) {
+               if (si < n_sel && d < E) p.ctx[ctx_off(p, b, h, top_list[si]) + d] = v;
+             });
   } else {
+    for (int i = tid; i < n_sel * LK; i += NT) {
+      const int si = i / LK, s_ = i - si * LK;
+      const int q = top_list[si];
+      float d = -INFINITY;
+      if (p.mode != 2 || s_ <= q) d = dot_rows<V4>(Qs + q * EP, Ks + s_ * EP, E) * p.scale;
+      S[i] = d;
+    }
+    __syncthreads();
+    softmax_rows(S, n_sel, LK, top_list, p.mode == 2, lane, wave);
+    __syncthreads();
     for (int i = tid; i < n_sel * E; i += NT) {
       const int si = i / E, d = i - si * E;
       const int q = top_list[si];
       const int kmax = (p.mode == 2) ? q + 1 : LK;
       const float* row = S + (long)si * LK;
       float a = 0.f;
-      for (int s = 0; s < kmax; ++s) a = fmaf(row[s], Vs[s * EP + d], a);
+      for (int s_ = 0; s_ < kmax; ++s_) a = fmaf(row[s_], Vs[s_ * EP + d], a);
       p.ctx[ctx_off(p, b, h, q) + d] = a;
     }
   }
@@ -252,12 +282,14 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int LQ = p.LQ, LK = p.LK, E = p.E, EP = pitch<V4>(E);
   const int n_sel = (p.mode == 0) ? LQ : p.n_top;
-  const int pl_elems = (n_sel * LK + 3) & ~3;
+  const int LKP = V4 ? ((LK + 3) & ~3) : LK;      // padded key count (MFMA k granule)
+  const int NSP = V4 ? ((n_sel + 3) & ~3) : n_sel;  // padded active-row count
+  const int pl_elems = (NSP * LKP + 3) & ~3;
   float* Ks = smem;
-  float* Vs = Ks + LK * EP;
-  float* Qsel = Vs + LK * EP;
-  float* dCsel = Qsel + n_sel * EP;
-  float* P = dCsel + n_sel * EP;
+  float* Vs = Ks + LKP * EP;
+  float* Qsel = Vs + LKP * EP;
+  float* dCsel = Qsel + NSP * EP;
+  float* P = dCsel + NSP * EP;
   float* dS = P + pl_elems;
   float* colsum = dS + pl_elems;
   int* top_list = reinterpret_cast<int*>(colsum + ((E + 3) & ~3));
@@ -265,6 +297,9 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
 
   load_head<V4>(Ks, p.k, p.k_ld, b, h, LK, E, EP, tid);
   load_head<V4>(Vs, p.v, p.v_ld, b, h, LK, E, EP, tid);
+  for (int i = tid; i < (LKP - LK) * EP; i += NT) { Ks[LK * EP + i] = 0.f; Vs[LK * EP + i] = 0.f; }
+  for (int i = tid; i < (NSP - n_sel) * EP; i += NT) { Qsel[n_sel * EP + i] = 0.f; dCsel[n_sel * EP + i] = 0.f; }
+  for (int i = tid; i < (NSP - n_sel) * LKP; i += NT) { P[n_sel * LKP + i] = 0.f; dS[n_sel * LKP + i] = 0.f; }
   for (int q = tid; q < LQ; q += NT) sel[q] = (p.mode == 0) ? q : -1;
   __syncthreads();
   if (p.mode == 0) {
@@ -282,57 +317,67 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
   }
   __syncthreads();
 
-  // phase 1: recompute P; dP = dC V^T; dS = P * (dP - rowsum(P*dP)) * scale; dQ = dS K
-  for (int i = tid; i < n_sel * LK; i += NT) {
-    const int si = i / LK, s = i - si * LK;
-    const int q = top_list[si];
-    float d = -INFINITY, dp = 0.f;
-    if (p.mode != 2 || s <= q) {
-      d = dot_rows<V4>(Qsel + si * EP, Ks + s * EP, E) * p.scale;
-      dp = dot_rows<V4>(dCsel + si * EP, Vs + s * EP, E);
+  // phase 1: recompute P = softmax(scale * Qsel K^T); dP = dC V^T; dS = P * (dP - rowsum(P*dP)) * scale
+  if constexpr (V4) {
+    const int TI = (n_sel + 15) >> 4, TJ = (LK + 15) >> 4;
+    mm_tiles(TI, TJ, E >> 2, lane, wave,
+             [&](int si) { return Qsel + min(si, n_sel - 1) * EP; }, 1,
+             [&](int s_) { return Ks + min(s_, LK - 1) * EP; }, 1,
+             [&](int si, int s_, float v) {
+               if (si < n_sel && s_ < LK)
+                 P[si * LKP + s_] = (p.mode == 2 && s_ > top_list[si]) ? -INFINITY : v * p.scale;
+             });
+    mm_tiles(TI, TJ, E >> 2, lane, wave,
+             [&](int si) { return dCsel + min(si, n_sel - 1) * EP; }, 1,
+             [&](int s_) { return Vs + min(s_, LK - 1) * EP; }, 1,
+             [&](int si, int s_, float v) {
+               if (si < n_sel && s_ < LK) dS[si * LKP + s_] = (p.mode == 2 && s_ > top_list[si]) ? 0.f : v;
+             });
+  } else {
+    for (int i = tid; i < n_sel * LK; i += NT) {
+      const int si = i / LK, s_ = i - si * LK;
+      const int q = top_list[si];
+      float d = -INFINITY, dp = 0.f;
+      if (p.mode != 2 || s_ <= q) {
+        d = dot_rows<V4>(Qsel + si * EP, Ks + s_ * EP, E) * p.scale;
+        dp = dot_rows<V4>(dCsel + si * EP, Vs + s_ * EP, E);
+      }
+      P[i] = d;
+      dS[i] = dp;
     }
-    P[i] = d;
-    dS[i] = dp;
   }
   __syncthreads();
-  softmax_rows(P, n_sel, LK, top_list, p.mode == 2, lane, wave);
+  softmax_rows(P, n_sel, LK, top_list, p.mode == 2, lane, wave, LKP);
   // same wave owns the same rows in softmax_rows and here: no barrier needed in between
   for (int si = wave; si < n_sel; si += NW) {
-    float* Pr = P + (long)si * LK;
-    float* dSr = dS + (long)si * LK;
+    float* Pr = P + (long)si * LKP;
+    float* dSr = dS + (long)si * LKP;
     float dot = 0.f;
-    for (int s = lane; s < LK; s += 64) dot += Pr[s] * dSr[s];
+    for (int s_ = lane; s_ < LK; s_ += 64) dot += Pr[s_] * dSr[s_];
     dot = wave_sum(dot);
-    for (int s = lane; s < LK; s += 64) dSr[s] = Pr[s] * (dSr[s] - dot) * p.scale;
+    for (int s_ = lane; s_ < LKP; s_ += 64) dSr[s_] = s_ < LK ? Pr[s_] * (dSr[s_] - dot) * p.scale : 0.f;
   }
   __syncthreads();
+
+  // dQ[q] = dS K for the active rows, zero for the others (the sampling stage is not differentiated)
   if constexpr (V4) {
-    const int E4 = E >> 2;
-    for (int i = tid; i < n_sel * E4; i += NT) {
-      const int si = i / E4, e = (i - si * E4) << 2;
-      const int q = top_list[si];
-      const int kmax = (p.mode == 2) ? q + 1 : LK;
-      const float* dSr = dS + (long)si * LK;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s = 0; s < kmax; ++s) {
-        const float g = dSr[s];
-        const float4 kv = *reinterpret_cast<const float4*>(Ks + s * EP + e);
-        a.x = fmaf(g, kv.x, a.x); a.y = fmaf(g, kv.y, a.y); a.z = fmaf(g, kv.z, a.z); a.w = fmaf(g, kv.w, a.w);
-      }
-      *reinterpret_cast<float4*>(p.dq + ((long)b * LQ + q) * p.dq_ld + (long)h * E + e) = a;
-    }
+    mm_tiles((n_sel + 15) >> 4, (E + 15) >> 4, LKP >> 2, lane, wave,
+             [&](int si) { return dS + min(si, n_sel - 1) * LKP; }, 1,
+             [&](int e) { return Ks + min(e, E - 1); }, EP,
+             [&](int si, int e, float v) {
+               if (si < n_sel && e < E) p.dq[((long)b * LQ + top_list[si]) * p.dq_ld + (long)h * E + e] = v;
+             });
   } else {
     for (int i = tid; i < n_sel * E; i += NT) {
       const int si = i / E, e = i - si * E;
       const int q = top_list[si];
       const int kmax = (p.mode == 2) ? q + 1 : LK;
-      const float* dSr = dS + (long)si * LK;
+      const float* dSr = dS + (long)si * LKP;
       float a = 0.f;
-      for (int s = 0; s < kmax; ++s) a = fmaf(dSr[s], Ks[s * EP + e], a);
+      for (int s_ = 0; s_ < kmax; ++s_) a = fmaf(dSr[s_], Ks[s_ * EP + e], a);
       p.dq[((long)b * LQ + q) * p.dq_ld + (long)h * E + e] = a;
     }
   }
-  // non-selected query rows get zero dQ (the sampling stage is not differentiated)
   for (int i = tid; i < LQ * E; i += NT) {
     const int q = i / E, e = i - q * E;
     if (sel[q] < 0) p.dq[((long)b * LQ + q) * p.dq_ld + (long)h * E + e] = 0.f;
@@ -340,10 +385,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
   // lazy-row gradient source: column sums of dctx over NON-selected rows (unmasked mode)
   if (p.mode == 1) {
     for (int d = tid; d < E; d += NT) {
-      float s = 0.f;
+      float s_ = 0.f;
       for (int ql = 0; ql < LQ; ++ql)
-        if (sel[ql] < 0) s += p.dctx[ctx_off(p, b, h, ql) + d];
-      colsum[d] = s / (float)LK;
+        if (sel[ql] < 0) s_ += p.dctx[ctx_off(p, b, h, ql) + d];
+      colsum[d] = s_ / (float)LK;
     }
   }
   __syncthreads();
@@ -355,57 +400,56 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
       float run = 0.f;
       for (int ql = LQ - 1; ql >= 0; --ql) {
         if (sel[ql] < 0) run += p.dctx[ctx_off(p, b, h, ql) + d];
-        // stash the running sum in the (no longer needed) V tile
-        Vs[ql * EP + d] = run;
+        Vs[ql * EP + d] = run;  // stash the running sum in the (no longer needed) V tile
       }
     }
     __syncthreads();
   }
   if constexpr (V4) {
-    const int E4 = E >> 2;
-    for (int i = tid; i < LK * E4; i += NT) {
-      const int s = i / E4, e = (i - s * E4) << 2;
-      float4 ak = make_float4(0.f, 0.f, 0.f, 0.f), av = ak;
-      for (int si = 0; si < n_sel; ++si) {
-        const float g = dS[(long)si * LK + s], pr = P[(long)si * LK + s];
-        const float4 qv = *reinterpret_cast<const float4*>(Qsel + si * EP + e);
-        const float4 cv = *reinterpret_cast<const float4*>(dCsel + si * EP + e);
-        ak.x = fmaf(g, qv.x, ak.x); ak.y = fmaf(g, qv.y, ak.y); ak.z = fmaf(g, qv.z, ak.z); ak.w = fmaf(g, qv.w, ak.w);
-        av.x = fmaf(pr, cv.x, av.x); av.y = fmaf(pr, cv.y, av.y); av.z = fmaf(pr, cv.z, av.z); av.w = fmaf(pr, cv.w, av.w);
-      }
-      if (p.mode == 1) { av.x += colsum[e]; av.y += colsum[e + 1]; av.z += colsum[e + 2]; av.w += colsum[e + 3]; }
-      if (p.mode == 2) {
-        const float4 r = *reinterpret_cast<const float4*>(Vs + s * EP + e);
-        av.x += r.x; av.y += r.y; av.z += r.z; av.w += r.w;
-      }
-      *reinterpret_cast<float4*>(p.dk + ((long)b * LK + s) * p.dk_ld + (long)h * E + e) = ak;
-      *reinterpret_cast<float4*>(p.dv + ((long)b * LK + s) * p.dv_ld + (long)h * E + e) = av;
-    }
+    const int TJ = (LK + 15) >> 4, TE = (E + 15) >> 4;
+    mm_tiles(TJ, TE, NSP >> 2, lane, wave,
+             [&](int s_) { return dS + min(s_, LK - 1); }, LKP,
+             [&](int e) { return Qsel + min(e, E - 1); }, EP,
+             [&](int s_, int e, float v) {
+               if (s_ < LK && e < E) p.dk[((long)b * LK + s_) * p.dk_ld + (long)h * E + e] = v;
+             });
+    mm_tiles(TJ, TE, NSP >> 2, lane, wave,
+             [&](int s_) { return P + min(s_, LK - 1); }, LKP,
+             [&](int d) { return dCsel + min(d, E - 1); }, EP,
+             [&](int s_, int d, float v) {
+               if (s_ < LK && d < E) {
+                 if (p.mode == 1) v += colsum[d];
+                 if (p.mode == 2) v += Vs[s_ * EP + d];
+                 p.dv[((long)b * LK + s_) * p.dv_ld + (long)h * E + d] = v;
+               }
+             });
   } else {
     for (int i = tid; i < LK * E; i += NT) {
-      const int s = i / E, e = i - s * E;
+      const int s_ = i / E, e = i - s_ * E;
       float ak = 0.f, av = 0.f;
       for (int si = 0; si < n_sel; ++si) {
-        ak = fmaf(dS[(long)si * LK + s], Qsel[si * EP + e], ak);
-        av = fmaf(P[(long)si * LK + s], dCsel[si * EP + e], av);
+        ak = fmaf(dS[(long)si * LKP + s_], Qsel[si * EP + e], ak);
+        av = fmaf(P[(long)si * LKP + s_], dCsel[si * EP + e], av);
       }
       if (p.mode == 1) av += colsum[e];
-      if (p.mode == 2) av += Vs[s * EP + e];
-      p.dk[((long)b * LK + s) * p.dk_ld + (long)h * E + e] = ak;
-      p.dv[((long)b * LK + s) * p.dv_ld + (long)h * E + e] = av;
+      if (p.mode == 2) av += Vs[s_ * EP + e];
+      p.dk[((long)b * LK + s_) * p.dk_ld + (long)h * E + e] = ak;
+      p.dv[((long)b * LK + s_) * p.dv_ld + (long)h * E + e] = av;
     }
   }
 }
 
 size_t fwd_lds(int LQ, int LK, int E, int n_sel, int sample_k, bool v4) {
   const size_t EP = v4 ? E + 4 : E + 1;
-  const size_t s_elems = (max((size_t)LQ * sample_k, (size_t)n_sel * LK) + 3) & ~(size_t)3;
-  return sizeof(float) * (LQ * EP + 2 * LK * EP + s_elems + LQ + E) + sizeof(int) * ((size_t)LQ + n_sel) + 16;
+  const size_t LKP = v4 ? ((LK + 3) & ~3) : LK;
+  const size_t s_elems = (max((size_t)LQ * sample_k, (size_t)n_sel * LKP) + 3) & ~(size_t)3;
+  return sizeof(float) * (LQ * EP + 2 * LKP * EP + s_elems + LQ + E) + sizeof(int) * ((size_t)LQ + n_sel) + 16;
 }
 size_t bwd_lds(int LQ, int LK, int E, int n_sel, bool v4) {
   const size_t EP = v4 ? E + 4 : E + 1;
-  const size_t pl = ((size_t)n_sel * LK + 3) & ~(size_t)3;
-  return sizeof(float) * (2 * LK * EP + 2 * n_sel * EP + 2 * pl + ((E + 3) & ~3)) + sizeof(int) * ((size_t)n_sel + LQ) + 16;
+  const size_t LKP = v4 ? ((LK + 3) & ~3) : LK, NSP = v4 ? ((n_sel + 3) & ~3) : n_sel;
+  const size_t pl = (NSP * LKP + 3) & ~(size_t)3;
+  return sizeof(float) * (2 * LKP * EP + 2 * NSP * EP + 2 * pl + ((E + 3) & ~3)) + sizeof(int) * ((size_t)n_sel + LQ) + 16;
 }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
