@@ -277,8 +277,9 @@ extern "C" int rf_layernorm_fwd(const float* x, const float* residual, const flo
 }
 
 extern "C" int rf_layernorm_bwd_parts(int rows) {
-  const int blocks = (rows + LN_WAVES - 1) / LN_WAVES;
-  return blocks > 128 ? 128 : blocks;
+  // enough workgroups to cover all 256 CUs a few times over; each writes one (dgamma, dbeta) partial row
+  const int blocks = (rows + 4 * LN_WAVES - 1) / (4 * LN_WAVES);
+  return blocks > 768 ? 768 : (blocks < 1 ? 1 : blocks);
 }
 
 extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,

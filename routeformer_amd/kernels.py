@@ -350,7 +350,7 @@ class _FFN(torch.autograd.Function):
     The activation and its derivative ride in GEMM epilogues."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act: str, g1, gb1, g2, gb2):
+    def forward(ctx, x, w1, b1, w2, b2, act: str, g1, gb1, g2, gb2, need_grad=True):
         _req(x, "ffn.x")
         F, D = w1.shape[0], w1.shape[1]
         w1, w2 = w1.reshape(F, D), w2.reshape(D, F)  # Conv1d(k=1) weights (out,in,1) viewed as matrices
@@ -359,7 +359,7 @@ class _FFN(torch.autograd.Function):
             x2 = x2.contiguous()
         M = x2.shape[0]
         h = torch.empty(M, F, device=x.device, dtype=torch.float32)
-        z = torch.empty_like(h) if act == "gelu" else None
+        z = torch.empty_like(h) if (act == "gelu" and need_grad) else None  # pre-activation: backward only
         gemm(x2, x2.stride(0), 1, w1, 1, D, h, F, M, F, D, bias=b1, act=ACT[act], preact=z, ldp=F)
         y = torch.empty(M, D, device=x.device, dtype=torch.float32)
         gemm(h, F, 1, w2, 1, F, y, D, M, D, F, bias=b2)
@@ -394,35 +394,36 @@ class _FFN(torch.autograd.Function):
         _wrote(g1, gb1, g2, gb2)
         if dw1 is not None:
             dw1, dw2 = dw1.view(F, D, 1), dw2.view(D, F, 1)
-        return dx, dw1, db1, dw2, db2, None, None, None, None, None
+        return dx, dw1, db1, dw2, db2, None, None, None, None, None, None
 
 
 def ffn(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str):
     """conv*_w: the Conv1d(k=1) weight parameters, shape (out, in, 1)."""
     assert conv1_w.dim() == 3 and conv2_w.dim() == 3
     return _FFN.apply(x, conv1_w, conv1_b, conv2_w, conv2_b, act, _slot(conv1_w), _slot(conv1_b),
-                      _slot(conv2_w), _slot(conv2_b))
+                      _slot(conv2_w), _slot(conv2_b), torch.is_grad_enabled())
 
 
 class _AddLayerNorm(torch.autograd.Function):
     """y = LayerNorm(x + residual) (eps 1e-5); residual optional."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, gg, gb):
+    def forward(ctx, x, residual, gamma, beta, eps, gg, gb, need_grad=True):
         _req(x, "layernorm.x")
         cols = x.shape[-1]
         x2 = x.reshape(-1, cols).contiguous()
         r2 = residual.reshape(-1, cols).contiguous() if residual is not None else None
         rows = x2.shape[0]
         y = torch.empty_like(x2)
-        xhat = torch.empty_like(x2)
-        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        xhat = torch.empty_like(x2) if need_grad else None  # normalised input + 1/sigma: backward only
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if need_grad else None
         ev = PROFILE.begin() if PROFILE.on else None
         check(_hip.lib().rf_layernorm_fwd(ptr(x2), ptr(r2), ptr(gamma), ptr(beta), ptr(y), ptr(xhat),
                                           ptr(rstd), rows, cols, eps, _stream()), "rf_layernorm_fwd")
         if ev is not None:
             PROFILE.end("layernorm_fwd_kernel", ev, 8.0 * rows * cols, 4.0 * rows * cols * (4 if r2 is not None else 3))
-        ctx.save_for_backward(xhat, rstd, gamma)
+        if need_grad:
+            ctx.save_for_backward(xhat, rstd, gamma)
         ctx.sinks = (gg, gb)
         ctx.has_res = residual is not None
         ctx.xshape = x.shape
@@ -450,11 +451,11 @@ class _AddLayerNorm(torch.autograd.Function):
         if sink:
             _wrote(gg, gb)
             dg = db = None
-        return dx, (dx if ctx.has_res else None), dg, db, None, None, None
+        return dx, (dx if ctx.has_res else None), dg, db, None, None, None, None
 
 
 def add_layer_norm(x, residual, gamma, beta, eps: float = 1e-5):
-    return _AddLayerNorm.apply(x, residual, gamma, beta, eps, _slot(gamma), _slot(beta))
+    return _AddLayerNorm.apply(x, residual, gamma, beta, eps, _slot(gamma), _slot(beta), torch.is_grad_enabled())
 
 
 class _Unfold3(torch.autograd.Function):
