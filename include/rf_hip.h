@@ -47,13 +47,17 @@ const char* rf_last_error(void);
  * other than that is allowed; summation order, hence the last bits, vary run to run).
  * a_rowsum (optional, needs atomic_accumulate and a row-contiguous A, i.e. lda_m == 1):
  * a_rowsum[m] += sum_k A[m,k] -- the bias gradient rides along with the weight-gradient GEMM
- * (dW = dY^T X, db = dY^T 1) instead of a second pass over dY. */
+ * (dW = dY^T X, db = dY^T 1) instead of a second pass over dY.
+ * tile_counters (optional): >= 4096 zero-initialised uint32 owned by the caller and used by ONE stream at
+ * a time; with it the split-K slabs are summed inside the launch by the last-arriving workgroup of each
+ * output tile (agent-scope release/acquire hand-off; slices summed in ascending order => deterministic)
+ * and the counters are left at zero again -- no second reduction launch. */
 int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k,
             int64_t ldb_n, float* C, int64_t ldc, int M, int N, int K, const float* bias,
             const float* residual, int64_t ldr, int res_rows, int res_before_act, int act,
             float* preact, int64_t ldp, const float* dact_src, int64_t ldd, int dact_mode,
             int prec, int splitk, float* workspace, int atomic_accumulate, float* a_rowsum,
-            void* stream);
+            uint32_t* tile_counters, void* stream);
 
 /* out[n] (+)= sum_m X[m*ldx + n] (bias gradients; accumulate=1 adds into out, e.g. a slot of the flat
  * gradient buffer).  workspace: parts*N floats, parts = rf_colsum_parts(M,N). */
@@ -119,6 +123,9 @@ int rf_layernorm_bwd_parts(int rows);
 int rf_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma,
                      float* dx, float* dgamma, float* dbeta, int accumulate, float* workspace, int rows,
                      int cols, void* stream);
+/* accumulate = 2: every workgroup adds its partial (dgamma, dbeta) into the outputs with fp32 atomics
+ * (outputs hold the running sum, e.g. slots of the zeroed flat gradient buffer): one launch, no workspace,
+ * summation order not reproducible to the last bit. */
 
 /* Informer distilling layer tail: BatchNorm1d (train: batch stats, eval: running stats) -> ELU ->
  * MaxPool1d(3,2,1) on (B,L,C), C innermost.  layers/TransformerEncoderDecoder.py:19-28.

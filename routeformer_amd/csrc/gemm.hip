@@ -34,6 +34,7 @@ struct GemmP {
   int kchunk;  // K range per split-K slice (multiple of BK)
   float* ws;   // split-K partials [splits][M][N] (null: single pass with epilogue)
   int atomic;  // 1: C += partial via fp32 atomics (no other epilogue)
+  unsigned* tile_cnt;  // split-K arrival counters (one per output tile, zero between launches) or null
   float* a_rowsum;  // optional: a_rowsum[m] += sum_k A[m,k] (A row-contiguous)
   // implicit-GEMM conv (A mode 3): A is the NHWC input, row m = output pixel
   int cH, cW, cCin, cKs, cStride, cPad, cHo, cWo;
@@ -501,7 +502,16 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
     }
   }
 
-  // ---- epilogue (identical to v1) ----
+  // ---- epilogue ----
+  auto finish = [&](float v, int m, int n) {
+    if (p.bias) v += p.bias[n];
+    if (p.res && p.res_before_act) v += p.res[(long)(m % p.res_rows) * p.ldr + n];
+    if (p.preact) p.preact[(long)m * p.ldp + n] = v;
+    v = apply_act(v, p.act);
+    if (p.dact) v *= act_grad(p.dsrc[(long)m * p.ldd + n], p.dact);
+    if (p.res && !p.res_before_act) v += p.res[(long)(m % p.res_rows) * p.ldr + n];
+    p.C[(long)m * p.ldc + n] = v;
+  };
 #pragma unroll
   for (int i = 0; i < C_::TM; ++i) {
 #pragma unroll
@@ -512,22 +522,53 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + (wm * C_::TM + i) * 16 + fq * 4 + r;
         if (m >= p.M) continue;
-        float v = acc[i][j][r];
-        if (p.atomic) {
-          atomicAdd(&p.C[(long)m * p.ldc + n], v);
-          continue;
+        const float v = acc[i][j][r];
+        if (p.atomic) atomicAdd(&p.C[(long)m * p.ldc + n], v);
+        else if (p.ws) p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = v;
+        else finish(v, m, n);
+      }
+    }
+  }
+
+  // ---- in-launch split-K reduction: the LAST K-slice workgroup of a tile to arrive sums all slices ----
+  // (placement-independent agent-scope release / acquire hand-off, cdna_hip_programming.md "In-launch
+  //  split-K reduction"; slices are summed in ascending order whichever workgroup does it -> deterministic)
+  if (p.ws && p.tile_cnt && !p.atomic) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its partial-slab stores
+    __syncthreads();
+    int* last_flag = reinterpret_cast<int*>(smem);    // LDS stages are dead after the K loop
+    unsigned* cnt = p.tile_cnt + (blockIdx.y * gridDim.x + blockIdx.x);
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == gridDim.z - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+      }
+      *last_flag = last;
+    }
+    __syncthreads();
+    if (*last_flag) {
+      const int splits = gridDim.z;
+      const long slab = (long)p.M * p.N;
+#pragma unroll
+      for (int i = 0; i < C_::TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < C_::TN; ++j) {
+          const int n = n0 + (wn * C_::TN + j) * 16 + fr;
+          if (n >= p.N) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = m0 + (wm * C_::TM + i) * 16 + fq * 4 + r;
+            if (m >= p.M) continue;
+            float v = 0.f;
+            for (int z = 0; z < splits; ++z) v += p.ws[z * slab + (long)m * p.N + n];
+            finish(v, m, n);
+          }
         }
-        if (p.ws) {
-          p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = v;
-          continue;
-        }
-        if (p.bias) v += p.bias[n];
-        if (p.res && p.res_before_act) v += p.res[(long)(m % p.res_rows) * p.ldr + n];
-        if (p.preact) p.preact[(long)m * p.ldp + n] = v;
-        v = apply_act(v, p.act);
-        if (p.dact) v *= act_grad(p.dsrc[(long)m * p.ldd + n], p.dact);
-        if (p.res && !p.res_before_act) v += p.res[(long)(m % p.res_rows) * p.ldr + n];
-        p.C[(long)m * p.ldc + n] = v;
       }
     }
   }
@@ -582,7 +623,7 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
                        const float* residual, int64_t ldr, int res_rows, int res_before_act, int act,
                        float* preact, int64_t ldp, const float* dact_src, int64_t ldd, int dact_mode,
                        int prec, int splitk, float* workspace, int atomic_accumulate, float* a_rowsum,
-                       void* stream) {
+                       uint32_t* tile_counters, void* stream) {
   RF_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0);
   RF_REQUIRE(prec == 0 || prec == 1);
   RF_REQUIRE(splitk >= 1 && (splitk == 1 || workspace != nullptr || atomic_accumulate));
@@ -603,6 +644,7 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
   splitk = (K + p.kchunk - 1) / p.kchunk;
   p.ws = (splitk > 1 && !atomic_accumulate) ? workspace : nullptr;
   p.atomic = atomic_accumulate; p.a_rowsum = a_rowsum;
+  p.tile_cnt = nullptr;
 
   int am = 2, bm = 2;
   if (lda_k == 1 && (lda_m % 4) == 0 && aligned16(A)) am = 0;
@@ -615,8 +657,13 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
     return RF_EUNSUPPORTED;
   }
   if (a_rowsum && am != 1) { rf_g_last_error = "a_rowsum needs a row-contiguous, aligned A"; return RF_EUNSUPPORTED; }
+  bool in_kernel_reduce = false;
   if (am <= 1 && bm <= 1) {  // both operands vectorizable: pipelined kernel
     const bool tall = M >= 4096 && N >= 64;
+    if (splitk > 1 && !atomic_accumulate && tile_counters) {
+      const long tiles = (long)((M + (tall ? 127 : 63)) / (tall ? 128 : 64)) * ((N + 63) / 64);
+      if (tiles <= 4096) { p.tile_cnt = tile_counters; in_kernel_reduce = true; }  // counter buffer: 4096 tiles
+    }
     if (prec == 0) dispatch2<0>(p, am, bm, tall, splitk, st);
     else dispatch2<1>(p, am, bm, tall, splitk, st);
   } else if (prec == 0) {
@@ -629,7 +676,7 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
     else dispatch_b<1, 2>(p, bm, splitk, st);
   }
   RF_CHECK_LAUNCH();
-  if (splitk > 1 && !atomic_accumulate) {
+  if (splitk > 1 && !atomic_accumulate && !in_kernel_reduce) {
     const long total = (long)M * N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;

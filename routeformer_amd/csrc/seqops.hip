@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
-                                                            float* __restrict__ ws, int rows, int cols) {
+                                                            float* __restrict__ ws, int rows, int cols,
+                                                            float* __restrict__ agamma, float* __restrict__ abeta) {
   __shared__ float red[LN_WAVES][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dg[LN_MAXV], db[LN_MAXV];
@@ -87,18 +88,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
   }
   // block partials -> ws[block][0][cols] (dgamma), ws[block][1][cols] (dbeta)
-  float* wg = ws + (long)blockIdx.x * 2 * cols;
+  float* wg = agamma ? nullptr : ws + (long)blockIdx.x * 2 * cols;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     if (i * 64 >= cols) break;
     const int c = i * 64 + lane;
     red[wave][lane] = dg[i];
     __syncthreads();
-    if (wave == 0 && c < cols) wg[c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (wave == 0 && c < cols) {
+      const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+      if (agamma) atomicAdd(&agamma[c], t); else wg[c] = t;
+    }
     __syncthreads();
     red[wave][lane] = db[i];
     __syncthreads();
-    if (wave == 0 && c < cols) wg[cols + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (wave == 0 && c < cols) {
+      const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+      if (abeta) atomicAdd(&abeta[c], t); else wg[cols + c] = t;
+    }
     __syncthreads();
   }
 }
@@ -285,12 +292,20 @@ extern "C" int rf_layernorm_bwd_parts(int rows) {
 extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,
                                 float* dgamma, float* dbeta, int accumulate, float* workspace, int rows, int cols,
                                 void* stream) {
-  RF_REQUIRE(dy && xhat && rstd && gamma && dx && dgamma && dbeta && workspace);
+  RF_REQUIRE(dy && xhat && rstd && gamma && dx && dgamma && dbeta && (workspace || accumulate == 2));
   RF_REQUIRE(rows > 0 && cols > 0 && cols <= 64 * LN_MAXV);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (accumulate == 2) {  // atomics straight into the running sums; few workgroups -> few same-address adds
+    int blocks = (rows + 4 * LN_WAVES - 1) / (4 * LN_WAVES);
+    blocks = blocks > 192 ? 192 : (blocks < 1 ? 1 : blocks);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, xhat, rstd, gamma, dx,
+                       static_cast<float*>(nullptr), rows, cols, dgamma, dbeta);
+    RF_CHECK_LAUNCH();
+    return RF_OK;
+  }
   const int parts = rf_layernorm_bwd_parts(rows);
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, st, dy, xhat, rstd, gamma, dx, workspace, rows,
-                     cols);
+                     cols, static_cast<float*>(nullptr), static_cast<float*>(nullptr));
   RF_CHECK_LAUNCH();
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, workspace, parts, cols,
                      dgamma, dbeta, accumulate);

@@ -171,6 +171,23 @@ def _splits(tiles: int, depth: int) -> int:
     return max(1, min(64, depth // 128, -(-512 // max(tiles, 1))))
 
 
+_TILE_COUNTERS = {}
+# In-launch split-K reduction (last-arriving workgroup sums the slabs behind an agent-scope release/acquire
+# hand-off) is implemented and tested, but measured SLOWER than the separate reduction launch at these slab
+# sizes (416 vs 460 samples/s: every workgroup pays the L2 write-back of the release fence), so it is off.
+IN_LAUNCH_SPLITK_REDUCE = __import__("os").environ.get("RF_SPLITK_INLAUNCH", "0") == "1"
+
+
+def _tile_counters(device):
+    """Split-K arrival counters: one persistent zeroed buffer per (device, stream) -- launches on one
+    stream are ordered, and every launch leaves its counters at zero again."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _TILE_COUNTERS.get(key)
+    if buf is None:
+        buf = _TILE_COUNTERS[key] = torch.zeros(4096, device=device, dtype=torch.int32)
+    return buf
+
+
 def _auto_split(M: int, N: int, K: int) -> int:
     """Split-K for launches that would leave most of the 256 CUs idle (small-M Informer GEMMs): aim for
     ~512 workgroups with >= 128 of reduction depth each."""
@@ -186,13 +203,15 @@ def gemm(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, *, bias=None, residu
          splitk=0, atomic=False, a_rowsum=None):
     if splitk == 0:
         splitk = _auto_split(M, N, K)
-    ws = None
+    ws = cnt = None
     if splitk > 1 and not atomic:
         ws = torch.empty(splitk * M * N, device=C.device, dtype=torch.float32)
+        if IN_LAUNCH_SPLITK_REDUCE:
+            cnt = _tile_counters(C.device)
     ev = PROFILE.begin() if PROFILE.on else None
     args = (ptr(A), lda_m, lda_k, ptr(B), ldb_k, ldb_n, ptr(C), ldc, M, N, K, ptr(bias), ptr(residual), ldr, res_rows,
             res_before_act, act, ptr(preact), ldp, ptr(dact_src), ldd, dact, _PRECISION, splitk, ptr(ws),
-            1 if atomic else 0, ptr(a_rowsum))
+            1 if atomic else 0, ptr(a_rowsum), ptr(cnt))
     check(_hip.lib().rf_gemm(*args, _stream()), "rf_gemm")
     if ev is not None:  # tag = the kernel symbol rf_gemm dispatches to (same rules as csrc/gemm.hip)
         def mode(t, ld_k, ld_row):
@@ -439,12 +458,15 @@ class _AddLayerNorm(torch.autograd.Function):
         sink = gg is not None and gb is not None
         dg = gg if sink else torch.empty(cols, device=dy.device, dtype=torch.float32)
         db = gb if sink else torch.empty(cols, device=dy.device, dtype=torch.float32)
-        parts = _hip.lib().rf_layernorm_bwd_parts(rows)
-        ws = torch.empty(parts * 2 * cols, device=dy.device, dtype=torch.float32)
+        atomic = sink and not DETERMINISTIC
+        ws = None
+        if not atomic:
+            parts = _hip.lib().rf_layernorm_bwd_parts(rows)
+            ws = torch.empty(parts * 2 * cols, device=dy.device, dtype=torch.float32)
         ev = PROFILE.begin() if PROFILE.on else None
         check(_hip.lib().rf_layernorm_bwd(ptr(dy2), ptr(xhat), ptr(rstd), ptr(gamma), ptr(dx), ptr(dg),
-                                          ptr(db), 1 if sink else 0, ptr(ws), rows, cols, _stream()),
-              "rf_layernorm_bwd")
+                                          ptr(db), 2 if atomic else (1 if sink else 0), ptr(ws), rows, cols,
+                                          _stream()), "rf_layernorm_bwd")
         if ev is not None:
             PROFILE.end("layernorm_bwd_kernel(+ln_param_reduce)", ev, 12.0 * rows * cols, 4.0 * rows * cols * 3)
         dx = dx.view(ctx.xshape)

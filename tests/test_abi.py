@@ -61,7 +61,7 @@ def test_argument_validation_without_gpu():
     from routeformer_amd import _hip
     lib = _hip.lib()
     assert lib.rf_gemm(None, 1, 1, None, 1, 1, None, 1, 4, 4, 4, None, None, 0, 0, 0, 0, None, 0, None, 0, 0, 0, 1,
-                       None, 0, None, None) == -1
+                       None, 0, None, None, None) == -1
     assert b"invalid argument" in lib.rf_last_error()
     assert lib.rf_layernorm_bwd_parts(12480) == 768 and lib.rf_colsum_parts(12480, 128) == 49
 
