@@ -140,6 +140,22 @@ int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const float* x, c
                        float* dgamma, float* dbeta, float* workspace, int B, int L, int C, float eps,
                        int training, void* stream);
 
+/* Trajectory head = postprocess_batch (routeformer.py:367-374) + the loss recipe of the train step
+ * (experiments/full_comparison.py:490-521, losses/future_discounted_mse.py:56-95, score/error.py:29,51):
+ *   positions = last_gps + cumsum(out[...,:2] * motion_std + motion_mean)
+ *   traj  = mean(gamma^t * SmoothL1(positions - target_gps)),  dense = mean(gamma^t * SmoothL1(out[...,2:2+E] - target_vis))
+ *   loss  = traj + w * dense,  w = dense_on ? dense_ratio * traj / max(dense, 1e-6) : 0  (w is a constant in backward)
+ *   ade = mean_bt ||positions - target||_2,  fde = ||positions[B-1] - target[B-1]||_F
+ * scalars[6] = {traj, dense, ade, fde, loss, w}; gpos (B,P,2) is kept for the backward launch, which writes
+ * dout (B,P,C) = d loss / d out * grad_loss[0] (channels beyond 2+E are NOT written: caller zero-fills). */
+int rf_traj_head_fwd(const float* out, const float* last_gps, const float* target_gps,
+                     const float* target_vis, float* positions, float* gpos, float* scalars, int B, int P,
+                     int C, int E, float gamma, float dense_ratio, int dense_on, float motion_std,
+                     float motion_mean, void* stream);
+int rf_traj_head_bwd(const float* out, const float* target_vis, const float* gpos, const float* scalars,
+                     const float* grad_loss, float* dout, int B, int P, int C, int E, float gamma,
+                     float motion_std, void* stream);
+
 /* ---- attention ------------------------------------------------------------------------------
  * One workgroup per (batch, head).  q[(b*LQ+l)*q_ld + h*E + e] etc. (row pitches in floats).
  * mode 0: full softmax(scale*QK^T)V          (cross_modal_transformer.py:51-69)

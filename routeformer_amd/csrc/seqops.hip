@@ -362,3 +362,123 @@ extern "C" int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const 
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Trajectory head: postprocess_batch (routeformer.py:367-374: de-normalise, cumsum to positions) + the
+// train-step loss recipe (full_comparison.py:490-521: gamma^t-discounted SmoothL1 on positions and on the
+// dense visual head, dense weight = ratio * traj / max(dense, 1e-6) once enabled, ADE, FDE) in ONE
+// single-workgroup launch each way -- these are ~90 tiny dependent torch kernels sitting exactly between the
+// forward and the backward pass, where nothing else can overlap them.
+// scal[0..4] = {traj, dense, ade, fde, loss};  gpos = gamma^t * sl1'(pos - tgt) (un-normalised).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float sl1(float d) { const float a = fabsf(d); return a < 1.f ? 0.5f * d * d : a - 0.5f; }
+__device__ __forceinline__ float sl1g(float d) { return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f); }
+
+__device__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void traj_head_fwd_kernel(const float* __restrict__ out, const float* __restrict__ last,
+                                                            const float* __restrict__ tgt, const float* __restrict__ tvis,
+                                                            float* __restrict__ pos, float* __restrict__ gpos,
+                                                            float* __restrict__ scal, int B, int P, int C, int E,
+                                                            float gamma, float ratio, int dense_on, float mstd,
+                                                            float mmean) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  // positions: one thread per (b, coordinate), sequential cumsum over the horizon (P <= a few dozen)
+  for (int i = tid; i < B * 2; i += 256) {
+    const int b = i >> 1, c = i & 1;
+    float run = last[b * 2 + c];
+    for (int t = 0; t < P; ++t) {
+      run += out[((long)b * P + t) * C + c] * mstd + mmean;
+      pos[((long)b * P + t) * 2 + c] = run;
+    }
+  }
+  __syncthreads();
+  float s_traj = 0.f, s_ade = 0.f, s_fde = 0.f;
+  for (int i = tid; i < B * P; i += 256) {
+    const int b = i / P, t = i - b * P;
+    const float w = powf(gamma, (float)t);
+    const float dx = pos[i * 2] - tgt[i * 2], dy = pos[i * 2 + 1] - tgt[i * 2 + 1];
+    s_traj += w * (sl1(dx) + sl1(dy));
+    gpos[i * 2] = w * sl1g(dx);
+    gpos[i * 2 + 1] = w * sl1g(dy);
+    const float d2 = dx * dx + dy * dy;
+    s_ade += sqrtf(d2);
+    if (b == B - 1) s_fde += d2;
+  }
+  float s_dense = 0.f;
+  if (tvis) {
+    for (long i = tid; i < (long)B * P * E; i += 256) {
+      const long bt = i / E;
+      const int e = (int)(i - bt * E), t = (int)(bt % P);
+      s_dense += powf(gamma, (float)t) * sl1(out[bt * C + 2 + e] - tvis[i]);
+    }
+  }
+  const float traj = block_sum(s_traj, red) / (float)(B * P * 2);
+  const float ade = block_sum(s_ade, red) / (float)(B * P);
+  const float fde = sqrtf(block_sum(s_fde, red));
+  const float dense = tvis ? block_sum(s_dense, red) / (float)((long)B * P * E) : 0.f;
+  if (tid == 0) {
+    const float w = (tvis && dense_on) ? ratio * traj / fmaxf(dense, 1e-6f) : 0.f;
+    scal[0] = traj; scal[1] = dense; scal[2] = ade; scal[3] = fde; scal[4] = traj + w * dense; scal[5] = w;
+  }
+}
+
+__global__ __launch_bounds__(256) void traj_head_bwd_kernel(const float* __restrict__ out, const float* __restrict__ tvis,
+                                                            const float* __restrict__ gpos, const float* __restrict__ scal,
+                                                            const float* __restrict__ gloss, float* __restrict__ dout,
+                                                            int B, int P, int C, int E, float gamma, float mstd) {
+  const int tid = threadIdx.x;
+  const float g = gloss ? gloss[0] : 1.f;
+  const float w = scal[5];
+  // d traj / d motion[b,s,c] = mstd * sum_{t>=s} gpos[b,t,c] / (B*P*2)
+  for (int i = tid; i < B * 2; i += 256) {
+    const int b = i >> 1, c = i & 1;
+    float run = 0.f;
+    for (int t = P - 1; t >= 0; --t) {
+      run += gpos[((long)b * P + t) * 2 + c];
+      dout[((long)b * P + t) * C + c] = g * mstd * run / (float)(B * P * 2);
+    }
+  }
+  if (tvis) {
+    const float k = g * w / (float)((long)B * P * E);
+    for (long i = tid; i < (long)B * P * E; i += 256) {
+      const long bt = i / E;
+      const int e = (int)(i - bt * E), t = (int)(bt % P);
+      dout[bt * C + 2 + e] = k * powf(gamma, (float)t) * sl1g(out[bt * C + 2 + e] - tvis[i]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int rf_traj_head_fwd(const float* out, const float* last_gps, const float* target_gps,
+                                const float* target_vis, float* positions, float* gpos, float* scalars, int B, int P,
+                                int C, int E, float gamma, float dense_ratio, int dense_on, float motion_std,
+                                float motion_mean, void* stream) {
+  RF_REQUIRE(out && last_gps && target_gps && positions && gpos && scalars && B > 0 && P > 0 && C >= 2);
+  RF_REQUIRE(!target_vis || C >= 2 + E);
+  hipLaunchKernelGGL(traj_head_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), out, last_gps,
+                     target_gps, target_vis, positions, gpos, scalars, B, P, C, E, gamma, dense_ratio, dense_on,
+                     motion_std, motion_mean);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_traj_head_bwd(const float* out, const float* target_vis, const float* gpos, const float* scalars,
+                                const float* grad_loss, float* dout, int B, int P, int C, int E, float gamma,
+                                float motion_std, void* stream) {
+  RF_REQUIRE(out && gpos && scalars && dout && B > 0 && P > 0 && C >= 2);
+  hipLaunchKernelGGL(traj_head_bwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), out, target_vis,
+                     gpos, scalars, grad_loss, dout, B, P, C, E, gamma, motion_std);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}

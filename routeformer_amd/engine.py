@@ -42,7 +42,13 @@ def train_step_losses(model, item, epoch: int = 0, trajectory_loss: Optional[Fut
         if overlap:  # fork point: the target-side pass must not wait for the input forward
             side = K.side_stream("target")
             side.wait_stream(torch.cuda.current_stream())
-        future_gps, future_vis = model(item["train"])
+        fused = (K.OVERLAP and target_gps.is_cuda and hasattr(model, "forward_raw") and model.training
+                 and not cfg.autoregressive and tl.loss_function == "smooth_l1" and dl.loss_function == "smooth_l1"
+                 and item["train"]["gps"].dtype == torch.float32)
+        if fused:
+            raw, last_gps = model.forward_raw(item["train"])
+        else:
+            future_gps, future_vis = model(item["train"])
         # host order stays "input forward, then target pass" (reference draw order, full_comparison.py:481-482);
         # on the device the two are independent, so the target pass gets its own stream
         with torch.no_grad():  # the reference detaches this branch (full_comparison.py:495)
@@ -52,6 +58,19 @@ def train_step_losses(model, item, epoch: int = 0, trajectory_loss: Optional[Fut
                 torch.cuda.current_stream().wait_stream(side)
             else:
                 _, target_vis = model.preprocess_batch(item["target"], training=False)
+        if fused:  # postprocess + both losses + metrics: one launch each way
+            E = cfg.image_embedding_size
+            g_t, g_d = tl.discount(), dl.discount()
+            assert g_t == g_d, "fused head assumes one discount table for both losses (as in the reference driver)"
+            target_vis = target_vis[:, : raw.shape[1]].contiguous()
+            loss, traj, dense, a_, f_, future_gps = K.traj_head(
+                raw, last_gps, target_gps, target_vis, g_t, cfg.dense_loss_ratio, epoch >= 10,
+                cfg.motion_std if cfg.normalize_motion else 1.0, cfg.motion_mean if cfg.normalize_motion else 0.0)
+            res.update(dense_loss=dense, future_vis=raw[:, :, 2:2 + E], target_vis=target_vis, loss=loss, traj_loss=traj,
+                       future_gps=future_gps, ade=a_, fde=f_)
+            if hasattr(model, "clear_video_tokens") and not tokens_ready:
+                model.clear_video_tokens()
+            return res
         target_vis = target_vis[:, : future_vis.shape[1]]
         step = cfg.autoregressive_step_size
         if cfg.autoregressive:

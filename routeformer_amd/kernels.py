@@ -677,3 +677,47 @@ def attention(a, b, offs, dims, mode: int, *, index_sample=None, n_top: int = 0,
     if index_sample is not None and index_sample.dim() == 3:
         assert idx_group > 0 and index_sample.shape[0] * idx_group == B, (index_sample.shape, idx_group, B)
     return _Attention.apply(a, b, offs, index_sample, dims, mode, n_top, out_layout, scale, forced_top, idx_group)
+
+
+class _TrajHead(torch.autograd.Function):
+    """postprocess_batch + discounted SmoothL1 losses + ADE/FDE in one launch (and one for backward)."""
+
+    @staticmethod
+    def forward(ctx, out, last_gps, target_gps, target_vis, gamma, ratio, dense_on, mstd, mmean):
+        _req(out, "traj_head.out")
+        out = out.contiguous()
+        B, P, C = out.shape
+        E = target_vis.shape[-1] if target_vis is not None else 0
+        last = last_gps.reshape(B, 2).to(torch.float32).contiguous()
+        tgt = target_gps.to(torch.float32).contiguous()
+        tv = target_vis.contiguous() if target_vis is not None else None
+        pos = torch.empty(B, P, 2, device=out.device, dtype=torch.float32)
+        gpos = torch.empty(B, P, 2, device=out.device, dtype=torch.float32)
+        scal = torch.empty(8, device=out.device, dtype=torch.float32)
+        check(_hip.lib().rf_traj_head_fwd(ptr(out), ptr(last), ptr(tgt), ptr(tv), ptr(pos), ptr(gpos), ptr(scal), B, P, C,
+                                          E, gamma, ratio, 1 if dense_on else 0, mstd, mmean, _stream()),
+              "rf_traj_head_fwd")
+        ctx.save_for_backward(out, tv if tv is not None else out, gpos, scal)
+        ctx.cfg = (B, P, C, E, gamma, mstd, tv is not None)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(pos)
+        return scal[4], scal[0], scal[1], scal[2], scal[3], pos
+
+    @staticmethod
+    def backward(ctx, g_loss, g_traj, g_dense, g_ade, g_fde, g_pos):
+        out, tv, gpos, scal = ctx.saved_tensors
+        B, P, C, E, gamma, mstd, has_vis = ctx.cfg
+        if g_traj is not None or g_dense is not None or g_ade is not None or g_fde is not None:
+            raise NotImplementedError("traj_head: only the combined loss is differentiable")
+        dout = torch.zeros_like(out) if C > 2 + E else torch.empty_like(out)
+        gl = g_loss.reshape(1).contiguous() if g_loss is not None else None
+        check(_hip.lib().rf_traj_head_bwd(ptr(out), ptr(tv) if has_vis else None, ptr(gpos), ptr(scal), ptr(gl), ptr(dout),
+                                          B, P, C, E, gamma, mstd, _stream()), "rf_traj_head_bwd")
+        return dout, None, None, None, None, None, None, None, None
+
+
+def traj_head(out, last_gps, target_gps, target_vis, gamma: float, ratio: float, dense_on: bool,
+              motion_std: float = 1.0, motion_mean: float = 0.0):
+    """-> (loss, traj_loss, dense_loss, ade, fde, positions); only ``loss`` carries gradient (to ``out``)."""
+    return _TrajHead.apply(out, last_gps, target_gps, target_vis, float(gamma), float(ratio), bool(dense_on),
+                           float(motion_std), float(motion_mean))

@@ -23,9 +23,14 @@ class FutureDiscountedLoss(nn.Module):
         self.epsilon = epsilon
         self.loss_function = loss_function
 
-    def forward(self, y_pred, y_true):
+    def discount(self) -> float:
+        """The discount in force at ``current_epoch`` (switches, stickily, when the epoch is a key)."""
         if self.current_epoch in self.discount_factor_dict:
             self.current_discount_factor = self.discount_factor_dict[self.current_epoch]
+        return self.current_discount_factor
+
+    def forward(self, y_pred, y_true):
+        self.discount()
         extra = y_pred.dim() - 2
         assert extra >= 0
         steps = torch.arange(y_pred.shape[1], device=y_pred.device)

@@ -113,6 +113,14 @@ class Routeformer(nn.Module):
             return positions, future_visual
         return positions
 
+    def forward_raw(self, batch):
+        """Training-path forward up to the backbone output: (out (B,P,c_out), last input position (B,1,2)).
+        ``postprocess_batch`` (+ the losses) can then run as one fused launch (``kernels.traj_head``)."""
+        assert self.training or not self.configs.autoregressive, "eval-time roll-out needs forward()"
+        motion, visual = self.preprocess_batch(batch)
+        out, _ = self._forward(motion, visual)
+        return out, batch["gps"][:, -1:, :]
+
     def _forward(self, motion, visual):
         c = self.configs
         angle, norm = estimate_angle_and_norm(motion)

@@ -433,6 +433,36 @@ def test_adamw_clip():
         assert rel_err(pd, pc) < 1e-5, step
 
 
+@pytest.mark.parametrize("B,P,E,extra,normalize,dense_on", [(8, 30, 64, 0, False, True), (3, 7, 16, 5, True, True),
+                                                              (4, 30, 64, 0, True, False), (1, 1, 4, 0, False, True)])
+def test_traj_head(B, P, E, extra, normalize, dense_on):
+    """Fused postprocess + discounted SmoothL1 (positions and dense head) + ADE/FDE vs the oracle's losses
+    (routeformer.py:367-374, future_discounted_mse.py:56-95, full_comparison.py:497-521), values and d/d out."""
+    from routeformer_amd import kernels as Kn
+    g = _g(5)
+    C = 2 + E + extra
+    out = torch.randn(B, P, C, generator=g) * 1.5
+    last = torch.randn(B, 1, 2, generator=g)
+    tgt = torch.randn(B, P, 2, generator=g) * 3
+    tvis = torch.randn(B, P, E, generator=g)
+    gamma, ratio, mstd, mmean = 0.97, 0.3, (2.5 if normalize else 1.0), (0.1 if normalize else 0.0)
+    o = out.clone().requires_grad_(True)
+    pos = last + torch.cumsum(o[:, :, :2] * mstd + mmean, dim=1)
+    traj = O.future_discounted_loss(pos, tgt, gamma, "smooth_l1")
+    dense = O.future_discounted_loss(o[:, :, 2:2 + E], tvis, gamma, "smooth_l1")
+    w = (ratio * traj / torch.clamp(dense, min=1e-6)).detach() if dense_on else 0
+    loss = traj + w * dense
+    (loss * 1.7).backward()
+    od = out.to(DEV).requires_grad_(True)
+    lastd, tgtd, tvisd = last.to(DEV), tgt.to(DEV), tvis.to(DEV)
+    l, tr, de, a, f, p = Kn.traj_head(od, lastd, tgtd, tvisd, gamma, ratio, dense_on, mstd, mmean)
+    (l * 1.7).backward()
+    assert rel_err(p, pos.detach()) < 1e-5
+    for got, want in ((l, loss), (tr, traj), (de, dense), (a, O.ade(pos, tgt)), (f, O.fde(pos, tgt))):
+        assert abs(got.item() - want.item()) <= 2e-5 * max(1.0, abs(want.item()))
+    assert rel_err(od.grad, o.grad) < 2e-5
+
+
 def test_cpu_tensor_is_refused():
     """No CPU fallback: handing the product a CPU tensor must fail loudly."""
     from routeformer_amd import _hip, kernels as Kn
