@@ -140,6 +140,23 @@ int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const float* x, c
                        float* dgamma, float* dbeta, float* workspace, int B, int L, int C, float eps,
                        int training, void* stream);
 
+/* ---- row-block kernels for the d_model = 128 stacks (bf16-input MFMA only) ----
+ * A workgroup owns 64 complete rows and stages the whole weight matrix in LDS, so the residual add and the
+ * LayerNorm of EncoderLayer / DecoderLayer (cross_modal_transformer.py:279-365) finish in the epilogue.
+ * rf_rowblock_linear:  y[M,N] = x[M,K] w[N,K]^T + bias [+ residual[M,N]]   (K in {128, 256}; w contiguous)
+ *   with ln_gamma != NULL (N == 128): y = LayerNorm(that) and, if xhat != NULL, xhat[M,128] / rstd[M] are
+ *   written for rf_layernorm_bwd.
+ * rf_rowblock_ffn_ln:  y = LayerNorm(x + conv2(act(conv1(x))))  for d_model 128, d_ff 256; h / z (M,256) =
+ *   activation output / pre-activation side outputs for the backward pass (either may be NULL). */
+int rf_rowblock_linear_supported(int N, int K, int with_ln);
+int rf_rowblock_linear(const float* x, int64_t ldx, const float* w, const float* bias, const float* residual,
+                       int64_t ldr, float* y, int64_t ldy, int M, int N, int K, const float* ln_gamma,
+                       const float* ln_beta, float* xhat, float* rstd, float eps, void* stream);
+int rf_rowblock_ffn_ln(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                       float* h, float* z, float* y, int M, int d_model, int d_ff, int act,
+                       const float* ln_gamma, const float* ln_beta, float* xhat, float* rstd, float eps,
+                       void* stream);
+
 /* Trajectory head = postprocess_batch (routeformer.py:367-374) + the loss recipe of the train step
  * (experiments/full_comparison.py:490-521, losses/future_discounted_mse.py:56-95, score/error.py:29,51):
  *   positions = last_gps + cumsum(out[...,:2] * motion_std + motion_mean)

@@ -503,30 +503,81 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
   }
 
   // ---- epilogue ----
-  auto finish = [&](float v, int m, int n) {
-    if (p.bias) v += p.bias[n];
-    if (p.res && p.res_before_act) v += p.res[(long)(m % p.res_rows) * p.ldr + n];
-    if (p.preact) p.preact[(long)m * p.ldp + n] = v;
-    v = apply_act(v, p.act);
-    if (p.dact) v *= act_grad(p.dsrc[(long)m * p.ldd + n], p.dact);
-    if (p.res && !p.res_before_act) v += p.res[(long)(m % p.res_rows) * p.ldr + n];
-    p.C[(long)m * p.ldc + n] = v;
-  };
+  // The accumulators go through an fp32 LDS tile and ONE rolled loop finishes them, a wave per output row
+  // segment: (a) the bias / activation / residual code exists once instead of once per accumulator
+  // register -- the unrolled form made this kernel 70-140 KB of instructions, more than the 64 KB
+  // instruction cache, so every launch streamed its own code from L2; (b) stores are row-contiguous
+  // (256 B per wave instruction) instead of 64-B column fragments of the MFMA layout.
+  constexpr int CP = BN + 4;  // pitch: conflict-free for the C-fragment writes
+  static_assert(BM * CP * 4 <= 2 * (BM + BN) * LD * (int)sizeof(T), "C staging tile must fit in the K-loop stages");
+  const int mode = p.atomic ? 1 : (p.ws ? 2 : 0);
+  if (mode != 0) {
+    // split-K partials (fp32 atomics into the gradient slot, or a slab of the workspace): nothing to
+    // compute, so they leave straight from the accumulator registers
 #pragma unroll
-  for (int i = 0; i < C_::TM; ++i) {
+    for (int i = 0; i < C_::TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < C_::TN; ++j) {
-      const int n = n0 + (wn * C_::TN + j) * 16 + fr;
-      if (n >= p.N) continue;
+      for (int j = 0; j < C_::TN; ++j) {
+        const int n = n0 + (wn * C_::TN + j) * 16 + fr;
+        if (n >= p.N) continue;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + (wm * C_::TM + i) * 16 + fq * 4 + r;
-        if (m >= p.M) continue;
-        const float v = acc[i][j][r];
-        if (p.atomic) atomicAdd(&p.C[(long)m * p.ldc + n], v);
-        else if (p.ws) p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = v;
-        else finish(v, m, n);
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + (wm * C_::TM + i) * 16 + fq * 4 + r;
+          if (m >= p.M) continue;
+          if (mode == 1) atomicAdd(&p.C[(long)m * p.ldc + n], acc[i][j][r]);
+          else p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
+        }
       }
+    }
+  }
+  float* ct = reinterpret_cast<float*>(smem);
+  if (mode == 0) {
+    __syncthreads();  // K-loop stages (and the row-sum scratch) are dead
+#pragma unroll
+    for (int i = 0; i < C_::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < C_::TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ct[((wm * C_::TM + i) * 16 + fq * 4 + r) * CP + (wn * C_::TN + j) * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+  }
+
+  // four elements per trip: all their loads (LDS tile, bias, residual, activation source) are issued before
+  // the first dependent use, so one trip costs one memory latency, not four
+  auto finish4 = [&](float (&v)[4], const int (&m)[4], const int (&n)[4], const bool (&ok)[4]) {
+    float bs[4], rs[4], ds[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bs[u] = (ok[u] && p.bias) ? p.bias[n[u]] : 0.f;
+      rs[u] = (ok[u] && p.res) ? p.res[(long)(m[u] % p.res_rows) * p.ldr + n[u]] : 0.f;
+      ds[u] = (ok[u] && p.dact) ? p.dsrc[(long)m[u] * p.ldd + n[u]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      float t = v[u] + bs[u];
+      if (p.res_before_act) t += rs[u];
+      if (p.preact) p.preact[(long)m[u] * p.ldp + n[u]] = t;
+      t = apply_act(t, p.act);
+      if (p.dact) t *= act_grad(ds[u], p.dact);
+      if (!p.res_before_act) t += rs[u];
+      p.C[(long)m[u] * p.ldc + n[u]] = t;
+    }
+  };
+  static_assert((BM * BN) % (4 * NT) == 0, "tile must split into 4-element trips");
+  if (mode == 0) {
+#pragma unroll 1
+    for (int e0 = tid; e0 < BM * BN; e0 += 4 * NT) {
+      float v[4]; int m[4], n[4]; bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * NT, rr = e / BN, cc = e % BN;
+        m[u] = m0 + rr; n[u] = n0 + cc;
+        ok[u] = m[u] < p.M && n[u] < p.N;
+        v[u] = ct[rr * CP + cc];
+      }
+      finish4(v, m, n, ok);
     }
   }
 
@@ -536,7 +587,7 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
   if (p.ws && p.tile_cnt && !p.atomic) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its partial-slab stores
     __syncthreads();
-    int* last_flag = reinterpret_cast<int*>(smem);    // LDS stages are dead after the K loop
+    int* last_flag = reinterpret_cast<int*>(smem);    // the staging tile is dead too
     unsigned* cnt = p.tile_cnt + (blockIdx.y * gridDim.x + blockIdx.x);
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -554,21 +605,19 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
     if (*last_flag) {
       const int splits = gridDim.z;
       const long slab = (long)p.M * p.N;
+#pragma unroll 1
+      for (int e0 = tid; e0 < BM * BN; e0 += 4 * NT) {
+        float v[4]; int m[4], n[4]; bool ok[4];
 #pragma unroll
-      for (int i = 0; i < C_::TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < C_::TN; ++j) {
-          const int n = n0 + (wn * C_::TN + j) * 16 + fr;
-          if (n >= p.N) continue;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = m0 + (wm * C_::TM + i) * 16 + fq * 4 + r;
-            if (m >= p.M) continue;
-            float v = 0.f;
-            for (int z = 0; z < splits; ++z) v += p.ws[z * slab + (long)m * p.N + n];
-            finish(v, m, n);
-          }
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u * NT;
+          m[u] = m0 + e / BN; n[u] = n0 + e % BN;
+          ok[u] = m[u] < p.M && n[u] < p.N;
+          v[u] = 0.f;
+          if (ok[u])
+            for (int z = 0; z < splits; ++z) v[u] += p.ws[z * slab + (long)m[u] * p.N + n[u]];
         }
+        finish4(v, m, n, ok);
       }
     }
   }

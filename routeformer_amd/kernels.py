@@ -7,6 +7,7 @@ and nothing falls back to eager PyTorch: a missing library or a CPU tensor raise
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -303,6 +304,27 @@ def _input_grad(dy2: torch.Tensor, w: torch.Tensor, **epi) -> torch.Tensor:
     return dx
 
 
+ROWBLOCK = os.environ.get("RF_ROWBLOCK", "1") != "0"  # row-block kernels (csrc/rowblock.hip) in bf16 mode
+
+
+def _rowblock_ok(x2, w, N, K, with_ln=False) -> bool:
+    return (ROWBLOCK and _PRECISION == 1 and (K == 128 or K == 256) and N % 4 == 0 and (not with_ln or N == 128) and x2.is_cuda
+            and x2.data_ptr() % 16 == 0 and x2.stride(0) % 4 == 0 and x2.stride(1) == 1 and w.data_ptr() % 16 == 0
+            and w.is_contiguous())
+
+
+def _rowblock_linear(x2, w, b, r2, y, M, N, K, ln=None, xhat=None, rstd=None, eps=1e-5):
+    ev = PROFILE.begin() if PROFILE.on else None
+    args = (ptr(x2), x2.stride(0), ptr(w), ptr(b), ptr(r2), N if r2 is not None else 0, ptr(y), N, M, N, K,
+            ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None, ptr(xhat), ptr(rstd), eps)
+    check(_hip.lib().rf_rowblock_linear(*args, _stream()), "rf_rowblock_linear")
+    if ev is not None:
+        keep = (x2, w, b, r2, y, ln, xhat, rstd)
+        PROFILE.end(f"rb_linear_kernel<{K}, {'true' if ln else 'false'}>", ev, 2.0 * M * N * K,
+                    4.0 * (M * K + N * K + M * N * (1 + (r2 is not None) + (xhat is not None))),
+                    replay=lambda a=args, k=keep: _hip.lib().rf_rowblock_linear(*a, _stream()))
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b (+ residual rows broadcast over the batch: y[m] += residual[m % R])."""
 
@@ -319,8 +341,13 @@ class _Linear(torch.autograd.Function):
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
         if residual is not None:
             r2 = residual.reshape(-1, N).contiguous()
-            gemm(x2, x2.stride(0), 1, w, 1, K, y, N, M, N, K, bias=b, residual=r2, ldr=N, res_rows=r2.shape[0])
+            if r2.shape[0] == M and _rowblock_ok(x2, w, N, K):
+                _rowblock_linear(x2, w, b, r2, y, M, N, K)
+            else:
+                gemm(x2, x2.stride(0), 1, w, 1, K, y, N, M, N, K, bias=b, residual=r2, ldr=N, res_rows=r2.shape[0])
             ctx.res_rows, ctx.res_shape = r2.shape[0], residual.shape
+        elif _rowblock_ok(x2, w, N, K):
+            _rowblock_linear(x2, w, b, None, y, M, N, K)
         else:
             gemm(x2, x2.stride(0), 1, w, 1, K, y, N, M, N, K, bias=b)
         ctx.save_for_backward(x2, w)
@@ -453,27 +480,153 @@ class _AddLayerNorm(torch.autograd.Function):
         xhat, rstd, gamma = ctx.saved_tensors
         gg, gb = ctx.sinks
         rows, cols = xhat.shape
-        dy2 = dy.reshape(rows, cols).contiguous()
-        dx = torch.empty_like(xhat)
-        sink = gg is not None and gb is not None
-        dg = gg if sink else torch.empty(cols, device=dy.device, dtype=torch.float32)
-        db = gb if sink else torch.empty(cols, device=dy.device, dtype=torch.float32)
-        atomic = sink and not DETERMINISTIC
-        ws = None
-        if not atomic:
-            parts = _hip.lib().rf_layernorm_bwd_parts(rows)
-            ws = torch.empty(parts * 2 * cols, device=dy.device, dtype=torch.float32)
-        ev = PROFILE.begin() if PROFILE.on else None
-        check(_hip.lib().rf_layernorm_bwd(ptr(dy2), ptr(xhat), ptr(rstd), ptr(gamma), ptr(dx), ptr(dg),
-                                          ptr(db), 2 if atomic else (1 if sink else 0), ptr(ws), rows, cols,
-                                          _stream()), "rf_layernorm_bwd")
-        if ev is not None:
-            PROFILE.end("layernorm_bwd_kernel(+ln_param_reduce)", ev, 12.0 * rows * cols, 4.0 * rows * cols * 3)
+        dx, dg, db = _ln_backward(dy.reshape(rows, cols).contiguous(), xhat, rstd, gamma, gg, gb)
         dx = dx.view(ctx.xshape)
-        if sink:
-            _wrote(gg, gb)
-            dg = db = None
         return dx, (dx if ctx.has_res else None), dg, db, None, None, None, None
+
+
+def _ln_backward(dy2, xhat, rstd, gamma, gg, gb):
+    """LayerNorm backward on saved (xhat, rstd): -> (d pre-norm input, dgamma, dbeta); with sinks the
+    parameter gradients are accumulated there and returned as None."""
+    rows, cols = xhat.shape
+    dx = torch.empty_like(xhat)
+    sink = gg is not None and gb is not None
+    dg = gg if sink else torch.empty(cols, device=dy2.device, dtype=torch.float32)
+    db = gb if sink else torch.empty(cols, device=dy2.device, dtype=torch.float32)
+    atomic = sink and not DETERMINISTIC
+    ws = None
+    if not atomic:
+        parts = _hip.lib().rf_layernorm_bwd_parts(rows)
+        ws = torch.empty(parts * 2 * cols, device=dy2.device, dtype=torch.float32)
+    ev = PROFILE.begin() if PROFILE.on else None
+    check(_hip.lib().rf_layernorm_bwd(ptr(dy2), ptr(xhat), ptr(rstd), ptr(gamma), ptr(dx), ptr(dg), ptr(db),
+                                      2 if atomic else (1 if sink else 0), ptr(ws), rows, cols, _stream()),
+          "rf_layernorm_bwd")
+    if ev is not None:
+        PROFILE.end("layernorm_bwd_kernel(+ln_param_reduce)", ev, 12.0 * rows * cols, 4.0 * rows * cols * 3)
+    if sink:
+        _wrote(gg, gb)
+        dg = db = None
+    return dx, dg, db
+
+
+class _LinearAddLN(torch.autograd.Function):
+    """y = LayerNorm(res + a W^T + b): attention out-projection + residual + norm in one row-block launch
+    (cross_modal_transformer.py:302-306 / :344-352)."""
+
+    @staticmethod
+    def forward(ctx, a, w, b, res, gamma, beta, eps, gw, gb, gg, gbeta, need_grad=True):
+        _req(a, "linear_ln.a")
+        K, N = a.shape[-1], w.shape[0]
+        a2 = a.reshape(-1, K)
+        r2 = res.reshape(-1, N).contiguous()
+        M = a2.shape[0]
+        y = torch.empty(M, N, device=a.device, dtype=torch.float32)
+        xhat = torch.empty_like(y) if need_grad else None
+        rstd = torch.empty(M, device=a.device, dtype=torch.float32) if need_grad else None
+        _rowblock_linear(a2, w, b, r2, y, M, N, K, ln=(gamma, beta), xhat=xhat, rstd=rstd, eps=eps)
+        if need_grad:
+            ctx.save_for_backward(a2, w, xhat, rstd, gamma)
+        ctx.sinks = (gw, gb, gg, gbeta)
+        ctx.shapes = (a.shape, res.shape)
+        return y.view(res.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a2, w, xhat, rstd, gamma = ctx.saved_tensors
+        gw, gb, gg, gbeta = ctx.sinks
+        M, N = xhat.shape
+        dy2 = dy.reshape(M, N).contiguous()
+        dpre, dgam, dbet = _ln_backward(dy2, xhat, rstd, gamma, gg, gbeta)
+        dw = db = None
+        fused_bias = False
+        if gw is not None:
+            fused_bias = _weight_grad(dpre, a2, into=gw, bias_into=gb) is True
+        else:
+            dw = _weight_grad(dpre, a2)
+        if not fused_bias:
+            db = colsum(dpre, into=gb)
+        da = _input_grad(dpre, w).view(ctx.shapes[0]) if ctx.needs_input_grad[0] else None
+        _wrote(gw, gb)
+        return da, dw, db, dpre.view(ctx.shapes[1]), dgam, dbet, None, None, None, None, None, None
+
+
+def linear_add_layer_norm(a, w, b, res, gamma, beta, eps: float = 1e-5):
+    """LayerNorm(res + linear(a, w, b)); one launch when the row-block kernel applies."""
+    a2 = a.reshape(-1, a.shape[-1])
+    if b is not None and a2.stride(1) == 1 and _rowblock_ok(a2, w, w.shape[0], a.shape[-1], with_ln=True):
+        return _LinearAddLN.apply(a, w, b, res, gamma, beta, eps, _slot(w), _slot(b), _slot(gamma), _slot(beta),
+                                  torch.is_grad_enabled())
+    return add_layer_norm(res, linear(a, w, b), gamma, beta, eps)
+
+
+class _FFNAddLN(torch.autograd.Function):
+    """y = LayerNorm(x + conv2(act(conv1(x)))) for d_model 128 / d_ff 256: one launch forward; backward =
+    LN backward, then the FFN chain with the residual gradient folded into the last dX epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act, gamma, beta, eps, g1, gb1, g2, gb2, gg, gbeta, need_grad=True):
+        _req(x, "ffn_ln.x")
+        F, D = w1.shape[0], w1.shape[1]
+        w1, w2 = w1.reshape(F, D), w2.reshape(D, F)
+        x2 = x.reshape(-1, D).contiguous()
+        M = x2.shape[0]
+        y = torch.empty_like(x2)
+        h = torch.empty(M, F, device=x.device, dtype=torch.float32) if need_grad else None
+        z = torch.empty_like(h) if (need_grad and act == "gelu") else None
+        xhat = torch.empty_like(x2) if need_grad else None
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32) if need_grad else None
+        ev = PROFILE.begin() if PROFILE.on else None
+        args = (ptr(x2), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(h), ptr(z), ptr(y), M, D, F, ACT[act], ptr(gamma),
+                ptr(beta), ptr(xhat), ptr(rstd), eps)
+        check(_hip.lib().rf_rowblock_ffn_ln(*args, _stream()), "rf_rowblock_ffn_ln")
+        if ev is not None:
+            keep = (x2, w1, b1, w2, b2, h, z, y, gamma, beta, xhat, rstd)
+            PROFILE.end("rb_ffn_ln_kernel", ev, 4.0 * M * D * F,
+                        4.0 * (M * D * (2 + (xhat is not None)) + 2 * D * F + M * F * ((h is not None) + (z is not None))),
+                        replay=lambda a=args, k=keep: _hip.lib().rf_rowblock_ffn_ln(*a, _stream()))
+        if need_grad:
+            ctx.save_for_backward(x2, w1, w2, h, z if z is not None else h, xhat, rstd, gamma)
+        ctx.sinks = (g1, gb1, g2, gb2, gg, gbeta)
+        ctx.act = act
+        ctx.xshape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, h, zsrc, xhat, rstd, gamma = ctx.saved_tensors
+        g1, gb1, g2, gb2, gg, gbeta = ctx.sinks
+        M, D = x2.shape
+        F = w1.shape[0]
+        dy2 = dy.reshape(M, D).contiguous()
+        dpre, dgam, dbet = _ln_backward(dy2, xhat, rstd, gamma, gg, gbeta)
+        dw2 = _weight_grad(dpre, h, into=None if g2 is None else g2.view(D, F), bias_into=gb2)
+        db2 = None if dw2 is True else colsum(dpre, into=gb2)
+        dz = _input_grad(dpre, w2, dact_src=zsrc, ldd=zsrc.stride(0), dact=ACT[ctx.act])
+        dw1 = _weight_grad(dz, x2, into=None if g1 is None else g1.view(F, D), bias_into=gb1)
+        db1 = None if dw1 is True else colsum(dz, into=gb1)
+        if dw1 is True or dw1 is False:
+            dw1 = None
+        if dw2 is True or dw2 is False:
+            dw2 = None
+        # dX = dZ W1 + d(pre-norm)  -- the residual branch rides in the GEMM epilogue, no separate add
+        dx = _input_grad(dz, w1, residual=dpre, ldr=D, res_rows=M).view(ctx.xshape)
+        _wrote(g1, gb1, g2, gb2)
+        if dw1 is not None:
+            dw1, dw2 = dw1.view(F, D, 1), dw2.view(D, F, 1)
+        return dx, dw1, db1, dw2, db2, None, dgam, dbet, None, None, None, None, None, None, None, None
+
+
+def ffn_add_layer_norm(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str, gamma, beta, eps: float = 1e-5):
+    """LayerNorm(x + ffn(x)); one launch when d_model = 128, d_ff = 256 in bf16 mode."""
+    F, D = conv1_w.shape[0], conv1_w.shape[1]
+    if (ROWBLOCK and _PRECISION == 1 and D == 128 and F == 256 and x.is_cuda and conv1_b is not None
+            and conv2_b is not None and conv1_w.is_contiguous() and conv2_w.is_contiguous()
+            and conv1_w.data_ptr() % 16 == 0 and conv2_w.data_ptr() % 16 == 0):
+        return _FFNAddLN.apply(x, conv1_w, conv1_b, conv2_w, conv2_b, act, gamma, beta, eps, _slot(conv1_w),
+                               _slot(conv1_b), _slot(conv2_w), _slot(conv2_b), _slot(gamma), _slot(beta),
+                               torch.is_grad_enabled())
+    return add_layer_norm(x, ffn(x, conv1_w, conv1_b, conv2_w, conv2_b, act), gamma, beta, eps)
 
 
 def add_layer_norm(x, residual, gamma, beta, eps: float = 1e-5):

@@ -178,8 +178,10 @@ class AttentionLayer(nn.Module):
         q, k, v = self.query_projection, self.key_projection, self.value_projection
         return [[q.weight, k.weight, v.weight], [q.bias, k.bias, v.bias]]
 
-    def forward(self, x, memory=None, idx=None, idx_group: int = 0):
-        """Self-attention when ``memory is None`` (one packed QKV GEMM), else queries from ``x`` and
+    def forward(self, x, memory=None, idx=None, idx_group: int = 0, norm=None):
+        """``norm`` = the LayerNorm that follows ``x + attention(x)`` in the layer: the out-projection, the
+        residual add and the norm then run as one launch and the NORMALISED tensor is returned.
+        Self-attention when ``memory is None`` (one packed QKV GEMM), else queries from ``x`` and
         keys/values from ``memory`` (packed KV GEMM).  ``idx`` (G,L,k) int32 on the device = pre-drawn
         key samples, one table per ``idx_group`` consecutive sequences (stream-batched encoders)."""
         B, L, _ = x.shape
@@ -223,6 +225,9 @@ class AttentionLayer(nn.Module):
         if self.mix and not self.gps_variant:
             ctx = ctx.transpose(2, 1).contiguous()
         ctx = ctx.view(B, L, HE)  # GPS variant: (B,H,L,D) memory reinterpreted -- the head scramble
+        if norm is not None:
+            return K.linear_add_layer_norm(ctx, self.out_projection.weight, self.out_projection.bias, x, norm.weight,
+                                           norm.bias, norm.eps)
         return K.linear(ctx, self.out_projection.weight, self.out_projection.bias)
 
 
@@ -244,10 +249,19 @@ class EncoderLayer(nn.Module):
             raise NotImplementedError("dropout inside the fused FFN is not implemented; use dropout=0")
         return K.ffn(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.act)
 
+    def _ffn_norm(self, x, norm):
+        if self.p > 0.0 and self.training:
+            raise NotImplementedError("dropout inside the fused FFN is not implemented; use dropout=0")
+        return K.ffn_add_layer_norm(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.act,
+                                    norm.weight, norm.bias, norm.eps)
+
     def forward(self, x, idx=None, idx_group: int = 0):
-        x = K.add_layer_norm(x, _dropout(self.attention(x, idx=idx, idx_group=idx_group), self.p, self.training),
-                             self.norm1.weight, self.norm1.bias)
-        return K.add_layer_norm(x, self._ffn(x), self.norm2.weight, self.norm2.bias)
+        if self.p > 0.0 and self.training:
+            x = K.add_layer_norm(x, _dropout(self.attention(x, idx=idx, idx_group=idx_group), self.p, self.training),
+                                 self.norm1.weight, self.norm1.bias)
+        else:
+            x = self.attention(x, idx=idx, idx_group=idx_group, norm=self.norm1)
+        return self._ffn_norm(x, self.norm2)
 
 
 class DecoderLayer(nn.Module):
@@ -266,13 +280,18 @@ class DecoderLayer(nn.Module):
         self.act = "relu" if activation == "relu" else "gelu"
 
     _ffn = EncoderLayer._ffn
+    _ffn_norm = EncoderLayer._ffn_norm
 
     def forward(self, x, memory):
-        x = K.add_layer_norm(x, _dropout(self.self_attention(x), self.p, self.training), self.norm1.weight,
-                             self.norm1.bias)
-        x = K.add_layer_norm(x, _dropout(self.cross_attention(x, memory), self.p, self.training),
-                             self.norm2.weight, self.norm2.bias)
-        return K.add_layer_norm(x, self._ffn(x), self.norm3.weight, self.norm3.bias)
+        if self.p > 0.0 and self.training:
+            x = K.add_layer_norm(x, _dropout(self.self_attention(x), self.p, self.training), self.norm1.weight,
+                                 self.norm1.bias)
+            x = K.add_layer_norm(x, _dropout(self.cross_attention(x, memory), self.p, self.training),
+                                 self.norm2.weight, self.norm2.bias)
+        else:
+            x = self.self_attention(x, norm=self.norm1)
+            x = self.cross_attention(x, memory, norm=self.norm2)
+        return self._ffn_norm(x, self.norm3)
 
 
 class DistilConv(nn.Module):

@@ -433,6 +433,102 @@ def test_adamw_clip():
         assert rel_err(pd, pc) < 1e-5, step
 
 
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("M,N,K,res,ln", [(12480, 384, 128, False, False), (325, 128, 128, True, True),
+                                          (64, 128, 256, True, True), (1300, 68, 256, True, False),
+                                          (7, 128, 128, False, True), (130, 200, 128, False, False)])
+def test_rowblock_linear(M, N, K, res, ln):
+    """Row-block linear (+residual, +LayerNorm epilogue) vs torch on bf16-rounded operands (the kernel rounds
+    x and W to bf16 while staging, accumulates in fp32; residual, bias and the norm are exact fp32)."""
+    from routeformer_amd import _hip
+    from routeformer_amd._hip import ptr
+    g = _g(21)
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g); r = torch.randn(M, N, generator=g) if res else None
+    gam = torch.rand(N, generator=g) + 0.5; bet = torch.randn(N, generator=g)
+    pre = _bf(x) @ _bf(w).T + b + (r if res else 0)
+    xd, wd, bd, gd, btd = (v.to(DEV) for v in (x, w, b, gam, bet))
+    rd = r.to(DEV) if res else None
+    y = torch.full((M, N), float("nan"), device=DEV)
+    xhat = torch.empty(M, N, device=DEV) if ln else None
+    rstd = torch.empty(M, device=DEV) if ln else None
+    assert _hip.lib().rf_rowblock_linear_supported(N, K, 1 if ln else 0)
+    rc = _hip.lib().rf_rowblock_linear(ptr(xd), K, ptr(wd), ptr(bd), ptr(rd), N if res else 0, ptr(y), N, M, N, K,
+                                       ptr(gd) if ln else None, ptr(btd) if ln else None, ptr(xhat), ptr(rstd), 1e-5,
+                                       torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _hip.lib().rf_last_error()
+    if ln:
+        mean, var = pre.mean(-1, keepdim=True), pre.var(-1, unbiased=False, keepdim=True)
+        want_hat = (pre - mean) / torch.sqrt(var + 1e-5)
+        assert rel_err(xhat, want_hat) < 1e-4
+        assert rel_err(rstd, (1 / torch.sqrt(var + 1e-5)).squeeze(-1)) < 1e-4
+        assert rel_err(y, want_hat * gam + bet) < 1e-4
+    else:
+        assert rel_err(y, pre) < 1e-4
+
+
+@pytest.mark.parametrize("M,act", [(12480, "gelu"), (325, "relu"), (7, "gelu")])
+def test_rowblock_ffn_ln(M, act):
+    """LayerNorm(x + conv2(act(conv1(x)))) in one launch vs torch with the same bf16 operand roundings."""
+    from routeformer_amd import _hip, kernels as Kn
+    from routeformer_amd._hip import ptr
+    g = _g(22)
+    D, Fd = 128, 256
+    x = torch.randn(M, D, generator=g); w1 = torch.randn(Fd, D, generator=g) / math.sqrt(D)
+    b1 = torch.randn(Fd, generator=g) * 0.1; w2 = torch.randn(D, Fd, generator=g) / math.sqrt(Fd)
+    b2 = torch.randn(D, generator=g) * 0.1
+    gam = torch.rand(D, generator=g) + 0.5; bet = torch.randn(D, generator=g)
+    z = _bf(x) @ _bf(w1).T + b1
+    h = F.gelu(z) if act == "gelu" else F.relu(z)
+    pre = x + _bf(h) @ _bf(w2).T + b2
+    want = F.layer_norm(pre, (D,), gam, bet, 1e-5)
+    d = [v.to(DEV) for v in (x, w1, b1, w2, b2, gam, bet)]
+    hd, zd = torch.empty(M, Fd, device=DEV), torch.empty(M, Fd, device=DEV)
+    y, xhat, rstd = torch.empty(M, D, device=DEV), torch.empty(M, D, device=DEV), torch.empty(M, device=DEV)
+    rc = _hip.lib().rf_rowblock_ffn_ln(ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), ptr(hd), ptr(zd), ptr(y), M,
+                                       D, Fd, Kn.ACT[act], ptr(d[5]), ptr(d[6]), ptr(xhat), ptr(rstd), 1e-5,
+                                       torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _hip.lib().rf_last_error()
+    assert rel_err(zd, z) < 1e-4 and rel_err(hd, h) < 1e-4
+    # h is re-rounded to bf16 for the second contraction: a 1-ulp bf16 flip of h moves `pre` by ~1e-3
+    assert rel_err(y, want) < 2e-3
+    assert rel_err(xhat, (want - bet) / gam) < 2e-3
+
+
+@pytest.mark.parametrize("M", [325, 1280])
+def test_rowblock_layer_ops_match_unfused(M):
+    """linear_add_layer_norm / ffn_add_layer_norm (row-block launches) vs the unfused bf16 path: outputs and
+    every gradient (same operand roundings, so the agreement is tight)."""
+    from routeformer_amd import kernels as Kn
+    Kn.set_precision("bf16")
+    g = _g(23)
+    D, Fd = 128, 256
+    base = dict(a=torch.randn(M, D, generator=g), x=torch.randn(M, D, generator=g),
+                w=torch.randn(D, D, generator=g) / math.sqrt(D), b=torch.randn(D, generator=g) * 0.1,
+                w1=torch.randn(Fd, D, 1, generator=g) / math.sqrt(D), b1=torch.randn(Fd, generator=g) * 0.1,
+                w2=torch.randn(D, Fd, 1, generator=g) / math.sqrt(Fd), b2=torch.randn(D, generator=g) * 0.1,
+                g1=torch.rand(D, generator=g) + 0.5, be1=torch.randn(D, generator=g),
+                g2=torch.rand(D, generator=g) + 0.5, be2=torch.randn(D, generator=g))
+    dy = torch.randn(M, D, generator=g).to(DEV)
+    outs = {}
+    for fused in (True, False):
+        Kn.ROWBLOCK = fused
+        try:
+            t = {k: v.to(DEV).requires_grad_(True) for k, v in base.items()}
+            u = Kn.linear_add_layer_norm(t["a"], t["w"], t["b"], t["x"], t["g1"], t["be1"])
+            y = Kn.ffn_add_layer_norm(u, t["w1"], t["b1"], t["w2"], t["b2"], "gelu", t["g2"], t["be2"])
+            y.backward(dy)
+            outs[fused] = (y.detach(), {k: v.grad for k, v in t.items()})
+        finally:
+            Kn.ROWBLOCK = True
+    assert rel_err(outs[True][0], outs[False][0]) < 2e-3
+    for k in base:
+        assert rel_err(outs[True][1][k], outs[False][1][k]) < 5e-3, k
+
+
 @pytest.mark.parametrize("B,P,E,extra,normalize,dense_on", [(8, 30, 64, 0, False, True), (3, 7, 16, 5, True, True),
                                                               (4, 30, 64, 0, True, False), (1, 1, 4, 0, False, True)])
 def test_traj_head(B, P, E, extra, normalize, dense_on):
