@@ -140,6 +140,19 @@ int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const float* x, c
                        float* dgamma, float* dbeta, float* workspace, int B, int L, int C, float eps,
                        int training, void* stream);
 
+/* Grouped weight gradients (the dW / db GEMMs of nn.Linear / Conv1d(k=1) backward, autograd's
+ * `grad_weight = grad_out^T @ input`): for each entry  dw[N,K] += dy[M,N]^T x[M,K]  and, if db != NULL,
+ * db[N] += column sums of dy -- fp32 atomics into gradient slots that were zeroed at the start of the step.
+ * Up to RF_WGRAD_MAX_GROUP problems per launch; `entries` is a HOST array (copied into the kernel arguments).
+ * dy / x: 16-B aligned, unit column stride, row pitches ld_dy / ld_x multiples of 4; dw contiguous (N,K).
+ * `splits` = requested split of the reduction dimension M (clamped); `kchunk` is filled in by the library. */
+#define RF_WGRAD_MAX_GROUP 48
+typedef struct RfWgradEntry {
+  const float* dy; const float* x; float* dw; float* db;
+  int M, N, K, ld_dy, ld_x, splits, kchunk, reserved;
+} RfWgradEntry;
+int rf_wgrad_grouped(const RfWgradEntry* entries, int count, int prec, void* stream);
+
 /* ---- row-block kernels for the d_model = 128 stacks (bf16-input MFMA only) ----
  * A workgroup owns 64 complete rows and stages the whole weight matrix in LDS, so the residual add and the
  * LayerNorm of EncoderLayer / DecoderLayer (cross_modal_transformer.py:279-365) finish in the epilogue.

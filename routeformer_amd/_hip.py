@@ -35,6 +35,7 @@ SIGNATURES = {
     "rf_bn_stats": [_P, _P, _P, _I, _I, _P],
     "rf_bn_elu_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
     "rf_bn_elu_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
+    "rf_wgrad_grouped": [_P, _I, _I, _P],
     "rf_rowblock_linear_supported": [_I, _I, _I],
     "rf_rowblock_linear": [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _F, _P],
     "rf_rowblock_ffn_ln": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P],
@@ -49,6 +50,16 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+WGRAD_MAX_GROUP = 48  # RF_WGRAD_MAX_GROUP
+
+
+class WgradEntry(ctypes.Structure):
+    """RfWgradEntry of include/rf_hip.h."""
+    _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("db", c_void_p), ("M", c_int), ("N", c_int),
+                ("K", c_int), ("ld_dy", c_int), ("ld_x", c_int), ("splits", c_int), ("kchunk", c_int),
+                ("reserved", c_int)]
 
 
 class HipLibraryError(RuntimeError):

@@ -344,8 +344,10 @@ __device__ __forceinline__ void lstore(T* __restrict__ S, const float4 (&r)[NV],
   }
 }
 
+struct BlockId { int x, y, z, gx, gz; };  // position of this workgroup inside ITS problem's grid
+
 template <int PREC, int AM, int BMODE, int CFG>
-__global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
+__device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
   using C_ = Cfg<CFG>;
   using L_ = Lds2<PREC>;
   using T = typename L_::T;
@@ -360,8 +362,8 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
   const int wm = wave / C_::WN, wn = wave % C_::WN;
   // blockIdx.x walks the N tiles: the column tiles that share one A row-panel are dispatched together,
   // so the panel is fetched from HBM once and re-read from L2
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * p.kchunk;
+  const int m0 = blk.y * BM, n0 = blk.x * BN;
+  const int kbeg = blk.z * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int fr = lane & 15, fq = lane >> 4;
 
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
   if constexpr (AM == 1) {
     // bias-gradient side product: only the first column tile of each row panel contributes (the other
     // column tiles stage the same A panel); rows of a thread: 4*(tid % (BM/4)) .. +3 in every slot
-    if (p.a_rowsum && blockIdx.x == 0) {
+    if (p.a_rowsum && blk.x == 0) {
       constexpr int VPK = BM / 4;
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
           const int m = m0 + (wm * C_::TM + i) * 16 + fq * 4 + r;
           if (m >= p.M) continue;
           if (mode == 1) atomicAdd(&p.C[(long)m * p.ldc + n], acc[i][j][r]);
-          else p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
+          else p.ws[((long)blk.z * p.M + m) * p.N + n] = acc[i][j][r];
         }
       }
     }
@@ -588,12 +590,12 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its partial-slab stores
     __syncthreads();
     int* last_flag = reinterpret_cast<int*>(smem);    // the staging tile is dead too
-    unsigned* cnt = p.tile_cnt + (blockIdx.y * gridDim.x + blockIdx.x);
+    unsigned* cnt = p.tile_cnt + (blk.y * blk.gx + blk.x);
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = ticket == gridDim.z - 1;
+      const int last = ticket == blk.gz - 1;
       if (last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
     }
     __syncthreads();
     if (*last_flag) {
-      const int splits = gridDim.z;
+      const int splits = blk.gz;
       const long slab = (long)p.M * p.N;
 #pragma unroll 1
       for (int e0 = tid; e0 < BM * BN; e0 += 4 * NT) {
@@ -621,6 +623,48 @@ __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
       }
     }
   }
+}
+
+template <int PREC, int AM, int BMODE, int CFG>
+__global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
+  gemm2_body<PREC, AM, BMODE, CFG>(p, BlockId{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x,
+                                              (int)gridDim.z});
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped weight gradients: dW_e[N_e, K_e] += dY_e[M_e, N_e]^T X_e[M_e, K_e] (+ db_e += colsum dY_e) for up
+// to RF_WGRAD_MAX_GROUP layers in ONE launch.  Weight gradients feed only the optimizer, so the backward
+// pass queues them and flushes the queue in a few launches that fill all 256 CUs, instead of ~150 small
+// split-K launches (13 us each, a handful of workgroups) interleaved with the dX chain.  The table rides in
+// the kernel arguments (no device-side descriptor upload; safe under hipGraph capture).
+// ---------------------------------------------------------------------------------------------
+struct WgradTable {
+  int count, pad;
+  RfWgradEntry e[RF_WGRAD_MAX_GROUP];
+  int first_block[RF_WGRAD_MAX_GROUP + 1];
+};
+
+template <int PREC>
+__global__ __launch_bounds__(NT) void wgrad_grouped_kernel(const WgradTable t) {
+  // which problem does this workgroup belong to?  (uniform binary search over the prefix of block counts)
+  const int b = blockIdx.x;
+  int lo = 0, hi = t.count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.first_block[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const RfWgradEntry& e = t.e[lo];
+  GemmP p{};
+  p.A = e.dy; p.lda_m = 1; p.lda_k = e.ld_dy;     // A = dY^T: "row" m = output feature, contiguous across m
+  p.B = e.x; p.ldb_k = e.ld_x; p.ldb_n = 1;
+  p.C = e.dw; p.ldc = e.K;
+  p.M = e.N; p.N = e.K; p.K = e.M;
+  p.res_rows = 1; p.atomic = 1; p.a_rowsum = e.db;
+  p.kchunk = e.kchunk;
+  const int gx = (e.K + 63) / 64, gy = (e.N + 63) / 64;
+  const int local = b - t.first_block[lo];
+  const int bz = local / (gx * gy), rem = local - bz * gx * gy;
+  gemm2_body<PREC, 1, 1, 0>(p, BlockId{rem % gx, rem / gx, bz, gx, e.splits});
 }
 
 template <int PREC, int AM, int BMODE, int CFG>
@@ -792,6 +836,32 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int parts, i
   out[n] = accumulate ? out[n] + s : s;
 }
 }  // namespace
+
+extern "C" int rf_wgrad_grouped(const RfWgradEntry* entries, int count, int prec, void* stream) {
+  RF_REQUIRE(entries && count >= 1 && count <= RF_WGRAD_MAX_GROUP && (prec == 0 || prec == 1));
+  WgradTable t{};
+  t.count = count;
+  int blocks = 0;
+  constexpr int KQ = 64;
+  for (int i = 0; i < count; ++i) {
+    RfWgradEntry e = entries[i];
+    RF_REQUIRE(e.dy && e.x && e.dw && e.M > 0 && e.N > 0 && e.K > 0 && e.splits >= 1);
+    RF_REQUIRE(aligned16(e.dy) && aligned16(e.x) && e.ld_dy % 4 == 0 && e.ld_x % 4 == 0);
+    const int ktiles = (e.M + KQ - 1) / KQ;
+    int splits = e.splits > ktiles ? ktiles : e.splits;
+    e.kchunk = ((ktiles + splits - 1) / splits) * KQ;
+    e.splits = (e.M + e.kchunk - 1) / e.kchunk;
+    t.e[i] = e;
+    t.first_block[i] = blocks;
+    blocks += ((e.K + 63) / 64) * ((e.N + 63) / 64) * e.splits;
+  }
+  t.first_block[count] = blocks;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (prec == 1) hipLaunchKernelGGL(wgrad_grouped_kernel<1>, dim3(blocks), dim3(NT), 0, st, t);
+  else hipLaunchKernelGGL(wgrad_grouped_kernel<0>, dim3(blocks), dim3(NT), 0, st, t);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
 
 extern "C" int rf_colsum_parts(int M, int N) { (void)N; return (M + CS_ROWS - 1) / CS_ROWS; }
 

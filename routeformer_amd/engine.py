@@ -258,6 +258,8 @@ class TrainEngine:
                  overlap: bool = True):
         self.model = model
         self.overlap = overlap  # independent sub-graphs of the step on separate HIP streams
+        # weight gradients queued during backward and flushed as grouped launches (kernels._WgradQueue)
+        self.group_wgrad = __import__("os").environ.get("RF_GROUP_WGRAD", "1") != "0"
         cfg = model.configs
         layers = [m for m in model.modules() if hasattr(m, "packing_groups")]
         groups = [g for m in layers for g in m.packing_groups()]
@@ -281,13 +283,15 @@ class TrainEngine:
         K.OVERLAP = self.overlap
         K.SINK.active = True  # kernels accumulate parameter gradients straight into the flat buffer
         K.SINK.on_write = self.reducer.on_sink_write if self.reducer.world > 1 else None
+        K.WGRAD.active = self.group_wgrad
         try:
             res = train_step_losses(self.model, item, epoch, self.tl, self.dl, tokens_ready=tokens_ready)
             res["loss"].backward()
+            K.flush_weight_grads()  # queued dW / db launches, each on the stream its operands were produced on
             if self.overlap:
                 K.join_side_streams()
         finally:
-            K.SINK.active, K.SINK.on_write, K.OVERLAP = False, None, False
+            K.SINK.active, K.SINK.on_write, K.OVERLAP, K.WGRAD.active = False, None, False, False
         return res
 
     def step(self, item, epoch: int = 0, next_item=None):

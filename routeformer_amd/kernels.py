@@ -254,6 +254,9 @@ def _weight_grad(dy2: torch.Tensor, x2: torch.Tensor, into: Optional[torch.Tenso
     K = x2.shape[1]
     tiles = -(-N // 64) * -(-K // 64)
     if into is not None and not DETERMINISTIC and _vec_ok(dy2) and _vec_ok(x2) and into.data_ptr() % 16 == 0:
+        if WGRAD.active and into.is_contiguous():
+            WGRAD.push(dy2, x2, into, bias_into, M, N, K, _splits(tiles, M))
+            return bias_into is not None
         gemm(dy2, 1, dy2.stride(0), x2, x2.stride(0), 1, into, K, N, K, M, splitk=_splits(tiles, M), atomic=True,
              a_rowsum=bias_into)
         return bias_into is not None
@@ -264,6 +267,66 @@ def _weight_grad(dy2: torch.Tensor, x2: torch.Tensor, into: Optional[torch.Tenso
     dw = torch.empty(N, K, device=dy2.device, dtype=torch.float32)
     gemm(dy2, 1, dy2.stride(0), x2, x2.stride(0), 1, dw, K, N, K, M, splitk=_splits(tiles, M))
     return dw
+
+
+class _WgradQueue:
+    """Deferred weight gradients (training engine only).  dW / db feed nothing but the optimizer, so
+    ``_weight_grad`` queues them while the backward pass runs and the queue is flushed -- per stream, in
+    launch order -- as grouped launches (``rf_wgrad_grouped``: up to 48 problems, thousands of workgroups)
+    instead of one small split-K launch per layer in the middle of the dX chain.  The queued operands are
+    kept alive until their launch; "slot written" notifications (DP bucket bookkeeping) are delivered at
+    flush time."""
+
+    def __init__(self):
+        self.active = False
+        self.queues = {}     # stream handle -> (torch stream, [items])
+        self.pending = set() # data_ptr of slots with a queued (not yet launched) write
+
+    def push(self, dy2, x2, into, bias_into, M, N, K, splits):
+        st = torch.cuda.current_stream()
+        q = self.queues.setdefault(st.cuda_stream, (st, []))[1]
+        q.append((dy2, x2, into, bias_into, M, N, K, splits))
+        self.pending.add(into.data_ptr())
+        if bias_into is not None:
+            self.pending.add(bias_into.data_ptr())
+        if len(q) >= _hip.WGRAD_MAX_GROUP:
+            self._flush(st, q)
+
+    def _flush(self, st, q):
+        if not q:
+            return
+        n = len(q)
+        arr = (_hip.WgradEntry * n)()
+        for e, (dy2, x2, into, bias_into, M, N, K, splits) in zip(arr, q):
+            e.dy, e.x, e.dw, e.db = ptr(dy2), ptr(x2), ptr(into), ptr(bias_into)
+            e.M, e.N, e.K, e.ld_dy, e.ld_x, e.splits = M, N, K, dy2.stride(0), x2.stride(0), splits
+        ev = PROFILE.begin() if PROFILE.on else None
+        with torch.cuda.stream(st):
+            check(_hip.lib().rf_wgrad_grouped(arr, n, _PRECISION, st.cuda_stream), "rf_wgrad_grouped")
+            if ev is not None:
+                PROFILE.end(f"wgrad_grouped_kernel<{_PRECISION}>", ev, sum(2.0 * i[4] * i[5] * i[6] for i in q),
+                            sum(4.0 * (i[4] * i[5] + i[4] * i[6] + 2 * i[5] * i[6]) for i in q))
+            for _, _, into, bias_into, *_ in q:
+                self.pending.discard(into.data_ptr())
+                if bias_into is not None:
+                    self.pending.discard(bias_into.data_ptr())
+                if SINK.on_write is not None:
+                    SINK.on_write(into)
+                    if bias_into is not None:
+                        SINK.on_write(bias_into)
+        q.clear()
+
+    def flush(self):
+        for st, q in list(self.queues.values()):
+            self._flush(st, q)
+        self.pending.clear()
+
+
+WGRAD = _WgradQueue()
+
+
+def flush_weight_grads():
+    WGRAD.flush()
 
 
 class _Sink:
@@ -281,7 +344,7 @@ SINK = _Sink()
 def _wrote(*views):
     if SINK.on_write is not None:
         for v in views:
-            if v is not None:
+            if v is not None and v.data_ptr() not in WGRAD.pending:  # queued writes report at flush time
                 SINK.on_write(v)
 
 

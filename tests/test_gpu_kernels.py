@@ -437,6 +437,34 @@ def _bf(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 1e-2)])
+def test_wgrad_grouped(prec, tol):
+    """Several dW[N,K] += dY^T X (+ db += colsum dY) problems of different shapes in one launch; slots start
+    non-zero (accumulate semantics)."""
+    import ctypes
+    from routeformer_amd import _hip, kernels as Kn
+    from routeformer_amd._hip import ptr
+    g = _g(31)
+    shapes = [(12480, 384, 128, True), (325, 128, 256, True), (560, 832, 832, False), (40, 2496, 832, True),
+              (130, 68, 132, True), (7, 128, 128, False)]
+    arr = (_hip.WgradEntry * len(shapes))()
+    keep, want = [], []
+    for e, (M, N, K, with_bias) in zip(arr, shapes):
+        dy, x = torch.randn(M, N, generator=g), torch.randn(M, K, generator=g)
+        dw0, db0 = torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+        d = [t.to(DEV) for t in (dy, x, dw0, db0)]
+        keep.append(d)
+        e.dy, e.x, e.dw, e.db = ptr(d[0]), ptr(d[1]), ptr(d[2]), (ptr(d[3]) if with_bias else None)
+        e.M, e.N, e.K, e.ld_dy, e.ld_x = M, N, K, N, K
+        e.splits = Kn._splits(-(-N // 64) * -(-K // 64), M)
+        want.append((dw0 + dy.T @ x, db0 + dy.sum(0) if with_bias else db0))
+    rc = _hip.lib().rf_wgrad_grouped(arr, len(shapes), 1 if prec == "bf16" else 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _hip.lib().rf_last_error()
+    for d, (dw, db), sh in zip(keep, want, shapes):
+        assert rel_err(d[2], dw) < tol, sh
+        assert rel_err(d[3], db) < 1e-4, sh
+
+
 @pytest.mark.parametrize("M,N,K,res,ln", [(12480, 384, 128, False, False), (325, 128, 128, True, True),
                                           (64, 128, 256, True, True), (1300, 68, 256, True, False),
                                           (7, 128, 128, False, True), (130, 200, 128, False, False)])
