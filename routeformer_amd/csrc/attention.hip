@@ -13,8 +13,10 @@
 
 namespace {
 
-constexpr int NT = 256;
-constexpr int NW = NT / 64;
+// Threads per workgroup are chosen at launch (threads_for): these kernels are chains of short barrier-
+// separated phases, so when a launch has fewer (batch, head) problems than CUs (the Informer / gaze /
+// fusion layers: 64 workgroups) each problem gets 16 waves instead of 4 to shorten every phase.
+inline int threads_for(int problems) { return problems <= 128 ? 1024 : (problems <= 512 ? 512 : 256); }
 
 struct AttnP {
   const float *q, *k, *v;
@@ -61,12 +63,12 @@ __device__ __forceinline__ void load_head(float* S, const float* G, long ld, int
   const float* base = G + (long)b * L * ld + (long)h * E;
   if constexpr (V4) {
     const int E4 = E >> 2;
-    for (int i = tid; i < L * E4; i += NT) {
+    for (int i = tid; i < L * E4; i += (int)blockDim.x) {
       const int l = i / E4, e = (i - l * E4) << 2;
       *reinterpret_cast<float4*>(S + l * EP + e) = *reinterpret_cast<const float4*>(base + (long)l * ld + e);
     }
   } else {
-    for (int i = tid; i < L * E; i += NT) {
+    for (int i = tid; i < L * E; i += (int)blockDim.x) {
       const int l = i / E, e = i - l * E;
       S[l * EP + e] = base[(long)l * ld + e];
     }
@@ -75,7 +77,7 @@ __device__ __forceinline__ void load_head(float* S, const float* G, long ld, int
 
 // Select the n_top rows of M (size LQ): sel[q] = position among the selected (ascending q) or -1.
 __device__ void select_top(float* Ms, int* sel, int* top_list, int LQ, int n_top, int tid) {
-  for (int q = tid; q < LQ; q += NT) {
+  for (int q = tid; q < LQ; q += (int)blockDim.x) {
     const float mq = Ms[q];
     int rank = 0;
     for (int o = 0; o < LQ; ++o) {
@@ -87,7 +89,7 @@ __device__ void select_top(float* Ms, int* sel, int* top_list, int LQ, int n_top
   __syncthreads();
   // positions go to a scratch array (Ms is dead now) so no thread reads a flag another one rewrites
   int* posbuf = reinterpret_cast<int*>(Ms);
-  for (int q = tid; q < LQ; q += NT) {
+  for (int q = tid; q < LQ; q += (int)blockDim.x) {
     int pos = -1;
     if (sel[q]) {
       pos = 0;
@@ -97,7 +99,7 @@ __device__ void select_top(float* Ms, int* sel, int* top_list, int LQ, int n_top
     posbuf[q] = pos;
   }
   __syncthreads();
-  for (int q = tid; q < LQ; q += NT) sel[q] = posbuf[q];
+  for (int q = tid; q < LQ; q += (int)blockDim.x) sel[q] = posbuf[q];
   __syncthreads();
 }
 
@@ -117,7 +119,7 @@ template <class PA, class PB, class FS>
 __device__ __forceinline__ void mm_tiles(int TI, int TJ, int KS, int lane, int wave, PA pa, int ask, PB pb, int bsk,
                                          FS fs) {
   const int lr = lane & 15, lq = lane >> 4;
-  for (int t = wave; t < TI * TJ; t += NW) {
+  for (int t = wave; t < TI * TJ; t += (int)(blockDim.x >> 6)) {
     const int ti = t / TJ, tj = t - ti * TJ;
     const float* ap = pa(16 * ti + lr) + lq * ask;
     const float* bp = pb(16 * tj + lr) + lq * bsk;
@@ -133,7 +135,7 @@ __device__ __forceinline__ void mm_tiles(int TI, int TJ, int KS, int lane, int w
 __device__ __forceinline__ void softmax_rows(float* S, int n_rows, int LK, const int* top_list, int masked,
                                              int lane, int wave, int ld = 0) {
   if (ld == 0) ld = LK;
-  for (int si = wave; si < n_rows; si += NW) {
+  for (int si = wave; si < n_rows; si += (int)(blockDim.x >> 6)) {
     float* row = S + (long)si * ld;
     const int kmax = masked ? top_list[si] + 1 : LK;
     float mx = -INFINITY;
@@ -152,7 +154,7 @@ __device__ __forceinline__ void softmax_rows(float* S, int n_rows, int LK, const
 }
 
 template <bool V4>
-__global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
+__global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
@@ -172,28 +174,28 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
   load_head<V4>(Qs, p.q, p.q_ld, b, h, LQ, E, EP, tid);
   load_head<V4>(Ks, p.k, p.k_ld, b, h, LK, E, EP, tid);
   load_head<V4>(Vs, p.v, p.v_ld, b, h, LK, E, EP, tid);
-  for (int i = tid; i < (LKP - LK) * EP; i += NT) { Ks[LK * EP + i] = 0.f; Vs[LK * EP + i] = 0.f; }
+  for (int i = tid; i < (LKP - LK) * EP; i += (int)blockDim.x) { Ks[LK * EP + i] = 0.f; Vs[LK * EP + i] = 0.f; }
   __syncthreads();
 
   if (p.mode == 0) {
-    for (int q = tid; q < LQ; q += NT) { sel[q] = q; top_list[q] = q; }
+    for (int q = tid; q < LQ; q += (int)blockDim.x) { sel[q] = q; top_list[q] = q; }
     __syncthreads();
   } else {
     int32_t* gtop = p.top + ((long)b * p.H + h) * p.n_top;
     if (p.force_top) {
-      for (int q = tid; q < LQ; q += NT) sel[q] = -1;
+      for (int q = tid; q < LQ; q += (int)blockDim.x) sel[q] = -1;
       __syncthreads();
-      for (int i = tid; i < n_sel; i += NT) { top_list[i] = gtop[i]; sel[gtop[i]] = i; }
+      for (int i = tid; i < n_sel; i += (int)blockDim.x) { top_list[i] = gtop[i]; sel[gtop[i]] = i; }
       __syncthreads();
     } else {
       // (1) sampled scores Q[q].K[idx[q,j]] (one table per group of `idx_group` consecutive batch rows)
       const int32_t* idx = p.idx + (long)(b / p.idx_group) * LQ * p.sample_k;
-      for (int i = tid; i < LQ * p.sample_k; i += NT) {
+      for (int i = tid; i < LQ * p.sample_k; i += (int)blockDim.x) {
         const int q = i / p.sample_k;
         S[i] = dot_rows<V4>(Qs + q * EP, Ks + idx[i] * EP, E);
       }
       __syncthreads();
-      for (int q = tid; q < LQ; q += NT) {
+      for (int q = tid; q < LQ; q += (int)blockDim.x) {
         float mx = -INFINITY, sm = 0.f;
         for (int j = 0; j < p.sample_k; ++j) {
           const float d = S[q * p.sample_k + j];
@@ -205,22 +207,22 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
       __syncthreads();
       // (2) top-u queries
       select_top(Ms, sel, top_list, LQ, n_sel, tid);
-      for (int i = tid; i < n_sel; i += NT) gtop[i] = top_list[i];
+      for (int i = tid; i < n_sel; i += (int)blockDim.x) gtop[i] = top_list[i];
     }
     // (4) lazy rows: mean(V) or cumsum(V)
     if (p.mode == 1) {
-      for (int d = tid; d < E; d += NT) {
+      for (int d = tid; d < E; d += (int)blockDim.x) {
         float s = 0.f;
         for (int l = 0; l < LK; ++l) s += Vs[l * EP + d];
         vmean[d] = s / (float)LK;
       }
       __syncthreads();
-      for (int i = tid; i < LQ * E; i += NT) {
+      for (int i = tid; i < LQ * E; i += (int)blockDim.x) {
         const int ql = i / E, d = i - ql * E;
         if (sel[ql] < 0) p.ctx[ctx_off(p, b, h, ql) + d] = vmean[d];
       }
     } else {
-      for (int d = tid; d < E; d += NT) {
+      for (int d = tid; d < E; d += (int)blockDim.x) {
         float s = 0.f;
         for (int ql = 0; ql < LQ; ++ql) {
           s += Vs[ql * EP + d];
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
                if (si < n_sel && d < E) p.ctx[ctx_off(p, b, h, top_list[si]) + d] = v;
              });
   } else {
-    for (int i = tid; i < n_sel * LK; i += NT) {
+    for (int i = tid; i < n_sel * LK; i += (int)blockDim.x) {
       const int si = i / LK, s_ = i - si * LK;
       const int q = top_list[si];
       float d = -INFINITY;
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
     __syncthreads();
     softmax_rows(S, n_sel, LK, top_list, p.mode == 2, lane, wave);
     __syncthreads();
-    for (int i = tid; i < n_sel * E; i += NT) {
+    for (int i = tid; i < n_sel * E; i += (int)blockDim.x) {
       const int si = i / E, d = i - si * E;
       const int q = top_list[si];
       const int kmax = (p.mode == 2) ? q + 1 : LK;
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnP p) {
 // Backward.  LDS carve (floats): Ks[LK*EP] Vs[LK*EP] Qsel[n*EP] dCsel[n*EP] P[n*LK] dS[n*LK]
 //            colsum[E] | ints: top[n] sel[LQ]
 template <bool V4>
-__global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
+__global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
@@ -297,20 +299,20 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
 
   load_head<V4>(Ks, p.k, p.k_ld, b, h, LK, E, EP, tid);
   load_head<V4>(Vs, p.v, p.v_ld, b, h, LK, E, EP, tid);
-  for (int i = tid; i < (LKP - LK) * EP; i += NT) { Ks[LK * EP + i] = 0.f; Vs[LK * EP + i] = 0.f; }
-  for (int i = tid; i < (NSP - n_sel) * EP; i += NT) { Qsel[n_sel * EP + i] = 0.f; dCsel[n_sel * EP + i] = 0.f; }
-  for (int i = tid; i < (NSP - n_sel) * LKP; i += NT) { P[n_sel * LKP + i] = 0.f; dS[n_sel * LKP + i] = 0.f; }
-  for (int q = tid; q < LQ; q += NT) sel[q] = (p.mode == 0) ? q : -1;
+  for (int i = tid; i < (LKP - LK) * EP; i += (int)blockDim.x) { Ks[LK * EP + i] = 0.f; Vs[LK * EP + i] = 0.f; }
+  for (int i = tid; i < (NSP - n_sel) * EP; i += (int)blockDim.x) { Qsel[n_sel * EP + i] = 0.f; dCsel[n_sel * EP + i] = 0.f; }
+  for (int i = tid; i < (NSP - n_sel) * LKP; i += (int)blockDim.x) { P[n_sel * LKP + i] = 0.f; dS[n_sel * LKP + i] = 0.f; }
+  for (int q = tid; q < LQ; q += (int)blockDim.x) sel[q] = (p.mode == 0) ? q : -1;
   __syncthreads();
   if (p.mode == 0) {
-    for (int i = tid; i < n_sel; i += NT) top_list[i] = i;
+    for (int i = tid; i < n_sel; i += (int)blockDim.x) top_list[i] = i;
   } else {
     const int32_t* gtop = p.top + ((long)b * p.H + h) * p.n_top;
-    for (int i = tid; i < n_sel; i += NT) { top_list[i] = gtop[i]; sel[gtop[i]] = i; }
+    for (int i = tid; i < n_sel; i += (int)blockDim.x) { top_list[i] = gtop[i]; sel[gtop[i]] = i; }
   }
   __syncthreads();
   const float* qbase = p.q + (long)b * LQ * p.q_ld + (long)h * E;
-  for (int i = tid; i < n_sel * E; i += NT) {
+  for (int i = tid; i < n_sel * E; i += (int)blockDim.x) {
     const int si = i / E, e = i - si * E, q = top_list[si];
     Qsel[si * EP + e] = qbase[(long)q * p.q_ld + e];
     dCsel[si * EP + e] = p.dctx[ctx_off(p, b, h, q) + e];
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
                if (si < n_sel && s_ < LK) dS[si * LKP + s_] = (p.mode == 2 && s_ > top_list[si]) ? 0.f : v;
              });
   } else {
-    for (int i = tid; i < n_sel * LK; i += NT) {
+    for (int i = tid; i < n_sel * LK; i += (int)blockDim.x) {
       const int si = i / LK, s_ = i - si * LK;
       const int q = top_list[si];
       float d = -INFINITY, dp = 0.f;
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
   __syncthreads();
   softmax_rows(P, n_sel, LK, top_list, p.mode == 2, lane, wave, LKP);
   // same wave owns the same rows in softmax_rows and here: no barrier needed in between
-  for (int si = wave; si < n_sel; si += NW) {
+  for (int si = wave; si < n_sel; si += (int)(blockDim.x >> 6)) {
     float* Pr = P + (long)si * LKP;
     float* dSr = dS + (long)si * LKP;
     float dot = 0.f;
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
                if (si < n_sel && e < E) p.dq[((long)b * LQ + top_list[si]) * p.dq_ld + (long)h * E + e] = v;
              });
   } else {
-    for (int i = tid; i < n_sel * E; i += NT) {
+    for (int i = tid; i < n_sel * E; i += (int)blockDim.x) {
       const int si = i / E, e = i - si * E;
       const int q = top_list[si];
       const int kmax = (p.mode == 2) ? q + 1 : LK;
@@ -378,13 +380,13 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
       p.dq[((long)b * LQ + q) * p.dq_ld + (long)h * E + e] = a;
     }
   }
-  for (int i = tid; i < LQ * E; i += NT) {
+  for (int i = tid; i < LQ * E; i += (int)blockDim.x) {
     const int q = i / E, e = i - q * E;
     if (sel[q] < 0) p.dq[((long)b * LQ + q) * p.dq_ld + (long)h * E + e] = 0.f;
   }
   // lazy-row gradient source: column sums of dctx over NON-selected rows (unmasked mode)
   if (p.mode == 1) {
-    for (int d = tid; d < E; d += NT) {
+    for (int d = tid; d < E; d += (int)blockDim.x) {
       float s_ = 0.f;
       for (int ql = 0; ql < LQ; ++ql)
         if (sel[ql] < 0) s_ += p.dctx[ctx_off(p, b, h, ql) + d];
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
   // phase 2: dK[s,e] = sum_q dS[q,s] Q[q,e];  dV[s,d] = sum_q P[q,s] dC[q,d] + lazy-row term
   if (p.mode == 2) {
     // masked lazy rows: ctx[q] = sum_{s<=q} V[s]  =>  dV[s] += sum_{q>=s, q not selected} dC[q]
-    for (int d = tid; d < E; d += NT) {
+    for (int d = tid; d < E; d += (int)blockDim.x) {
       float run = 0.f;
       for (int ql = LQ - 1; ql >= 0; --ql) {
         if (sel[ql] < 0) run += p.dctx[ctx_off(p, b, h, ql) + d];
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(AttnP p) {
                }
              });
   } else {
-    for (int i = tid; i < LK * E; i += NT) {
+    for (int i = tid; i < LK * E; i += (int)blockDim.x) {
       const int s_ = i / E, e = i - s_ * E;
       float ak = 0.f, av = 0.f;
       for (int si = 0; si < n_sel; ++si) {
@@ -480,8 +482,8 @@ extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  if (v4) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(B * H), dim3(NT), lds, static_cast<hipStream_t>(stream), p);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(B * H), dim3(NT), lds, static_cast<hipStream_t>(stream), p);
+  if (v4) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(B * H), dim3(threads_for(B * H)), lds, static_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(B * H), dim3(threads_for(B * H)), lds, static_cast<hipStream_t>(stream), p);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
@@ -511,8 +513,8 @@ extern "C" int rf_attn_bwd(const float* q, const float* k, const float* v, int64
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  if (v4) hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(B * H), dim3(NT), lds, static_cast<hipStream_t>(stream), p);
-  else hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(B * H), dim3(NT), lds, static_cast<hipStream_t>(stream), p);
+  if (v4) hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(B * H), dim3(threads_for(B * H)), lds, static_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(B * H), dim3(threads_for(B * H)), lds, static_cast<hipStream_t>(stream), p);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

@@ -297,7 +297,7 @@ extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float*
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (accumulate == 2) {  // atomics straight into the running sums; few workgroups -> few same-address adds
     int blocks = (rows + 4 * LN_WAVES - 1) / (4 * LN_WAVES);
-    blocks = blocks > 192 ? 192 : (blocks < 1 ? 1 : blocks);
+    blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, xhat, rstd, gamma, dx,
                        static_cast<float*>(nullptr), rows, cols, dgamma, dbeta);
     RF_CHECK_LAUNCH();
