@@ -30,8 +30,24 @@ struct AttnP {
   float *dq, *dk, *dv;
   long dq_ld, dk_ld, dv_ld;
   int B, H, LQ, LK, E, sample_k, n_top, mode, idx_group;
+  int Qs_rows;  // rows of Q staged by load_qkv (LQ in forward, 0 in backward: only the selected rows are needed)
   float scale;
 };
+
+// XCD-aware problem order.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its
+// own L2, and the H heads of one sequence read interleaved 4E-byte pieces of the same packed rows.  With
+// the plain (b, h) = (blk / H, blk % H) order the heads of a sequence land on different XCDs and every
+// 128-B line is fetched by two of them; here one XCD walks all heads of a sequence back to back.
+__device__ __forceinline__ void problem_of(int blk, int B, int H, int& b, int& h) {
+  if ((B & 7) == 0) {
+    const int xcd = blk & 7, j = blk >> 3;
+    b = (j / H) * 8 + xcd;
+    h = j % H;
+  } else {
+    b = blk / H;
+    h = blk % H;
+  }
+}
 
 __device__ __forceinline__ long ctx_off(const AttnP& p, int b, int h, int l) {
   return p.out_layout == 0 ? (((long)b * p.LQ + l) * p.H + h) * p.E : (((long)b * p.H + h) * p.LQ + l) * p.E;
@@ -75,28 +91,81 @@ __device__ __forceinline__ void load_head(float* S, const float* G, long ld, int
   }
 }
 
+// Q, K and V head slices in one go: every global load of the three slices is issued before the first LDS
+// store (one memory round trip for the whole prologue instead of one per slice and loop trip).
+template <bool V4>
+__device__ __forceinline__ void load_qkv(float* Qs, float* Ks, float* Vs, const AttnP& p, int b, int h, int EP, int tid) {
+  const int nt = blockDim.x;
+  if constexpr (V4) {
+    const int E4 = p.E >> 2, nq = p.Qs_rows * E4, nk = p.LK * E4;
+    if (nq <= 3 * nt && nk <= 3 * nt) {
+      const float* qb = p.q + (long)b * p.LQ * p.q_ld + (long)h * p.E;
+      const float* kb = p.k + (long)b * p.LK * p.k_ld + (long)h * p.E;
+      const float* vb = p.v + (long)b * p.LK * p.v_ld + (long)h * p.E;
+      float4 rq[3], rk[3], rv[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int i = tid + u * nt, l = i / E4, e = (i - l * E4) << 2;
+        if (i < nq) rq[u] = *reinterpret_cast<const float4*>(qb + (long)l * p.q_ld + e);
+        if (i < nk) {
+          rk[u] = *reinterpret_cast<const float4*>(kb + (long)l * p.k_ld + e);
+          rv[u] = *reinterpret_cast<const float4*>(vb + (long)l * p.v_ld + e);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int i = tid + u * nt, l = i / E4, e = (i - l * E4) << 2;
+        if (i < nq) *reinterpret_cast<float4*>(Qs + l * EP + e) = rq[u];
+        if (i < nk) {
+          *reinterpret_cast<float4*>(Ks + l * EP + e) = rk[u];
+          *reinterpret_cast<float4*>(Vs + l * EP + e) = rv[u];
+        }
+      }
+      return;
+    }
+  }
+  if (p.Qs_rows) load_head<V4>(Qs, p.q, p.q_ld, b, h, p.LQ, p.E, EP, tid);
+  load_head<V4>(Ks, p.k, p.k_ld, b, h, p.LK, p.E, EP, tid);
+  load_head<V4>(Vs, p.v, p.v_ld, b, h, p.LK, p.E, EP, tid);
+}
+
+__device__ __forceinline__ int quad_sum(int v) {  // all-reduce over each aligned group of 4 lanes (DPP)
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+  return v;
+}
+
 // Select the n_top rows of M (size LQ): sel[q] = position among the selected (ascending q) or -1.
 __device__ void select_top(float* Ms, int* sel, int* top_list, int LQ, int n_top, int tid) {
-  for (int q = tid; q < LQ; q += (int)blockDim.x) {
-    const float mq = Ms[q];
+  // four lanes share one query: each counts a quarter of the competitors, a quad DPP add combines them
+  const int quads = blockDim.x >> 2, sub = tid & 3;
+  for (int q0 = 0; q0 < LQ; q0 += quads) {
+    const int q = q0 + (tid >> 2);
     int rank = 0;
-    for (int o = 0; o < LQ; ++o) {
-      const float mo = Ms[o];
-      rank += (mo > mq) || (mo == mq && o < q);
+    if (q < LQ) {
+      const float mq = Ms[q];
+      for (int o = sub; o < LQ; o += 4) {
+        const float mo = Ms[o];
+        rank += (mo > mq) || (mo == mq && o < q);
+      }
     }
-    sel[q] = rank < n_top ? 1 : 0;
+    rank = quad_sum(rank);
+    if (q < LQ && sub == 0) sel[q] = rank < n_top ? 1 : 0;
   }
   __syncthreads();
   // positions go to a scratch array (Ms is dead now) so no thread reads a flag another one rewrites
   int* posbuf = reinterpret_cast<int*>(Ms);
-  for (int q = tid; q < LQ; q += (int)blockDim.x) {
-    int pos = -1;
-    if (sel[q]) {
-      pos = 0;
-      for (int o = 0; o < q; ++o) pos += sel[o];
-      top_list[pos] = q;
+  for (int q0 = 0; q0 < LQ; q0 += quads) {
+    const int q = q0 + (tid >> 2);
+    int before = 0;
+    if (q < LQ)
+      for (int o = sub; o < q; o += 4) before += sel[o];
+    before = quad_sum(before);
+    if (q < LQ && sub == 0) {
+      const int pos = sel[q] ? before : -1;
+      if (pos >= 0) top_list[pos] = q;
+      posbuf[q] = pos;
     }
-    posbuf[q] = pos;
   }
   __syncthreads();
   for (int q = tid; q < LQ; q += (int)blockDim.x) sel[q] = posbuf[q];
@@ -131,33 +200,51 @@ __device__ __forceinline__ void mm_tiles(int TI, int TJ, int KS, int lane, int w
   }
 }
 
-// Row softmax over S (row pitch ld >= LK; columns [kmax, ld) are set to 0).
-__device__ __forceinline__ void softmax_rows(float* S, int n_rows, int LK, const int* top_list, int masked,
-                                             int lane, int wave, int ld = 0) {
+// Row softmax over S (row pitch ld >= LK; columns [kmax, ld) are set to 0).  Sixteen lanes per row (four
+// rows per wave trip): the two reductions are 4-step DPP row reductions, and a 16..160-wide row keeps all
+// of its lanes busy.  row_of() is the row -> lane-group mapping, shared with the backward's dS pass.
+__device__ __forceinline__ int rows_per_trip() { return (blockDim.x >> 6) * 4; }
+__device__ __forceinline__ int row_of(int trip_base) { return trip_base + (threadIdx.x >> 6) * 4 + ((threadIdx.x & 63) >> 4); }
+
+__device__ __forceinline__ void softmax_rows(float* S, int n_rows, int LK, const int* top_list, int masked, int ld = 0) {
   if (ld == 0) ld = LK;
-  for (int si = wave; si < n_rows; si += (int)(blockDim.x >> 6)) {
-    float* row = S + (long)si * ld;
-    const int kmax = masked ? top_list[si] + 1 : LK;
+  const int l16 = threadIdx.x & 15;
+  for (int base = 0; base < n_rows; base += rows_per_trip()) {
+    const int si = row_of(base);
+    const bool live = si < n_rows;
+    float* row = S + (long)(live ? si : 0) * ld;
+    const int kmax = live ? (masked ? top_list[si] + 1 : LK) : 0;
     float mx = -INFINITY;
-    for (int s = lane; s < kmax; s += 64) mx = fmaxf(mx, row[s]);
-    mx = wave_max(mx);
+    for (int s = l16; s < kmax; s += 16) mx = fmaxf(mx, row[s]);
+    mx = row16_max(mx);
     float sum = 0.f;
-    for (int s = lane; s < kmax; s += 64) {
-      const float e_ = expf(row[s] - mx);
+    for (int s = l16; s < kmax; s += 16) {
+      const float e_ = __expf(row[s] - mx);
       row[s] = e_;
       sum += e_;
     }
-    sum = wave_sum(sum);
+    sum = row16_sum(sum);
     const float inv = 1.f / sum;
-    for (int s = lane; s < ld; s += 64) row[s] = s < kmax ? row[s] * inv : 0.f;
+    if (live)
+      for (int s = l16; s < ld; s += 16) row[s] = s < kmax ? row[s] * inv : 0.f;
   }
 }
+
+// Phase timing aid (tools/attn_phase_probe.py builds a private copy with -DRF_ATTN_TIMING): thread 0 of every
+// workgroup stamps the shader clock after each phase into rf_attn_timing (16 slots per workgroup).
+#ifdef RF_ATTN_TIMING
+__device__ unsigned long long rf_attn_timing[16 * 4096];
+#define RF_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) rf_attn_timing[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RF_MARK(k) do {} while (0)
+#endif
 
 template <bool V4>
 __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  int b, h;
+  problem_of(blockIdx.x, p.B, p.H, b, h);
   const int LQ = p.LQ, LK = p.LK, E = p.E, EP = pitch<V4>(E);
   const int n_sel = (p.mode == 0) ? LQ : p.n_top;
   const int LKP = V4 ? ((LK + 3) & ~3) : LK;  // key rows / score columns padded to the MFMA k granule
@@ -171,11 +258,19 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
   int* sel = reinterpret_cast<int*>(vmean + E);
   int* top_list = sel + LQ;
 
-  load_head<V4>(Qs, p.q, p.q_ld, b, h, LQ, E, EP, tid);
-  load_head<V4>(Ks, p.k, p.k_ld, b, h, LK, E, EP, tid);
-  load_head<V4>(Vs, p.v, p.v_ld, b, h, LK, E, EP, tid);
+  RF_MARK(0);
+  // the key-sample table rides along with the head loads: its entries wait in the score buffer, each
+  // later overwritten by the dot product it selects (same thread, same slot)
+  const bool sampling = p.mode != 0 && !p.force_top;
+  int* Sidx = reinterpret_cast<int*>(S);
+  if (sampling) {
+    const int32_t* idx = p.idx + (long)(b / p.idx_group) * LQ * p.sample_k;
+    for (int i = tid; i < LQ * p.sample_k; i += (int)blockDim.x) Sidx[i] = idx[i];
+  }
+  load_qkv<V4>(Qs, Ks, Vs, p, b, h, EP, tid);
   for (int i = tid; i < (LKP - LK) * EP; i += (int)blockDim.x) { Ks[LK * EP + i] = 0.f; Vs[LK * EP + i] = 0.f; }
   __syncthreads();
+  RF_MARK(1);
 
   if (p.mode == 0) {
     for (int q = tid; q < LQ; q += (int)blockDim.x) { sel[q] = q; top_list[q] = q; }
@@ -189,12 +284,12 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
       __syncthreads();
     } else {
       // (1) sampled scores Q[q].K[idx[q,j]] (one table per group of `idx_group` consecutive batch rows)
-      const int32_t* idx = p.idx + (long)(b / p.idx_group) * LQ * p.sample_k;
       for (int i = tid; i < LQ * p.sample_k; i += (int)blockDim.x) {
         const int q = i / p.sample_k;
-        S[i] = dot_rows<V4>(Qs + q * EP, Ks + idx[i] * EP, E);
+        S[i] = dot_rows<V4>(Qs + q * EP, Ks + Sidx[i] * EP, E);
       }
       __syncthreads();
+      RF_MARK(2);
       for (int q = tid; q < LQ; q += (int)blockDim.x) {
         float mx = -INFINITY, sm = 0.f;
         for (int j = 0; j < p.sample_k; ++j) {
@@ -205,16 +300,35 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
         Ms[q] = mx - sm / (float)LK;
       }
       __syncthreads();
+      RF_MARK(3);
       // (2) top-u queries
       select_top(Ms, sel, top_list, LQ, n_sel, tid);
+      RF_MARK(4);
       for (int i = tid; i < n_sel; i += (int)blockDim.x) gtop[i] = top_list[i];
     }
     // (4) lazy rows: mean(V) or cumsum(V)
     if (p.mode == 1) {
-      for (int d = tid; d < E; d += (int)blockDim.x) {
-        float s = 0.f;
-        for (int l = 0; l < LK; ++l) s += Vs[l * EP + d];
-        vmean[d] = s / (float)LK;
+      // column means of V: `parts` threads per column, partial sums through the (currently dead) score buffer
+      const int parts = min(min((int)blockDim.x / E, s_elems / E), 16);
+      if (parts >= 2) {
+        for (int i = tid; i < parts * E; i += (int)blockDim.x) {
+          const int part = i / E, d = i - part * E;
+          float s = 0.f;
+          for (int l = part; l < LK; l += parts) s += Vs[l * EP + d];
+          S[i] = s;
+        }
+        __syncthreads();
+        for (int d = tid; d < E; d += (int)blockDim.x) {
+          float s = 0.f;
+          for (int part = 0; part < parts; ++part) s += S[part * E + d];
+          vmean[d] = s / (float)LK;
+        }
+      } else {
+        for (int d = tid; d < E; d += (int)blockDim.x) {
+          float s = 0.f;
+          for (int l = 0; l < LK; ++l) s += Vs[l * EP + d];
+          vmean[d] = s / (float)LK;
+        }
       }
       __syncthreads();
       for (int i = tid; i < LQ * E; i += (int)blockDim.x) {
@@ -231,6 +345,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
       }
     }
     __syncthreads();  // S is re-used below
+    RF_MARK(5);
   }
 
   // (3) active rows.  A: scores = scale * Qsel K^T, B: row softmax, C: P V
@@ -244,14 +359,17 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
                  S[si * LKP + s_] = (p.mode == 2 && s_ > top_list[si]) ? -INFINITY : v * p.scale;
              });
     __syncthreads();
-    softmax_rows(S, n_sel, LK, top_list, p.mode == 2, lane, wave, LKP);
+    RF_MARK(6);
+    softmax_rows(S, n_sel, LK, top_list, p.mode == 2, LKP);
     __syncthreads();
+    RF_MARK(7);
     mm_tiles(TI, (E + 15) >> 4, LKP >> 2, lane, wave,
              [&](int si) { return S + min(si, n_sel - 1) * LKP; }, 1,
              [&](int d) { return Vs + min(d, E - 1); }, EP,
              [&](int si, int d, float v) {
                if (si < n_sel && d < E) p.ctx[ctx_off(p, b, h, top_list[si]) + d] = v;
              });
+    RF_MARK(8);
   } else {
     for (int i = tid; i < n_sel * LK; i += (int)blockDim.x) {
       const int si = i / LK, s_ = i - si * LK;
@@ -261,7 +379,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
       S[i] = d;
     }
     __syncthreads();
-    softmax_rows(S, n_sel, LK, top_list, p.mode == 2, lane, wave);
+    softmax_rows(S, n_sel, LK, top_list, p.mode == 2);
     __syncthreads();
     for (int i = tid; i < n_sel * E; i += (int)blockDim.x) {
       const int si = i / E, d = i - si * E;
@@ -281,7 +399,8 @@ template <bool V4>
 __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  int b, h;
+  problem_of(blockIdx.x, p.B, p.H, b, h);
   const int LQ = p.LQ, LK = p.LK, E = p.E, EP = pitch<V4>(E);
   const int n_sel = (p.mode == 0) ? LQ : p.n_top;
   const int LKP = V4 ? ((LK + 3) & ~3) : LK;      // padded key count (MFMA k granule)
@@ -297,8 +416,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   int* top_list = reinterpret_cast<int*>(colsum + ((E + 3) & ~3));
   int* sel = top_list + n_sel;
 
-  load_head<V4>(Ks, p.k, p.k_ld, b, h, LK, E, EP, tid);
-  load_head<V4>(Vs, p.v, p.v_ld, b, h, LK, E, EP, tid);
+  load_qkv<V4>(nullptr, Ks, Vs, p, b, h, EP, tid);
   for (int i = tid; i < (LKP - LK) * EP; i += (int)blockDim.x) { Ks[LK * EP + i] = 0.f; Vs[LK * EP + i] = 0.f; }
   for (int i = tid; i < (NSP - n_sel) * EP; i += (int)blockDim.x) { Qsel[n_sel * EP + i] = 0.f; dCsel[n_sel * EP + i] = 0.f; }
   for (int i = tid; i < (NSP - n_sel) * LKP; i += (int)blockDim.x) { P[n_sel * LKP + i] = 0.f; dS[n_sel * LKP + i] = 0.f; }
@@ -349,15 +467,19 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
     }
   }
   __syncthreads();
-  softmax_rows(P, n_sel, LK, top_list, p.mode == 2, lane, wave, LKP);
-  // same wave owns the same rows in softmax_rows and here: no barrier needed in between
-  for (int si = wave; si < n_sel; si += (int)(blockDim.x >> 6)) {
-    float* Pr = P + (long)si * LKP;
-    float* dSr = dS + (long)si * LKP;
+  softmax_rows(P, n_sel, LK, top_list, p.mode == 2, LKP);
+  // the same 16 lanes own the same row in softmax_rows and here: no barrier needed in between
+  for (int base = 0; base < n_sel; base += rows_per_trip()) {
+    const int si = row_of(base), l16 = tid & 15;
+    const bool live = si < n_sel;
+    float* Pr = P + (long)(live ? si : 0) * LKP;
+    float* dSr = dS + (long)(live ? si : 0) * LKP;
     float dot = 0.f;
-    for (int s_ = lane; s_ < LK; s_ += 64) dot += Pr[s_] * dSr[s_];
-    dot = wave_sum(dot);
-    for (int s_ = lane; s_ < LKP; s_ += 64) dSr[s_] = s_ < LK ? Pr[s_] * (dSr[s_] - dot) * p.scale : 0.f;
+    if (live)
+      for (int s_ = l16; s_ < LK; s_ += 16) dot += Pr[s_] * dSr[s_];
+    dot = row16_sum(dot);
+    if (live)
+      for (int s_ = l16; s_ < LKP; s_ += 16) dSr[s_] = s_ < LK ? Pr[s_] * (dSr[s_] - dot) * p.scale : 0.f;
   }
   __syncthreads();
 
@@ -474,7 +596,7 @@ extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64
   p.q = q; p.k = k; p.v = v; p.q_ld = q_ld; p.k_ld = k_ld; p.v_ld = v_ld; p.ctx = ctx;
   p.out_layout = out_layout; p.idx = index_sample; p.top = top_idx; p.force_top = force_top;
   p.B = B; p.H = H; p.LQ = LQ; p.LK = LK; p.E = E; p.sample_k = sample_k; p.n_top = n_top;
-  p.mode = mode; p.scale = scale;
+  p.mode = mode; p.scale = scale; p.Qs_rows = LQ;
   p.idx_group = (idx_group <= 0 || idx_group > B) ? B : idx_group;
   static bool attr_set = false;
   if (!attr_set) {
@@ -487,6 +609,14 @@ extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
+
+#ifdef RF_ATTN_TIMING
+extern "C" void* rf_attn_timing_address() {
+  void* a = nullptr;
+  (void)hipGetSymbolAddress(&a, HIP_SYMBOL(rf_attn_timing));
+  return a;
+}
+#endif
 
 extern "C" int rf_attn_bwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
                            int64_t v_ld, const float* dctx, int out_layout, const int32_t* top_idx,
@@ -506,7 +636,7 @@ extern "C" int rf_attn_bwd(const float* q, const float* k, const float* v, int64
   p.q = q; p.k = k; p.v = v; p.q_ld = q_ld; p.k_ld = k_ld; p.v_ld = v_ld; p.dctx = dctx;
   p.out_layout = out_layout; p.top = const_cast<int32_t*>(top_idx); p.dq = dq; p.dk = dk; p.dv = dv;
   p.dq_ld = dq_ld; p.dk_ld = dk_ld; p.dv_ld = dv_ld; p.B = B; p.H = H; p.LQ = LQ; p.LK = LK;
-  p.E = E; p.n_top = n_top; p.mode = mode; p.scale = scale;
+  p.E = E; p.n_top = n_top; p.mode = mode; p.scale = scale; p.Qs_rows = 0;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -103,11 +103,6 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
-__device__ __forceinline__ float row16_sum(float v) {  // over the 16 lanes (fr) that share an output row
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-  return v;
-}
-
 // LayerNorm over the 128 columns a wave holds for each of its rows (two-pass, biased variance, as nn.LayerNorm)
 __device__ __forceinline__ void layer_norm_rows(f32x4 (&v)[8], f32x4 (&y)[8], const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, float eps, float (&rstd)[4], int lane) {
