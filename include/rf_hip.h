@@ -129,15 +129,19 @@ int rf_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, cons
 
 /* Informer distilling layer tail: BatchNorm1d (train: batch stats, eval: running stats) -> ELU ->
  * MaxPool1d(3,2,1) on (B,L,C), C innermost.  layers/TransformerEncoderDecoder.py:19-28.
- * stats: mean[C], var[C] (biased) computed by rf_bn_stats in train mode. */
-int rf_bn_stats(const float* x, float* mean, float* var, int rows, int C, void* stream);
+ * stats: mean[C], var[C] (biased) computed by rf_bn_stats in train mode; with running_mean != NULL the same
+ * launch applies nn.BatchNorm1d's running-statistics update (momentum, unbiased variance) and bumps
+ * num_batches_tracked (int64 scalar on the device, may be NULL). */
+int rf_bn_stats(const float* x, float* mean, float* var, int rows, int C, float* running_mean,
+                float* running_var, int64_t* num_batches_tracked, float momentum, void* stream);
 int rf_bn_elu_pool_fwd(const float* x, const float* mean, const float* var, const float* gamma,
                        const float* beta, float* y, int32_t* argmax, int B, int L, int C, float eps,
                        void* stream);
-/* dx for the whole BN(train)->ELU->pool chain; dgamma/dbeta too.  training=0: stats are constants. */
+/* dx for the whole BN(train)->ELU->pool chain; dgamma/dbeta too (accumulate=1: added to what is there).
+ * training=0: stats are constants. */
 int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const float* x, const float* mean,
                        const float* var, const float* gamma, const float* beta, float* dx,
-                       float* dgamma, float* dbeta, float* workspace, int B, int L, int C, float eps,
+                       float* dgamma, float* dbeta, int accumulate, int B, int L, int C, float eps,
                        int training, void* stream);
 
 /* Grouped weight gradients (the dW / db GEMMs of nn.Linear / Conv1d(k=1) backward, autograd's

@@ -170,7 +170,9 @@ __global__ void fold3_kernel(const float* __restrict__ dcols, float* __restrict_
 
 // ---- BatchNorm1d statistics over rows (biased variance), block = 64 channels x 4 row lanes ----
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ mean,
-                                                       float* __restrict__ var, int rows, int C) {
+                                                       float* __restrict__ var, int rows, int C,
+                                                       float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                       long long* __restrict__ batches, float momentum) {
   __shared__ float red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -185,9 +187,17 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   red[ty][tx] = q;
   __syncthreads();
   if (ty == 0 && c < C) {
+    const float v = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)rows;
     mean[c] = m;
-    var[c] = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)rows;
+    var[c] = v;
+    if (run_mean) {  // nn.BatchNorm1d running statistics (unbiased variance), same launch
+      const float keep = 1.0f - momentum;
+      const float unbias = momentum * ((float)rows / (float)max(rows - 1, 1));
+      run_mean[c] = run_mean[c] * keep + momentum * m;
+      run_var[c] = run_var[c] * keep + unbias * v;
+    }
   }
+  if (batches && blockIdx.x == 0 && threadIdx.x == 0) *batches += 1;
 }
 
 __device__ __forceinline__ float elu(float z) { return z > 0.f ? z : expm1f(z); }
@@ -226,7 +236,8 @@ __global__ __launch_bounds__(256) void bn_elu_pool_bwd_kernel(const float* __res
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ dx,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              int B, int L, int C, int Lout, float eps, int training) {
+                                                              int B, int L, int C, int Lout, float eps, int training,
+                                                              int accumulate) {
   __shared__ float red[2][4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -258,7 +269,10 @@ __global__ __launch_bounds__(256) void bn_elu_pool_bwd_kernel(const float* __res
   const float S1 = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
   const float S2 = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
   if (c >= C) return;
-  if (ty == 0) { dbeta[c] = S1; dgamma[c] = S2; }
+  if (ty == 0) {
+    if (accumulate) { dbeta[c] += S1; dgamma[c] += S2; }
+    else { dbeta[c] = S1; dgamma[c] = S2; }
+  }
   const float m1 = S1 / (float)rows, m2 = S2 / (float)rows;
   for (int r = ty; r < rows; r += 4) {
     float xh;
@@ -331,10 +345,12 @@ extern "C" int rf_fold3_circular(const float* dcols, float* dx, int B, int L, in
   return RF_OK;
 }
 
-extern "C" int rf_bn_stats(const float* x, float* mean, float* var, int rows, int C, void* stream) {
-  RF_REQUIRE(x && mean && var && rows > 0 && C > 0);
+extern "C" int rf_bn_stats(const float* x, float* mean, float* var, int rows, int C, float* running_mean,
+                           float* running_var, int64_t* num_batches_tracked, float momentum, void* stream) {
+  RF_REQUIRE(x && mean && var && rows > 0 && C > 0 && (!running_mean == !running_var));
   hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), x, mean,
-                     var, rows, C);
+                     var, rows, C, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked),
+                     momentum);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
@@ -352,13 +368,12 @@ extern "C" int rf_bn_elu_pool_fwd(const float* x, const float* mean, const float
 
 extern "C" int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const float* x, const float* mean,
                                   const float* var, const float* gamma, const float* beta, float* dx, float* dgamma,
-                                  float* dbeta, float* workspace, int B, int L, int C, float eps, int training,
+                                  float* dbeta, int accumulate, int B, int L, int C, float eps, int training,
                                   void* stream) {
-  (void)workspace;
   RF_REQUIRE(dy && argmax && x && mean && var && gamma && beta && dx && dgamma && dbeta && B > 0 && L > 0 && C > 0);
   const int Lout = (L - 1) / 2 + 1;
   hipLaunchKernelGGL(bn_elu_pool_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), dy,
-                     argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, B, L, C, Lout, eps, training);
+                     argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, B, L, C, Lout, eps, training, accumulate);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

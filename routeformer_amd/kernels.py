@@ -392,7 +392,10 @@ class _Linear(torch.autograd.Function):
     """y = x W^T + b (+ residual rows broadcast over the batch: y[m] += residual[m % R])."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, gw, gb):
+    def forward(ctx, x, w, b, residual, gw, gb, fork=False):
+        """``fork``: also return an alias of ``x`` for the layer's skip connection.  Its gradient then comes
+        back into THIS node and is added in the dX GEMM epilogue -- otherwise autograd would sum the two
+        gradients of ``x`` (projection path + skip path) with a separate elementwise launch."""
         _req(x, "linear.x"); _req(w, "linear.w")
         K = x.shape[-1]
         N = w.shape[0]
@@ -417,12 +420,16 @@ class _Linear(torch.autograd.Function):
         ctx.sinks = (gw, gb)  # plain attributes: slots of a buffer other kernels also write (no version check)
         ctx.has_bias = b is not None
         ctx.xshape = x.shape
+        if fork:
+            return y.view(*x.shape[:-1], N), x.view_as(x)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x2, w = ctx.saved_tensors
         gw, gb = ctx.sinks
+        if dy is None:  # only the skip branch was used downstream
+            return dskip, None, None, None, None, None, None
         dy2 = dy.reshape(-1, dy.shape[-1])
         if dy2.stride(1) != 1 or dy2.stride(0) != dy2.shape[1]:
             dy2 = dy2.contiguous()
@@ -436,22 +443,30 @@ class _Linear(torch.autograd.Function):
             if ctx.has_bias and not fused_bias and (gb is not None or ctx.needs_input_grad[2]):
                 db = colsum(dy2, into=gb)
         if ctx.needs_input_grad[0]:
-            dx = _input_grad(dy2, w).view(ctx.xshape)
+            if dskip is not None:
+                K_ = w.shape[1]
+                ds2 = dskip.reshape(-1, K_)
+                if ds2.stride(1) != 1 or ds2.stride(0) != K_:
+                    ds2 = ds2.contiguous()
+                dx = _input_grad(dy2, w, residual=ds2, ldr=K_, res_rows=ds2.shape[0]).view(ctx.xshape)
+            else:
+                dx = _input_grad(dy2, w).view(ctx.xshape)
         _wrote(gw, gb)
         if ctx.needs_input_grad[3]:  # residual rows are shared by M / R row blocks
             dres = colsum(dy2.view(-1, ctx.res_rows * dy2.shape[1])).view(ctx.res_shape)
-        return dx, dw, db, dres, None, None
+        return dx, dw, db, dres, None, None, None
 
 
-def linear(x, w, b=None, residual=None):
-    """``w`` / ``b`` may be parameters (gradient sinks are picked up from them) or plain views."""
-    return _Linear.apply(x, w, b, residual, _slot(w), _slot(b))
+def linear(x, w, b=None, residual=None, fork: bool = False):
+    """``w`` / ``b`` may be parameters (gradient sinks are picked up from them) or plain views.
+    ``fork=True`` -> (y, alias of x for the skip connection), see ``_Linear.forward``."""
+    return _Linear.apply(x, w, b, residual, _slot(w), _slot(b), fork)
 
 
-def linear_packed(x, w, b, gw, gb):
+def linear_packed(x, w, b, gw, gb, fork: bool = False):
     """Linear over a packed (non-parameter) weight view, e.g. [Wq;Wk;Wv] in the flat buffer; gradients go
     to the matching packed gradient views."""
-    return _Linear.apply(x, w, b, None, gw, gb)
+    return _Linear.apply(x, w, b, None, gw, gb, fork)
 
 
 class _FFN(torch.autograd.Function):
@@ -459,7 +474,7 @@ class _FFN(torch.autograd.Function):
     The activation and its derivative ride in GEMM epilogues."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act: str, g1, gb1, g2, gb2, need_grad=True):
+    def forward(ctx, x, w1, b1, w2, b2, act: str, g1, gb1, g2, gb2, need_grad=True, fork=False):
         _req(x, "ffn.x")
         F, D = w1.shape[0], w1.shape[1]
         w1, w2 = w1.reshape(F, D), w2.reshape(D, F)  # Conv1d(k=1) weights (out,in,1) viewed as matrices
@@ -477,10 +492,12 @@ class _FFN(torch.autograd.Function):
         ctx.act = act
         ctx.xshape = x.shape
         ctx.wshapes = (F, D)
+        if fork:  # alias of x for the skip connection: its gradient is folded into the last dX epilogue
+            return y.view(x.shape), x.view_as(x)
         return y.view(x.shape)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x2, w1, w2, h, zsrc = ctx.saved_tensors
         g1, gb1, g2, gb2 = ctx.sinks
         F, D = ctx.wshapes
@@ -499,18 +516,26 @@ class _FFN(torch.autograd.Function):
             dw1 = None
         if dw2 is True or dw2 is False:
             dw2 = None
-        dx = _input_grad(dz, w1).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if dskip is not None:
+                ds2 = dskip.reshape(-1, D)
+                if ds2.stride(1) != 1 or ds2.stride(0) != D:
+                    ds2 = ds2.contiguous()
+                dx = _input_grad(dz, w1, residual=ds2, ldr=D, res_rows=ds2.shape[0]).view(ctx.xshape)
+            else:
+                dx = _input_grad(dz, w1).view(ctx.xshape)
         _wrote(g1, gb1, g2, gb2)
         if dw1 is not None:
             dw1, dw2 = dw1.view(F, D, 1), dw2.view(D, F, 1)
-        return dx, dw1, db1, dw2, db2, None, None, None, None, None, None
+        return dx, dw1, db1, dw2, db2, None, None, None, None, None, None, None
 
 
-def ffn(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str):
-    """conv*_w: the Conv1d(k=1) weight parameters, shape (out, in, 1)."""
+def ffn(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str, fork: bool = False):
+    """conv*_w: the Conv1d(k=1) weight parameters, shape (out, in, 1).  ``fork`` as in ``linear``."""
     assert conv1_w.dim() == 3 and conv2_w.dim() == 3
     return _FFN.apply(x, conv1_w, conv1_b, conv2_w, conv2_b, act, _slot(conv1_w), _slot(conv1_b),
-                      _slot(conv2_w), _slot(conv2_b), torch.is_grad_enabled())
+                      _slot(conv2_w), _slot(conv2_b), torch.is_grad_enabled(), fork)
 
 
 class _AddLayerNorm(torch.autograd.Function):
@@ -689,7 +714,8 @@ def ffn_add_layer_norm(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str, gamma, b
         return _FFNAddLN.apply(x, conv1_w, conv1_b, conv2_w, conv2_b, act, gamma, beta, eps, _slot(conv1_w),
                                _slot(conv1_b), _slot(conv2_w), _slot(conv2_b), _slot(gamma), _slot(beta),
                                torch.is_grad_enabled())
-    return add_layer_norm(x, ffn(x, conv1_w, conv1_b, conv2_w, conv2_b, act), gamma, beta, eps)
+    y, skip = ffn(x, conv1_w, conv1_b, conv2_w, conv2_b, act, fork=True)
+    return add_layer_norm(skip, y, gamma, beta, eps)
 
 
 def add_layer_norm(x, residual, gamma, beta, eps: float = 1e-5):
@@ -732,7 +758,7 @@ class _BnEluPool(torch.autograd.Function):
     """BatchNorm1d -> ELU -> MaxPool1d(3,2,1) over (B,L,C) (Informer distilling tail)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, mean, var, eps, training):
+    def forward(ctx, x, gamma, beta, mean, var, eps, training, gg=None, gb=None):
         x = x.contiguous()
         B, L, C = x.shape
         Lout = (L - 1) // 2 + 1
@@ -742,27 +768,38 @@ class _BnEluPool(torch.autograd.Function):
                                             ptr(arg), B, L, C, eps, _stream()), "rf_bn_elu_pool_fwd")
         ctx.save_for_backward(x, gamma, beta, mean, var, arg)
         ctx.eps, ctx.training = eps, training
+        ctx.sinks = (gg, gb)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, mean, var, arg = ctx.saved_tensors
+        gg, gb = ctx.sinks
         B, L, C = x.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dg = torch.empty(C, device=x.device, dtype=torch.float32)
-        db = torch.empty(C, device=x.device, dtype=torch.float32)
+        sink = gg is not None and gb is not None
+        dg = gg if sink else torch.empty(C, device=x.device, dtype=torch.float32)
+        db = gb if sink else torch.empty(C, device=x.device, dtype=torch.float32)
         check(_hip.lib().rf_bn_elu_pool_bwd(ptr(dy), ptr(arg), ptr(x), ptr(mean), ptr(var), ptr(gamma),
-                                            ptr(beta), ptr(dx), ptr(dg), ptr(db), None, B, L, C, ctx.eps,
+                                            ptr(beta), ptr(dx), ptr(dg), ptr(db), 1 if sink else 0, B, L, C, ctx.eps,
                                             1 if ctx.training else 0, _stream()), "rf_bn_elu_pool_bwd")
-        return dx, dg, db, None, None, None, None
+        if sink:
+            _wrote(gg, gb)
+            dg = db = None
+        return dx, dg, db, None, None, None, None, None, None
 
 
-def bn_stats(x3: torch.Tensor):
+def bn_stats(x3: torch.Tensor, running_mean=None, running_var=None, num_batches_tracked=None, momentum: float = 0.1):
+    """Batch mean / biased variance per channel; with running buffers the nn.BatchNorm1d running-statistics
+    update (momentum, unbiased variance, batch counter) happens in the same launch."""
     B, L, C = x3.shape
     mean = torch.empty(C, device=x3.device, dtype=torch.float32)
     var = torch.empty(C, device=x3.device, dtype=torch.float32)
-    check(_hip.lib().rf_bn_stats(ptr(x3), ptr(mean), ptr(var), B * L, C, _stream()), "rf_bn_stats")
+    if num_batches_tracked is not None:
+        assert num_batches_tracked.dtype == torch.int64 and num_batches_tracked.is_cuda
+    check(_hip.lib().rf_bn_stats(ptr(x3), ptr(mean), ptr(var), B * L, C, ptr(running_mean), ptr(running_var),
+                                 ptr(num_batches_tracked), momentum, _stream()), "rf_bn_stats")
     return mean, var
 
 
@@ -770,16 +807,10 @@ def bn_elu_pool(x, gamma, beta, running_mean, running_var, num_batches_tracked, 
                 momentum: float = 0.1, eps: float = 1e-5):
     x = x.contiguous()
     if training:
-        mean, var = bn_stats(x.detach())
-        n = x.shape[0] * x.shape[1]
-        with torch.no_grad():  # running-stat update (unbiased variance), nn.BatchNorm1d semantics
-            running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-            running_var.mul_(1 - momentum).add_(var, alpha=momentum * n / max(n - 1, 1))
-            if num_batches_tracked is not None:
-                num_batches_tracked.add_(1)
+        mean, var = bn_stats(x.detach(), running_mean, running_var, num_batches_tracked, momentum)
     else:
         mean, var = running_mean, running_var
-    return _BnEluPool.apply(x, gamma, beta, mean, var, eps, training)
+    return _BnEluPool.apply(x, gamma, beta, mean, var, eps, training, _slot(gamma), _slot(beta))
 
 
 class TopSelection:

@@ -190,18 +190,27 @@ class AttentionLayer(nn.Module):
         HE = qp.weight.shape[0]
         E = HE // H
         pk = self.__dict__.get("_packed") if K.SINK.active else None
+        # with a norm to follow, the projection that consumes x also hands back an alias of x for the skip
+        # connection, so both gradients of x meet inside that projection's dX GEMM (no autograd add launch)
+        fork = norm is not None and torch.is_grad_enabled() and x.requires_grad
+        skip = x
         if memory is None:
             S = L
             if pk is not None:  # [Wq;Wk;Wv] are adjacent in the engine's flat buffers: no cat, one dW GEMM
-                a = bm = K.linear_packed(x.reshape(B * L, -1), pk["w"], pk["b"], pk["gw"], pk["gb"])
+                a = K.linear_packed(x.reshape(B * L, -1), pk["w"], pk["b"], pk["gw"], pk["gb"], fork=fork)
             else:
                 w = torch.cat([qp.weight, kp.weight, vp.weight], dim=0)
                 b = torch.cat([qp.bias, kp.bias, vp.bias], dim=0)
-                a = bm = K.linear(x.reshape(B * L, -1), w, b)
+                a = K.linear(x.reshape(B * L, -1), w, b, fork=fork)
+            if fork:
+                a, skip = a[0], a[1].view(x.shape)
+            bm = a
             offs = (0, HE, 2 * HE)
         else:
             S = memory.shape[1]
-            a = K.linear(x.reshape(B * L, -1), qp.weight, qp.bias)
+            a = K.linear(x.reshape(B * L, -1), qp.weight, qp.bias, fork=fork)
+            if fork:
+                a, skip = a[0], a[1].view(x.shape)
             if pk is not None:
                 bm = K.linear_packed(memory.reshape(B * S, -1), pk["w"][HE:], pk["b"][HE:], pk["gw"][HE:], pk["gb"][HE:])
             else:
@@ -226,7 +235,7 @@ class AttentionLayer(nn.Module):
             ctx = ctx.transpose(2, 1).contiguous()
         ctx = ctx.view(B, L, HE)  # GPS variant: (B,H,L,D) memory reinterpreted -- the head scramble
         if norm is not None:
-            return K.linear_add_layer_norm(ctx, self.out_projection.weight, self.out_projection.bias, x, norm.weight,
+            return K.linear_add_layer_norm(ctx, self.out_projection.weight, self.out_projection.bias, skip, norm.weight,
                                            norm.bias, norm.eps)
         return K.linear(ctx, self.out_projection.weight, self.out_projection.bias)
 
