@@ -72,11 +72,15 @@ def prob_sizes(L_Q: int, L_K: int, factor: int):
     return (U_part if U_part < L_K else L_K), (u if u < L_Q else L_Q)
 
 
-def full_attention(q, k, v, scale=None):
-    """softmax(scale * Q K^T) V, unmasked -- cross_modal_transformer.py:51-69.  (B,L,H,E) in/out."""
+def full_attention(q, k, v, scale=None, masked: bool = False):
+    """softmax(scale * Q K^T) V -- cross_modal_transformer.py:51-69; ``masked`` = the TriangularCausalMask
+    branch of the GPS copy (layers/SelfAttentionFamily.py:9-17,53-57).  (B,L,H,E) in/out."""
     E = q.shape[-1]
     scale = scale or 1.0 / math.sqrt(E)
     s = torch.einsum("blhe,bshe->bhls", q, k)
+    if masked:
+        L = q.shape[1]
+        s = s.masked_fill(torch.triu(torch.ones(L, s.shape[-1], dtype=torch.bool), diagonal=1), float("-inf"))
     a = torch.softmax(scale * s, dim=-1)
     return torch.einsum("bhls,bshd->blhd", a, v).contiguous()
 
@@ -125,14 +129,14 @@ def _linear(sd: SD, p: str, x):
 def attention_layer(sd: SD, p: str, xq, xk, xv, n_heads: int, kind: str, idx: IndexSource,
                     factor: int = 5, gps_variant: bool = False, mix: bool = False):
     """AttentionLayer -- cross_modal_transformer.py:169-198 / SelfAttentionFamily.py:168-194.
-    kind in {"prob", "prob_masked", "full"}."""
+    kind in {"prob", "prob_masked", "full", "full_masked"}."""
     B, L, _ = xq.shape
     S = xk.shape[1]
     q = _linear(sd, p + ".query_projection", xq).view(B, L, n_heads, -1)
     k = _linear(sd, p + ".key_projection", xk).view(B, S, n_heads, -1)
     v = _linear(sd, p + ".value_projection", xv).view(B, S, n_heads, -1)
-    if kind == "full":
-        out = full_attention(q, k, v)
+    if kind in ("full", "full_masked"):
+        out = full_attention(q, k, v, masked=kind == "full_masked")
     else:
         sample_k, _ = prob_sizes(L, S, factor)
         index_sample = idx.randint(S, (L, sample_k))
@@ -160,18 +164,18 @@ def _ffn(sd: SD, p: str, x, activation: str):
     return F.linear(y, w2, sd[p + ".conv2.bias"])
 
 
-def encoder_layer(sd: SD, p: str, x, n_heads, idx, factor, activation, gps_variant):
+def encoder_layer(sd: SD, p: str, x, n_heads, idx, factor, activation, gps_variant, kind: str = "prob"):
     """Post-LN encoder block -- cross_modal_transformer.py:288-301."""
-    x = x + attention_layer(sd, p + ".attention", x, x, x, n_heads, "prob", idx, factor,
+    x = x + attention_layer(sd, p + ".attention", x, x, x, n_heads, kind, idx, factor,
                             gps_variant)
     x = _ln(sd, p + ".norm1", x)
     return _tap(p, _ln(sd, p + ".norm2", x + _ffn(sd, p, x, activation)))
 
 
 def decoder_layer(sd: SD, p: str, x, cross, n_heads, idx, factor, activation, gps_variant,
-                  cross_kind: str, mix: bool = False):
+                  cross_kind: str, mix: bool = False, self_kind: str = "prob_masked"):
     """Decoder block -- cross_modal_transformer.py:223-233 / TransformerEncoderDecoder.py:106-115."""
-    x = x + attention_layer(sd, p + ".self_attention", x, x, x, n_heads, "prob_masked", idx, factor,
+    x = x + attention_layer(sd, p + ".self_attention", x, x, x, n_heads, self_kind, idx, factor,
                             gps_variant, mix=mix)
     x = _ln(sd, p + ".norm1", x)
     x = x + attention_layer(sd, p + ".cross_attention", x, cross, cross, n_heads, cross_kind, idx,
@@ -289,6 +293,47 @@ def informer(sd: SD, p: str, x, *, pred_len: int, n_heads: int, factor: int, act
                           gps_variant=True, cross_kind="prob")
     d = _ln(sd, p + ".decoder.norm", d)
     return _tap(p, _linear(sd, p + ".decoder.projection", d)[:, -pred_len:, :])
+
+
+def transformer_gps(sd: SD, p: str, x, *, pred_len: int, n_heads: int, activation: str):
+    """The vanilla ``Transformer`` GPS backbone -- gps_backbone/Transformer.py:98-141:
+    FullAttention encoder, causal FullAttention + cross FullAttention decoder, decoder input = history
+    followed by ``pred_len`` zero rows, no distilling, no host RNG."""
+    x_dec = torch.cat([x, torch.zeros(x.shape[0], pred_len, x.shape[-1])], dim=1)
+    h = data_embedding(sd, p + ".enc_embedding", x)
+    for i in range(_count(sd, p + ".encoder.attn_layers")):
+        h = encoder_layer(sd, f"{p}.encoder.attn_layers.{i}", h, n_heads, None, 0, activation, False, kind="full")
+    enc = _ln(sd, p + ".encoder.norm", h)
+    d = data_embedding(sd, p + ".dec_embedding", x_dec)
+    for i in range(_count(sd, p + ".decoder.layers")):
+        d = decoder_layer(sd, f"{p}.decoder.layers.{i}", d, enc, n_heads, None, 0, activation, False,
+                          cross_kind="full", self_kind="full_masked")
+    d = _ln(sd, p + ".decoder.norm", d)
+    return _linear(sd, p + ".decoder.projection", d)[:, -pred_len:, :]
+
+
+def warmup_cosine_lr(base_lr: float, epochs: int, warmup_epochs: int, max_epochs: int,
+                     warmup_start_lr: float = 0.0, eta_min: float = 0.0):
+    """Learning rate in force during epochs 0 .. epochs-1 under LinearWarmupCosineAnnealingLR stepped once
+    per epoch (optimizers/lr_scheduler.py:62-113, the CHAINABLE form Lightning drives; driver:
+    full_comparison.py:702-709 with warmup_epochs=2, max_epochs=200).  Python floats, same expression
+    order as the reference so the values are equal bit for bit."""
+    lrs, lr = [], base_lr
+    for e in range(epochs):
+        if e == warmup_epochs:
+            lr = base_lr
+        elif e == 0:
+            lr = warmup_start_lr
+        elif e < warmup_epochs:
+            lr = lr + (base_lr - warmup_start_lr) / (warmup_epochs - 1)
+        elif (e - 1 - max_epochs) % (2 * (max_epochs - warmup_epochs)) == 0:
+            lr = lr + (base_lr - eta_min) * (1 - math.cos(math.pi / (max_epochs - warmup_epochs))) / 2
+        else:
+            lr = ((1 + math.cos(math.pi * (e - warmup_epochs) / (max_epochs - warmup_epochs)))
+                  / (1 + math.cos(math.pi * (e - warmup_epochs - 1) / (max_epochs - warmup_epochs)))
+                  * (lr - eta_min) + eta_min)
+        lrs.append(lr)
+    return lrs
 
 
 # ---------------------------------------------------------------------------------------------
@@ -537,8 +582,12 @@ class OracleRouteformer:
         if cfg._only_motion:
             parts[-1] = torch.zeros_like(parts[-1])
         x = torch.cat(parts, dim=-1)
-        out = informer(self.sd, "gps_backbone", x, pred_len=pred_len, training=self.training,
-                       idx=self.idx, bn_state=self.bn_state, **self.gps_kw)
+        if getattr(self, "gps_kind", "informer") == "transformer":
+            out = transformer_gps(self.sd, "gps_backbone", x, pred_len=pred_len, n_heads=self.gps_kw["n_heads"],
+                                  activation=self.gps_kw["activation"])
+        else:
+            out = informer(self.sd, "gps_backbone", x, pred_len=pred_len, training=self.training,
+                           idx=self.idx, bn_state=self.bn_state, **self.gps_kw)
         if cfg.decoder_mode == "recursive":
             out = out + (x[:, -1:, :] if cfg.dense_prediction else x[:, -1:, :2])
         if cfg.rotate_motion:
@@ -579,6 +628,22 @@ class OracleRouteformer:
             if cfg.with_video:
                 fvis = torch.cat([o[1] for o in outs], dim=1)[:, : self.pred_len]
         return (pos, fvis) if cfg.dense_prediction else pos
+
+    # -- the evaluation protocol (experiments/full_comparison.py:654-679) ------------------------
+    def eval_step(self, item, epoch: int = 0, passes: int = 5):
+        """Mean trajectory over ``passes`` forwards (each consuming fresh key samples from ``self.idx``),
+        then per-sample discounted loss / ADE / FDE.  -> (losses (B,), ades (B,), fdes (B,), mean (B,P,2))."""
+        gamma = discount_for_epoch(self.cfg.discount_factor, epoch)
+        runs = []
+        for _ in range(passes):
+            out = self.forward(item["train"])
+            runs.append(out[0] if self.cfg.dense_prediction else out)
+        mean = torch.stack(runs).mean(dim=0)
+        tgt = item["target"]["gps"]
+        rows = [(future_discounted_loss(mean[i:i + 1], tgt[i:i + 1], gamma), ade(mean[i:i + 1], tgt[i:i + 1]),
+                 fde(mean[i:i + 1], tgt[i:i + 1])) for i in range(mean.shape[0])]
+        return (torch.stack([r[0] for r in rows]), torch.stack([r[1] for r in rows]),
+                torch.stack([r[2] for r in rows]), mean)
 
     # -- the train-step recipe (experiments/full_comparison.py:476-521) -------------------------
     def train_step(self, item, epoch: int = 0):

@@ -238,9 +238,12 @@ __global__ __launch_bounds__(256) void bn_elu_pool_bwd_kernel(const float* __res
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               int B, int L, int C, int Lout, float eps, int training,
                                                               int accumulate) {
-  __shared__ float red[2][4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + tx;
+  // block = 16 channels x 16 row lanes: C / 16 workgroups (52 at d_model 832) instead of C / 64, and a
+  // 16x shorter serial row loop per thread -- this launch sits alone on the backward critical path
+  constexpr int CH = 16, RL = 16;
+  __shared__ float red[2][RL][CH];
+  const int tx = threadIdx.x % CH, ty = threadIdx.x / CH;
+  const int c = blockIdx.x * CH + tx;
   const int rows = B * L;
   float g = 0.f, istd = 0.f, mu = 0.f, bt = 0.f;
   if (c < C) { g = gamma[c]; istd = 1.0f / sqrtf(var[c] + eps); mu = mean[c]; bt = beta[c]; }
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256) void bn_elu_pool_bwd_kernel(const float* __res
   };
   float s1 = 0.f, s2 = 0.f;
   if (c < C)
-    for (int r = ty; r < rows; r += 4) {
+    for (int r = ty; r < rows; r += RL) {
       float xh;
       const float d = dpre(r, xh);
       s1 += d;
@@ -266,15 +269,16 @@ __global__ __launch_bounds__(256) void bn_elu_pool_bwd_kernel(const float* __res
   red[0][ty][tx] = s1;
   red[1][ty][tx] = s2;
   __syncthreads();
-  const float S1 = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
-  const float S2 = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+  float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < RL; ++k) { S1 += red[0][k][tx]; S2 += red[1][k][tx]; }
   if (c >= C) return;
   if (ty == 0) {
     if (accumulate) { dbeta[c] += S1; dgamma[c] += S2; }
     else { dbeta[c] = S1; dgamma[c] = S2; }
   }
   const float m1 = S1 / (float)rows, m2 = S2 / (float)rows;
-  for (int r = ty; r < rows; r += 4) {
+  for (int r = ty; r < rows; r += RL) {
     float xh;
     const float d = dpre(r, xh);
     dx[(long)r * C + c] = training ? g * istd * (d - m1 - xh * m2) : g * istd * d;
@@ -372,7 +376,7 @@ extern "C" int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const 
                                   void* stream) {
   RF_REQUIRE(dy && argmax && x && mean && var && gamma && beta && dx && dgamma && dbeta && B > 0 && L > 0 && C > 0);
   const int Lout = (L - 1) / 2 + 1;
-  hipLaunchKernelGGL(bn_elu_pool_bwd_kernel, dim3((C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), dy,
+  hipLaunchKernelGGL(bn_elu_pool_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), dy,
                      argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, B, L, C, Lout, eps, training, accumulate);
   RF_CHECK_LAUNCH();
   return RF_OK;

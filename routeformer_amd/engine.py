@@ -97,6 +97,31 @@ def train_step_losses(model, item, epoch: int = 0, trajectory_loss: Optional[Fut
     return res
 
 
+def eval_step(model, item, trajectory_loss: Optional[FutureDiscountedLoss] = None, epoch: int = 0, passes: int = 5,
+              seed: int = 12345):
+    """The reference's evaluation protocol (``ParallelTrainer._eval_step``, full_comparison.py:654-679):
+    reseed the host RNG, average the predicted trajectory over ``passes`` forward passes (each draws fresh
+    ProbSparse key samples), then per-sample loss / ADE / FDE.  Returns (losses, ades, fdes, mean
+    trajectory), the first three of shape (B,)."""
+    cfg = model.configs
+    tl = trajectory_loss or FutureDiscountedLoss(cfg.discount_factor, cfg.epsilon, loss_function="smooth_l1")
+    tl.current_epoch = epoch
+    torch.manual_seed(seed)
+    target_gps = item["target"]["gps"]
+    runs = []
+    with torch.no_grad():
+        for _ in range(passes):
+            out = model(item["train"])
+            runs.append(out[0] if cfg.dense_prediction else out)
+        future_gps = torch.stack(runs).mean(dim=0)
+        losses, ades, fdes = [], [], []
+        for i in range(future_gps.shape[0]):
+            f, t = future_gps[i:i + 1], target_gps[i:i + 1]
+            losses.append(tl(f, t)); ades.append(ade(f, t)); fdes.append(fde(f, t))
+    torch.seed()
+    return torch.stack(losses), torch.stack(ades), torch.stack(fdes), future_gps
+
+
 def trainable_parameters(model) -> List[torch.nn.Parameter]:
     """Everything but the frozen video backbone (full_comparison.py:689-691), registration order."""
     return [p for n, p in model.named_parameters() if "video_backbone" not in n and p.requires_grad]
@@ -235,8 +260,17 @@ class FusedAdamW:
         self.m = torch.zeros_like(flat_param)
         self.v = torch.zeros_like(flat_param)
         self.sumsq = torch.zeros(1, device=flat_param.device, dtype=torch.float32)
-        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.betas, self.eps, self.wd, self.max_norm = betas, eps, weight_decay, max_grad_norm
+        self.param_groups = [{"lr": lr}]  # what an LR scheduler drives (optimizers.LinearWarmupCosineAnnealingLR)
         self.t = 0
+
+    @property
+    def lr(self) -> float:
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, value: float):
+        self.param_groups[0]["lr"] = value
 
     def step(self, grad_scale: float = 1.0):
         from routeformer_amd import _hip, kernels as K

@@ -159,7 +159,8 @@ class DataEmbedding(nn.Module):
 class AttentionLayer(nn.Module):
     """Q/K/V/O projections around the attention kernel.
 
-    kind: "prob" | "prob_masked" | "full".  ``gps_variant`` reproduces the Informer copy whose core
+    kind: "prob" | "prob_masked" | "full" | "full_masked" (causal softmax attention, the
+    TriangularCausalMask branch of layers/SelfAttentionFamily.py:53-57).  ``gps_variant`` reproduces the Informer copy whose core
     returns (B,H,L,D) and is then *viewed* as (B,L,H*D) without a transpose."""
 
     def __init__(self, kind: str, d_model: int, n_heads: int, factor: int = 5, gps_variant: bool = False,
@@ -225,6 +226,13 @@ class AttentionLayer(nn.Module):
                 raise NotImplementedError("attention-probability dropout (FullAttention) is not implemented "
                                           "in the HIP kernel; run with feature_dropout=0")
             ctx = K.attention(a, bm, offs, dims, 0, out_layout=layout)
+        elif self.kind == "full_masked":
+            # causal softmax attention = the masked ProbSparse kernel with EVERY query row active (imposed
+            # selection 0..L-1: the sampling stage is skipped, no lazy rows remain)
+            if self.attn_dropout > 0.0 and self.training:
+                raise NotImplementedError("attention-probability dropout is not implemented; run with dropout=0")
+            every = torch.arange(L, device=x.device, dtype=torch.int32).expand(B, H, L).contiguous()
+            ctx = K.attention(a, bm, offs, dims, 2, n_top=L, out_layout=layout, forced_top=every)
         else:
             sample_k, n_top = K.prob_sizes(L, S, self.factor)
             if idx is None:

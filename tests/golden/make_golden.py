@@ -365,7 +365,91 @@ def gen_case(name):
     save(name, **out)
 
 
-GENERATORS = {"attention": gen_attention, "blocks": gen_blocks, "informer": gen_informer,
+def gen_widen():
+    """Fixtures for the SURVEY 8(f) rows: the Transformer GPS backbone, the LR schedule and the 5-pass
+    evaluation protocol -- each produced by the reference's own classes / call sequence."""
+    out = {}
+    # (1) vanilla Transformer GPS backbone (gps_backbone/Transformer.py), stand-alone and inside Routeformer
+    for tag, kw, B, T, P, cin in (("tiny", presets.GPS_TINY, 3, 20, 10, 69), ("default", presets.GPS_DEFAULT, 4, 10, 15, 5)):
+        gcfg = REF.gps.GPSBackboneConfig(seq_len=T, label_len=T, pred_len=P, **kw)
+        gcfg.output_attention = False
+        gcfg._enc_in = cin
+        gcfg._c_out = cin - 3
+        torch.manual_seed(0)
+        net = REF.gps.Transformer(gcfg)
+        load_synth(net)
+        g = torch.Generator().manual_seed(17)
+        x = torch.randn(B, T, cin, generator=g)
+        net.eval()
+        out[f"transformer.{tag}.eval.y"] = net(x)
+        net.train()
+        net.zero_grad()
+        y = net(x)
+        y.square().mean().backward()
+        out[f"transformer.{tag}.train.y"] = y
+        out.update({f"transformer.{tag}.train.{k}": v for k, v in grad_summary(net, full=(
+            "decoder.projection.bias", "encoder.norm.weight", "decoder.layers.0.self_attention.query_projection.bias",
+            "enc_embedding.temporal_embedding.embed.weight")).items()})
+        out[f"transformer.{tag}.x"] = x
+        out[f"transformer.{tag}.digest"] = np.array(synthetic.state_dict_digest(net.state_dict()))
+    c = presets.case("c1_default")
+    gps_cfg, rf_cfg = presets.build_configs(c, REF.gps.GPSBackboneConfig, REF.cfg.RouteformerConfig, REF.vbc.VideoBackboneConfig)
+    torch.manual_seed(0)
+    model = REF.rf.Routeformer(rf_cfg, gps_backbone=REF.gps.Transformer, video_backbone=None)
+    load_synth(model)
+    item = synthetic.synth_item(c["B"], c["T"], c["P"], DSEED, c["H"], c["W"], streams=c["streams"], gaze=c["gaze"])
+    model.train()
+    model.zero_grad()
+    res = ref_train_step(model, item, 0)
+    res["loss"].backward()
+    out["transformer.c1.train.future_gps"] = res["future_gps"]
+    out["transformer.c1.train.scalars"] = np.array([float(res[k]) for k in ("loss", "ade", "fde")])
+    out.update({f"transformer.c1.train.{k}": v for k, v in grad_summary(model, full=("gps_backbone.decoder.projection.bias",)).items()})
+
+    # (2) LinearWarmupCosineAnnealingLR as the driver steps it (full_comparison.py:702-709): one step per epoch
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_lr", f"{ref_bootstrap.REF}/routeformer/optimizers/lr_scheduler.py")
+    lrmod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lrmod)
+    for tag, (base, warm, mx, n) in {"driver": (1e-5, 2, 200, 205), "short": (3e-4, 5, 30, 70)}.items():
+        opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=base)
+        sch = lrmod.LinearWarmupCosineAnnealingLR(opt, warmup_epochs=warm, max_epochs=mx)
+        lrs = []
+        for _ in range(n):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        out[f"lr.{tag}"] = np.array(lrs, dtype=np.float64)
+        out[f"lr.{tag}.args"] = np.array([base, warm, mx, n], dtype=np.float64)
+
+    # (3) the evaluation protocol, ParallelTrainer._eval_step (full_comparison.py:654-679), call for call
+    for name in ("c1_default", "c2_small"):
+        c = presets.case(name)
+        model, cfg = build_ref_model(c)
+        load_synth(model)
+        model.eval()
+        item = synthetic.synth_item(c["B"], c["T"], c["P"], DSEED, c["H"], c["W"], streams=c["streams"], gaze=c["gaze"])
+        tl = REF.loss.FutureDiscountedLoss(cfg.discount_factor, cfg.epsilon, loss_function="smooth_l1")
+        tl.current_epoch = 0
+        log = []
+        with torch.no_grad(), record_randint(log):
+            torch.manual_seed(12345)
+            runs = []
+            for _ in range(5):
+                o = model(item["train"])
+                runs.append(o[0] if cfg.dense_prediction else o)
+            mean = torch.stack(runs).mean(dim=0)
+            tgt = item["target"]["gps"]
+            rows = [[float(tl(mean[i:i + 1], tgt[i:i + 1])), float(REF.score.ade(mean[i:i + 1], tgt[i:i + 1])),
+                     float(REF.score.fde(mean[i:i + 1], tgt[i:i + 1]))] for i in range(mean.shape[0])]
+        out[f"eval.{name}.mean_gps"] = mean
+        out[f"eval.{name}.rows"] = np.array(rows, dtype=np.float64)
+        out[f"eval.{name}.n_draws"] = np.array(len(log))
+        out.update({f"eval.{name}.{k}": v for k, v in pack_draws(log).items()})
+    save("widen", **out)
+
+
+GENERATORS = {"widen": gen_widen, "attention": gen_attention, "blocks": gen_blocks, "informer": gen_informer,
               "hrnet": gen_hrnet, "helpers": gen_helpers}
 
 if __name__ == "__main__":
