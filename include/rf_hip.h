@@ -84,10 +84,12 @@ int rf_conv3x3_bf16_supported(int cin, int cout);
 int rf_conv3x3_bf16(const float* x, const void* w_bf16, const float* bias, const float* residual, float* y,
                     int N, int H, int W, int cin, int cout, int relu, void* stream);
 
-/* Stem: frame gather + fp16->fp32 + conv0 (3->3, k2 s2, no BN; hrnetv2.py:292-293,432-433).
- * video: (B,T,3,H,W) fp16 (video_is_f32=0) or fp32 (=1); frame_idx[F] picks frames (routeformer.py:418-421);
+/* Stem: frame gather + cast + conv0 (3->3, k2 s2, no BN; hrnetv2.py:292-293,432-433).
+ * video: (B,T,3,H,W), video_dtype 0 = fp16 in [0,1] (what the dataset emits), 1 = fp32, 2 = raw uint8 camera
+ * bytes -- the dataset's `astype(float16) / 255` (io/dataset.py:1506-1523) is then applied on the fly, bit for
+ * bit, so clips can stay uint8 in HBM; frame_idx[F] picks frames (routeformer.py:418-421);
  * y: (B*F, H/2, W/2, 4) fp32 NHWC with a zero 4th channel. w: (3,3,2,2) as in the state dict. */
-int rf_stem_conv0(const void* video, int video_is_f32, const int32_t* frame_idx, const float* w,
+int rf_stem_conv0(const void* video, int video_dtype, const int32_t* frame_idx, const float* w,
                   float* y, int B, int T, int F, int H, int W, void* stream);
 
 /* y[n,ho,wo,c] = (accumulate ? y : 0) + (addend ? addend[n,ho,wo,c] : 0) + bilinear(x)[n,ho,wo,c]

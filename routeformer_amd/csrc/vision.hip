@@ -15,6 +15,9 @@ inline int grid_for(long total, int block = 256, int cap = 8192) {
 
 __device__ __forceinline__ float ldf(const __half* p) { return __half2float(*p); }
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
+// raw camera bytes: the dataset's `frame.astype(np.float16) / 255.0` (io/dataset.py:1506-1523) happens here --
+// quotient rounded to fp16 exactly as numpy's half division does (computed in fp32, stored as fp16)
+__device__ __forceinline__ float ldf(const uint8_t* p) { return __half2float(__float2half((float)*p / 255.0f)); }
 
 template <typename TIn>
 __global__ void stem_conv0_kernel(const TIn* __restrict__ video, const int32_t* __restrict__ fidx,
@@ -141,12 +144,15 @@ __global__ void adamw_clip_kernel(float* __restrict__ p, const float* __restrict
 
 }  // namespace
 
-extern "C" int rf_stem_conv0(const void* video, int video_is_f32, const int32_t* frame_idx, const float* w, float* y,
+extern "C" int rf_stem_conv0(const void* video, int video_dtype, const int32_t* frame_idx, const float* w, float* y,
                              int B, int T, int F, int H, int W, void* stream) {
   RF_REQUIRE(video && frame_idx && w && y && B > 0 && T > 0 && F > 0 && H > 1 && W > 1);
-  RF_REQUIRE(H % 2 == 0 && W % 2 == 0);
+  RF_REQUIRE(H % 2 == 0 && W % 2 == 0 && video_dtype >= 0 && video_dtype <= 2);
   const long total = (long)B * F * (H / 2) * (W / 2);
-  if (video_is_f32)
+  if (video_dtype == 2)
+    hipLaunchKernelGGL(stem_conv0_kernel<uint8_t>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint8_t*>(video), frame_idx, w, y, B, T, F, H, W);
+  else if (video_dtype == 1)
     hipLaunchKernelGGL(stem_conv0_kernel<float>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float*>(video), frame_idx, w, y, B, T, F, H, W);
   else

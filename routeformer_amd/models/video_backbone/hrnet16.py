@@ -274,7 +274,7 @@ class HRNet16Backbone(VideoBackboneModule):
         for v, fi in clips:
             if not v.is_cuda:
                 raise _hip.HipLibraryError("HRNet16Backbone runs on the GPU only; there is no CPU path")
-            v = (v if v.dtype in (torch.float16, torch.float32) else v.float()).contiguous()
+            v = (v if v.dtype in (torch.float16, torch.float32, torch.uint8) else v.float()).contiguous()
             B, T, C3, H, Wd = v.shape
             assert C3 == 3 and H % 2 == 0 and Wd % 2 == 0 and v.shape[3:] == clips[0][0].shape[3:]
             dev = v.device
@@ -293,7 +293,7 @@ class HRNet16Backbone(VideoBackboneModule):
         x = torch.empty(N, H // 2, Wd // 2, 4, device=dev, dtype=torch.float32)
         off = 0
         for v, fi, n in zip(vids, fidx, counts):
-            check(_hip.lib().rf_stem_conv0(ptr(v), 1 if v.dtype == torch.float32 else 0, ptr(fi), ptr(W["conv0"][0]),
+            check(_hip.lib().rf_stem_conv0(ptr(v), {torch.float16: 0, torch.float32: 1, torch.uint8: 2}[v.dtype], ptr(fi), ptr(W["conv0"][0]),
                                            x.data_ptr() + 4 * off * (H // 2) * (Wd // 2) * 4, v.shape[0], v.shape[1],
                                            fi.numel(), H, Wd, K._stream()), "rf_stem_conv0")
             off += n

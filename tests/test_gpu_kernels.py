@@ -392,6 +392,18 @@ def test_vision_helpers():
         _hip.check(_hip.lib().rf_stem_conv0(vid.data_ptr(), is32, idx_d.data_ptr(), w0_d.data_ptr(), y.data_ptr(),
                                             2, 5, 3, 16, 20, Kn._stream()), "stem")
         assert rel_err(y[..., :3], _nhwc(ref)) < 1e-5 and torch.all(y[..., 3] == 0)
+    # raw uint8 camera bytes: the dataset's `astype(np.float16) / 255.0` (io/dataset.py:1506-1523) fused into the
+    # stem must give EXACTLY what the fp16 path gives on the numpy-converted clip
+    raw = torch.randint(0, 256, (2, 5, 3, 16, 20), generator=g, dtype=torch.uint8)
+    as_f16 = torch.from_numpy(raw.numpy().astype(np.float16) / 255.0)
+    assert as_f16.dtype == torch.float16
+    y8, y16 = torch.empty_like(y), torch.empty_like(y)
+    raw_d, f16_d = raw.to(DEV), as_f16.to(DEV)
+    _hip.check(_hip.lib().rf_stem_conv0(raw_d.data_ptr(), 2, idx_d.data_ptr(), w0_d.data_ptr(), y8.data_ptr(), 2, 5, 3, 16,
+                                        20, Kn._stream()), "stem u8")
+    _hip.check(_hip.lib().rf_stem_conv0(f16_d.data_ptr(), 0, idx_d.data_ptr(), w0_d.data_ptr(), y16.data_ptr(), 2, 5, 3, 16,
+                                        20, Kn._stream()), "stem f16")
+    assert torch.equal(y8, y16)
 
 
 @pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16", 5e-2)])

@@ -362,3 +362,23 @@ def test_full_size_batch_consistency(case_name, B):
     for i in (0, B - 1):
         single = run({k: v[i:i + 1] for k, v in batch.items()}, 5)
         assert rel_err(single[0], full[i]) < 1e-4, (case_name, i)
+
+
+def test_uint8_clips_equal_fp16_clips():
+    """SURVEY 8(f) #3 (video ingest): a batch whose clips are raw uint8 frames gives bit-identical predictions to
+    the same batch converted the dataset's way (`astype(np.float16) / 255.0`, io/dataset.py:1506-1523)."""
+    from routeformer_amd.models.blocks import SAMPLER
+    model, cfg, sd, c = build_product_model("c2_small", DEV)
+    model.eval()
+    item = case_item(c)["train"]
+    g = torch.Generator().manual_seed(3)
+    raw = {k: torch.randint(0, 256, v.shape, generator=g, dtype=torch.uint8) for k, v in item.items() if k.endswith("_video")}
+    outs = []
+    for conv in (False, True):
+        batch = {k: v.to(DEV) for k, v in item.items() if not k.endswith("_video")}
+        for k, v in raw.items():
+            batch[k] = (torch.from_numpy(v.numpy().astype(np.float16) / 255.0) if conv else v).to(DEV)
+        torch.manual_seed(5)
+        with torch.no_grad():
+            outs.append(model(batch))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
