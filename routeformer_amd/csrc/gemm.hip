@@ -35,6 +35,7 @@ struct GemmP {
   float* ws;   // split-K partials [splits][M][N] (null: single pass with epilogue)
   int atomic;  // 1: C += partial via fp32 atomics (no other epilogue)
   unsigned* tile_cnt;  // split-K arrival counters (one per output tile, zero between launches) or null
+  int gx, gy, share;   // tile grid and XCD grouping of the launch (gemm2_kernel): 0 = plain, 1 = column tiles, 2 = row tiles
   float* a_rowsum;  // optional: a_rowsum[m] += sum_k A[m,k] (A row-contiguous)
   // implicit-GEMM conv (A mode 3): A is the NHWC input, row m = output pixel
   int cH, cW, cCin, cKs, cStride, cPad, cHo, cWo;
@@ -625,10 +626,28 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
   }
 }
 
+// XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order and each XCD has its
+// own L2.  share == 1 (few row tiles, big weight matrix -- the M <= 560 layers): all row tiles of one COLUMN
+// tile go to the same XCD, so a weight tile is fetched from HBM once instead of once per XCD that happens to
+// hold one of its row tiles.  share == 2 (tall activations / implicit-GEMM convs, few column tiles): all
+// column tiles of one ROW tile share an XCD, so the activation panel is fetched once.  The 1-D launch is padded
+// to a multiple of 8 groups; workgroups that fall outside the tile grid exit at once.
 template <int PREC, int AM, int BMODE, int CFG>
 __global__ __launch_bounds__(NT) void gemm2_kernel(GemmP p) {
-  gemm2_body<PREC, AM, BMODE, CFG>(p, BlockId{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x,
-                                              (int)gridDim.z});
+  int x, y;
+  const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+  if (p.share == 1) {
+    y = j % p.gy;
+    x = (j / p.gy) * 8 + xcd;
+  } else if (p.share == 2) {
+    x = j % p.gx;
+    y = (j / p.gx) * 8 + xcd;
+  } else {
+    x = id % p.gx;
+    y = id / p.gx;
+  }
+  if (x >= p.gx || y >= p.gy) return;
+  gemm2_body<PREC, AM, BMODE, CFG>(p, BlockId{x, y, (int)blockIdx.z, p.gx, (int)gridDim.z});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -671,8 +690,13 @@ template <int PREC, int AM, int BMODE, int CFG>
 void launch2(const GemmP& p, int splits, hipStream_t st) {
   using C_ = Cfg<CFG>;
   constexpr int BM = C_::WM * C_::TM * 16, BN = C_::WN * C_::TN * 16;
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, splits);
-  hipLaunchKernelGGL((gemm2_kernel<PREC, AM, BMODE, CFG>), grid, dim3(NT), 0, st, p);
+  GemmP q = p;
+  q.gx = (p.N + BN - 1) / BN;
+  q.gy = (p.M + BM - 1) / BM;
+  // which operand is worth keeping on one XCD?  the one whose panel is re-read by the other dimension's tiles
+  q.share = (q.gx >= 2 && q.gy >= 2) ? (q.gy <= q.gx ? 1 : 2) : 0;
+  const int blocks = q.share == 1 ? 8 * q.gy * ((q.gx + 7) / 8) : (q.share == 2 ? 8 * q.gx * ((q.gy + 7) / 8) : q.gx * q.gy);
+  hipLaunchKernelGGL((gemm2_kernel<PREC, AM, BMODE, CFG>), dim3(blocks, 1, splits), dim3(NT), 0, st, q);
 }
 
 template <int PREC>
