@@ -367,6 +367,9 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
   const int kbeg = blk.z * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int fr = lane & 15, fq = lane >> 4;
+  // the epilogue column of this thread and its bias: requested now, needed after the K loop
+  const int ecol = n0 + tid % BN;
+  const float bias_v = (p.bias && ecol < p.N) ? p.bias[ecol] : 0.f;
 
   f32x4 acc[C_::TM][C_::TN];
 #pragma unroll
@@ -546,41 +549,47 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
     __syncthreads();
   }
 
-  // four elements per trip: all their loads (LDS tile, bias, residual, activation source) are issued before
-  // the first dependent use, so one trip costs one memory latency, not four
-  auto finish4 = [&](float (&v)[4], const int (&m)[4], const int (&n)[4], const bool (&ok)[4]) {
-    float bs[4], rs[4], ds[4];
+  // Every element a thread finishes lies in ONE column (NT % BN == 0) at rows er0, er0 + RSTEP, ...: its bias
+  // was loaded at the top of the kernel, and the residual / activation-source loads of trip t + 1 are issued
+  // before trip t is computed -- the epilogue no longer pays one L2 latency per four elements.
+  constexpr int RSTEP = NT / BN, EPT = BM * BN / NT;
+  static_assert(NT % BN == 0 && EPT % 4 == 0, "tile must split into 4-element single-column trips");
+  const int er0 = tid / BN;
+  auto epi_inputs = [&](int k0, float (&rs)[4], float (&ds)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      bs[u] = (ok[u] && p.bias) ? p.bias[n[u]] : 0.f;
-      rs[u] = (ok[u] && p.res) ? p.res[(long)(m[u] % p.res_rows) * p.ldr + n[u]] : 0.f;
-      ds[u] = (ok[u] && p.dact) ? p.dsrc[(long)m[u] * p.ldd + n[u]] : 0.f;
+      const int m = m0 + er0 + (k0 + u) * RSTEP;
+      const bool ok = m < p.M && ecol < p.N;
+      rs[u] = (ok && p.res) ? p.res[(long)(m % p.res_rows) * p.ldr + ecol] : 0.f;
+      ds[u] = (ok && p.dact) ? p.dsrc[(long)m * p.ldd + ecol] : 0.f;
     }
+  };
+  auto finish_trip = [&](int k0, const float (&v)[4], const float (&rs)[4], const float (&ds)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (!ok[u]) continue;
-      float t = v[u] + bs[u];
+      const int m = m0 + er0 + (k0 + u) * RSTEP;
+      if (m >= p.M || ecol >= p.N) continue;
+      float t = v[u] + bias_v;
       if (p.res_before_act) t += rs[u];
-      if (p.preact) p.preact[(long)m[u] * p.ldp + n[u]] = t;
+      if (p.preact) p.preact[(long)m * p.ldp + ecol] = t;
       t = apply_act(t, p.act);
       if (p.dact) t *= act_grad(ds[u], p.dact);
       if (!p.res_before_act) t += rs[u];
-      p.C[(long)m[u] * p.ldc + n[u]] = t;
+      p.C[(long)m * p.ldc + ecol] = t;
     }
   };
-  static_assert((BM * BN) % (4 * NT) == 0, "tile must split into 4-element trips");
   if (mode == 0) {
+    float rs[4], ds[4], nrs[4] = {0.f, 0.f, 0.f, 0.f}, nds[4] = {0.f, 0.f, 0.f, 0.f};
+    epi_inputs(0, rs, ds);
 #pragma unroll 1
-    for (int e0 = tid; e0 < BM * BN; e0 += 4 * NT) {
-      float v[4]; int m[4], n[4]; bool ok[4];
+    for (int k0 = 0; k0 < EPT; k0 += 4) {
+      if (k0 + 4 < EPT) epi_inputs(k0 + 4, nrs, nds);
+      float v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u * NT, rr = e / BN, cc = e % BN;
-        m[u] = m0 + rr; n[u] = n0 + cc;
-        ok[u] = m[u] < p.M && n[u] < p.N;
-        v[u] = ct[rr * CP + cc];
-      }
-      finish4(v, m, n, ok);
+      for (int u = 0; u < 4; ++u) v[u] = ct[(er0 + (k0 + u) * RSTEP) * CP + tid % BN];
+      finish_trip(k0, v, rs, ds);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { rs[u] = nrs[u]; ds[u] = nds[u]; }
     }
   }
 
@@ -609,18 +618,17 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
       const int splits = blk.gz;
       const long slab = (long)p.M * p.N;
 #pragma unroll 1
-      for (int e0 = tid; e0 < BM * BN; e0 += 4 * NT) {
-        float v[4]; int m[4], n[4]; bool ok[4];
+      for (int k0 = 0; k0 < EPT; k0 += 4) {
+        float v[4], rs[4], ds[4];
+        epi_inputs(k0, rs, ds);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int e = e0 + u * NT;
-          m[u] = m0 + e / BN; n[u] = n0 + e % BN;
-          ok[u] = m[u] < p.M && n[u] < p.N;
+          const int m = m0 + er0 + (k0 + u) * RSTEP;
           v[u] = 0.f;
-          if (ok[u])
-            for (int z = 0; z < splits; ++z) v[u] += p.ws[z * slab + (long)m[u] * p.N + n[u]];
+          if (m < p.M && ecol < p.N)
+            for (int z = 0; z < splits; ++z) v[u] += p.ws[z * slab + (long)m * p.N + ecol];
         }
-        finish4(v, m, n, ok);
+        finish_trip(k0, v, rs, ds);
       }
     }
   }
