@@ -176,6 +176,19 @@ int rf_rowblock_ffn_ln(const float* x, const float* w1, const float* b1, const f
                        const float* ln_gamma, const float* ln_beta, float* xhat, float* rstd, float eps,
                        void* stream);
 
+/* Backward counterpart of the row-block kernels:  y[M,NOUT] = A[M,KC] w[KC,NOUT]  (w = the forward weight,
+ * out_features = KC rows: the dX product of nn.Linear / Conv1d(k=1)), epilogue: y *= act'(dact_src) when
+ * dact_mode != 0, then y += residual (the skip-branch gradient).  bf16-input MFMA only.
+ * With ln_dy != NULL (KC == 128) A is not read: it is the LayerNorm backward of (ln_dy, ln_xhat, ln_rstd,
+ * ln_gamma), written to dpre[M,128] in fp32 and used as bf16; dgamma / dbeta[128] += by fp32 atomics.
+ * Supported: ln: NOUT in {128, 256}; plain: KC in {128, 256, 384}, NOUT == 128. */
+int rf_rowblock_linear_nn_supported(int KC, int NOUT, int ln_bwd);
+int rf_rowblock_linear_nn(const float* a, int64_t lda, const float* ln_dy, const float* ln_xhat,
+                          const float* ln_rstd, const float* ln_gamma, float* dpre, float* dgamma,
+                          float* dbeta, const float* w, const float* residual, int64_t ldr,
+                          const float* dact_src, int64_t ldd, int dact_mode, float* y, int64_t ldy, int M,
+                          int KC, int NOUT, void* stream);
+
 /* Trajectory head = postprocess_batch (routeformer.py:367-374) + the loss recipe of the train step
  * (experiments/full_comparison.py:490-521, losses/future_discounted_mse.py:56-95, score/error.py:29,51):
  *   positions = last_gps + cumsum(out[...,:2] * motion_std + motion_mean)

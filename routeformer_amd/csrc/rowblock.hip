@@ -302,6 +302,174 @@ __global__ __launch_bounds__(NT) void rb_ffn_ln_kernel(FfnP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Backward counterpart: y[M, NOUT] = A[M, KC] W[KC, NOUT] (+ epilogue), W row-major as the forward weight
+// (out_features = KC rows, in_features = NOUT columns) -- the dX product of nn.Linear / Conv1d(k=1).  The
+// weight is staged TRANSPOSED into LDS ([n][k], bf16) so the B fragments are contiguous.
+//   LNBWD: A is not read but produced: the LayerNorm backward of the layer's norm (dy, x-hat, 1/sigma, gamma
+//          -> d pre-norm input), written out in fp32 (it is also the skip-branch gradient and the dW operand)
+//          and fed to the MFMAs as bf16; d gamma / d beta go to the gradient slots by fp32 atomics.
+//   epilogue: multiply by act'(dsrc) (FFN backward), add a residual (skip-branch gradient), coalesced stores.
+// One launch replaces LayerNorm-backward + dX GEMM (and its split-K reduce) of a d_model = 128 layer.
+// ---------------------------------------------------------------------------------------------------
+struct NnP {
+  const float* a; long lda;
+  const float* dy; const float* xhat; const float* rstd; const float* gamma;
+  float* dpre; float* dgamma; float* dbeta;
+  const float* w;
+  const float* res; long ldr;
+  const float* dsrc; long ldd; int dact;
+  float* y; long ldy;
+  int M;
+};
+
+__device__ __forceinline__ float quad_sumf(float v) {
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  return v;
+}
+
+template <int KC, int NOUT, bool LNBWD>
+__global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
+  static_assert(!LNBWD || KC == 128, "the LayerNorm-backward prologue works on 128-wide rows");
+  constexpr int LD = KC + 8, NJ = NOUT / 16, SPN = NOUT + 4;
+  constexpr int W_EL = NOUT * LD, STAGE_EL = RB * SPN * 2;
+  __shared__ __attribute__((aligned(16))) __bf16 smem[(W_EL > STAGE_EL ? W_EL : STAGE_EL) + RB * LD];
+  __shared__ float red[4][128];
+  __bf16* ws = smem;
+  __bf16* as = smem + (W_EL > STAGE_EL ? W_EL : STAGE_EL);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.x * RB;
+
+  // ---- A operand ----
+  if constexpr (LNBWD) {
+    const int r = tid >> 2, c0 = (tid & 3) * 32, m = m0 + r;
+    float g[32], xh[32];
+    float s1 = 0.f, s2 = 0.f;
+    const float rs = m < p.M ? p.rstd[m] : 0.f;
+#pragma unroll
+    for (int v4 = 0; v4 < 8; ++v4) {
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f), x = d;
+      if (m < p.M) {
+        d = *reinterpret_cast<const float4*>(p.dy + (long)m * 128 + c0 + v4 * 4);
+        x = *reinterpret_cast<const float4*>(p.xhat + (long)m * 128 + c0 + v4 * 4);
+      }
+      const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c0 + v4 * 4);
+      g[v4 * 4 + 0] = d.x * gm.x; g[v4 * 4 + 1] = d.y * gm.y; g[v4 * 4 + 2] = d.z * gm.z; g[v4 * 4 + 3] = d.w * gm.w;
+      xh[v4 * 4 + 0] = x.x; xh[v4 * 4 + 1] = x.y; xh[v4 * 4 + 2] = x.z; xh[v4 * 4 + 3] = x.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { s1 += g[i]; s2 += g[i] * xh[i]; }
+    const float m1 = quad_sumf(s1) * (1.f / 128.f), m2 = quad_sumf(s2) * (1.f / 128.f);
+#pragma unroll
+    for (int v4 = 0; v4 < 8; ++v4) {
+      float4 o;
+      o.x = rs * (g[v4 * 4 + 0] - m1 - xh[v4 * 4 + 0] * m2);
+      o.y = rs * (g[v4 * 4 + 1] - m1 - xh[v4 * 4 + 1] * m2);
+      o.z = rs * (g[v4 * 4 + 2] - m1 - xh[v4 * 4 + 2] * m2);
+      o.w = rs * (g[v4 * 4 + 3] - m1 - xh[v4 * 4 + 3] * m2);
+      if (m < p.M) *reinterpret_cast<float4*>(p.dpre + (long)m * 128 + c0 + v4 * 4) = o;
+      st_bf16x4(as + r * LD + c0 + v4 * 4, o);
+    }
+  } else {
+    Tile<RB, KC> ta;
+    ta.load(p.a, p.lda, m0, p.M, tid);
+    ta.store(as, tid);
+  }
+
+  // ---- W (KC x NOUT, row-major) -> LDS [n][k] ----
+  // a wave covers an 8 (k) x 32 (n) patch per trip: lane = (k & 7) + 8 * (n / 4): global reads are 128-B row
+  // segments, and the four transposed 2-byte LDS writes of a lane land 16 B apart within a group of 8 lanes
+  {
+    constexpr int TRIPS = KC * NOUT / 1024, KT = KC / 8;
+    const int kk = lane & 7, g4 = (lane >> 3) * 4;
+#pragma unroll 1
+    for (int s0 = 0; s0 < TRIPS; s0 += 8) {
+      float4 r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int T = wave + 4 * (s0 + u), k = (T % KT) * 8 + kk, n = (T / KT) * 32 + g4;
+        r[u] = *reinterpret_cast<const float4*>(p.w + (long)k * NOUT + n);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int T = wave + 4 * (s0 + u), k = (T % KT) * 8 + kk, n = (T / KT) * 32 + g4;
+        ws[(n + 0) * LD + k] = (__bf16)r[u].x;
+        ws[(n + 1) * LD + k] = (__bf16)r[u].y;
+        ws[(n + 2) * LD + k] = (__bf16)r[u].z;
+        ws[(n + 3) * LD + k] = (__bf16)r[u].w;
+      }
+    }
+  }
+  __syncthreads();
+
+  if constexpr (LNBWD) {
+    // d gamma / d beta: column sums over this block's rows (dy, x-hat re-read from L2, column-major work split)
+    const int c = tid & 127, half = tid >> 7;
+    float sb = 0.f, sg = 0.f;
+    for (int r = half * 32; r < half * 32 + 32; ++r) {
+      const int m = m0 + r;
+      if (m < p.M) {
+        const float d = p.dy[(long)m * 128 + c];
+        sb += d;
+        sg += d * p.xhat[(long)m * 128 + c];
+      }
+    }
+    red[half][c] = sb;
+    red[2 + half][c] = sg;
+  }
+
+  f32x4 acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  mma_rows<KC, NJ>(acc, as + wave * 16 * LD, ws, lane);
+  __syncthreads();  // weights dead: their LDS becomes the output staging tile; `red` complete
+
+  if constexpr (LNBWD) {
+    if (tid < 128) {
+      atomicAdd(p.dbeta + tid, red[0][tid] + red[1][tid]);
+      atomicAdd(p.dgamma + tid, red[2][tid] + red[3][tid]);
+    }
+  }
+
+  // ---- epilogue through the staging tile: row-contiguous float4 work ----
+  float* st = reinterpret_cast<float*>(smem) + wave * 16 * SPN;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * SPN + j * 16 + fr] = acc[j][r];
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  constexpr int V4R = NOUT / 4;  // float4 per row
+#pragma unroll 1
+  for (int it = 0; it < 16 * V4R / 64; it += 2) {
+    float4 o[2], rz[2], dz[2];
+    int mrow[2], col[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = (it + u) * 64 + lane, rr = i / V4R;
+      col[u] = (i % V4R) * 4;
+      mrow[u] = m0 + wave * 16 + rr;
+      o[u] = *reinterpret_cast<const float4*>(st + rr * SPN + col[u]);
+      rz[u] = dz[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mrow[u] < p.M) {
+        if (p.res) rz[u] = *reinterpret_cast<const float4*>(p.res + (long)mrow[u] * p.ldr + col[u]);
+        if (p.dact) dz[u] = *reinterpret_cast<const float4*>(p.dsrc + (long)mrow[u] * p.ldd + col[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (mrow[u] >= p.M) continue;
+      if (p.dact) {
+        o[u].x *= act_grad(dz[u].x, p.dact); o[u].y *= act_grad(dz[u].y, p.dact);
+        o[u].z *= act_grad(dz[u].z, p.dact); o[u].w *= act_grad(dz[u].w, p.dact);
+      }
+      o[u].x += rz[u].x; o[u].y += rz[u].y; o[u].z += rz[u].z; o[u].w += rz[u].w;
+      *reinterpret_cast<float4*>(p.y + (long)mrow[u] * p.ldy + col[u]) = o[u];
+    }
+  }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -339,6 +507,36 @@ extern "C" int rf_rowblock_ffn_ln(const float* x, const float* w1, const float* 
   RF_REQUIRE(al16(x) && al16(w1) && al16(w2) && al16(y) && (!xhat || (rstd && al16(xhat))));
   FfnP p{x, w1, b1, w2, b2, h, z, y, M, act, ln_gamma, ln_beta, xhat, rstd, eps};
   hipLaunchKernelGGL(rb_ffn_ln_kernel, dim3((M + RB - 1) / RB), dim3(NT), 0, static_cast<hipStream_t>(stream), p);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_rowblock_linear_nn_supported(int KC, int NOUT, int ln_bwd) {
+  if (ln_bwd) return KC == 128 && (NOUT == 128 || NOUT == 256);
+  return (KC == 128 || KC == 256 || KC == 384) && NOUT == 128;
+}
+
+extern "C" int rf_rowblock_linear_nn(const float* a, int64_t lda, const float* ln_dy, const float* ln_xhat,
+                                     const float* ln_rstd, const float* ln_gamma, float* dpre, float* dgamma,
+                                     float* dbeta, const float* w, const float* residual, int64_t ldr,
+                                     const float* dact_src, int64_t ldd, int dact_mode, float* y, int64_t ldy, int M,
+                                     int KC, int NOUT, void* stream) {
+  const bool ln = ln_dy != nullptr;
+  RF_REQUIRE(w && y && M > 0 && rf_rowblock_linear_nn_supported(KC, NOUT, ln));
+  RF_REQUIRE(ln ? (ln_xhat && ln_rstd && ln_gamma && dpre && dgamma && dbeta && al16(ln_dy) && al16(ln_xhat) &&
+                   al16(ln_gamma) && al16(dpre))
+                : (a && al16(a) && lda % 4 == 0));
+  RF_REQUIRE(al16(w) && al16(y) && ldy % 4 == 0 && (!residual || (al16(residual) && ldr % 4 == 0)));
+  RF_REQUIRE(!dact_mode || (dact_src && al16(dact_src) && ldd % 4 == 0));
+  NnP p{a, lda, ln_dy, ln_xhat, ln_rstd, ln_gamma, dpre, dgamma, dbeta, w, residual, ldr,
+        dact_mode ? dact_src : nullptr, ldd, dact_mode, y, ldy, M};
+  dim3 grid((M + RB - 1) / RB);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (ln && NOUT == 128) hipLaunchKernelGGL((rb_nn_kernel<128, 128, true>), grid, dim3(NT), 0, st, p);
+  else if (ln) hipLaunchKernelGGL((rb_nn_kernel<128, 256, true>), grid, dim3(NT), 0, st, p);
+  else if (KC == 128) hipLaunchKernelGGL((rb_nn_kernel<128, 128, false>), grid, dim3(NT), 0, st, p);
+  else if (KC == 256) hipLaunchKernelGGL((rb_nn_kernel<256, 128, false>), grid, dim3(NT), 0, st, p);
+  else hipLaunchKernelGGL((rb_nn_kernel<384, 128, false>), grid, dim3(NT), 0, st, p);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

@@ -391,6 +391,35 @@ def _rowblock_linear(x2, w, b, r2, y, M, N, K, ln=None, xhat=None, rstd=None, ep
                     replay=lambda a=args, k=keep: _hip.lib().rf_rowblock_linear(*a, _stream()))
 
 
+def _rowblock_nn_ok(w2d, ln: bool = False) -> bool:
+    """Can dX = dY w (w = forward weight (out, in), contiguous) run as the row-block NN kernel?"""
+    if not (ROWBLOCK and _PRECISION == 1 and w2d.is_cuda and w2d.is_contiguous() and w2d.data_ptr() % 16 == 0):
+        return False
+    return bool(_hip.lib().rf_rowblock_linear_nn_supported(w2d.shape[0], w2d.shape[1], 1 if ln else 0))
+
+
+def _rowblock_nn(w2d, M, *, a=None, ln=None, dpre=None, dgam=None, dbet=None, res=None, dsrc=None, dact=0):
+    """-> y (M, in_features).  ``ln`` = (dy2, xhat, rstd, gamma): LayerNorm-backward prologue (writes ``dpre``)."""
+    KC, NOUT = w2d.shape
+    y = torch.empty(M, NOUT, device=w2d.device, dtype=torch.float32)
+    ev = PROFILE.begin() if PROFILE.on else None
+    args = (ptr(a), a.stride(0) if a is not None else 0, ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None,
+            ptr(ln[2]) if ln else None, ptr(ln[3]) if ln else None, ptr(dpre), ptr(dgam), ptr(dbet), ptr(w2d), ptr(res),
+            res.stride(0) if res is not None else 0, ptr(dsrc), dsrc.stride(0) if dsrc is not None else 0, dact, ptr(y),
+            NOUT, M, KC, NOUT)
+    check(_hip.lib().rf_rowblock_linear_nn(*args, _stream()), "rf_rowblock_linear_nn")
+    if ev is not None:
+        keep = (a, ln, dpre, dgam, dbet, w2d, res, dsrc, y)
+        lnbwd = "true" if ln else "false"
+        PROFILE.end(f"rb_nn_kernel<{KC}, {NOUT}, {lnbwd}>", ev, 2.0 * M * KC * NOUT,
+                    4.0 * (M * KC * (3 if ln else 1) + KC * NOUT + M * NOUT * (1 + (res is not None) + (dsrc is not None))))
+    return y
+
+
+def _vec_rows(t, cols) -> bool:
+    return t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and t.shape[1] == cols
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b (+ residual rows broadcast over the batch: y[m] += residual[m % R])."""
 
@@ -446,12 +475,16 @@ class _Linear(torch.autograd.Function):
             if ctx.has_bias and not fused_bias and (gb is not None or ctx.needs_input_grad[2]):
                 db = colsum(dy2, into=gb)
         if ctx.needs_input_grad[0]:
+            ds2 = None
             if dskip is not None:
                 K_ = w.shape[1]
                 ds2 = dskip.reshape(-1, K_)
                 if ds2.stride(1) != 1 or ds2.stride(0) != K_:
                     ds2 = ds2.contiguous()
-                dx = _input_grad(dy2, w, residual=ds2, ldr=K_, res_rows=ds2.shape[0]).view(ctx.xshape)
+            if _rowblock_nn_ok(w) and _vec_rows(dy2, w.shape[0]) and (ds2 is None or ds2.data_ptr() % 16 == 0):
+                dx = _rowblock_nn(w, dy2.shape[0], a=dy2, res=ds2).view(ctx.xshape)
+            elif ds2 is not None:
+                dx = _input_grad(dy2, w, residual=ds2, ldr=ds2.shape[1], res_rows=ds2.shape[0]).view(ctx.xshape)
             else:
                 dx = _input_grad(dy2, w).view(ctx.xshape)
         _wrote(gw, gb)
@@ -628,7 +661,16 @@ class _LinearAddLN(torch.autograd.Function):
         gw, gb, gg, gbeta = ctx.sinks
         M, N = xhat.shape
         dy2 = dy.reshape(M, N).contiguous()
-        dpre, dgam, dbet = _ln_backward(dy2, xhat, rstd, gamma, gg, gbeta)
+        da = None
+        sink = gg is not None and gbeta is not None and not DETERMINISTIC
+        if sink and ctx.needs_input_grad[0] and _rowblock_nn_ok(w, ln=True) and dy2.data_ptr() % 16 == 0:
+            # LayerNorm backward + dX of the out-projection in one launch
+            dpre = torch.empty_like(xhat)
+            da = _rowblock_nn(w, M, ln=(dy2, xhat, rstd, gamma), dpre=dpre, dgam=gg, dbet=gbeta).view(ctx.shapes[0])
+            _wrote(gg, gbeta)
+            dgam = dbet = None
+        else:
+            dpre, dgam, dbet = _ln_backward(dy2, xhat, rstd, gamma, gg, gbeta)
         dw = db = None
         fused_bias = False
         if gw is not None:
@@ -637,7 +679,8 @@ class _LinearAddLN(torch.autograd.Function):
             dw = _weight_grad(dpre, a2)
         if not fused_bias:
             db = colsum(dpre, into=gb)
-        da = _input_grad(dpre, w).view(ctx.shapes[0]) if ctx.needs_input_grad[0] else None
+        if da is None and ctx.needs_input_grad[0]:
+            da = _input_grad(dpre, w).view(ctx.shapes[0])
         _wrote(gw, gb)
         return da, dw, db, dpre.view(ctx.shapes[1]), dgam, dbet, None, None, None, None, None, None
 
@@ -690,10 +733,19 @@ class _FFNAddLN(torch.autograd.Function):
         M, D = x2.shape
         F = w1.shape[0]
         dy2 = dy.reshape(M, D).contiguous()
-        dpre, dgam, dbet = _ln_backward(dy2, xhat, rstd, gamma, gg, gbeta)
+        sink = gg is not None and gbeta is not None and not DETERMINISTIC
+        fused = sink and _rowblock_nn_ok(w2, ln=True) and _rowblock_nn_ok(w1) and dy2.data_ptr() % 16 == 0
+        if fused:  # LayerNorm backward + (dPre W2) * act'(z) in one launch
+            dpre = torch.empty_like(xhat)
+            dz = _rowblock_nn(w2, M, ln=(dy2, xhat, rstd, gamma), dpre=dpre, dgam=gg, dbet=gbeta, dsrc=zsrc,
+                              dact=ACT[ctx.act])
+            _wrote(gg, gbeta)
+            dgam = dbet = None
+        else:
+            dpre, dgam, dbet = _ln_backward(dy2, xhat, rstd, gamma, gg, gbeta)
+            dz = _input_grad(dpre, w2, dact_src=zsrc, ldd=zsrc.stride(0), dact=ACT[ctx.act])
         dw2 = _weight_grad(dpre, h, into=None if g2 is None else g2.view(D, F), bias_into=gb2)
         db2 = None if dw2 is True else colsum(dpre, into=gb2)
-        dz = _input_grad(dpre, w2, dact_src=zsrc, ldd=zsrc.stride(0), dact=ACT[ctx.act])
         dw1 = _weight_grad(dz, x2, into=None if g1 is None else g1.view(F, D), bias_into=gb1)
         db1 = None if dw1 is True else colsum(dz, into=gb1)
         if dw1 is True or dw1 is False:
@@ -701,7 +753,10 @@ class _FFNAddLN(torch.autograd.Function):
         if dw2 is True or dw2 is False:
             dw2 = None
         # dX = dZ W1 + d(pre-norm)  -- the residual branch rides in the GEMM epilogue, no separate add
-        dx = _input_grad(dz, w1, residual=dpre, ldr=D, res_rows=M).view(ctx.xshape)
+        if fused:
+            dx = _rowblock_nn(w1, M, a=dz, res=dpre).view(ctx.xshape)
+        else:
+            dx = _input_grad(dz, w1, residual=dpre, ldr=D, res_rows=M).view(ctx.xshape)
         _wrote(g1, gb1, g2, gb2)
         if dw1 is not None:
             dw1, dw2 = dw1.view(F, D, 1), dw2.view(D, F, 1)

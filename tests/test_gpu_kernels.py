@@ -538,6 +538,55 @@ def test_rowblock_ffn_ln(M, act):
     assert rel_err(xhat, (want - bet) / gam) < 2e-3
 
 
+@pytest.mark.parametrize("M,KC,NOUT,ln,res,dact", [(12480, 384, 128, False, True, 0), (325, 128, 128, False, False, 0),
+                                                   (70, 256, 128, False, True, 0), (325, 128, 128, True, False, 0),
+                                                   (12480, 128, 256, True, False, 2), (7, 128, 256, True, False, 1)])
+def test_rowblock_linear_nn(M, KC, NOUT, ln, res, dact):
+    """dX row-block kernel: y = A W (* act'(src)) (+ res), optionally with the LayerNorm-backward prologue, vs
+    torch on bf16-rounded operands (A and W are rounded while staged; everything else is fp32)."""
+    from routeformer_amd import _hip
+    from routeformer_amd._hip import ptr
+    g = _g(41)
+    w = torch.randn(KC, NOUT, generator=g) / math.sqrt(KC)
+    r = torch.randn(M, NOUT, generator=g) if res else None
+    src = torch.randn(M, NOUT, generator=g) if dact else None
+    dev = lambda v: None if v is None else v.to(DEV)
+    y = torch.full((M, NOUT), float("nan"), device=DEV)
+    wd, rd, sd_ = dev(w), dev(r), dev(src)
+    st = torch.cuda.current_stream().cuda_stream
+    if ln:
+        dy = torch.randn(M, 128, generator=g); xhat = torch.randn(M, 128, generator=g)
+        rstd = torch.rand(M, generator=g) + 0.5; gam = torch.rand(128, generator=g) + 0.5
+        gg = dy * gam
+        a = rstd[:, None] * (gg - gg.mean(-1, keepdim=True) - xhat * (gg * xhat).mean(-1, keepdim=True))
+        dg0, db0 = torch.randn(128, generator=g), torch.randn(128, generator=g)
+        t_ = [dev(v) for v in (dy, xhat, rstd, gam, dg0, db0)]
+        dpre = torch.empty(M, 128, device=DEV)
+        rc = _hip.lib().rf_rowblock_linear_nn(None, 0, ptr(t_[0]), ptr(t_[1]), ptr(t_[2]), ptr(t_[3]), ptr(dpre), ptr(t_[4]),
+                                              ptr(t_[5]), ptr(wd), ptr(rd), NOUT if res else 0, ptr(sd_), NOUT if dact else 0,
+                                              dact, ptr(y), NOUT, M, KC, NOUT, st)
+        assert rc == 0, _hip.lib().rf_last_error()
+        assert rel_err(dpre, a) < 2e-5
+        assert rel_err(t_[4], dg0 + (dy * xhat).sum(0)) < 2e-5 and rel_err(t_[5], db0 + dy.sum(0)) < 2e-5
+    else:
+        a = torch.randn(M, KC, generator=g)
+        ad = dev(a)
+        rc = _hip.lib().rf_rowblock_linear_nn(ptr(ad), KC, None, None, None, None, None, None, None, ptr(wd), ptr(rd),
+                                              NOUT if res else 0, ptr(sd_), NOUT if dact else 0, dact, ptr(y), NOUT, M, KC,
+                                              NOUT, st)
+        assert rc == 0, _hip.lib().rf_last_error()
+    want = _bf(a) @ _bf(w)
+    if dact == 1:
+        want = want * (src > 0).float()
+    elif dact == 2:
+        cdf = 0.5 * (1 + torch.erf(src / math.sqrt(2.0)))
+        want = want * (cdf + src * torch.exp(-0.5 * src * src) / math.sqrt(2 * math.pi))
+    if res:
+        want = want + r
+    # the LN prologue feeds the MFMA with bf16(dpre) computed on the device: a 1-ulp bf16 flip of an operand
+    assert rel_err(y, want) < (2e-3 if ln else 1e-4)
+
+
 @pytest.mark.parametrize("M", [325, 1280])
 def test_rowblock_layer_ops_match_unfused(M):
     """linear_add_layer_norm / ffn_add_layer_norm (row-block launches) vs the unfused bf16 path: outputs and
