@@ -91,6 +91,21 @@ __device__ __forceinline__ void load_head(float* S, const float* G, long ld, int
   }
 }
 
+// (row, col) of a flattened index that advances by the workgroup size: two integer divisions when the
+// iterator is built instead of one per trip (integer division is ~25 VALU instructions on CDNA and these
+// kernels are instruction-bound: ~1.7k VALU instructions per wave measured)
+struct RowCol {
+  int r, c, dr, dc, w;
+  __device__ __forceinline__ RowCol(int start, int step, int width) : w(width) {
+    r = start / width; c = start - r * width;
+    dr = step / width; dc = step - dr * width;
+  }
+  __device__ __forceinline__ void next() {
+    r += dr; c += dc;
+    if (c >= w) { c -= w; ++r; }
+  }
+};
+
 // Q, K and V head slices in one go: every global load of the three slices is issued before the first LDS
 // store (one memory round trip for the whole prologue instead of one per slice and loop trip).
 template <bool V4>
@@ -103,9 +118,13 @@ __device__ __forceinline__ void load_qkv(float* Qs, float* Ks, float* Vs, const 
       const float* kb = p.k + (long)b * p.LK * p.k_ld + (long)h * p.E;
       const float* vb = p.v + (long)b * p.LK * p.v_ld + (long)h * p.E;
       float4 rq[3], rk[3], rv[3];
+      int ls[3], es[3];
+      RowCol it(tid, nt, E4);
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
-        const int i = tid + u * nt, l = i / E4, e = (i - l * E4) << 2;
+        const int i = tid + u * nt, l = it.r, e = it.c << 2;
+        ls[u] = l; es[u] = e;
+        it.next();
         if (i < nq) rq[u] = *reinterpret_cast<const float4*>(qb + (long)l * p.q_ld + e);
         if (i < nk) {
           rk[u] = *reinterpret_cast<const float4*>(kb + (long)l * p.k_ld + e);
@@ -114,7 +133,7 @@ __device__ __forceinline__ void load_qkv(float* Qs, float* Ks, float* Vs, const 
       }
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
-        const int i = tid + u * nt, l = i / E4, e = (i - l * E4) << 2;
+        const int i = tid + u * nt, l = ls[u], e = es[u];
         if (i < nq) *reinterpret_cast<float4*>(Qs + l * EP + e) = rq[u];
         if (i < nk) {
           *reinterpret_cast<float4*>(Ks + l * EP + e) = rk[u];
@@ -284,10 +303,9 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
       __syncthreads();
     } else {
       // (1) sampled scores Q[q].K[idx[q,j]] (one table per group of `idx_group` consecutive batch rows)
-      for (int i = tid; i < LQ * p.sample_k; i += (int)blockDim.x) {
-        const int q = i / p.sample_k;
-        S[i] = dot_rows<V4>(Qs + q * EP, Ks + Sidx[i] * EP, E);
-      }
+      RowCol qs(tid, blockDim.x, p.sample_k);
+      for (int i = tid; i < LQ * p.sample_k; i += (int)blockDim.x, qs.next())
+        S[i] = dot_rows<V4>(Qs + qs.r * EP, Ks + Sidx[i] * EP, E);
       __syncthreads();
       RF_MARK(2);
       for (int q = tid; q < LQ; q += (int)blockDim.x) {
@@ -331,9 +349,12 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
         }
       }
       __syncthreads();
-      for (int i = tid; i < LQ * E; i += (int)blockDim.x) {
-        const int ql = i / E, d = i - ql * E;
-        if (sel[ql] < 0) p.ctx[ctx_off(p, b, h, ql) + d] = vmean[d];
+      {
+        RowCol rc(tid, blockDim.x, E);
+        const long row_step = p.out_layout == 0 ? (long)p.H * E : (long)E;
+        float* base = p.ctx + ctx_off(p, b, h, 0);
+        for (int i = tid; i < LQ * E; i += (int)blockDim.x, rc.next())
+          if (sel[rc.r] < 0) base[rc.r * row_step + rc.c] = vmean[rc.c];
       }
     } else {
       for (int d = tid; d < E; d += (int)blockDim.x) {
@@ -430,10 +451,15 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   }
   __syncthreads();
   const float* qbase = p.q + (long)b * LQ * p.q_ld + (long)h * E;
-  for (int i = tid; i < n_sel * E; i += (int)blockDim.x) {
-    const int si = i / E, e = i - si * E, q = top_list[si];
-    Qsel[si * EP + e] = qbase[(long)q * p.q_ld + e];
-    dCsel[si * EP + e] = p.dctx[ctx_off(p, b, h, q) + e];
+  {
+    RowCol rc(tid, blockDim.x, E);
+    const long row_step = p.out_layout == 0 ? (long)p.H * E : (long)E;
+    const float* dbase = p.dctx + ctx_off(p, b, h, 0);
+    for (int i = tid; i < n_sel * E; i += (int)blockDim.x, rc.next()) {
+      const int q = top_list[rc.r];
+      Qsel[rc.r * EP + rc.c] = qbase[(long)q * p.q_ld + rc.c];
+      dCsel[rc.r * EP + rc.c] = dbase[q * row_step + rc.c];
+    }
   }
   __syncthreads();
 
@@ -502,9 +528,11 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
       p.dq[((long)b * LQ + q) * p.dq_ld + (long)h * E + e] = a;
     }
   }
-  for (int i = tid; i < LQ * E; i += (int)blockDim.x) {
-    const int q = i / E, e = i - q * E;
-    if (sel[q] < 0) p.dq[((long)b * LQ + q) * p.dq_ld + (long)h * E + e] = 0.f;
+  {
+    RowCol rc(tid, blockDim.x, E);
+    float* qb_ = p.dq + (long)b * LQ * p.dq_ld + (long)h * E;
+    for (int i = tid; i < LQ * E; i += (int)blockDim.x, rc.next())
+      if (sel[rc.r] < 0) qb_[(long)rc.r * p.dq_ld + rc.c] = 0.f;
   }
   // lazy-row gradient source: column sums of dctx over NON-selected rows (unmasked mode)
   if (p.mode == 1) {

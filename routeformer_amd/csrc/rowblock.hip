@@ -103,6 +103,22 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// d/dx of erf-GELU = Phi(x) + x phi(x), same erf approximation (abs error <= ~2e-7), exp through v_exp_f32
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+  const float u = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = __expf(-u * u);  // = exp(-x^2 / 2)
+  const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * t * e, x));
+  return fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+__device__ __forceinline__ float act_grad_fast(float src, int mode) {
+  return mode == RF_ACT_GELU ? gelu_grad_fast(src) : act_grad(src, mode);
+}
+
 // LayerNorm over the 128 columns a wave holds for each of its rows (two-pass, biased variance, as nn.LayerNorm)
 __device__ __forceinline__ void layer_norm_rows(f32x4 (&v)[8], f32x4 (&y)[8], const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, float eps, float (&rstd)[4], int lane) {
@@ -461,8 +477,8 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
     for (int u = 0; u < 2; ++u) {
       if (mrow[u] >= p.M) continue;
       if (p.dact) {
-        o[u].x *= act_grad(dz[u].x, p.dact); o[u].y *= act_grad(dz[u].y, p.dact);
-        o[u].z *= act_grad(dz[u].z, p.dact); o[u].w *= act_grad(dz[u].w, p.dact);
+        o[u].x *= act_grad_fast(dz[u].x, p.dact); o[u].y *= act_grad_fast(dz[u].y, p.dact);
+        o[u].z *= act_grad_fast(dz[u].z, p.dact); o[u].w *= act_grad_fast(dz[u].w, p.dact);
       }
       o[u].x += rz[u].x; o[u].y += rz[u].y; o[u].z += rz[u].z; o[u].w += rz[u].w;
       *reinterpret_cast<float4*>(p.y + (long)mrow[u] * p.ldy + col[u]) = o[u];
