@@ -120,9 +120,8 @@ __device__ __forceinline__ float act_grad_fast(float src, int mode) {
 }
 
 // LayerNorm over the 128 columns a wave holds for each of its rows (two-pass, biased variance, as nn.LayerNorm)
-__device__ __forceinline__ void layer_norm_rows(f32x4 (&v)[8], f32x4 (&y)[8], const float* __restrict__ gamma,
-                                                const float* __restrict__ beta, float eps, float (&rstd)[4], int lane) {
-  const int fr = lane & 15;
+__device__ __forceinline__ void layer_norm_rows(f32x4 (&v)[8], f32x4 (&y)[8], const float (&gam)[8],
+                                                const float (&bet)[8], float eps, float (&rstd)[4]) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float s = 0.f;
@@ -137,11 +136,9 @@ __device__ __forceinline__ void layer_norm_rows(f32x4 (&v)[8], f32x4 (&y)[8], co
     for (int j = 0; j < 8; ++j) v[j][r] = (v[j][r] - mean) * rstd[r];  // v becomes x-hat
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float g = gamma[j * 16 + fr], b = beta[j * 16 + fr];
+  for (int j = 0; j < 8; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) y[j][r] = v[j][r] * g + b;
-  }
+    for (int r = 0; r < 4; ++r) y[j][r] = v[j][r] * gam[j] + bet[j];
 }
 
 struct LinP {
@@ -172,29 +169,36 @@ __global__ __launch_bounds__(NT) void rb_linear_kernel(LinP p) {
   tw.store(ws, tid);
   __syncthreads();
 
+  // epilogue operands are requested before the matrix work: their latency hides behind it
+  float bv[8], gam[8], bet[8];
+  f32x4 rv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = n0 + j * 16 + fr;
+    bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    if constexpr (LN) { gam[j] = p.gamma[j * 16 + fr]; bet[j] = p.beta[j * 16 + fr]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wave * 16 + fq * 4 + r;
+      rv[j][r] = (p.res && m < p.M && n < p.N) ? p.res[(long)m * p.ldr + n] : 0.f;
+    }
+  }
+
   f32x4 acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   mma_rows<KC, 8>(acc, xs + wave * 16 * LD, ws, lane);
 
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int n = n0 + j * 16 + fr;
-    const float b = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+  for (int j = 0; j < 8; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wave * 16 + fq * 4 + r;
-      float v = acc[j][r] + b;
-      if (p.res && m < p.M && n < p.N) v += p.res[(long)m * p.ldr + n];
-      acc[j][r] = v;
-    }
-  }
+    for (int r = 0; r < 4; ++r) acc[j][r] += bv[j] + rv[j][r];
   __syncthreads();  // every wave is done with the weights: their LDS becomes the output staging tile
   float* stage_w = reinterpret_cast<float*>(smem) + wave * 16 * SP;
   if constexpr (LN) {
     f32x4 y[8];
     float rstd[4];
-    layer_norm_rows(acc, y, p.gamma, p.beta, p.eps, rstd, lane);
+    layer_norm_rows(acc, y, gam, bet, p.eps, rstd);
     store_rows(y, stage_w, p.y, p.ldy, m0 + wave * 16, p.M, 0, 128, lane);
     if (p.xhat) {
       store_rows(acc, stage_w, p.xhat, 128, m0 + wave * 16, p.M, 0, 128, lane);
@@ -249,6 +253,9 @@ __global__ __launch_bounds__(NT) void rb_ffn_ln_kernel(FfnP p) {
   // wave-private fp32 LDS tile so that bias + activation exist once in a rolled loop (code stays small: the
   // instruction cache is 64 KB) and z / h leave as row-contiguous 256-B stores
   float* zt = zs + wave * 16 * 68;
+  float b1v[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) b1v[c] = p.b1[c * 64 + lane];
 #pragma unroll 1
   for (int c = 0; c < 4; ++c) {
     f32x4 a1[4];
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(NT) void rb_ffn_ln_kernel(FfnP p) {
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int f = c * 64 + lane;
-    const float b = p.b1[f];
+    const float b = c == 0 ? b1v[0] : (c == 1 ? b1v[1] : (c == 2 ? b1v[2] : b1v[3]));
 #pragma unroll 1
     for (int r0 = 0; r0 < 16; r0 += 4) {
       float zz[4];
@@ -284,6 +291,19 @@ __global__ __launch_bounds__(NT) void rb_ffn_ln_kernel(FfnP p) {
   }
   __syncthreads();  // W1 dead everywhere, hs complete
   t2.store(wb, tid);
+  // epilogue operands (bias, exact fp32 residual, norm parameters) are requested now, used after the MFMAs
+  float b2v[8], gam[8], bet[8];
+  f32x4 xres[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = j * 16 + fr;
+    b2v[j] = p.b2[n]; gam[j] = p.gamma[n]; bet[j] = p.beta[n];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wave * 16 + fq * 4 + r;
+      xres[j][r] = m < p.M ? p.x[(long)m * D + n] : 0.f;
+    }
+  }
   __syncthreads();
 
   f32x4 acc[8];
@@ -291,20 +311,14 @@ __global__ __launch_bounds__(NT) void rb_ffn_ln_kernel(FfnP p) {
   for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   mma_rows<F, 8>(acc, hs + wave * 16 * LDH, wb, lane);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int n = j * 16 + fr;
-    const float b = p.b2[n];
+  for (int j = 0; j < 8; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wave * 16 + fq * 4 + r;
-      acc[j][r] += b + (m < p.M ? p.x[(long)m * D + n] : 0.f);  // exact fp32 residual
-    }
-  }
+    for (int r = 0; r < 4; ++r) acc[j][r] += b2v[j] + xres[j][r];
   __syncthreads();
   float* stage_w = reinterpret_cast<float*>(smem) + wave * 16 * SP;
   f32x4 y[8];
   float rstd[4];
-  layer_norm_rows(acc, y, p.gamma, p.beta, p.eps, rstd, lane);
+  layer_norm_rows(acc, y, gam, bet, p.eps, rstd);
   store_rows(y, stage_w, p.y, D, m0 + wave * 16, p.M, 0, D, lane);
   if (p.xhat) {
     store_rows(acc, stage_w, p.xhat, D, m0 + wave * 16, p.M, 0, D, lane);
@@ -399,14 +413,14 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
   {
     constexpr int TRIPS = KC * NOUT / 1024, KT = KC / 8;
     const int kk = lane & 7, g4 = (lane >> 3) * 4;
-#pragma unroll 1
-    for (int s0 = 0; s0 < TRIPS; s0 += 8) {
-      float4 r[8];
+    auto wload = [&](float4 (&r)[8], int s0) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int T = wave + 4 * (s0 + u), k = (T % KT) * 8 + kk, n = (T / KT) * 32 + g4;
         r[u] = *reinterpret_cast<const float4*>(p.w + (long)k * NOUT + n);
       }
+    };
+    auto wstore = [&](const float4 (&r)[8], int s0) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int T = wave + 4 * (s0 + u), k = (T % KT) * 8 + kk, n = (T / KT) * 32 + g4;
@@ -415,6 +429,16 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
         ws[(n + 2) * LD + k] = (__bf16)r[u].z;
         ws[(n + 3) * LD + k] = (__bf16)r[u].w;
       }
+    };
+    // two register batches: the loads of batch t + 1 are in flight while batch t is transposed into LDS
+    float4 ra[8], rb[8];
+    wload(ra, 0);
+#pragma unroll 1
+    for (int s0 = 0; s0 < TRIPS; s0 += 16) {
+      if (s0 + 8 < TRIPS) wload(rb, s0 + 8);
+      wstore(ra, s0);
+      if (s0 + 16 < TRIPS) wload(ra, s0 + 16);
+      if (s0 + 8 < TRIPS) wstore(rb, s0 + 8);
     }
   }
   __syncthreads();
@@ -423,13 +447,17 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
     // d gamma / d beta: column sums over this block's rows (dy, x-hat re-read from L2, column-major work split)
     const int c = tid & 127, half = tid >> 7;
     float sb = 0.f, sg = 0.f;
-    for (int r = half * 32; r < half * 32 + 32; ++r) {
-      const int m = m0 + r;
-      if (m < p.M) {
-        const float d = p.dy[(long)m * 128 + c];
-        sb += d;
-        sg += d * p.xhat[(long)m * 128 + c];
+#pragma unroll 1
+    for (int r0 = half * 32; r0 < half * 32 + 32; r0 += 8) {  // 16 loads in flight per trip, not 2
+      float d[8], x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = m0 + r0 + u;
+        d[u] = m < p.M ? p.dy[(long)m * 128 + c] : 0.f;
+        x[u] = m < p.M ? p.xhat[(long)m * 128 + c] : 0.f;
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { sb += d[u]; sg += d[u] * x[u]; }
     }
     red[half][c] = sb;
     red[2 + half][c] = sg;
