@@ -564,7 +564,19 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
       ds[u] = (ok && p.dact) ? p.dsrc[(long)m * p.ldd + ecol] : 0.f;
     }
   };
+  const bool plain = !p.act && !p.dact && !p.preact;  // bias (+ residual) only: the common case
   auto finish_trip = [&](int k0, const float (&v)[4], const float (&rs)[4], const float (&ds)[4]) {
+    if (plain) {  // four independent, branch-free chains (one wave per SIMD: dependent issue is ~8 cycles)
+      float t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = v[u] + bias_v + rs[u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int m = m0 + er0 + (k0 + u) * RSTEP;
+        if (m < p.M && ecol < p.N) p.C[(long)m * p.ldc + ecol] = t[u];
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int m = m0 + er0 + (k0 + u) * RSTEP;

@@ -215,6 +215,19 @@ __global__ __launch_bounds__(NT) void rb_linear_kernel(LinP p) {
   }
 }
 
+// Phase timing aid (tools/rb_phase_probe.py builds a private copy with -DRF_RB_TIMING)
+#ifdef RF_RB_TIMING
+__device__ unsigned long long rf_rb_timing[16 * 1024];
+#define RB_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) rf_rb_timing[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+extern "C" void* rf_rb_timing_address() {
+  void* a = nullptr;
+  (void)hipGetSymbolAddress(&a, HIP_SYMBOL(rf_rb_timing));
+  return a;
+}
+#else
+#define RB_MARK(k) do {} while (0)
+#endif
+
 struct FfnP {
   const float* x;   // (M, 128) contiguous: FFN input AND residual
   const float* w1; const float* b1;  // (256, 128), (256)
@@ -236,6 +249,7 @@ __global__ __launch_bounds__(NT) void rb_ffn_ln_kernel(FfnP p) {
   float* zs = reinterpret_cast<float*>(hs + RB * LDH);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
   const int m0 = blockIdx.x * RB;
+  RB_MARK(0);
 
   {
     Tile<RB, D> tx;
@@ -246,21 +260,28 @@ __global__ __launch_bounds__(NT) void rb_ffn_ln_kernel(FfnP p) {
     t1.store(wb, tid);
   }
   __syncthreads();
+  RB_MARK(1);
   Tile<D, F> t2;  // W2 travels while the first contraction runs
   t2.load(p.w2, F, 0, D, tid);
 
   // first contraction in four passes of 64 hidden columns; each pass's 16 x 64 block goes through a
   // wave-private fp32 LDS tile so that bias + activation exist once in a rolled loop (code stays small: the
   // instruction cache is 64 KB) and z / h leave as row-contiguous 256-B stores
+  // Epilogue of each 64-column pass through a wave-private fp32 LDS tile, four consecutive columns per lane:
+  // one float4 tile read, four independent GELU chains, one 8-byte bf16 LDS write and two float4 global
+  // stores per four elements.  (This loop is instruction-issue bound at one wave per SIMD -- 4.5k of 6.6k
+  // cycles per pass in the scalar form, tools/rb_phase_probe.py -- so instructions per element matter.)
   float* zt = zs + wave * 16 * 68;
-  float b1v[4];
+  const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+  float4 b1v[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) b1v[c] = p.b1[c * 64 + lane];
+  for (int c = 0; c < 4; ++c) b1v[c] = *reinterpret_cast<const float4*>(p.b1 + c * 64 + c4);
 #pragma unroll 1
   for (int c = 0; c < 4; ++c) {
     f32x4 a1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) a1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c == 0) RB_MARK(6);
     mma_rows<D, 4>(a1, xs + wave * 16 * LDX, wb + c * 64 * LDX, lane);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -268,28 +289,35 @@ __global__ __launch_bounds__(NT) void rb_ffn_ln_kernel(FfnP p) {
       for (int r = 0; r < 4; ++r) zt[(fq * 4 + r) * 68 + j * 16 + fr] = a1[j][r];
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int f = c * 64 + lane;
-    const float b = c == 0 ? b1v[0] : (c == 1 ? b1v[1] : (c == 2 ? b1v[2] : b1v[3]));
-#pragma unroll 1
-    for (int r0 = 0; r0 < 16; r0 += 4) {
-      float zz[4];
+    if (c == 0) RB_MARK(7);
+    const float4 b = c == 0 ? b1v[0] : (c == 1 ? b1v[1] : (c == 2 ? b1v[2] : b1v[3]));
+    const int f = c * 64 + c4;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) zz[u] = zt[(r0 + u) * 68 + lane] + b;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int rl = wave * 16 + r0 + u, m = m0 + rl;
-        const float hh = p.act == RF_ACT_GELU ? gelu_fast(zz[u]) : apply_act(zz[u], p.act);
-        if (m < p.M) {
-          if (p.z) p.z[(long)m * F + f] = zz[u];
-          if (p.h) p.h[(long)m * F + f] = hh;
-        }
-        hs[rl * LDH + f] = (__bf16)hh;
+    for (int it = 0; it < 4; ++it) {
+      const int rl = wave * 16 + it * 4 + rsub, m = m0 + rl;
+      float4 zz = *reinterpret_cast<const float4*>(zt + (it * 4 + rsub) * 68 + c4);
+      zz.x += b.x; zz.y += b.y; zz.z += b.z; zz.w += b.w;
+      float4 hh;
+      if (p.act == RF_ACT_GELU) {
+        hh.x = gelu_fast(zz.x); hh.y = gelu_fast(zz.y); hh.z = gelu_fast(zz.z); hh.w = gelu_fast(zz.w);
+      } else if (p.act == RF_ACT_RELU) {
+        hh.x = fmaxf(zz.x, 0.f); hh.y = fmaxf(zz.y, 0.f); hh.z = fmaxf(zz.z, 0.f); hh.w = fmaxf(zz.w, 0.f);
+      } else {
+        hh.x = apply_act(zz.x, p.act); hh.y = apply_act(zz.y, p.act); hh.z = apply_act(zz.z, p.act);
+        hh.w = apply_act(zz.w, p.act);
+      }
+      st_bf16x4(hs + rl * LDH + f, hh);
+      if (m < p.M) {
+        if (p.z) *reinterpret_cast<float4*>(p.z + (long)m * F + f) = zz;
+        if (p.h) *reinterpret_cast<float4*>(p.h + (long)m * F + f) = hh;
       }
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (c == 0) RB_MARK(8);
   }
   __syncthreads();  // W1 dead everywhere, hs complete
+  RB_MARK(2);
   t2.store(wb, tid);
   // epilogue operands (bias, exact fp32 residual, norm parameters) are requested now, used after the MFMAs
   float b2v[8], gam[8], bet[8];
@@ -305,6 +333,7 @@ __global__ __launch_bounds__(NT) void rb_ffn_ln_kernel(FfnP p) {
     }
   }
   __syncthreads();
+  RB_MARK(3);
 
   f32x4 acc[8];
 #pragma unroll
@@ -315,6 +344,7 @@ __global__ __launch_bounds__(NT) void rb_ffn_ln_kernel(FfnP p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[j][r] += b2v[j] + xres[j][r];
   __syncthreads();
+  RB_MARK(4);
   float* stage_w = reinterpret_cast<float*>(smem) + wave * 16 * SP;
   f32x4 y[8];
   float rstd[4];
@@ -330,6 +360,7 @@ __global__ __launch_bounds__(NT) void rb_ffn_ln_kernel(FfnP p) {
       }
     }
   }
+  RB_MARK(5);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -504,9 +535,15 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       if (mrow[u] >= p.M) continue;
-      if (p.dact) {
-        o[u].x *= act_grad_fast(dz[u].x, p.dact); o[u].y *= act_grad_fast(dz[u].y, p.dact);
-        o[u].z *= act_grad_fast(dz[u].z, p.dact); o[u].w *= act_grad_fast(dz[u].w, p.dact);
+      if (p.dact == RF_ACT_GELU) {  // four independent straight-line chains
+        o[u].x *= gelu_grad_fast(dz[u].x); o[u].y *= gelu_grad_fast(dz[u].y);
+        o[u].z *= gelu_grad_fast(dz[u].z); o[u].w *= gelu_grad_fast(dz[u].w);
+      } else if (p.dact == RF_ACT_RELU) {
+        o[u].x = dz[u].x > 0.f ? o[u].x : 0.f; o[u].y = dz[u].y > 0.f ? o[u].y : 0.f;
+        o[u].z = dz[u].z > 0.f ? o[u].z : 0.f; o[u].w = dz[u].w > 0.f ? o[u].w : 0.f;
+      } else if (p.dact) {
+        o[u].x *= act_grad(dz[u].x, p.dact); o[u].y *= act_grad(dz[u].y, p.dact);
+        o[u].z *= act_grad(dz[u].z, p.dact); o[u].w *= act_grad(dz[u].w, p.dact);
       }
       o[u].x += rz[u].x; o[u].y += rz[u].y; o[u].z += rz[u].z; o[u].w += rz[u].w;
       *reinterpret_cast<float4*>(p.y + (long)mrow[u] * p.ldy + col[u]) = o[u];
