@@ -226,11 +226,13 @@ int rf_attn_bwd(const float* q, const float* k, const float* v, int64_t q_ld, in
                 int LQ, int LK, int E, int n_top, int mode, float scale, void* stream);
 
 /* ---- optimizer (experiments/full_comparison.py:694-702,829-830) -------------------------------
- * sumsq[0] += sum g^2 over n floats (caller zeroes sumsq). */
+ * sumsq[k] = partial sum of g^2 of workgroup k, k < rf_sumsq_parts(n) (no atomics: the consumer adds the
+ * partials in ascending order, so the global norm is reproducible bit for bit across runs and ranks). */
+int rf_sumsq_parts(int64_t n);
 int rf_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
-/* AdamW with global-norm clipping fused: g *= min(1, max_norm/(sqrt(sumsq)+1e-6)); decoupled
+/* AdamW with global-norm clipping fused: g *= min(1, max_norm/(sqrt(sum_k sumsq[k])+1e-6)); decoupled
  * weight decay; bias-corrected moments (torch.optim.AdamW semantics).  max_norm<=0 disables. */
-int rf_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
+int rf_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, int sumsq_parts,
                   float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
                   float grad_scale, void* stream);
 

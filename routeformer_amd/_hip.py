@@ -46,8 +46,9 @@ SIGNATURES = {
     "rf_attn_fwd": [_P, _P, _P, _L, _L, _L, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "rf_attn_bwd": [_P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _I,
                     _I, _I, _F, _P],
+    "rf_sumsq_parts": [_L],
     "rf_sumsq": [_P, _L, _P, _P],
-    "rf_adamw_clip": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _I, _F, _P],
+    "rf_adamw_clip": [_P, _P, _P, _P, _L, _P, _I, _F, _F, _F, _F, _F, _F, _I, _F, _P],
     "rf_version": [],
 }
 

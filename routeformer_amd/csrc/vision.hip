@@ -116,16 +116,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  // one partial per workgroup, summed in fixed order by the consumer: the global norm (hence the clip factor,
+  // hence every parameter) is bit-identical on every rank and every run -- an atomicAdd here let data-parallel
+  // replicas drift apart by an ulp per step
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
 __global__ void adamw_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                   float* __restrict__ v, long n, const float* __restrict__ sumsq, float max_norm,
                                   float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                  float grad_scale) {
+                                  float grad_scale, int sumsq_parts) {
   float coef = grad_scale;
   if (max_norm > 0.f) {
-    const float total = grad_scale * sqrtf(*sumsq);
+    float ss = 0.f;
+    for (int k = 0; k < sumsq_parts; ++k) ss += sumsq[k];  // uniform, ascending: same value in every workgroup
+    const float total = grad_scale * sqrtf(ss);
     const float c = max_norm / (total + 1e-6f);
     if (c < 1.f) coef *= c;
   }
@@ -187,22 +192,25 @@ extern "C" int rf_avgpool8_tokens(const float* x, float* tokens, int N, int H, i
   return RF_OK;
 }
 
+extern "C" int rf_sumsq_parts(int64_t n) { return grid_for(n, 256, 1024); }
+
 extern "C" int rf_sumsq(const float* g, int64_t n, float* sumsq, void* stream) {
   RF_REQUIRE(g && sumsq && n > 0);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), g,
+  hipLaunchKernelGGL(sumsq_kernel, dim3(rf_sumsq_parts(n)), dim3(256), 0, static_cast<hipStream_t>(stream), g,
                      (long)n, sumsq);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
 
 extern "C" int rf_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
-                             float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
-                             float grad_scale, void* stream) {
-  RF_REQUIRE(p && g && m && v && n > 0 && step >= 1 && (max_norm <= 0.f || sumsq));
+                             int sumsq_parts, float max_norm, float lr, float beta1, float beta2, float eps, float wd,
+                             int step, float grad_scale, void* stream) {
+  RF_REQUIRE(p && g && m && v && n > 0 && step >= 1 && (max_norm <= 0.f || (sumsq && sumsq_parts >= 1)));
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adamw_clip_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     p, g, m, v, (long)n, sumsq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, grad_scale);
+                     p, g, m, v, (long)n, sumsq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, grad_scale,
+                     sumsq_parts);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

@@ -215,6 +215,10 @@ class GradReducer:
     # -- per-step protocol: zero() -> backward -> finish() -----------------------------------------
     def zero(self):
         self.flat_grad.zero_()
+        self.begin_step()
+
+    def begin_step(self):
+        """Reset the per-step bucket bookkeeping (a HIP-graph replay zeroes the buffer itself, on the device)."""
         self._pending = list(self._members)
         self._launched = [False] * len(self.buckets)
         self._works = []
@@ -233,6 +237,25 @@ class GradReducer:
         self._pending[b] -= 1
         if self._pending[b] == 0 and not self._launched[b]:
             self._launch(b)
+
+    def launch_complete_prefix(self, names_of: Dict[int, str], prefix: str) -> int:
+        """All-reduce, now, every bucket made up ONLY of parameters whose name starts with ``prefix`` (their
+        gradients are final).  Returns how many were launched."""
+        n = 0
+        if self.world > 1:
+            for b in range(len(self.buckets)):
+                if not self._launched[b] and self._bucket_prefix_ok(b, names_of, prefix):
+                    self._launch(b)
+                    n += 1
+        return n
+
+    def _bucket_prefix_ok(self, b, names_of, prefix):
+        key = (b, prefix)
+        hit = self.__dict__.setdefault("_prefix_cache", {}).get(key)
+        if hit is None:
+            hit = all(names_of[id(p)].startswith(prefix) for p in self.params if self._bucket_of[id(p)] == b)
+            self._prefix_cache[key] = hit
+        return hit
 
     def finish(self):
         """Flush buckets whose parameters got no gradient this step (e.g. gaze branch dropped), then
@@ -259,7 +282,9 @@ class FusedAdamW:
         self.p, self.g = flat_param, flat_grad
         self.m = torch.zeros_like(flat_param)
         self.v = torch.zeros_like(flat_param)
-        self.sumsq = torch.zeros(1, device=flat_param.device, dtype=torch.float32)
+        from routeformer_amd import _hip
+        self.parts = int(_hip.lib().rf_sumsq_parts(flat_param.numel()))
+        self.sumsq = torch.zeros(self.parts, device=flat_param.device, dtype=torch.float32)  # per-workgroup partials
         self.betas, self.eps, self.wd, self.max_norm = betas, eps, weight_decay, max_grad_norm
         self.param_groups = [{"lr": lr}]  # what an LR scheduler drives (optimizers.LinearWarmupCosineAnnealingLR)
         self.t = 0
@@ -276,10 +301,9 @@ class FusedAdamW:
         from routeformer_amd import _hip, kernels as K
         self.t += 1
         n = self.p.numel()
-        self.sumsq.zero_()
         _hip.check(_hip.lib().rf_sumsq(self.g.data_ptr(), n, self.sumsq.data_ptr(), K._stream()), "rf_sumsq")
         _hip.check(_hip.lib().rf_adamw_clip(self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                            n, self.sumsq.data_ptr(), self.max_norm, self.lr, self.betas[0],
+                                            n, self.sumsq.data_ptr(), self.parts, self.max_norm, self.lr, self.betas[0],
                                             self.betas[1], self.eps, self.wd, self.t, grad_scale, K._stream()),
                    "rf_adamw_clip")
 
@@ -298,6 +322,12 @@ class TrainEngine:
         layers = [m for m in model.modules() if hasattr(m, "packing_groups")]
         groups = [g for m in layers for g in m.packing_groups()]
         self.reducer = GradReducer(trainable_parameters(model), bucket_mb, groups=groups)
+        # Kernels write parameter gradients through sinks and through deferred grouped launches, and autograd's
+        # post-accumulate hooks also fire for parameters whose Function returned None -- "this slot is final" is
+        # only known at the end of backward (or at the stage boundary of the two-graph step), so buckets are
+        # reduced there, not from per-parameter hooks.  (A 2-rank GPU test caught hook-driven launches going out
+        # before queued weight gradients had been written.)
+        self.reducer.hooks_enabled = False
         for m in layers:  # hand each attention layer its packed [Wq;Wk;Wv] / [bq;bk;bv] views
             gw, gb = m.packing_groups()
             vw, vb = self.reducer.packed_view(gw), self.reducer.packed_view(gb)
@@ -316,7 +346,7 @@ class TrainEngine:
         self.reducer.zero()
         K.OVERLAP = self.overlap
         K.SINK.active = True  # kernels accumulate parameter gradients straight into the flat buffer
-        K.SINK.on_write = self.reducer.on_sink_write if self.reducer.world > 1 else None
+        K.SINK.on_write = None
         K.WGRAD.active = self.group_wgrad
         try:
             res = train_step_losses(self.model, item, epoch, self.tl, self.dl, tokens_ready=tokens_ready)
@@ -327,6 +357,52 @@ class TrainEngine:
         finally:
             K.SINK.active, K.SINK.on_write, K.OVERLAP, K.WGRAD.active = False, None, False, False
         return res
+
+    # -- the same step in two stages (GraphedTrainEngine with N > 1): stage 1 = forward + the backward of the
+    #    GPS backbone, which owns 95 % of the trainable bytes and is differentiated FIRST; stage 2 = the rest.
+    #    The all-reduce of the backbone's buckets then runs underneath stage 2. ---------------------------------
+    def _enter(self):
+        from routeformer_amd import kernels as K
+        K.OVERLAP = self.overlap
+        K.SINK.active = True
+        K.SINK.on_write = None
+        K.WGRAD.active = self.group_wgrad
+
+    def _leave(self):
+        from routeformer_amd import kernels as K
+        K.SINK.active, K.SINK.on_write, K.OVERLAP, K.WGRAD.active = False, None, False, False
+
+    def _stage1(self, item, epoch, tokens_ready: bool = False):
+        from routeformer_amd import kernels as K
+        self.reducer.zero()
+        self.model._keep_gps_input = True
+        try:
+            res = train_step_losses(self.model, item, epoch, self.tl, self.dl, tokens_ready=tokens_ready)
+        finally:
+            self.model._keep_gps_input = False
+        cut = self.model.__dict__.pop("_gps_input", None)
+        if cut is None or not cut.requires_grad:  # GPS-only model: nothing upstream of the backbone
+            res["loss"].backward()
+            K.flush_weight_grads()
+            return res, None
+        # gradients of the cut AND of the backbone parameters that autograd itself accumulates (the few that no
+        # kernel writes through a sink, e.g. the time-feature embedding): they would otherwise be skipped
+        bp = [p for n, p in self.model.named_parameters() if n.startswith("gps_backbone.") and p.requires_grad]
+        grads = torch.autograd.grad(res["loss"], [cut] + bp, allow_unused=True)
+        for p, g in zip(bp, grads[1:]):
+            if g is not None:
+                p.grad.add_(g)
+        K.flush_weight_grads()
+        return res, (cut, grads[0])
+
+    def _stage2(self, carry):
+        from routeformer_amd import kernels as K
+        if carry is not None:
+            cut, dcut = carry
+            cut.backward(dcut)
+            K.flush_weight_grads()
+        if self.overlap:
+            K.join_side_streams()
 
     def step(self, item, epoch: int = 0, next_item=None):
         self.model.train()
@@ -364,6 +440,11 @@ class GraphedTrainEngine(TrainEngine):
         self._trunk_graphs = {}
         self._ready_key = None
         self._tstream = None
+        # N > 1: capture the step as two graphs so that the gradient all-reduce of the GPS backbone overlaps the
+        # rest of the backward pass (RF_SPLIT_BWD=1 forces it at N = 1, =0 disables it)
+        env = __import__("os").environ.get("RF_SPLIT_BWD")
+        self.split = (self.reducer.world > 1) if env is None else env == "1"
+        self._names = {id(p): n for n, p in model.named_parameters()}
         c = model.configs
         if c.view_dropout > 0 or c.gaze_dropout > 0 or c.motion_noise > 0 or c.feature_dropout > 0:
             raise ValueError("GraphedTrainEngine needs a draw-independent step (all dropouts / noise 0)")
@@ -454,15 +535,37 @@ class GraphedTrainEngine(TrainEngine):
         from routeformer_amd.models.blocks import SAMPLER
         SAMPLER.rewind_static()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            cur = torch.cuda.current_stream()
-            if key is not None:
-                self._tstream.wait_stream(cur)
-                with torch.cuda.stream(self._tstream):
-                    self.model.video_backbone.encode_clips(clips, out=self._tok_next)
-            out = self._fwd_bwd(self._static_item, self._epoch, tokens_ready=self._pipelined)
-            if key is not None:
-                cur.wait_stream(self._tstream)
+        if not self.split:
+            with torch.cuda.graph(g):
+                cur = torch.cuda.current_stream()
+                if key is not None:
+                    self._tstream.wait_stream(cur)
+                    with torch.cuda.stream(self._tstream):
+                        self.model.video_backbone.encode_clips(clips, out=self._tok_next)
+                out = self._fwd_bwd(self._static_item, self._epoch, tokens_ready=self._pipelined)
+                if key is not None:
+                    cur.wait_stream(self._tstream)
+        else:
+            # two graphs over one memory pool, replayed back to back: the host can start the all-reduce of the GPS
+            # backbone's gradient buckets between them (see step())
+            g2 = torch.cuda.CUDAGraph()
+            self._enter()
+            try:
+                with torch.cuda.graph(g):
+                    cur = torch.cuda.current_stream()
+                    if key is not None:
+                        self._tstream.wait_stream(cur)
+                        with torch.cuda.stream(self._tstream):
+                            self.model.video_backbone.encode_clips(clips, out=self._tok_next)
+                    out, carry = self._stage1(self._static_item, self._epoch, tokens_ready=self._pipelined)
+                    if key is not None:
+                        cur.wait_stream(self._tstream)
+                with torch.cuda.graph(g2, pool=g.pool()):
+                    self._stage2(carry)
+            finally:
+                self._leave()
+            del carry
+            g = (g, g2)
         self.model.clear_video_tokens()
         self._graphs[key] = (g, out, clips)
         return g, out
@@ -486,7 +589,14 @@ class GraphedTrainEngine(TrainEngine):
                 if v.dim() != 5 and v.data_ptr() != dst.data_ptr():
                     dst.copy_(v, non_blocking=True)
         SAMPLER.refill_static()
-        g.replay()
+        self.reducer.begin_step()  # the replay does not run the Python bookkeeping of zero()
+        if isinstance(g, tuple):
+            g[0].replay()
+            # 95 % of the gradient bytes (the GPS backbone's) are final here: reduce them underneath stage 2
+            self.reducer.launch_complete_prefix(self._names, "gps_backbone.")
+            g[1].replay()
+        else:
+            g.replay()
         if self._pipelined and next_item is not None:
             self._ready_key = self._vkey(next_item)
         scale = self.reducer.finish()

@@ -135,6 +135,8 @@ class Routeformer(nn.Module):
         if c._only_motion:
             feats[-1] = torch.zeros_like(feats[-1])
         x = torch.cat(feats, dim=-1)
+        if getattr(self, "_keep_gps_input", False):
+            self._gps_input = x  # cut point of the engine's two-stage backward (GPS backbone first)
         out = self.gps_backbone(x)
         if c.decoder_mode == "recursive":
             out = out + (x[:, -1:, :] if c.dense_prediction else x[:, -1:, :2])

@@ -437,11 +437,15 @@ def test_adamw_clip():
         torch.nn.utils.clip_grad_norm_([pc], 2.5)
         opt.step()
         gd = gs.to(DEV)
-        ss = torch.zeros(1, device=DEV)
+        parts = _hip.lib().rf_sumsq_parts(n)
+        ss = torch.full((parts,), float("nan"), device=DEV)  # per-workgroup partials, every slot overwritten
+        ss2 = torch.empty_like(ss)
         _hip.check(_hip.lib().rf_sumsq(gd.data_ptr(), n, ss.data_ptr(), Kn._stream()), "sumsq")
-        assert abs(float(ss) - float(gs.double().square().sum())) < 1e-3 * float(gs.double().square().sum())
+        _hip.check(_hip.lib().rf_sumsq(gd.data_ptr(), n, ss2.data_ptr(), Kn._stream()), "sumsq")
+        assert torch.equal(ss, ss2)  # no atomics: bit-reproducible (data-parallel replicas must not drift)
+        assert abs(float(ss.sum()) - float(gs.double().square().sum())) < 1e-3 * float(gs.double().square().sum())
         _hip.check(_hip.lib().rf_adamw_clip(pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, ss.data_ptr(),
-                                            2.5, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, 1.0, Kn._stream()), "adamw")
+                                            parts, 2.5, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, 1.0, Kn._stream()), "adamw")
         assert rel_err(pd, pc) < 1e-5, step
 
 
