@@ -401,6 +401,35 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
   __bf16* as = smem + (W_EL > STAGE_EL ? W_EL : STAGE_EL);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
   const int m0 = blockIdx.x * RB;
+  RB_MARK(0);
+
+  // Transposed weight staging, a wave covers a 16 (k) x 32 (n) patch per trip: lane = (k pair) + 8 * (n / 4)
+  // reads two 128-B row segments (rows k, k + 1) and writes four packed bf16x2 words [n + e][k, k + 1].
+  // Two register batches of four trips alternate, so loads are in flight while the other batch is written.
+  constexpr int TRIPS = KC * NOUT / 2048, KT = KC / 16;
+  const int kp2 = (lane & 7) * 2, g4 = (lane >> 3) * 4;
+  float4 ra[8], rb[8];
+  auto wload = [&](float4 (&r)[8], int s0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int T = wave + 4 * (s0 + u), k = (T % KT) * 16 + kp2, n = (T / KT) * 32 + g4;
+      r[2 * u] = *reinterpret_cast<const float4*>(p.w + (long)k * NOUT + n);
+      r[2 * u + 1] = *reinterpret_cast<const float4*>(p.w + (long)(k + 1) * NOUT + n);
+    }
+  };
+  auto wstore = [&](const float4 (&r)[8], int s0) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int T = wave + 4 * (s0 + u), k = (T % KT) * 16 + kp2, n = (T / KT) * 32 + g4;
+      const float4 lo = r[2 * u], hi = r[2 * u + 1];
+      *reinterpret_cast<bf16x2*>(ws + (n + 0) * LD + k) = bf16x2{(__bf16)lo.x, (__bf16)hi.x};
+      *reinterpret_cast<bf16x2*>(ws + (n + 1) * LD + k) = bf16x2{(__bf16)lo.y, (__bf16)hi.y};
+      *reinterpret_cast<bf16x2*>(ws + (n + 2) * LD + k) = bf16x2{(__bf16)lo.z, (__bf16)hi.z};
+      *reinterpret_cast<bf16x2*>(ws + (n + 3) * LD + k) = bf16x2{(__bf16)lo.w, (__bf16)hi.w};
+    }
+  };
+  wload(ra, 0);
 
   // ---- A operand ----
   if constexpr (LNBWD) {
@@ -438,41 +467,20 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
     ta.store(as, tid);
   }
 
+  RB_MARK(1);
   // ---- W (KC x NOUT, row-major) -> LDS [n][k] ----
-  // a wave covers an 8 (k) x 32 (n) patch per trip: lane = (k & 7) + 8 * (n / 4): global reads are 128-B row
-  // segments, and the four transposed 2-byte LDS writes of a lane land 16 B apart within a group of 8 lanes
+  // (its first register batch was requested before the A operand was built)
   {
-    constexpr int TRIPS = KC * NOUT / 1024, KT = KC / 8;
-    const int kk = lane & 7, g4 = (lane >> 3) * 4;
-    auto wload = [&](float4 (&r)[8], int s0) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int T = wave + 4 * (s0 + u), k = (T % KT) * 8 + kk, n = (T / KT) * 32 + g4;
-        r[u] = *reinterpret_cast<const float4*>(p.w + (long)k * NOUT + n);
-      }
-    };
-    auto wstore = [&](const float4 (&r)[8], int s0) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int T = wave + 4 * (s0 + u), k = (T % KT) * 8 + kk, n = (T / KT) * 32 + g4;
-        ws[(n + 0) * LD + k] = (__bf16)r[u].x;
-        ws[(n + 1) * LD + k] = (__bf16)r[u].y;
-        ws[(n + 2) * LD + k] = (__bf16)r[u].z;
-        ws[(n + 3) * LD + k] = (__bf16)r[u].w;
-      }
-    };
-    // two register batches: the loads of batch t + 1 are in flight while batch t is transposed into LDS
-    float4 ra[8], rb[8];
-    wload(ra, 0);
 #pragma unroll 1
-    for (int s0 = 0; s0 < TRIPS; s0 += 16) {
-      if (s0 + 8 < TRIPS) wload(rb, s0 + 8);
+    for (int s0 = 0; s0 < TRIPS; s0 += 8) {
+      if (s0 + 4 < TRIPS) wload(rb, s0 + 4);
       wstore(ra, s0);
-      if (s0 + 16 < TRIPS) wload(ra, s0 + 16);
-      if (s0 + 8 < TRIPS) wstore(rb, s0 + 8);
+      if (s0 + 8 < TRIPS) wload(ra, s0 + 8);
+      if (s0 + 4 < TRIPS) wstore(rb, s0 + 4);
     }
   }
   __syncthreads();
+  RB_MARK(2);
 
   if constexpr (LNBWD) {
     // d gamma / d beta: column sums over this block's rows (dy, x-hat re-read from L2, column-major work split)
@@ -494,6 +502,7 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
     red[2 + half][c] = sg;
   }
 
+  RB_MARK(3);
   f32x4 acc[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -507,6 +516,7 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
     }
   }
 
+  RB_MARK(4);
   // ---- epilogue through the staging tile: row-contiguous float4 work ----
   float* st = reinterpret_cast<float*>(smem) + wave * 16 * SPN;
 #pragma unroll
@@ -515,40 +525,48 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
     for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * SPN + j * 16 + fr] = acc[j][r];
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  constexpr int V4R = NOUT / 4;  // float4 per row
-#pragma unroll 1
-  for (int it = 0; it < 16 * V4R / 64; it += 2) {
-    float4 o[2], rz[2], dz[2];
-    int mrow[2], col[2];
+  constexpr int V4R = NOUT / 4;   // float4 per row
+  constexpr int NIT = 16 * V4R / 64;  // float4 per lane
+  // two float4 per trip; the residual / activation-source loads of trip t + 1 are issued before trip t is
+  // computed (a trip would otherwise wait a full L2 round trip for its own loads)
+  auto fetch = [&](int it, float4 (&rz)[2], float4 (&dz)[2]) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int i = (it + u) * 64 + lane, rr = i / V4R;
-      col[u] = (i % V4R) * 4;
-      mrow[u] = m0 + wave * 16 + rr;
-      o[u] = *reinterpret_cast<const float4*>(st + rr * SPN + col[u]);
+      const int i = (it + u) * 64 + lane, rr = i / V4R, col = (i % V4R) * 4, m = m0 + wave * 16 + rr;
       rz[u] = dz[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (mrow[u] < p.M) {
-        if (p.res) rz[u] = *reinterpret_cast<const float4*>(p.res + (long)mrow[u] * p.ldr + col[u]);
-        if (p.dact) dz[u] = *reinterpret_cast<const float4*>(p.dsrc + (long)mrow[u] * p.ldd + col[u]);
+      if (m < p.M) {
+        if (p.res) rz[u] = *reinterpret_cast<const float4*>(p.res + (long)m * p.ldr + col);
+        if (p.dact) dz[u] = *reinterpret_cast<const float4*>(p.dsrc + (long)m * p.ldd + col);
       }
     }
+  };
+  float4 rz[2], dz[2], nrz[2], ndz[2];
+  fetch(0, rz, dz);
+#pragma unroll 1
+  for (int it = 0; it < NIT; it += 2) {
+    if (it + 2 < NIT) fetch(it + 2, nrz, ndz);
+    else { nrz[0] = nrz[1] = ndz[0] = ndz[1] = make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      if (mrow[u] >= p.M) continue;
+      const int i = (it + u) * 64 + lane, rr = i / V4R, col = (i % V4R) * 4, m = m0 + wave * 16 + rr;
+      float4 o = *reinterpret_cast<const float4*>(st + rr * SPN + col);
       if (p.dact == RF_ACT_GELU) {  // four independent straight-line chains
-        o[u].x *= gelu_grad_fast(dz[u].x); o[u].y *= gelu_grad_fast(dz[u].y);
-        o[u].z *= gelu_grad_fast(dz[u].z); o[u].w *= gelu_grad_fast(dz[u].w);
+        o.x *= gelu_grad_fast(dz[u].x); o.y *= gelu_grad_fast(dz[u].y);
+        o.z *= gelu_grad_fast(dz[u].z); o.w *= gelu_grad_fast(dz[u].w);
       } else if (p.dact == RF_ACT_RELU) {
-        o[u].x = dz[u].x > 0.f ? o[u].x : 0.f; o[u].y = dz[u].y > 0.f ? o[u].y : 0.f;
-        o[u].z = dz[u].z > 0.f ? o[u].z : 0.f; o[u].w = dz[u].w > 0.f ? o[u].w : 0.f;
+        o.x = dz[u].x > 0.f ? o.x : 0.f; o.y = dz[u].y > 0.f ? o.y : 0.f;
+        o.z = dz[u].z > 0.f ? o.z : 0.f; o.w = dz[u].w > 0.f ? o.w : 0.f;
       } else if (p.dact) {
-        o[u].x *= act_grad(dz[u].x, p.dact); o[u].y *= act_grad(dz[u].y, p.dact);
-        o[u].z *= act_grad(dz[u].z, p.dact); o[u].w *= act_grad(dz[u].w, p.dact);
+        o.x *= act_grad(dz[u].x, p.dact); o.y *= act_grad(dz[u].y, p.dact);
+        o.z *= act_grad(dz[u].z, p.dact); o.w *= act_grad(dz[u].w, p.dact);
       }
-      o[u].x += rz[u].x; o[u].y += rz[u].y; o[u].z += rz[u].z; o[u].w += rz[u].w;
-      *reinterpret_cast<float4*>(p.y + (long)mrow[u] * p.ldy + col[u]) = o[u];
+      o.x += rz[u].x; o.y += rz[u].y; o.z += rz[u].z; o.w += rz[u].w;
+      if (m < p.M) *reinterpret_cast<float4*>(p.y + (long)m * p.ldy + col) = o;
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { rz[u] = nrz[u]; dz[u] = ndz[u]; }
   }
+  RB_MARK(5);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

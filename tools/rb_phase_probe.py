@@ -35,3 +35,21 @@ for nm, v in zip(names, np.diff(t, axis=1).mean(0)): print(f"{nm:40s} {v:9.0f} c
 print(f"{'total per workgroup':40s} {(t[:, 5] - t[:, 0]).mean():9.0f} cycles")
 t2 = buf.cpu().numpy().reshape(1024, 16)[:n, 6:9].astype(np.float64)
 print(f"chunk 0 of phase 1 (wave 0): MFMA + tile write {np.mean(t2[:, 1] - t2[:, 0]):.0f} cycles, bias/GELU/stores loop {np.mean(t2[:, 2] - t2[:, 1]):.0f} cycles")
+
+# ---- rb_nn_kernel<128, 256, true>: LayerNorm-backward prologue + dZ = (dPre W2) * gelu'(z) ----
+dy = torch.randn(M, 128, device=dev); rstd = torch.rand(M, device=dev) + 0.5; dpre = torch.empty(M, 128, device=dev)
+dg = torch.zeros(128, device=dev); db = torch.zeros(128, device=dev); yy = torch.empty(M, 256, device=dev)
+def call_nn():
+    return lib.rf_rowblock_linear_nn(None, ctypes.c_int64(0), P(dy.data_ptr()), P(xh.data_ptr()), P(rstd.data_ptr()), P(g.data_ptr()),
+                                     P(dpre.data_ptr()), P(dg.data_ptr()), P(db.data_ptr()), P(w2.data_ptr()), None, ctypes.c_int64(0),
+                                     P(z.data_ptr()), ctypes.c_int64(256), 2, P(yy.data_ptr()), ctypes.c_int64(256), M, 128, 256,
+                                     P(torch.cuda.current_stream().cuda_stream))
+for _ in range(3): assert call_nn() == 0
+torch.cuda.synchronize()
+s.record(); [call_nn() for _ in range(20)]; e.record(); torch.cuda.synchronize()
+print(f"rb_nn<128,256,ln>: {s.elapsed_time(e) / 20 * 1e3:.1f} us")
+hip.hipMemcpy(P(buf.data_ptr()), P(lib.rf_rb_timing_address()), ctypes.c_size_t(8 * 16 * 1024), 3)
+t = buf.cpu().numpy().reshape(1024, 16)[:n, :6].astype(np.float64)
+for nm, v in zip(["LN backward prologue (+dpre store)", "W -> LDS (transposed)", "column sums (dgamma, dbeta)", "MFMA", "epilogue (gelu', stores)"],
+                 np.diff(t, axis=1).mean(0)):
+    print(f"{nm:40s} {v:9.0f} cycles")
