@@ -28,14 +28,14 @@ __device__ __forceinline__ void st_bf16x4(__bf16* s, const float4& v) {
 }
 
 // ROWS x KC fp32 (k contiguous, row pitch ld) -> registers; rows >= nrows read as zero
-template <int ROWS, int KC>
+template <int ROWS, int KC, int NTH = NT>
 struct Tile {
-  static constexpr int VPR = KC / 4, NV = ROWS * VPR / NT;
+  static constexpr int VPR = KC / 4, NV = ROWS * VPR / NTH;
   float4 r[NV];
   __device__ __forceinline__ void load(const float* __restrict__ g, long ld, int row0, int nrows, int tid) {
 #pragma unroll
     for (int s = 0; s < NV; ++s) {
-      const int i = tid + s * NT, rr = i / VPR, kv = (i % VPR) * 4;
+      const int i = tid + s * NTH, rr = i / VPR, kv = (i % VPR) * 4;
       r[s] = (row0 + rr < nrows) ? *reinterpret_cast<const float4*>(g + (long)(row0 + rr) * ld + kv)
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -43,7 +43,7 @@ struct Tile {
   __device__ __forceinline__ void store(__bf16* __restrict__ lds, int tid) const {  // [row][k], pitch KC + 8
 #pragma unroll
     for (int s = 0; s < NV; ++s) {
-      const int i = tid + s * NT;
+      const int i = tid + s * NTH;
       st_bf16x4(lds + (i / VPR) * (KC + 8) + (i % VPR) * 4, r[s]);
     }
   }
@@ -390,29 +390,35 @@ __device__ __forceinline__ float quad_sumf(float v) {
   return v;
 }
 
-template <int KC, int NOUT, bool LNBWD>
-__global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
+// WAVES = 8: two waves per SIMD share a row block (wave = 4 * column-half + row-group).  These kernels are
+// instruction-issue bound at one wave per SIMD (tools/rb_phase_probe.py: the GELU' epilogue alone was 15k of
+// 44k cycles), so the second wave per SIMD is close to a 2x on every phase; LDS use is unchanged.
+template <int KC, int NOUT, bool LNBWD, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rb_nn_kernel(NnP p) {
   static_assert(!LNBWD || KC == 128, "the LayerNorm-backward prologue works on 128-wide rows");
-  constexpr int LD = KC + 8, NJ = NOUT / 16, SPN = NOUT + 4;
-  constexpr int W_EL = NOUT * LD, STAGE_EL = RB * SPN * 2;
+  constexpr int NTH = 64 * WAVES, CH = WAVES / 4, NCOL = NOUT / CH;  // threads, column groups, columns per wave
+  constexpr int LD = KC + 8, NJ = NCOL / 16, SPW = NCOL + 4;
+  constexpr int W_EL = NOUT * LD, STAGE_EL = WAVES * 16 * SPW * 2;
   __shared__ __attribute__((aligned(16))) __bf16 smem[(W_EL > STAGE_EL ? W_EL : STAGE_EL) + RB * LD];
-  __shared__ float red[4][128];
+  __shared__ float red[2 * (NTH / 128)][128];
   __bf16* ws = smem;
   __bf16* as = smem + (W_EL > STAGE_EL ? W_EL : STAGE_EL);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int rw = wave & 3, ch = wave >> 2;
   const int m0 = blockIdx.x * RB;
   RB_MARK(0);
 
   // Transposed weight staging, a wave covers a 16 (k) x 32 (n) patch per trip: lane = (k pair) + 8 * (n / 4)
   // reads two 128-B row segments (rows k, k + 1) and writes four packed bf16x2 words [n + e][k, k + 1].
   // Two register batches of four trips alternate, so loads are in flight while the other batch is written.
-  constexpr int TRIPS = KC * NOUT / 2048, KT = KC / 16;
+  constexpr int TRIPS = KC * NOUT / (512 * WAVES), KT = KC / 16;
+  static_assert(TRIPS % 4 == 0, "weight staging works in batches of four trips");
   const int kp2 = (lane & 7) * 2, g4 = (lane >> 3) * 4;
   float4 ra[8], rb[8];
   auto wload = [&](float4 (&r)[8], int s0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int T = wave + 4 * (s0 + u), k = (T % KT) * 16 + kp2, n = (T / KT) * 32 + g4;
+      const int T = wave + WAVES * (s0 + u), k = (T % KT) * 16 + kp2, n = (T / KT) * 32 + g4;
       r[2 * u] = *reinterpret_cast<const float4*>(p.w + (long)k * NOUT + n);
       r[2 * u + 1] = *reinterpret_cast<const float4*>(p.w + (long)(k + 1) * NOUT + n);
     }
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int T = wave + 4 * (s0 + u), k = (T % KT) * 16 + kp2, n = (T / KT) * 32 + g4;
+      const int T = wave + WAVES * (s0 + u), k = (T % KT) * 16 + kp2, n = (T / KT) * 32 + g4;
       const float4 lo = r[2 * u], hi = r[2 * u + 1];
       *reinterpret_cast<bf16x2*>(ws + (n + 0) * LD + k) = bf16x2{(__bf16)lo.x, (__bf16)hi.x};
       *reinterpret_cast<bf16x2*>(ws + (n + 1) * LD + k) = bf16x2{(__bf16)lo.y, (__bf16)hi.y};
@@ -433,12 +439,13 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
 
   // ---- A operand ----
   if constexpr (LNBWD) {
-    const int r = tid >> 2, c0 = (tid & 3) * 32, m = m0 + r;
-    float g[32], xh[32];
+    constexpr int LPR = NTH / 64, CPL = 128 / LPR, V4 = CPL / 4;  // lanes per row, columns / float4 per lane
+    const int r = tid / LPR, c0 = (tid % LPR) * CPL, m = m0 + r;
+    float g[CPL], xh[CPL];
     float s1 = 0.f, s2 = 0.f;
     const float rs = m < p.M ? p.rstd[m] : 0.f;
 #pragma unroll
-    for (int v4 = 0; v4 < 8; ++v4) {
+    for (int v4 = 0; v4 < V4; ++v4) {
       float4 d = make_float4(0.f, 0.f, 0.f, 0.f), x = d;
       if (m < p.M) {
         d = *reinterpret_cast<const float4*>(p.dy + (long)m * 128 + c0 + v4 * 4);
@@ -449,10 +456,12 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
       xh[v4 * 4 + 0] = x.x; xh[v4 * 4 + 1] = x.y; xh[v4 * 4 + 2] = x.z; xh[v4 * 4 + 3] = x.w;
     }
 #pragma unroll
-    for (int i = 0; i < 32; ++i) { s1 += g[i]; s2 += g[i] * xh[i]; }
-    const float m1 = quad_sumf(s1) * (1.f / 128.f), m2 = quad_sumf(s2) * (1.f / 128.f);
+    for (int i = 0; i < CPL; ++i) { s1 += g[i]; s2 += g[i] * xh[i]; }
+    s1 = quad_sumf(s1); s2 = quad_sumf(s2);
+    if constexpr (LPR == 8) { s1 += dpp_move<0x141>(s1); s2 += dpp_move<0x141>(s2); }  // the other quad of the row
+    const float m1 = s1 * (1.f / 128.f), m2 = s2 * (1.f / 128.f);
 #pragma unroll
-    for (int v4 = 0; v4 < 8; ++v4) {
+    for (int v4 = 0; v4 < V4; ++v4) {
       float4 o;
       o.x = rs * (g[v4 * 4 + 0] - m1 - xh[v4 * 4 + 0] * m2);
       o.y = rs * (g[v4 * 4 + 1] - m1 - xh[v4 * 4 + 1] * m2);
@@ -462,32 +471,30 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
       st_bf16x4(as + r * LD + c0 + v4 * 4, o);
     }
   } else {
-    Tile<RB, KC> ta;
+    Tile<RB, KC, NTH> ta;
     ta.load(p.a, p.lda, m0, p.M, tid);
     ta.store(as, tid);
   }
 
   RB_MARK(1);
-  // ---- W (KC x NOUT, row-major) -> LDS [n][k] ----
-  // (its first register batch was requested before the A operand was built)
-  {
+  // ---- W (KC x NOUT, row-major) -> LDS [n][k]  (first register batch requested before the A operand) ----
 #pragma unroll 1
-    for (int s0 = 0; s0 < TRIPS; s0 += 8) {
-      if (s0 + 4 < TRIPS) wload(rb, s0 + 4);
-      wstore(ra, s0);
-      if (s0 + 8 < TRIPS) wload(ra, s0 + 8);
-      if (s0 + 4 < TRIPS) wstore(rb, s0 + 4);
-    }
+  for (int s0 = 0; s0 < TRIPS; s0 += 8) {
+    if (s0 + 4 < TRIPS) wload(rb, s0 + 4);
+    wstore(ra, s0);
+    if (s0 + 8 < TRIPS) wload(ra, s0 + 8);
+    if (s0 + 4 < TRIPS) wstore(rb, s0 + 4);
   }
   __syncthreads();
   RB_MARK(2);
 
   if constexpr (LNBWD) {
     // d gamma / d beta: column sums over this block's rows (dy, x-hat re-read from L2, column-major work split)
-    const int c = tid & 127, half = tid >> 7;
+    constexpr int GR = NTH / 128, RPG = RB / GR;  // row groups, rows per group
+    const int c = tid & 127, grp = tid >> 7;
     float sb = 0.f, sg = 0.f;
 #pragma unroll 1
-    for (int r0 = half * 32; r0 < half * 32 + 32; r0 += 8) {  // 16 loads in flight per trip, not 2
+    for (int r0 = grp * RPG; r0 < grp * RPG + RPG; r0 += 8) {  // 16 loads in flight per trip
       float d[8], x[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -498,41 +505,45 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) { sb += d[u]; sg += d[u] * x[u]; }
     }
-    red[half][c] = sb;
-    red[2 + half][c] = sg;
+    red[grp][c] = sb;
+    red[GR + grp][c] = sg;
   }
 
   RB_MARK(3);
   f32x4 acc[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  mma_rows<KC, NJ>(acc, as + wave * 16 * LD, ws, lane);
+  mma_rows<KC, NJ>(acc, as + rw * 16 * LD, ws + ch * NCOL * LD, lane);
   __syncthreads();  // weights dead: their LDS becomes the output staging tile; `red` complete
 
   if constexpr (LNBWD) {
     if (tid < 128) {
-      atomicAdd(p.dbeta + tid, red[0][tid] + red[1][tid]);
-      atomicAdd(p.dgamma + tid, red[2][tid] + red[3][tid]);
+      constexpr int GR = NTH / 128;
+      float sb = 0.f, sg = 0.f;
+#pragma unroll
+      for (int k = 0; k < GR; ++k) { sb += red[k][tid]; sg += red[GR + k][tid]; }
+      atomicAdd(p.dbeta + tid, sb);
+      atomicAdd(p.dgamma + tid, sg);
     }
   }
 
   RB_MARK(4);
   // ---- epilogue through the staging tile: row-contiguous float4 work ----
-  float* st = reinterpret_cast<float*>(smem) + wave * 16 * SPN;
+  float* st = reinterpret_cast<float*>(smem) + wave * 16 * SPW;
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * SPN + j * 16 + fr] = acc[j][r];
+    for (int r = 0; r < 4; ++r) st[(fq * 4 + r) * SPW + j * 16 + fr] = acc[j][r];
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  constexpr int V4R = NOUT / 4;   // float4 per row
-  constexpr int NIT = 16 * V4R / 64;  // float4 per lane
-  // two float4 per trip; the residual / activation-source loads of trip t + 1 are issued before trip t is
-  // computed (a trip would otherwise wait a full L2 round trip for its own loads)
+  constexpr int V4R = NCOL / 4;        // float4 per row of this wave's column group
+  constexpr int NIT = 16 * V4R / 64;   // float4 per lane
+  static_assert(NIT % 2 == 0, "two float4 per trip");
+  // two float4 per trip; the residual / activation-source loads of trip t + 1 are issued before trip t is computed
   auto fetch = [&](int it, float4 (&rz)[2], float4 (&dz)[2]) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int i = (it + u) * 64 + lane, rr = i / V4R, col = (i % V4R) * 4, m = m0 + wave * 16 + rr;
+      const int i = (it + u) * 64 + lane, rr = i / V4R, col = ch * NCOL + (i % V4R) * 4, m = m0 + rw * 16 + rr;
       rz[u] = dz[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < p.M) {
         if (p.res) rz[u] = *reinterpret_cast<const float4*>(p.res + (long)m * p.ldr + col);
@@ -548,8 +559,8 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
     else { nrz[0] = nrz[1] = ndz[0] = ndz[1] = make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int i = (it + u) * 64 + lane, rr = i / V4R, col = (i % V4R) * 4, m = m0 + wave * 16 + rr;
-      float4 o = *reinterpret_cast<const float4*>(st + rr * SPN + col);
+      const int i = (it + u) * 64 + lane, rr = i / V4R, cl = (i % V4R) * 4, m = m0 + rw * 16 + rr;
+      float4 o = *reinterpret_cast<const float4*>(st + rr * SPW + cl);
       if (p.dact == RF_ACT_GELU) {  // four independent straight-line chains
         o.x *= gelu_grad_fast(dz[u].x); o.y *= gelu_grad_fast(dz[u].y);
         o.z *= gelu_grad_fast(dz[u].z); o.w *= gelu_grad_fast(dz[u].w);
@@ -561,7 +572,7 @@ __global__ __launch_bounds__(NT) void rb_nn_kernel(NnP p) {
         o.z *= act_grad(dz[u].z, p.dact); o.w *= act_grad(dz[u].w, p.dact);
       }
       o.x += rz[u].x; o.y += rz[u].y; o.z += rz[u].z; o.w += rz[u].w;
-      if (m < p.M) *reinterpret_cast<float4*>(p.y + (long)m * p.ldy + col) = o;
+      if (m < p.M) *reinterpret_cast<float4*>(p.y + (long)m * p.ldy + ch * NCOL + cl) = o;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) { rz[u] = nrz[u]; dz[u] = ndz[u]; }
@@ -631,11 +642,12 @@ extern "C" int rf_rowblock_linear_nn(const float* a, int64_t lda, const float* l
         dact_mode ? dact_src : nullptr, ldd, dact_mode, y, ldy, M};
   dim3 grid((M + RB - 1) / RB);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (ln && NOUT == 128) hipLaunchKernelGGL((rb_nn_kernel<128, 128, true>), grid, dim3(NT), 0, st, p);
-  else if (ln) hipLaunchKernelGGL((rb_nn_kernel<128, 256, true>), grid, dim3(NT), 0, st, p);
-  else if (KC == 128) hipLaunchKernelGGL((rb_nn_kernel<128, 128, false>), grid, dim3(NT), 0, st, p);
-  else if (KC == 256) hipLaunchKernelGGL((rb_nn_kernel<256, 128, false>), grid, dim3(NT), 0, st, p);
-  else hipLaunchKernelGGL((rb_nn_kernel<384, 128, false>), grid, dim3(NT), 0, st, p);
+  constexpr int W = 8;  // waves per workgroup
+  if (ln && NOUT == 128) hipLaunchKernelGGL((rb_nn_kernel<128, 128, true, W>), grid, dim3(64 * W), 0, st, p);
+  else if (ln) hipLaunchKernelGGL((rb_nn_kernel<128, 256, true, W>), grid, dim3(64 * W), 0, st, p);
+  else if (KC == 128) hipLaunchKernelGGL((rb_nn_kernel<128, 128, false, W>), grid, dim3(64 * W), 0, st, p);
+  else if (KC == 256) hipLaunchKernelGGL((rb_nn_kernel<256, 128, false, W>), grid, dim3(64 * W), 0, st, p);
+  else hipLaunchKernelGGL((rb_nn_kernel<384, 128, false, W>), grid, dim3(64 * W), 0, st, p);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
