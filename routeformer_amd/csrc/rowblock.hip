@@ -141,6 +141,75 @@ __device__ __forceinline__ void layer_norm_rows(f32x4 (&v)[8], f32x4 (&y)[8], co
     for (int r = 0; r < 4; ++r) y[j][r] = v[j][r] * gam[j] + bet[j];
 }
 
+// 8-wave variants: a wave holds 16 rows x 64 columns (4 tiles); wave = 4 * column-half + row-group.
+// 16 x 64 tile (MFMA C layout) -> wave-private LDS staging (pitch 68) -> row-contiguous float4 stores
+__device__ __forceinline__ void store_rows64(const f32x4 (&v)[4], float* __restrict__ stage_w, float* __restrict__ g,
+                                             long ld, int row0, int nrows, int col0, int ncols, int lane) {
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stage_w[(fq * 4 + r) * 68 + j * 16 + fr] = v[j][r];
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int i = it * 64 + lane, rr = i >> 4, c4 = (i & 15) * 4;
+    if (row0 + rr < nrows && col0 + c4 < ncols) {
+      const float4 o = *reinterpret_cast<const float4*>(stage_w + rr * 68 + c4);
+      float* p = g + (long)(row0 + rr) * ld + col0 + c4;
+      if (col0 + c4 + 3 < ncols) *reinterpret_cast<float4*>(p) = o;
+      else { p[0] = o.x; if (col0 + c4 + 1 < ncols) p[1] = o.y; if (col0 + c4 + 2 < ncols) p[2] = o.z; }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// LayerNorm over 128 columns held by TWO waves (64 each): per-row partial sums meet in LDS (lnred[2][64]),
+// two block barriers (mean, then centred variance: the same two-pass arithmetic as the one-wave form).
+__device__ __forceinline__ void layer_norm_rows_split(f32x4 (&v)[4], f32x4 (&y)[4], const float (&gam)[4],
+                                                      const float (&bet)[4], float eps, float (&rstd)[4],
+                                                      float* __restrict__ lnred, int rw, int ch, int lane) {
+  const int fr = lane & 15, fq = lane >> 4;
+  float mean[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += v[j][r];
+    s = row16_sum(s);
+    if (fr == 0) lnred[ch * 64 + rw * 16 + fq * 4 + r] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = rw * 16 + fq * 4 + r;
+    mean[r] = (lnred[row] + lnred[64 + row]) * (1.f / 128.f);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float d = v[j][r] - mean[r]; q += d * d; }
+    q = row16_sum(q);
+    if (fr == 0) lnred[ch * 64 + rw * 16 + fq * 4 + r] = q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = rw * 16 + fq * 4 + r;
+    rstd[r] = 1.0f / sqrtf((lnred[row] + lnred[64 + row]) * (1.f / 128.f) + eps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j][r] = (v[j][r] - mean[r]) * rstd[r];  // v becomes x-hat
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[j][r] = v[j][r] * gam[j] + bet[j];
+}
+
 struct LinP {
   const float* x; long ldx;
   const float* w;           // (N, KC) row-major, contiguous
@@ -151,18 +220,22 @@ struct LinP {
   const float* gamma; const float* beta; float* xhat; float* rstd; float eps;  // LN = true only (N == 128)
 };
 
+constexpr int NT8 = 512;  // 8 waves: two per SIMD (these kernels are instruction-issue bound at one)
+
 template <int KC, bool LN>
-__global__ __launch_bounds__(NT) void rb_linear_kernel(LinP p) {
+__global__ __launch_bounds__(NT8) void rb_linear_kernel(LinP p) {
   constexpr int LD = KC + 8;
-  constexpr int W_EL = 128 * LD, STAGE_EL = RB * SP * 2;  // staging (fp32) expressed in bf16 elements
+  constexpr int W_EL = 128 * LD, STAGE_EL = 8 * 16 * 68 * 2;  // staging (fp32) expressed in bf16 elements
   __shared__ __attribute__((aligned(16))) __bf16 smem[(W_EL > STAGE_EL ? W_EL : STAGE_EL) + RB * LD];
+  __shared__ float lnred[128];
   __bf16* ws = smem;
   __bf16* xs = smem + (W_EL > STAGE_EL ? W_EL : STAGE_EL);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int rw = wave & 3, ch = wave >> 2;
   const int m0 = blockIdx.y * RB, n0 = blockIdx.x * 128;
 
-  Tile<RB, KC> tx;
-  Tile<128, KC> tw;
+  Tile<RB, KC, NT8> tx;
+  Tile<128, KC, NT8> tw;
   tx.load(p.x, p.ldx, m0, p.M, tid);
   tw.load(p.w, KC, n0, p.N, tid);
   tx.store(xs, tid);
@@ -170,48 +243,48 @@ __global__ __launch_bounds__(NT) void rb_linear_kernel(LinP p) {
   __syncthreads();
 
   // epilogue operands are requested before the matrix work: their latency hides behind it
-  float bv[8], gam[8], bet[8];
-  f32x4 rv[8];
+  float bv[4], gam[4], bet[4];
+  f32x4 rv[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int n = n0 + j * 16 + fr;
+  for (int j = 0; j < 4; ++j) {
+    const int cl = ch * 64 + j * 16 + fr, n = n0 + cl;
     bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-    if constexpr (LN) { gam[j] = p.gamma[j * 16 + fr]; bet[j] = p.beta[j * 16 + fr]; }
+    if constexpr (LN) { gam[j] = p.gamma[cl]; bet[j] = p.beta[cl]; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wave * 16 + fq * 4 + r;
+      const int m = m0 + rw * 16 + fq * 4 + r;
       rv[j][r] = (p.res && m < p.M && n < p.N) ? p.res[(long)m * p.ldr + n] : 0.f;
     }
   }
 
-  f32x4 acc[8];
+  f32x4 acc[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  mma_rows<KC, 8>(acc, xs + wave * 16 * LD, ws, lane);
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  mma_rows<KC, 4>(acc, xs + rw * 16 * LD, ws + ch * 64 * LD, lane);
 
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[j][r] += bv[j] + rv[j][r];
   __syncthreads();  // every wave is done with the weights: their LDS becomes the output staging tile
-  float* stage_w = reinterpret_cast<float*>(smem) + wave * 16 * SP;
+  float* stage_w = reinterpret_cast<float*>(smem) + wave * 16 * 68;
   if constexpr (LN) {
-    f32x4 y[8];
+    f32x4 y[4];
     float rstd[4];
-    layer_norm_rows(acc, y, gam, bet, p.eps, rstd);
-    store_rows(y, stage_w, p.y, p.ldy, m0 + wave * 16, p.M, 0, 128, lane);
+    layer_norm_rows_split(acc, y, gam, bet, p.eps, rstd, lnred, rw, ch, lane);
+    store_rows64(y, stage_w, p.y, p.ldy, m0 + rw * 16, p.M, ch * 64, 128, lane);
     if (p.xhat) {
-      store_rows(acc, stage_w, p.xhat, 128, m0 + wave * 16, p.M, 0, 128, lane);
-      if (fr == 0) {
+      store_rows64(acc, stage_w, p.xhat, 128, m0 + rw * 16, p.M, ch * 64, 128, lane);
+      if (fr == 0 && ch == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = m0 + wave * 16 + fq * 4 + r;
+          const int m = m0 + rw * 16 + fq * 4 + r;
           if (m < p.M) p.rstd[m] = rstd[r];
         }
       }
     }
   } else {
-    store_rows(acc, stage_w, p.y, p.ldy, m0 + wave * 16, p.M, n0, p.N, lane);
+    store_rows64(acc, stage_w, p.y, p.ldy, m0 + rw * 16, p.M, n0 + ch * 64, p.N, lane);
   }
 }
 
@@ -599,11 +672,11 @@ extern "C" int rf_rowblock_linear(const float* x, int64_t ldx, const float* w, c
   dim3 grid((N + 127) / 128, (M + RB - 1) / RB);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (K == 128) {
-    if (ln) hipLaunchKernelGGL((rb_linear_kernel<128, true>), grid, dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL((rb_linear_kernel<128, false>), grid, dim3(NT), 0, st, p);
+    if (ln) hipLaunchKernelGGL((rb_linear_kernel<128, true>), grid, dim3(NT8), 0, st, p);
+    else hipLaunchKernelGGL((rb_linear_kernel<128, false>), grid, dim3(NT8), 0, st, p);
   } else {
-    if (ln) hipLaunchKernelGGL((rb_linear_kernel<256, true>), grid, dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL((rb_linear_kernel<256, false>), grid, dim3(NT), 0, st, p);
+    if (ln) hipLaunchKernelGGL((rb_linear_kernel<256, true>), grid, dim3(NT8), 0, st, p);
+    else hipLaunchKernelGGL((rb_linear_kernel<256, false>), grid, dim3(NT8), 0, st, p);
   }
   RF_CHECK_LAUNCH();
   return RF_OK;
