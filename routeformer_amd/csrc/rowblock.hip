@@ -312,21 +312,24 @@ struct FfnP {
   const float* gamma; const float* beta; float* xhat; float* rstd; float eps;
 };
 
-__global__ __launch_bounds__(NT) void rb_ffn_ln_kernel(FfnP p) {
-  constexpr int D = 128, F = 256, LDX = D + 8, LDH = F + 8;
+__global__ __launch_bounds__(NT8) void rb_ffn_ln_kernel(FfnP p) {
+  // 8 waves: wave = 4 * column-half + row-group (16 rows); LDS as in the 4-wave form (the weights dominate)
+  constexpr int D = 128, F = 256, LDX = D + 8, LDH = F + 8, ZP = 36;  // ZP: pitch of the 16 x 32 z tile
   constexpr int WB = (F * LDX > D * LDH) ? F * LDX : D * LDH;  // W1 (256 x 136) then W2 (128 x 264), bf16
-  __shared__ __attribute__((aligned(16))) __bf16 smem[WB + RB * LDX + RB * LDH + RB * 68 * 2];
+  __shared__ __attribute__((aligned(16))) __bf16 smem[WB + RB * LDX + RB * LDH + 8 * 16 * ZP * 2];
+  __shared__ float lnred[128];
   __bf16* wb = smem;
   __bf16* xs = smem + WB;
   __bf16* hs = xs + RB * LDX;
   float* zs = reinterpret_cast<float*>(hs + RB * LDH);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int rw = wave & 3, ch = wave >> 2;
   const int m0 = blockIdx.x * RB;
   RB_MARK(0);
 
   {
-    Tile<RB, D> tx;
-    Tile<F, D> t1;
+    Tile<RB, D, NT8> tx;
+    Tile<F, D, NT8> t1;
     tx.load(p.x, D, m0, p.M, tid);
     t1.load(p.w1, D, 0, F, tid);
     tx.store(xs, tid);
@@ -334,41 +337,37 @@ __global__ __launch_bounds__(NT) void rb_ffn_ln_kernel(FfnP p) {
   }
   __syncthreads();
   RB_MARK(1);
-  Tile<D, F> t2;  // W2 travels while the first contraction runs
+  Tile<D, F, NT8> t2;  // W2 travels while the first contraction runs
   t2.load(p.w2, F, 0, D, tid);
 
-  // first contraction in four passes of 64 hidden columns; each pass's 16 x 64 block goes through a
-  // wave-private fp32 LDS tile so that bias + activation exist once in a rolled loop (code stays small: the
-  // instruction cache is 64 KB) and z / h leave as row-contiguous 256-B stores
-  // Epilogue of each 64-column pass through a wave-private fp32 LDS tile, four consecutive columns per lane:
-  // one float4 tile read, four independent GELU chains, one 8-byte bf16 LDS write and two float4 global
-  // stores per four elements.  (This loop is instruction-issue bound at one wave per SIMD -- 4.5k of 6.6k
-  // cycles per pass in the scalar form, tools/rb_phase_probe.py -- so instructions per element matter.)
-  float* zt = zs + wave * 16 * 68;
-  const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+  // First contraction in four passes of 64 hidden columns (32 per wave).  Each wave's 16 x 32 block goes
+  // through a wave-private fp32 LDS tile, then four consecutive columns per lane: one float4 tile read, four
+  // independent GELU chains, one 8-byte bf16 LDS write and two float4 global stores per four elements.  (The
+  // loop is instruction-issue bound -- tools/rb_phase_probe.py -- hence float4 work and two waves per SIMD.)
+  float* zt = zs + wave * 16 * ZP;
+  const int c4 = (lane & 7) * 4, rsub = lane >> 3;  // 8 float4 per 32-column row, 8 rows per trip
   float4 b1v[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) b1v[c] = *reinterpret_cast<const float4*>(p.b1 + c * 64 + c4);
+  for (int c = 0; c < 4; ++c) b1v[c] = *reinterpret_cast<const float4*>(p.b1 + c * 64 + ch * 32 + c4);
 #pragma unroll 1
   for (int c = 0; c < 4; ++c) {
-    f32x4 a1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 a1[2];
+    a1[0] = a1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c == 0) RB_MARK(6);
-    mma_rows<D, 4>(a1, xs + wave * 16 * LDX, wb + c * 64 * LDX, lane);
+    mma_rows<D, 2>(a1, xs + rw * 16 * LDX, wb + (c * 64 + ch * 32) * LDX, lane);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) zt[(fq * 4 + r) * 68 + j * 16 + fr] = a1[j][r];
+      for (int r = 0; r < 4; ++r) zt[(fq * 4 + r) * ZP + j * 16 + fr] = a1[j][r];
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (c == 0) RB_MARK(7);
     const float4 b = c == 0 ? b1v[0] : (c == 1 ? b1v[1] : (c == 2 ? b1v[2] : b1v[3]));
-    const int f = c * 64 + c4;
+    const int f = c * 64 + ch * 32 + c4;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int rl = wave * 16 + it * 4 + rsub, m = m0 + rl;
-      float4 zz = *reinterpret_cast<const float4*>(zt + (it * 4 + rsub) * 68 + c4);
+    for (int it = 0; it < 2; ++it) {
+      const int rl = rw * 16 + it * 8 + rsub, m = m0 + rl;
+      float4 zz = *reinterpret_cast<const float4*>(zt + (it * 8 + rsub) * ZP + c4);
       zz.x += b.x; zz.y += b.y; zz.z += b.z; zz.w += b.w;
       float4 hh;
       if (p.act == RF_ACT_GELU) {
@@ -393,42 +392,42 @@ __global__ __launch_bounds__(NT) void rb_ffn_ln_kernel(FfnP p) {
   RB_MARK(2);
   t2.store(wb, tid);
   // epilogue operands (bias, exact fp32 residual, norm parameters) are requested now, used after the MFMAs
-  float b2v[8], gam[8], bet[8];
-  f32x4 xres[8];
+  float b2v[4], gam[4], bet[4];
+  f32x4 xres[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int n = j * 16 + fr;
+  for (int j = 0; j < 4; ++j) {
+    const int n = ch * 64 + j * 16 + fr;
     b2v[j] = p.b2[n]; gam[j] = p.gamma[n]; bet[j] = p.beta[n];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wave * 16 + fq * 4 + r;
+      const int m = m0 + rw * 16 + fq * 4 + r;
       xres[j][r] = m < p.M ? p.x[(long)m * D + n] : 0.f;
     }
   }
   __syncthreads();
   RB_MARK(3);
 
-  f32x4 acc[8];
+  f32x4 acc[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  mma_rows<F, 8>(acc, hs + wave * 16 * LDH, wb, lane);
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  mma_rows<F, 4>(acc, hs + rw * 16 * LDH, wb + ch * 64 * LDH, lane);
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[j][r] += b2v[j] + xres[j][r];
   __syncthreads();
   RB_MARK(4);
-  float* stage_w = reinterpret_cast<float*>(smem) + wave * 16 * SP;
-  f32x4 y[8];
+  float* stage_w = reinterpret_cast<float*>(smem) + wave * 16 * 68;
+  f32x4 y[4];
   float rstd[4];
-  layer_norm_rows(acc, y, gam, bet, p.eps, rstd);
-  store_rows(y, stage_w, p.y, D, m0 + wave * 16, p.M, 0, D, lane);
+  layer_norm_rows_split(acc, y, gam, bet, p.eps, rstd, lnred, rw, ch, lane);
+  store_rows64(y, stage_w, p.y, D, m0 + rw * 16, p.M, ch * 64, D, lane);
   if (p.xhat) {
-    store_rows(acc, stage_w, p.xhat, D, m0 + wave * 16, p.M, 0, D, lane);
-    if (fr == 0) {
+    store_rows64(acc, stage_w, p.xhat, D, m0 + rw * 16, p.M, ch * 64, D, lane);
+    if (fr == 0 && ch == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wave * 16 + fq * 4 + r;
+        const int m = m0 + rw * 16 + fq * 4 + r;
         if (m < p.M) p.rstd[m] = rstd[r];
       }
     }
@@ -689,7 +688,7 @@ extern "C" int rf_rowblock_ffn_ln(const float* x, const float* w1, const float* 
   RF_REQUIRE(x && w1 && b1 && w2 && b2 && y && ln_gamma && ln_beta && M > 0 && d_model == 128 && d_ff == 256);
   RF_REQUIRE(al16(x) && al16(w1) && al16(w2) && al16(y) && (!xhat || (rstd && al16(xhat))));
   FfnP p{x, w1, b1, w2, b2, h, z, y, M, act, ln_gamma, ln_beta, xhat, rstd, eps};
-  hipLaunchKernelGGL(rb_ffn_ln_kernel, dim3((M + RB - 1) / RB), dim3(NT), 0, static_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(rb_ffn_ln_kernel, dim3((M + RB - 1) / RB), dim3(NT8), 0, static_cast<hipStream_t>(stream), p);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
