@@ -437,6 +437,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   int* top_list = reinterpret_cast<int*>(colsum + ((E + 3) & ~3));
   int* sel = top_list + n_sel;
 
+  RF_MARK(9);
   load_qkv<V4>(nullptr, Ks, Vs, p, b, h, EP, tid);
   for (int i = tid; i < (LKP - LK) * EP; i += (int)blockDim.x) { Ks[LK * EP + i] = 0.f; Vs[LK * EP + i] = 0.f; }
   for (int i = tid; i < (NSP - n_sel) * EP; i += (int)blockDim.x) { Qsel[n_sel * EP + i] = 0.f; dCsel[n_sel * EP + i] = 0.f; }
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   }
   __syncthreads();
 
+  RF_MARK(10);
   // phase 1: recompute P = softmax(scale * Qsel K^T); dP = dC V^T; dS = P * (dP - rowsum(P*dP)) * scale
   if constexpr (V4) {
     const int TI = (n_sel + 15) >> 4, TJ = (LK + 15) >> 4;
@@ -493,6 +495,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
     }
   }
   __syncthreads();
+  RF_MARK(11);
   softmax_rows(P, n_sel, LK, top_list, p.mode == 2, LKP);
   // the same 16 lanes own the same row in softmax_rows and here: no barrier needed in between
   for (int base = 0; base < n_sel; base += rows_per_trip()) {
@@ -509,6 +512,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   }
   __syncthreads();
 
+  RF_MARK(12);
   // dQ[q] = dS K for the active rows, zero for the others (the sampling stage is not differentiated)
   if constexpr (V4) {
     mm_tiles((n_sel + 15) >> 4, (E + 15) >> 4, LKP >> 2, lane, wave,
@@ -534,17 +538,34 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
     for (int i = tid; i < LQ * E; i += (int)blockDim.x, rc.next())
       if (sel[rc.r] < 0) qb_[(long)rc.r * p.dq_ld + rc.c] = 0.f;
   }
-  // lazy-row gradient source: column sums of dctx over NON-selected rows (unmasked mode)
+  // lazy-row gradient source: column sums of dctx over NON-selected rows (unmasked mode).  All threads take
+  // part ((row part, column) work split, partials through the V tile, which is dead after phase 1 in this
+  // mode): done by E threads walking all L_Q rows one dependent global load at a time, this was 40 % of the
+  // whole backward kernel (tools/attn_phase_probe.py)
   if (p.mode == 1) {
+    const int parts = max(1, min(min((int)blockDim.x / E, LK), 16));
+    const long row_step = p.out_layout == 0 ? (long)p.H * E : (long)E;
+    const float* dbase = p.dctx + ctx_off(p, b, h, 0);
+    for (int i = tid; i < parts * E; i += (int)blockDim.x) {
+      const int part = i / E, d = i - part * E;
+      float s_ = 0.f;
+#pragma unroll 4
+      for (int ql = part; ql < LQ; ql += parts) {
+        const float v = sel[ql] < 0 ? dbase[ql * row_step + d] : 0.f;
+        s_ += v;
+      }
+      Vs[i] = s_;
+    }
+    __syncthreads();
     for (int d = tid; d < E; d += (int)blockDim.x) {
       float s_ = 0.f;
-      for (int ql = 0; ql < LQ; ++ql)
-        if (sel[ql] < 0) s_ += p.dctx[ctx_off(p, b, h, ql) + d];
+      for (int part = 0; part < parts; ++part) s_ += Vs[part * E + d];
       colsum[d] = s_ / (float)LK;
     }
   }
   __syncthreads();
 
+  RF_MARK(13);
   // phase 2: dK[s,e] = sum_q dS[q,s] Q[q,e];  dV[s,d] = sum_q P[q,s] dC[q,d] + lazy-row term
   if (p.mode == 2) {
     // masked lazy rows: ctx[q] = sum_{s<=q} V[s]  =>  dV[s] += sum_{q>=s, q not selected} dC[q]
@@ -589,6 +610,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
       p.dv[((long)b * LK + s_) * p.dv_ld + (long)h * E + e] = av;
     }
   }
+  RF_MARK(14);
 }
 
 size_t fwd_lds(int LQ, int LK, int E, int n_sel, int sample_k, bool v4) {

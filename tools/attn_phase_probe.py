@@ -48,3 +48,24 @@ print("phase                 mean cycles   (shader clock)")
 for n, v in zip(names, d.mean(0)):
     print(f"{n:22s} {v:10.0f}")
 print(f"{'total per workgroup':22s} {(t[:, 8] - t[:, 0]).mean():10.0f};  first start -> last end: {t[:, 8].max() - t[:, 0].min():.0f} cycles")
+
+# ---- backward ----
+dctx = torch.randn(B * L, HE, device=dev)
+dqkv = torch.empty(B * L, 3 * HE, device=dev)
+def call_bwd():
+    return lib.rf_attn_bwd(P(qkv.data_ptr()), P(qkv.data_ptr() + 4 * HE), P(qkv.data_ptr() + 8 * HE), ctypes.c_int64(3 * HE),
+                           ctypes.c_int64(3 * HE), ctypes.c_int64(3 * HE), P(dctx.data_ptr()), 0, P(top.data_ptr()),
+                           P(dqkv.data_ptr()), P(dqkv.data_ptr() + 4 * HE), P(dqkv.data_ptr() + 8 * HE), ctypes.c_int64(3 * HE),
+                           ctypes.c_int64(3 * HE), ctypes.c_int64(3 * HE), B, H, L, L, E, nt, mode, ctypes.c_float(1 / math.sqrt(E)),
+                           P(torch.cuda.current_stream().cuda_stream))
+for _ in range(3):
+    assert call_bwd() == 0
+torch.cuda.synchronize()
+s.record(); [call_bwd() for _ in range(20)]; e.record(); torch.cuda.synchronize()
+print(f"backward launch: {s.elapsed_time(e) / 20 * 1e3:.1f} us")
+hip.hipMemcpy(P(buf.data_ptr()), P(addr), ctypes.c_size_t(8 * 16 * 4096), 3)
+t = buf.cpu().numpy().reshape(4096, 16)[: min(B * H, 4096), 9:15].astype(np.float64)
+for n_, v in zip(["load K,V + gather Qsel,dCsel", "P and dP (mfma)", "softmax + dS", "dQ (mfma) + zero fill + colsum", "dK, dV (mfma) + stores"],
+                 np.diff(t, axis=1).mean(0)):
+    print(f"{n_:34s} {v:10.0f}")
+print(f"{'total per workgroup':34s} {(t[:, 5] - t[:, 0]).mean():10.0f}")
