@@ -569,11 +569,21 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   // phase 2: dK[s,e] = sum_q dS[q,s] Q[q,e];  dV[s,d] = sum_q P[q,s] dC[q,d] + lazy-row term
   if (p.mode == 2) {
     // masked lazy rows: ctx[q] = sum_{s<=q} V[s]  =>  dV[s] += sum_{q>=s, q not selected} dC[q]
+    // (1) all threads fetch the lazy rows of dC into the (no longer needed) V tile, (2) E threads turn it into
+    // the reverse running sum in LDS -- not E threads doing L_Q dependent global loads each
+    {
+      RowCol rc(tid, blockDim.x, E);
+      const long row_step = p.out_layout == 0 ? (long)p.H * E : (long)E;
+      const float* dbase = p.dctx + ctx_off(p, b, h, 0);
+      for (int i = tid; i < LQ * E; i += (int)blockDim.x, rc.next())
+        Vs[rc.r * EP + rc.c] = sel[rc.r] < 0 ? dbase[rc.r * row_step + rc.c] : 0.f;
+    }
+    __syncthreads();
     for (int d = tid; d < E; d += (int)blockDim.x) {
       float run = 0.f;
       for (int ql = LQ - 1; ql >= 0; --ql) {
-        if (sel[ql] < 0) run += p.dctx[ctx_off(p, b, h, ql) + d];
-        Vs[ql * EP + d] = run;  // stash the running sum in the (no longer needed) V tile
+        run += Vs[ql * EP + d];
+        Vs[ql * EP + d] = run;
       }
     }
     __syncthreads();
