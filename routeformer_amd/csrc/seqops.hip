@@ -314,7 +314,9 @@ extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float*
   RF_REQUIRE(rows > 0 && cols > 0 && cols <= 64 * LN_MAXV);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (accumulate == 2) {  // atomics straight into the running sums; few workgroups -> few same-address adds
-    int blocks = (rows + 4 * LN_WAVES - 1) / (4 * LN_WAVES);
+    // one row per wave until 512 workgroups (M <= 560 layers: 80-140 workgroups instead of 20-35 -- these
+    // launches are latency-bound), then grid-stride
+    int blocks = (rows + LN_WAVES - 1) / LN_WAVES;
     blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, xhat, rstd, gamma, dx,
                        static_cast<float*>(nullptr), rows, cols, dgamma, dbeta);
