@@ -411,7 +411,7 @@ def _rowblock_nn(w2d, M, *, a=None, ln=None, dpre=None, dgam=None, dbet=None, re
     if ev is not None:
         keep = (a, ln, dpre, dgam, dbet, w2d, res, dsrc, y)
         lnbwd = "true" if ln else "false"
-        PROFILE.end(f"rb_nn_kernel<{KC}, {NOUT}, {lnbwd}>", ev, 2.0 * M * KC * NOUT,
+        PROFILE.end(f"rb_nn_kernel<{KC}, {NOUT}, {lnbwd}, 8>", ev, 2.0 * M * KC * NOUT,
                     4.0 * (M * KC * (3 if ln else 1) + KC * NOUT + M * NOUT * (1 + (res is not None) + (dsrc is not None))))
     return y
 
