@@ -151,11 +151,14 @@ int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const float* x, c
  * db[N] += column sums of dy -- fp32 atomics into gradient slots that were zeroed at the start of the step.
  * Up to RF_WGRAD_MAX_GROUP problems per launch; `entries` is a HOST array (copied into the kernel arguments).
  * dy / x: 16-B aligned, unit column stride, row pitches ld_dy / ld_x multiples of 4; dw contiguous (N,K).
- * `splits` = requested split of the reduction dimension M (clamped); `kchunk` is filled in by the library. */
+ * `splits` = requested split of the reduction dimension M (clamped); `kchunk` is filled in by the library.
+ * `exclusive` != 0: the caller guarantees that nothing else writes dw during this launch and that dw holds
+ * zeros; if the problem also ends up with a single K slice the tile is then written with plain stores
+ * instead of fp32 atomics (most of the bytes of a backward pass: the large weights have shallow reductions). */
 #define RF_WGRAD_MAX_GROUP 48
 typedef struct RfWgradEntry {
   const float* dy; const float* x; float* dw; float* db;
-  int M, N, K, ld_dy, ld_x, splits, kchunk, reserved;
+  int M, N, K, ld_dy, ld_x, splits, kchunk, exclusive;
 } RfWgradEntry;
 int rf_wgrad_grouped(const RfWgradEntry* entries, int count, int prec, void* stream);
 

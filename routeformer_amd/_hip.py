@@ -62,7 +62,7 @@ class WgradEntry(ctypes.Structure):
     """RfWgradEntry of include/rf_hip.h."""
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("db", c_void_p), ("M", c_int), ("N", c_int),
                 ("K", c_int), ("ld_dy", c_int), ("ld_x", c_int), ("splits", c_int), ("kchunk", c_int),
-                ("reserved", c_int)]
+                ("exclusive", c_int)]
 
 
 class HipLibraryError(RuntimeError):

@@ -33,7 +33,7 @@ struct GemmP {
   const float* dsrc; long ldd; int dact;
   int kchunk;  // K range per split-K slice (multiple of BK)
   float* ws;   // split-K partials [splits][M][N] (null: single pass with epilogue)
-  int atomic;  // 1: C += partial via fp32 atomics (no other epilogue)
+  int atomic;  // 1: C += partial via fp32 atomics (no other epilogue); 2: C = partial, plain stores (exclusive tile)
   unsigned* tile_cnt;  // split-K arrival counters (one per output tile, zero between launches) or null
   int gx, gy, share;   // tile grid and XCD grouping of the launch (gemm2_kernel): 0 = plain, 1 = column tiles, 2 = row tiles
   float* a_rowsum;  // optional: a_rowsum[m] += sum_k A[m,k] (A row-contiguous)
@@ -530,8 +530,12 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
         for (int r = 0; r < 4; ++r) {
           const int m = m0 + (wm * C_::TM + i) * 16 + fq * 4 + r;
           if (m >= p.M) continue;
-          if (mode == 1) atomicAdd(&p.C[(long)m * p.ldc + n], acc[i][j][r]);
-          else p.ws[((long)blk.z * p.M + m) * p.N + n] = acc[i][j][r];
+          if (mode == 1) {
+            if (p.atomic == 2) p.C[(long)m * p.ldc + n] = acc[i][j][r];
+            else atomicAdd(&p.C[(long)m * p.ldc + n], acc[i][j][r]);
+          } else {
+            p.ws[((long)blk.z * p.M + m) * p.N + n] = acc[i][j][r];
+          }
         }
       }
     }
@@ -698,7 +702,7 @@ __global__ __launch_bounds__(NT) void wgrad_grouped_kernel(const WgradTable t) {
   p.B = e.x; p.ldb_k = e.ld_x; p.ldb_n = 1;
   p.C = e.dw; p.ldc = e.K;
   p.M = e.N; p.N = e.K; p.K = e.M;
-  p.res_rows = 1; p.atomic = 1; p.a_rowsum = e.db;
+  p.res_rows = 1; p.atomic = (e.exclusive && e.splits == 1) ? 2 : 1; p.a_rowsum = e.db;
   p.kchunk = e.kchunk;
   const int gx = (e.K + 63) / 64, gy = (e.N + 63) / 64;
   const int local = b - t.first_block[lo];

@@ -216,6 +216,8 @@ class GradReducer:
     def zero(self):
         self.flat_grad.zero_()
         self.begin_step()
+        from routeformer_amd import kernels as K
+        K.WGRAD.begin_step()
 
     def begin_step(self):
         """Reset the per-step bucket bookkeeping (a HIP-graph replay zeroes the buffer itself, on the device)."""

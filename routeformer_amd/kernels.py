@@ -281,6 +281,12 @@ class _WgradQueue:
         self.active = False
         self.queues = {}     # stream handle -> (torch stream, [items])
         self.pending = set() # data_ptr of slots with a queued (not yet launched) write
+        self.written = set() # data_ptr of slots already written by a grouped launch this step
+
+    def begin_step(self):
+        """Gradient slots were just zeroed: the first (and, per launch, only) writer of a slot may use plain
+        stores instead of atomics (``RfWgradEntry.exclusive``)."""
+        self.written.clear()
 
     def push(self, dy2, x2, into, bias_into, M, N, K, splits):
         st = torch.cuda.current_stream()
@@ -300,9 +306,14 @@ class _WgradQueue:
             return
         n = len(q)
         arr = (_hip.WgradEntry * n)()
+        uses = {}
+        for item in q:
+            uses[item[2].data_ptr()] = uses.get(item[2].data_ptr(), 0) + 1
         for e, (dy2, x2, into, bias_into, M, N, K, splits) in zip(arr, q):
             e.dy, e.x, e.dw, e.db = ptr(dy2), ptr(x2), ptr(into), ptr(bias_into)
             e.M, e.N, e.K, e.ld_dy, e.ld_x, e.splits = M, N, K, dy2.stride(0), x2.stride(0), splits
+            e.exclusive = 1 if (uses[into.data_ptr()] == 1 and into.data_ptr() not in self.written) else 0
+        self.written.update(uses)
         ev = PROFILE.begin() if PROFILE.on else None
         with torch.cuda.stream(st):
             check(_hip.lib().rf_wgrad_grouped(arr, n, _PRECISION, st.cuda_stream), "rf_wgrad_grouped")
