@@ -129,15 +129,24 @@ def main():
     use_graph = not args.no_graph
     engine = GraphedTrainEngine(model) if use_graph else TrainEngine(model)
     if use_graph:
-        try:  # capture once up front; any failure falls back to eager launches (same arithmetic)
-            engine.capture(item, epoch=10)
-        except Exception as exc:  # noqa: BLE001
-            print(f"[bench] HIP-graph capture failed ({type(exc).__name__}: {exc}); using eager launches",
-                  file=sys.stderr, flush=True)
-            from routeformer_amd.models.blocks import SAMPLER
-            SAMPLER.drop_static()
-            use_graph = False
-            engine = TrainEngine(model)
+        # capture once up front; fall back step by step (same arithmetic and the same collective order in every
+        # mode): two-graph step (N > 1) -> one graph -> eager launches
+        from routeformer_amd.models.blocks import SAMPLER
+        for attempt in ("as configured", "single graph"):
+            try:
+                engine.capture(item, epoch=10)
+                break
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] HIP-graph capture failed ({attempt}; {type(exc).__name__}: {exc})", file=sys.stderr, flush=True)
+                SAMPLER.drop_static()
+                if attempt == "as configured" and engine.split:
+                    engine = GraphedTrainEngine(model)
+                    engine.split = False
+                else:
+                    print("[bench] using eager launches", file=sys.stderr, flush=True)
+                    use_graph = False
+                    engine = TrainEngine(model)
+                    break
 
     def sync():
         torch.cuda.synchronize()
