@@ -56,6 +56,19 @@ def test_gemm_linear_layouts(M, N, K, prec):
     y2 = torch.empty(M, N, device=DEV)
     Kn.gemm(xd, K, 1, wd, 1, K, y2, N, M, N, K, bias=bd, splitk=3)
     assert rel_err(y2, ref) < tol
+    # ... and with the in-launch reduction (last-arriving workgroup sums the slabs; off by default, slower)
+    was = Kn.IN_LAUNCH_SPLITK_REDUCE
+    Kn.IN_LAUNCH_SPLITK_REDUCE = True
+    try:
+        y3 = torch.empty(M, N, device=DEV)
+        for _ in range(2):  # twice: the arrival counters must be back at zero after a launch
+            y3.fill_(float("nan"))
+            Kn.gemm(xd, K, 1, wd, 1, K, y3, N, M, N, K, bias=bd, splitk=3)
+            assert rel_err(y3, ref) < tol
+        if K >= 192:
+            assert torch.equal(y3, y2)  # slabs are summed in slice order either way: same bits
+    finally:
+        Kn.IN_LAUNCH_SPLITK_REDUCE = was
     assert rel_err(Kn.colsum(dyd), dy.double().sum(0)) < 1e-5
     # gradient-sink form: dW and db accumulated with fp32 atomics into pre-filled slots, one launch
     if N % 4 == 0 and K % 4 == 0:
