@@ -215,14 +215,16 @@ int rf_traj_head_bwd(const float* out, const float* target_vis, const float* gpo
  * mode 2: ProbSparse, masked (ProbMask+cumsum context)
  * index_sample: int32 [G, LQ, sample_k]; batch row b uses table b / idx_group (idx_group <= 0: one
  * table shared by all (b,h), as in the reference's single host-RNG draw, :95).  Batching several
- * encoder calls of the reference (one per video stream) into one launch keeps each call's own draw.
+ * encoder calls of the reference (one per video stream) into one launch keeps each call's own draw;
+ * idx_group_stride = elements between consecutive tables (<= 0: LQ*sample_k, i.e. packed) -- the tables of a
+ * layer then stay where the host laid the draws out, in the reference's call order, without a gather copy.
  * top_idx: int32 [B,H,n_top] selected query rows, ascending; written unless force_top (then read).
  * out_layout 0: ctx[b,l,h,:] (cross-modal variant), 1: ctx[b,h,l,:] (GPS variant,
  * layers/SelfAttentionFamily.py:165 -- the un-transposed "head scramble"). */
 int rf_attn_fwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
                 int64_t v_ld, float* ctx, int out_layout, const int32_t* index_sample, int idx_group,
-                int32_t* top_idx, int force_top, int B, int H, int LQ, int LK, int E, int sample_k,
-                int n_top, int mode, float scale, void* stream);
+                int64_t idx_group_stride, int32_t* top_idx, int force_top, int B, int H, int LQ, int LK, int E,
+                int sample_k, int n_top, int mode, float scale, void* stream);
 int rf_attn_bwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
                 int64_t v_ld, const float* dctx, int out_layout, const int32_t* top_idx, float* dq,
                 float* dk, float* dv, int64_t dq_ld, int64_t dk_ld, int64_t dv_ld, int B, int H,

@@ -30,6 +30,7 @@ struct AttnP {
   float *dq, *dk, *dv;
   long dq_ld, dk_ld, dv_ld;
   int B, H, LQ, LK, E, sample_k, n_top, mode, idx_group;
+  long idx_stride;  // elements between the key-sample tables of consecutive groups
   int Qs_rows;  // rows of Q staged by load_qkv (LQ in forward, 0 in backward: only the selected rows are needed)
   float scale;
 };
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
   const bool sampling = p.mode != 0 && !p.force_top;
   int* Sidx = reinterpret_cast<int*>(S);
   if (sampling) {
-    const int32_t* idx = p.idx + (long)(b / p.idx_group) * LQ * p.sample_k;
+    const int32_t* idx = p.idx + (long)(b / p.idx_group) * p.idx_stride;
     for (int i = tid; i < LQ * p.sample_k; i += (int)blockDim.x) Sidx[i] = idx[i];
   }
   load_qkv<V4>(Qs, Ks, Vs, p, b, h, EP, tid);
@@ -641,7 +642,8 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
                            int64_t v_ld, float* ctx, int out_layout, const int32_t* index_sample,
-                           int idx_group, int32_t* top_idx, int force_top, int B, int H, int LQ, int LK,
+                           int idx_group, int64_t idx_group_stride, int32_t* top_idx, int force_top, int B, int H,
+                           int LQ, int LK,
                            int E, int sample_k, int n_top, int mode, float scale, void* stream) {
   RF_REQUIRE(q && k && v && ctx && B > 0 && H > 0 && LQ > 0 && LK > 0 && E > 0);
   RF_REQUIRE(mode >= 0 && mode <= 2);
@@ -658,6 +660,7 @@ extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64
   p.B = B; p.H = H; p.LQ = LQ; p.LK = LK; p.E = E; p.sample_k = sample_k; p.n_top = n_top;
   p.mode = mode; p.scale = scale; p.Qs_rows = LQ;
   p.idx_group = (idx_group <= 0 || idx_group > B) ? B : idx_group;
+  p.idx_stride = idx_group_stride > 0 ? idx_group_stride : (long)LQ * sample_k;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

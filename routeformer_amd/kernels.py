@@ -945,7 +945,8 @@ class _Attention(torch.autograd.Function):
             sample_k = index_sample.shape[-1] if index_sample is not None else 0
         ev = PROFILE.begin() if PROFILE.on else None
         fargs = (a.data_ptr() + 4 * q_off, b.data_ptr() + 4 * k_off, b.data_ptr() + 4 * v_off, a.stride(0),
-                 b.stride(0), b.stride(0), ptr(out), out_layout, ptr(index_sample), idx_group, ptr(top),
+                 b.stride(0), b.stride(0), ptr(out), out_layout, ptr(index_sample), idx_group,
+                 (index_sample.stride(0) if (index_sample is not None and index_sample.dim() == 3) else 0), ptr(top),
                  1 if forced_top is not None else 0, B, H, LQ, LK, E, sample_k, n_top, mode, scale)
         check(_hip.lib().rf_attn_fwd(*fargs, _stream()), "rf_attn_fwd")
         if ev is not None:
@@ -992,6 +993,10 @@ def attention(a, b, offs, dims, mode: int, *, index_sample=None, n_top: int = 0,
         assert a.shape[1] == H * E and b.shape[1] == 2 * H * E
     if index_sample is not None and index_sample.dim() == 3:
         assert idx_group > 0 and index_sample.shape[0] * idx_group == B, (index_sample.shape, idx_group, B)
+        # tables may be a strided view over the host-drawn buffer (equal spacing between groups), rows packed
+        assert index_sample.stride(2) == 1 and index_sample.stride(1) == index_sample.shape[2]
+    elif index_sample is not None:
+        assert index_sample.is_contiguous()
     return _Attention.apply(a, b, offs, index_sample, dims, mode, n_top, out_layout, scale, forced_top, idx_group)
 
 

@@ -308,6 +308,26 @@ class Routeformer(nn.Module):
             return tokens[spans[0][0]: spans[-1][0] + spans[-1][1]]  # contiguous: a view, no copy
         return torch.cat([tokens[o:o + n] for o, n in spans], dim=0)
 
+    @staticmethod
+    def _group_tables(tables):
+        """(G, L, k) key-sample tables of one layer for the G batched encoder calls.  When the draws sit equally
+        spaced in one device buffer (the engine's static sampler lays them out in call order) this is a strided
+        view -- the attention kernel takes the group stride -- otherwise a stacked copy."""
+        t0 = tables[0]
+        if len(tables) == 1:
+            return t0.unsqueeze(0)
+        if t0.is_cuda and all(t.is_contiguous() and t.shape == t0.shape and t.dtype == t0.dtype for t in tables):
+            try:
+                same = all(t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() for t in tables)
+            except Exception:  # noqa: BLE001
+                same = False
+            if same:
+                offs = [t.storage_offset() for t in tables]
+                step = offs[1] - offs[0]
+                if step >= t0.numel() and all(offs[i + 1] - offs[i] == step for i in range(len(offs) - 1)):
+                    return torch.as_strided(t0, (len(tables),) + tuple(t0.shape), (step,) + tuple(t0.stride()))
+        return torch.stack(tables)
+
     def _device_index(self, idx: torch.Tensor, dev) -> torch.Tensor:
         """Frame indices on the device, cached (no host->device copy inside a captured step)."""
         key = (tuple(idx.tolist()), str(dev))
@@ -346,7 +366,7 @@ class Routeformer(nn.Module):
                     toks.append(torch.cat([t, -torch.ones_like(t)[:, :1, :]], dim=1))
                 tokens = torch.cat(toks, dim=0)
             n_per = tokens.shape[0] // len(members)
-            idx_list = [torch.stack([m[3][layer] for m in members]) for layer in range(len(members[0][3]))]
+            idx_list = [self._group_tables([m[3][layer] for m in members]) for layer in range(len(members[0][3]))]
             K.TOPS.merge_forced(len(members), len(idx_list))  # test hooks only (no-ops in production)
             emb = self.frame_encoder(tokens.to(dtype), idx_list, n_per).view(len(members), B, -1, E)
             K.TOPS.split_record(len(members), len(idx_list))

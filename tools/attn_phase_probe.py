@@ -25,7 +25,7 @@ top = torch.empty(B * H * nt, device=dev, dtype=torch.int32)
 P = ctypes.c_void_p
 def call():
     return lib.rf_attn_fwd(P(qkv.data_ptr()), P(qkv.data_ptr() + 4 * HE), P(qkv.data_ptr() + 8 * HE), ctypes.c_int64(3 * HE),
-                           ctypes.c_int64(3 * HE), ctypes.c_int64(3 * HE), P(ctx.data_ptr()), 0, P(idx.data_ptr()), 0, P(top.data_ptr()), 0,
+                           ctypes.c_int64(3 * HE), ctypes.c_int64(3 * HE), P(ctx.data_ptr()), 0, P(idx.data_ptr()), 0, ctypes.c_int64(0), P(top.data_ptr()), 0,
                            B, H, L, L, E, sk, nt, mode, ctypes.c_float(1 / math.sqrt(E)), P(torch.cuda.current_stream().cuda_stream))
 for _ in range(3):
     assert call() == 0
