@@ -192,6 +192,14 @@ int rf_rowblock_linear_nn(const float* a, int64_t lda, const float* ln_dy, const
                           const float* dact_src, int64_t ldd, int dact_mode, float* y, int64_t ldy, int M,
                           int KC, int NOUT, void* stream);
 
+/* Input of the fusion encoder (routeformer.py:331-345): out[b, s*T + t, :] = streams[s][b, t, :] + embeddings[s]
+ * for s < S <= 4 (streams[s] == NULL: zeros, i.e. the learned output-query tokens); `streams`, `embeddings`,
+ * `demb` are HOST arrays of S device pointers.  Backward: demb[s][e] += sum_{b,t} dout[b, s*T + t, e] (E <= 64;
+ * NULL entries skipped); the stream gradients are the slices of dout themselves. */
+int rf_assemble_streams_fwd(const float* const* streams, const float* const* embeddings, float* out, int B,
+                            int T, int E, int S, void* stream);
+int rf_assemble_streams_bwd(const float* dout, float* const* demb, int B, int T, int E, int S, void* stream);
+
 /* Trajectory head = postprocess_batch (routeformer.py:367-374) + the loss recipe of the train step
  * (experiments/full_comparison.py:490-521, losses/future_discounted_mse.py:56-95, score/error.py:29,51):
  *   positions = last_gps + cumsum(out[...,:2] * motion_std + motion_mean)

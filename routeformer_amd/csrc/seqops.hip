@@ -503,3 +503,77 @@ extern "C" int rf_traj_head_bwd(const float* out, const float* target_vis, const
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Fusion-encoder input: out[b, s*T + t, :] = stream_s[b, t, :] + emb_s   (stream NULL = zeros: the learned
+// "video output" query tokens) -- the per-stream embedding adds, the zeros_like and the cat of
+// routeformer.py:331-345 in one launch; backward: emb gradients = sums over (b, t) of the matching slice.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct AsmP {
+  const float* stream[4];
+  const float* emb[4];
+  float* demb[4];
+  float* out;
+  const float* dout;
+  int B, T, E, S;
+};
+
+__global__ __launch_bounds__(256) void assemble_fwd_kernel(AsmP p) {
+  const int E4 = p.E >> 2;
+  const long total = (long)p.B * p.S * p.T * E4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i % E4) * 4;
+    long r = i / E4;
+    const int t = (int)(r % p.T); r /= p.T;
+    const int s = (int)(r % p.S);
+    const int b = (int)(r / p.S);
+    float4 v = *reinterpret_cast<const float4*>(p.emb[s] + e);
+    if (p.stream[s]) {
+      const float4 x = *reinterpret_cast<const float4*>(p.stream[s] + ((long)b * p.T + t) * p.E + e);
+      v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+    }
+    *reinterpret_cast<float4*>(p.out + (((long)b * p.S + s) * p.T + t) * p.E + e) = v;
+  }
+}
+
+// one workgroup per stream: columns x 4 row lanes (E <= 64), += into the embedding's gradient slot
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(AsmP p) {
+  __shared__ float red[4][64];
+  const int s = blockIdx.x, c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  if (!p.demb[s]) return;
+  float a = 0.f;
+  if (c < p.E)
+    for (int r = rl; r < p.B * p.T; r += 4) {
+      const int b = r / p.T, t = r - b * p.T;
+      a += p.dout[(((long)b * p.S + s) * p.T + t) * p.E + c];
+    }
+  red[rl][c] = a;
+  __syncthreads();
+  if (rl == 0 && c < p.E) p.demb[s][c] += red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+}  // namespace
+
+extern "C" int rf_assemble_streams_fwd(const float* const* streams, const float* const* embeddings, float* out, int B,
+                                       int T, int E, int S, void* stream) {
+  RF_REQUIRE(streams && embeddings && out && B > 0 && T > 0 && S >= 1 && S <= 4 && E % 4 == 0);
+  AsmP p{};
+  for (int s = 0; s < S; ++s) { p.stream[s] = streams[s]; p.emb[s] = embeddings[s]; RF_REQUIRE(embeddings[s]); }
+  p.out = out; p.B = B; p.T = T; p.E = E; p.S = S;
+  hipLaunchKernelGGL(assemble_fwd_kernel, dim3(grid_for((long)B * S * T * (E / 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_assemble_streams_bwd(const float* dout, float* const* demb, int B, int T, int E, int S, void* stream) {
+  RF_REQUIRE(dout && demb && B > 0 && T > 0 && S >= 1 && S <= 4 && E <= 64);
+  AsmP p{};
+  for (int s = 0; s < S; ++s) p.demb[s] = demb[s];
+  p.dout = dout; p.B = B; p.T = T; p.E = E; p.S = S;
+  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}

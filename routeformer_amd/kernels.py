@@ -1042,3 +1042,55 @@ def traj_head(out, last_gps, target_gps, target_vis, gamma: float, ratio: float,
     """-> (loss, traj_loss, dense_loss, ade, fde, positions); only ``loss`` carries gradient (to ``out``)."""
     return _TrajHead.apply(out, last_gps, target_gps, target_vis, float(gamma), float(ratio), bool(dense_on),
                            float(motion_std), float(motion_mean))
+
+
+class _AssembleStreams(torch.autograd.Function):
+    """cat([stream_s + emb_s for s], dim=1) with ``None`` streams standing for zeros -- one launch each way."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        streams, embs, sinks = args[:n], args[n:2 * n], args[2 * n:3 * n]
+        first = next(t for t in streams if t is not None)
+        B, T, E = first.shape
+        xs = [None if t is None else t.contiguous() for t in streams]
+        es = [e.reshape(-1).contiguous() for e in embs]
+        out = torch.empty(B, n * T, E, device=first.device, dtype=torch.float32)
+        import ctypes
+        sp = (ctypes.c_void_p * n)(*[ptr(t) for t in xs])
+        ep = (ctypes.c_void_p * n)(*[ptr(t) for t in es])
+        check(_hip.lib().rf_assemble_streams_fwd(sp, ep, ptr(out), B, T, E, n, _stream()), "rf_assemble_streams_fwd")
+        ctx.dims = (n, B, T, E)
+        ctx.sinks = sinks
+        ctx.present = [t is not None for t in streams]
+        ctx.emb_shapes = [e.shape for e in embs]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+        n, B, T, E = ctx.dims
+        dout = dout.contiguous()
+        sink = all(s is not None for s in ctx.sinks)
+        dembs = list(ctx.sinks) if sink else [torch.zeros(E, device=dout.device, dtype=torch.float32) for _ in range(n)]
+        dp = (ctypes.c_void_p * n)(*[ptr(t) for t in dembs])
+        check(_hip.lib().rf_assemble_streams_bwd(ptr(dout), dp, B, T, E, n, _stream()), "rf_assemble_streams_bwd")
+        if sink:
+            _wrote(*dembs)
+        d4 = dout.view(B, n, T, E)
+        dstreams = [d4[:, s] if ctx.present[s] else None for s in range(n)]
+        dembs_out = [None] * n if sink else [d.view(sh) for d, sh in zip(dembs, ctx.emb_shapes)]
+        return (None, *dstreams, *dembs_out, *([None] * n))
+
+
+def assemble_streams(streams, embeddings):
+    """Fusion-encoder input (routeformer.py:331-345): streams (B,T,E) or None (= zeros) + their learned embeddings,
+    concatenated along time."""
+    n = len(streams)
+    assert n == len(embeddings) and 1 <= n <= 4
+    first = next(t for t in streams if t is not None)
+    _req(first, "assemble_streams")
+    E = first.shape[-1]
+    if E % 4 or E > 64 or any(t is not None and t.dtype != torch.float32 for t in streams):
+        # sizes outside the kernel's range: same arithmetic from device-side torch ops
+        return torch.cat([(torch.zeros_like(first) if t is None else t) + e for t, e in zip(streams, embeddings)], dim=1)
+    return _AssembleStreams.apply(n, *streams, *embeddings, *[_slot(e) for e in embeddings])

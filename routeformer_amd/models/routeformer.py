@@ -212,13 +212,14 @@ class Routeformer(nn.Module):
                     torch.cuda.current_stream().wait_stream(fork)
                 visual[-1] = self.gaze_video_decoder(gaze_video, tokens)[:, : gaze_video.shape[1]]
         if self.with_video:
+            embs = []
             if self.with_scene:
-                visual[0] = visual[0] + self.left_video_embedding
-                visual[1] = visual[1] + self.right_video_embedding
+                embs += [self.left_video_embedding, self.right_video_embedding]
             if self.with_gaze:
-                visual[-1] = visual[-1] + self.gaze_video_embedding
-            visual.append(torch.zeros_like(visual[-1]) + self.video_output_embedding)
-            visual = self.video_encoder(torch.cat(visual, dim=1))
+                embs.append(self.gaze_video_embedding)
+            # stream + its learned embedding, the output-query tokens (zeros + embedding) and the cat: one launch
+            seq = K.assemble_streams(list(visual) + [None], embs + [self.video_output_embedding])
+            visual = self.video_encoder(seq)
         return motion, visual
 
     def postprocess_batch(self, last_input_gps, output):
