@@ -312,6 +312,31 @@ def transformer_gps(sd: SD, p: str, x, *, pred_len: int, n_heads: int, activatio
     return _linear(sd, p + ".decoder.projection", d)[:, -pred_len:, :]
 
 
+def multimodal_transformer(sd: SD, cfg, batch, idx: IndexSource):
+    """The "simple multi-modal transformer" baseline --
+    experiments/multimodal_transformer/multimodal_transformer.py:67-122: every frame of the three streams through
+    the frozen conv encoder and the frame encoder (calls in the order left, right, front), Linear(2,h) on motion
+    and on median-downsampled gaze, cat, vanilla Transformer backbone, cumsum from the last position."""
+    gps = batch["gps"].to(torch.float32)
+    motions = F.pad(gps[:, 1:] - gps[:, :-1], (0, 0, 1, 0))
+    g = cfg.gps_backbone_config
+
+    def single(video):
+        B = video.shape[0]
+        fmap = hrnet16_features(sd, "video_backbone._Backbone", video.flatten(0, 1).to(torch.float32))
+        t = fmap.permute(0, 2, 3, 1).reshape(fmap.shape[0], -1, fmap.shape[1])
+        t = torch.cat([t, -torch.ones_like(t)[:, :1, :]], dim=1)
+        return perceive_encoder(sd, "frame_encoder", t, cfg.encoder_heads, 1, idx).view(B, -1, cfg.image_embedding_size)
+
+    left = batch["left_video"]
+    feats = [_linear(sd, "motion_linear", motions), single(left), single(batch.get("right_video", left)),
+             single(batch["front_video"]),
+             _linear(sd, "gaze_linear", median_downsampler(batch["gaze"].to(torch.float32), g.seq_len))]
+    out = transformer_gps(sd, "transformer", torch.cat(feats, dim=2), pred_len=g.pred_len, n_heads=g.n_heads,
+                          activation=g.activation)
+    return gps[:, -1:, :] + torch.cumsum(out, dim=1)
+
+
 def warmup_cosine_lr(base_lr: float, epochs: int, warmup_epochs: int, max_epochs: int,
                      warmup_start_lr: float = 0.0, eta_min: float = 0.0):
     """Learning rate in force during epochs 0 .. epochs-1 under LinearWarmupCosineAnnealingLR stepped once

@@ -41,6 +41,10 @@ CASES = {
                      rf=dict(RF_DEFAULT, with_video=True, with_gaze=True, dense_prediction=True,
                              dense_loss_ratio=0.5, decoder_mode="smart", encoder_layers=2,
                              cross_modal_decoder_layers=1)),
+    # the PerceiveEncoder-based baseline (experiments/multimodal_transformer): every frame is encoded (T = 8)
+    "mmt_small": dict(B=2, T=8, P=6, H=64, W=64,
+                      streams=("left_video", "right_video", "front_video"), gaze=True, gps=GPS_TINY,
+                      rf=dict(RF_DEFAULT, with_video=True, with_gaze=True, encoder_layers=2)),
     "c2_paper": dict(B=2, T=40, P=30, H=224, W=224,
                      streams=("left_video", "right_video", "front_video"), gaze=True, gps=GPS_PAPER,
                      rf=dict(RF_PAPER, with_video=True, with_gaze=True)),

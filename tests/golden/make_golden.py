@@ -446,6 +446,36 @@ def gen_widen():
         out[f"eval.{name}.rows"] = np.array(rows, dtype=np.float64)
         out[f"eval.{name}.n_draws"] = np.array(len(log))
         out.update({f"eval.{name}.{k}": v for k, v in pack_draws(log).items()})
+    # (4) the PerceiveEncoder-based baseline, experiments/multimodal_transformer/multimodal_transformer.py
+    import types
+    vb = sys.modules["routeformer.models.video_backbone"]
+    if not hasattr(vb, "SwinV2"):
+        vb.SwinV2 = None  # the experiment file imports the (timm) class by name only; it is not used here
+    spec = importlib.util.spec_from_file_location(
+        "_ref_mmt", f"{ref_bootstrap.REF}/experiments/multimodal_transformer/multimodal_transformer.py")
+    mmt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mmt)
+    c = presets.case("mmt_small")
+    gps_cfg, rf_cfg = presets.build_configs(c, REF.gps.GPSBackboneConfig, REF.cfg.RouteformerConfig, REF.vbc.VideoBackboneConfig)
+    torch.manual_seed(0)
+    model = mmt.MultiModalTransformer(rf_cfg, video_backbone=RefHRNet16)
+    load_synth(model)
+    item = synthetic.synth_item(c["B"], c["T"], c["P"], DSEED, c["H"], c["W"], streams=c["streams"], gaze=c["gaze"])
+    model.train()
+    model.zero_grad()
+    log = []
+    torch.manual_seed(RSEED)
+    with record_randint(log):
+        y = model(item["train"])
+    loss = REF.loss.FutureDiscountedLoss(rf_cfg.discount_factor, rf_cfg.epsilon, loss_function="smooth_l1")(
+        y, item["target"]["gps"].to(torch.float32))
+    loss.backward()
+    out["mmt.future_gps"] = y
+    out["mmt.loss"] = np.array(float(loss))
+    out["mmt.digest"] = np.array(synthetic.state_dict_digest(model.state_dict()))
+    out.update({f"mmt.{k}": v for k, v in pack_draws(log).items()})
+    out.update({f"mmt.{k}": v for k, v in grad_summary(model, full=("motion_linear.bias", "gaze_linear.weight",
+                                                                      "frame_encoder.projection.bias")).items()})
     save("widen", **out)
 
 

@@ -117,9 +117,85 @@ def test_oracle_transformer_inside_routeformer():
         assert abs(float(res[k]) - float(want)) < 1e-4 * max(1.0, abs(float(want))), k
 
 
+def _mmt(device="cpu"):
+    from routeformer_amd import presets, synthetic
+    from routeformer_amd.experiments import MultiModalTransformer
+    from routeformer_amd.models import RouteformerConfig
+    from routeformer_amd.models.gps_backbone import GPSBackboneConfig
+    from routeformer_amd.models.video_backbone import HRNet16Backbone, VideoBackboneConfig
+    c = presets.case("mmt_small")
+    _, cfg = presets.build_configs(c, GPSBackboneConfig, RouteformerConfig, VideoBackboneConfig)
+    model = MultiModalTransformer(cfg, video_backbone=HRNet16Backbone)
+    sd = synthetic.synth_state_dict(model.state_dict(), 7)
+    model.load_state_dict(sd)
+    item = synthetic.synth_item(c["B"], c["T"], c["P"], DSEED, c["H"], c["W"], streams=c["streams"], gaze=c["gaze"])
+    return model.to(device), cfg, sd, item
+
+
+def test_oracle_multimodal_transformer_baseline():
+    """experiments/multimodal_transformer: state_dict layout, forward, loss and gradients vs the reference."""
+    from routeformer_amd import synthetic
+    model, cfg, sd, item = _mmt()
+    G = golden("widen")
+    want = float(G["mmt.digest"])
+    assert abs(synthetic.state_dict_digest(sd) - want) < 1e-6 * want
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "video_backbone" not in k and not k.endswith(".pe"))
+           for k, v in sd.items()}
+    src = O.IndexSource(draws(G, "mmt."))
+    y = O.multimodal_transformer(sdg, cfg, item["train"], src)
+    assert len(src.log) == len(draws(G, "mmt."))
+    assert rel_err(y, G["mmt.future_gps"]) < 1e-4
+    loss = O.future_discounted_loss(y, item["target"]["gps"].to(torch.float32), O.discount_for_epoch(cfg.discount_factor, 0))
+    assert abs(float(loss) - float(G["mmt.loss"])) < 1e-4 * max(1.0, float(G["mmt.loss"]))
+    loss.backward()
+    for n, (nrm, _) in zip((str(s) for s in G["mmt.grad_names"]), G["mmt.grad_stats"]):
+        g = sdg[n].grad
+        got = 0.0 if g is None else float(g.double().norm())
+        assert abs(got - nrm) <= 1e-3 * max(1e-3 * float(G["mmt.grad_stats"][:, 0].max()), nrm), (n, got, nrm)
+
+
 # ------------------------------------------------------------------------------------------------
 # GPU: the product
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_gpu_multimodal_transformer_baseline():
+    """The baseline on the HIP kernels vs the reference: same host-RNG draws, trajectory within 1e-3 (fp32 mode,
+    oracle selections imposed), loss and per-parameter gradient norms."""
+    from routeformer_amd import kernels as K
+    from routeformer_amd.losses import FutureDiscountedLoss
+    from routeformer_amd.models import blocks
+    model, cfg, sd, item = _mmt(DEV)
+    G = golden("widen")
+    with torch.no_grad():
+        src = O.IndexSource(draws(G, "mmt."))
+        O.multimodal_transformer(sd, cfg, item["train"], src)
+    model.train()
+    batch = {k: v.to(DEV) for k, v in item["train"].items()}
+    log = []
+    blocks.SAMPLER.log = log
+    K.TOPS.forced = [tp.clone() for tp in src.tops]
+    torch.manual_seed(1234)
+    try:
+        y = model(batch)
+    finally:
+        K.TOPS.forced = None
+        blocks.SAMPLER.log = None
+    want = draws(G, "mmt.")
+    assert len(log) == len(want) and all(torch.equal(a.cpu().long(), b) for a, b in zip(log, want))
+    assert rel_err(y, G["mmt.future_gps"]) < 1e-3
+    tl = FutureDiscountedLoss(cfg.discount_factor, cfg.epsilon, loss_function="smooth_l1")
+    loss = tl(y, item["target"]["gps"].to(DEV).float())
+    assert abs(float(loss) - float(G["mmt.loss"])) < 1e-3 * max(1.0, float(G["mmt.loss"]))
+    loss.backward()
+    named = dict(model.named_parameters())
+    floor = 1e-3 * float(G["mmt.grad_stats"][:, 0].max())
+    for n, (nrm, _) in zip((str(s) for s in G["mmt.grad_names"]), G["mmt.grad_stats"]):
+        g = named[n].grad
+        got = 0.0 if g is None else float(g.double().norm())
+        assert abs(got - nrm) <= 5e-3 * max(floor, nrm), (n, got, nrm)
+    for f in G.files:
+        if f.startswith("mmt.grad::"):
+            assert rel_err(named[f[len("mmt.grad::"):]].grad, G[f]) < 5e-3, f
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["tiny", "default"])
 @pytest.mark.parametrize("prec,tol", [("f32", 1e-3), ("bf16", 3e-2)])
