@@ -141,22 +141,26 @@ __device__ __forceinline__ void layer_norm_rows(f32x4 (&v)[8], f32x4 (&y)[8], co
     for (int r = 0; r < 4; ++r) y[j][r] = v[j][r] * gam[j] + bet[j];
 }
 
-// 8-wave variants: a wave holds 16 rows x 64 columns (4 tiles); wave = 4 * column-half + row-group.
-// 16 x 64 tile (MFMA C layout) -> wave-private LDS staging (pitch 68) -> row-contiguous float4 stores
-__device__ __forceinline__ void store_rows64(const f32x4 (&v)[4], float* __restrict__ stage_w, float* __restrict__ g,
+// 8-wave variants: a wave holds 16 rows x (16 NJ) columns; wave = RG * column-group + row-group, where a
+// workgroup owns RBT = 64 rows (RG = 4 row groups, 2 column groups) or, for the launches with few row blocks
+// (M <= 2048: per-workgroup latency is what counts there), RBT = 32 rows (RG = 2, 4 column groups).
+// 16 x 16 NJ tile (MFMA C layout) -> wave-private LDS staging -> row-contiguous float4 stores
+template <int NJ>
+__device__ __forceinline__ void store_rows_w(const f32x4 (&v)[NJ], float* __restrict__ stage_w, float* __restrict__ g,
                                              long ld, int row0, int nrows, int col0, int ncols, int lane) {
+  constexpr int PW = 16 * NJ + 4, V4 = 4 * NJ;  // staging pitch, float4 per row
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) stage_w[(fq * 4 + r) * 68 + j * 16 + fr] = v[j][r];
+    for (int r = 0; r < 4; ++r) stage_w[(fq * 4 + r) * PW + j * 16 + fr] = v[j][r];
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int i = it * 64 + lane, rr = i >> 4, c4 = (i & 15) * 4;
+  for (int it = 0; it < NJ; ++it) {  // 16 * V4 float4 / 64 lanes = NJ trips
+    const int i = it * 64 + lane, rr = i / V4, c4 = (i % V4) * 4;
     if (row0 + rr < nrows && col0 + c4 < ncols) {
-      const float4 o = *reinterpret_cast<const float4*>(stage_w + rr * 68 + c4);
+      const float4 o = *reinterpret_cast<const float4*>(stage_w + rr * PW + c4);
       float* p = g + (long)(row0 + rr) * ld + col0 + c4;
       if (col0 + c4 + 3 < ncols) *reinterpret_cast<float4*>(p) = o;
       else { p[0] = o.x; if (col0 + c4 + 1 < ncols) p[1] = o.y; if (col0 + c4 + 2 < ncols) p[2] = o.z; }
@@ -166,46 +170,52 @@ __device__ __forceinline__ void store_rows64(const f32x4 (&v)[4], float* __restr
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// LayerNorm over 128 columns held by TWO waves (64 each): per-row partial sums meet in LDS (lnred[2][64]),
-// two block barriers (mean, then centred variance: the same two-pass arithmetic as the one-wave form).
-__device__ __forceinline__ void layer_norm_rows_split(f32x4 (&v)[4], f32x4 (&y)[4], const float (&gam)[4],
-                                                      const float (&bet)[4], float eps, float (&rstd)[4],
-                                                      float* __restrict__ lnred, int rw, int ch, int lane) {
+// LayerNorm over 128 columns held by CH waves (16 NJ columns each): per-row partial sums meet in LDS
+// (lnred[CH][RBT]), block barriers between the passes (mean, then centred variance: the same two-pass
+// arithmetic as the one-wave form).  row = this wave's first row inside the block.
+template <int NJ, int CH, int RBT>
+__device__ __forceinline__ void layer_norm_rows_split(f32x4 (&v)[NJ], f32x4 (&y)[NJ], const float (&gam)[NJ],
+                                                      const float (&bet)[NJ], float eps, float (&rstd)[4],
+                                                      float* __restrict__ lnred, int row, int cg, int lane) {
   const int fr = lane & 15, fq = lane >> 4;
   float mean[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s += v[j][r];
+    for (int j = 0; j < NJ; ++j) s += v[j][r];
     s = row16_sum(s);
-    if (fr == 0) lnred[ch * 64 + rw * 16 + fq * 4 + r] = s;
+    if (fr == 0) lnred[cg * RBT + row + fq * 4 + r] = s;
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int row = rw * 16 + fq * 4 + r;
-    mean[r] = (lnred[row] + lnred[64 + row]) * (1.f / 128.f);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) t += lnred[k * RBT + row + fq * 4 + r];
+    mean[r] = t * (1.f / 128.f);
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const float d = v[j][r] - mean[r]; q += d * d; }
+    for (int j = 0; j < NJ; ++j) { const float d = v[j][r] - mean[r]; q += d * d; }
     q = row16_sum(q);
-    if (fr == 0) lnred[ch * 64 + rw * 16 + fq * 4 + r] = q;
+    if (fr == 0) lnred[cg * RBT + row + fq * 4 + r] = q;
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int row = rw * 16 + fq * 4 + r;
-    rstd[r] = 1.0f / sqrtf((lnred[row] + lnred[64 + row]) * (1.f / 128.f) + eps);
+    float t = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j][r] = (v[j][r] - mean[r]) * rstd[r];  // v becomes x-hat
+    for (int k = 0; k < CH; ++k) t += lnred[k * RBT + row + fq * 4 + r];
+    rstd[r] = 1.0f / sqrtf(t * (1.f / 128.f) + eps);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) v[j][r] = (v[j][r] - mean[r]) * rstd[r];  // v becomes x-hat
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) y[j][r] = v[j][r] * gam[j] + bet[j];
 }
@@ -222,19 +232,20 @@ struct LinP {
 
 constexpr int NT8 = 512;  // 8 waves: two per SIMD (these kernels are instruction-issue bound at one)
 
-template <int KC, bool LN>
+template <int KC, bool LN, int RBT>
 __global__ __launch_bounds__(NT8) void rb_linear_kernel(LinP p) {
+  constexpr int RG = RBT / 16, CH = 8 / RG, NCOL = 128 / CH, NJ = NCOL / 16, PW = NCOL + 4;
   constexpr int LD = KC + 8;
-  constexpr int W_EL = 128 * LD, STAGE_EL = 8 * 16 * 68 * 2;  // staging (fp32) expressed in bf16 elements
-  __shared__ __attribute__((aligned(16))) __bf16 smem[(W_EL > STAGE_EL ? W_EL : STAGE_EL) + RB * LD];
-  __shared__ float lnred[128];
+  constexpr int W_EL = 128 * LD, STAGE_EL = 8 * 16 * PW * 2;  // staging (fp32) expressed in bf16 elements
+  __shared__ __attribute__((aligned(16))) __bf16 smem[(W_EL > STAGE_EL ? W_EL : STAGE_EL) + RBT * LD];
+  __shared__ float lnred[CH * RBT];
   __bf16* ws = smem;
   __bf16* xs = smem + (W_EL > STAGE_EL ? W_EL : STAGE_EL);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-  const int rw = wave & 3, ch = wave >> 2;
-  const int m0 = blockIdx.y * RB, n0 = blockIdx.x * 128;
+  const int rw = wave % RG, ch = wave / RG;
+  const int m0 = blockIdx.y * RBT, n0 = blockIdx.x * 128;
 
-  Tile<RB, KC, NT8> tx;
+  Tile<RBT, KC, NT8> tx;
   Tile<128, KC, NT8> tw;
   tx.load(p.x, p.ldx, m0, p.M, tid);
   tw.load(p.w, KC, n0, p.N, tid);
@@ -243,11 +254,11 @@ __global__ __launch_bounds__(NT8) void rb_linear_kernel(LinP p) {
   __syncthreads();
 
   // epilogue operands are requested before the matrix work: their latency hides behind it
-  float bv[4], gam[4], bet[4];
-  f32x4 rv[4];
+  float bv[NJ], gam[NJ], bet[NJ];
+  f32x4 rv[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int cl = ch * 64 + j * 16 + fr, n = n0 + cl;
+  for (int j = 0; j < NJ; ++j) {
+    const int cl = ch * NCOL + j * 16 + fr, n = n0 + cl;
     bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
     if constexpr (LN) { gam[j] = p.gamma[cl]; bet[j] = p.beta[cl]; }
 #pragma unroll
@@ -257,24 +268,24 @@ __global__ __launch_bounds__(NT8) void rb_linear_kernel(LinP p) {
     }
   }
 
-  f32x4 acc[4];
+  f32x4 acc[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  mma_rows<KC, 4>(acc, xs + rw * 16 * LD, ws + ch * 64 * LD, lane);
+  for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  mma_rows<KC, NJ>(acc, xs + rw * 16 * LD, ws + ch * NCOL * LD, lane);
 
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[j][r] += bv[j] + rv[j][r];
   __syncthreads();  // every wave is done with the weights: their LDS becomes the output staging tile
-  float* stage_w = reinterpret_cast<float*>(smem) + wave * 16 * 68;
+  float* stage_w = reinterpret_cast<float*>(smem) + wave * 16 * PW;
   if constexpr (LN) {
-    f32x4 y[4];
+    f32x4 y[NJ];
     float rstd[4];
-    layer_norm_rows_split(acc, y, gam, bet, p.eps, rstd, lnred, rw, ch, lane);
-    store_rows64(y, stage_w, p.y, p.ldy, m0 + rw * 16, p.M, ch * 64, 128, lane);
+    layer_norm_rows_split<NJ, CH, RBT>(acc, y, gam, bet, p.eps, rstd, lnred, rw * 16, ch, lane);
+    store_rows_w<NJ>(y, stage_w, p.y, p.ldy, m0 + rw * 16, p.M, ch * NCOL, 128, lane);
     if (p.xhat) {
-      store_rows64(acc, stage_w, p.xhat, 128, m0 + rw * 16, p.M, ch * 64, 128, lane);
+      store_rows_w<NJ>(acc, stage_w, p.xhat, 128, m0 + rw * 16, p.M, ch * NCOL, 128, lane);
       if (fr == 0 && ch == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(NT8) void rb_linear_kernel(LinP p) {
       }
     }
   } else {
-    store_rows64(acc, stage_w, p.y, p.ldy, m0 + rw * 16, p.M, n0 + ch * 64, p.N, lane);
+    store_rows_w<NJ>(acc, stage_w, p.y, p.ldy, m0 + rw * 16, p.M, n0 + ch * NCOL, p.N, lane);
   }
 }
 
@@ -312,23 +323,27 @@ struct FfnP {
   const float* gamma; const float* beta; float* xhat; float* rstd; float eps;
 };
 
+template <int RBT>
 __global__ __launch_bounds__(NT8) void rb_ffn_ln_kernel(FfnP p) {
-  // 8 waves: wave = 4 * column-half + row-group (16 rows); LDS as in the 4-wave form (the weights dominate)
-  constexpr int D = 128, F = 256, LDX = D + 8, LDH = F + 8, ZP = 36;  // ZP: pitch of the 16 x 32 z tile
+  // 8 waves: wave = RG * column-group + row-group (16 rows); RBT = 64 rows (2 column groups) or 32 (4).
+  constexpr int RG = RBT / 16, CH = 8 / RG;
+  constexpr int D = 128, F = 256, LDX = D + 8, LDH = F + 8;
+  constexpr int ZC = 64 / CH, ZJ = ZC / 16, ZP = ZC + 4;   // phase 1: columns / tiles per wave and pass, z-tile pitch
+  constexpr int NC2 = D / CH, NJ2 = NC2 / 16, PW = NC2 + 4;  // phase 2: output columns / tiles per wave
   constexpr int WB = (F * LDX > D * LDH) ? F * LDX : D * LDH;  // W1 (256 x 136) then W2 (128 x 264), bf16
-  __shared__ __attribute__((aligned(16))) __bf16 smem[WB + RB * LDX + RB * LDH + 8 * 16 * ZP * 2];
-  __shared__ float lnred[128];
+  __shared__ __attribute__((aligned(16))) __bf16 smem[WB + RBT * LDX + RBT * LDH + 8 * 16 * ZP * 2];
+  __shared__ float lnred[CH * RBT];
   __bf16* wb = smem;
   __bf16* xs = smem + WB;
-  __bf16* hs = xs + RB * LDX;
-  float* zs = reinterpret_cast<float*>(hs + RB * LDH);
+  __bf16* hs = xs + RBT * LDX;
+  float* zs = reinterpret_cast<float*>(hs + RBT * LDH);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-  const int rw = wave & 3, ch = wave >> 2;
-  const int m0 = blockIdx.x * RB;
+  const int rw = wave % RG, ch = wave / RG;
+  const int m0 = blockIdx.x * RBT;
   RB_MARK(0);
 
   {
-    Tile<RB, D, NT8> tx;
+    Tile<RBT, D, NT8> tx;
     Tile<F, D, NT8> t1;
     tx.load(p.x, D, m0, p.M, tid);
     t1.load(p.w1, D, 0, F, tid);
@@ -340,34 +355,36 @@ __global__ __launch_bounds__(NT8) void rb_ffn_ln_kernel(FfnP p) {
   Tile<D, F, NT8> t2;  // W2 travels while the first contraction runs
   t2.load(p.w2, F, 0, D, tid);
 
-  // First contraction in four passes of 64 hidden columns (32 per wave).  Each wave's 16 x 32 block goes
+  // First contraction in four passes of 64 hidden columns (ZC per wave).  Each wave's 16 x ZC block goes
   // through a wave-private fp32 LDS tile, then four consecutive columns per lane: one float4 tile read, four
   // independent GELU chains, one 8-byte bf16 LDS write and two float4 global stores per four elements.  (The
   // loop is instruction-issue bound -- tools/rb_phase_probe.py -- hence float4 work and two waves per SIMD.)
   float* zt = zs + wave * 16 * ZP;
-  const int c4 = (lane & 7) * 4, rsub = lane >> 3;  // 8 float4 per 32-column row, 8 rows per trip
+  constexpr int V4 = ZC / 4, RPT = 64 / V4, TRIPS = 16 / RPT;  // float4 per row, rows per trip, trips
+  const int c4 = (lane % V4) * 4, rsub = lane / V4;
   float4 b1v[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) b1v[c] = *reinterpret_cast<const float4*>(p.b1 + c * 64 + ch * 32 + c4);
+  for (int c = 0; c < 4; ++c) b1v[c] = *reinterpret_cast<const float4*>(p.b1 + c * 64 + ch * ZC + c4);
 #pragma unroll 1
   for (int c = 0; c < 4; ++c) {
-    f32x4 a1[2];
-    a1[0] = a1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (c == 0) RB_MARK(6);
-    mma_rows<D, 2>(a1, xs + rw * 16 * LDX, wb + (c * 64 + ch * 32) * LDX, lane);
+    f32x4 a1[ZJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < ZJ; ++j) a1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c == 0) RB_MARK(6);
+    mma_rows<D, ZJ>(a1, xs + rw * 16 * LDX, wb + (c * 64 + ch * ZC) * LDX, lane);
+#pragma unroll
+    for (int j = 0; j < ZJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) zt[(fq * 4 + r) * ZP + j * 16 + fr] = a1[j][r];
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (c == 0) RB_MARK(7);
     const float4 b = c == 0 ? b1v[0] : (c == 1 ? b1v[1] : (c == 2 ? b1v[2] : b1v[3]));
-    const int f = c * 64 + ch * 32 + c4;
+    const int f = c * 64 + ch * ZC + c4;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int rl = rw * 16 + it * 8 + rsub, m = m0 + rl;
-      float4 zz = *reinterpret_cast<const float4*>(zt + (it * 8 + rsub) * ZP + c4);
+    for (int it = 0; it < TRIPS; ++it) {
+      const int rl = rw * 16 + it * RPT + rsub, m = m0 + rl;
+      float4 zz = *reinterpret_cast<const float4*>(zt + (it * RPT + rsub) * ZP + c4);
       zz.x += b.x; zz.y += b.y; zz.z += b.z; zz.w += b.w;
       float4 hh;
       if (p.act == RF_ACT_GELU) {
@@ -392,11 +409,11 @@ __global__ __launch_bounds__(NT8) void rb_ffn_ln_kernel(FfnP p) {
   RB_MARK(2);
   t2.store(wb, tid);
   // epilogue operands (bias, exact fp32 residual, norm parameters) are requested now, used after the MFMAs
-  float b2v[4], gam[4], bet[4];
-  f32x4 xres[4];
+  float b2v[NJ2], gam[NJ2], bet[NJ2];
+  f32x4 xres[NJ2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = ch * 64 + j * 16 + fr;
+  for (int j = 0; j < NJ2; ++j) {
+    const int n = ch * NC2 + j * 16 + fr;
     b2v[j] = p.b2[n]; gam[j] = p.gamma[n]; bet[j] = p.beta[n];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -407,23 +424,23 @@ __global__ __launch_bounds__(NT8) void rb_ffn_ln_kernel(FfnP p) {
   __syncthreads();
   RB_MARK(3);
 
-  f32x4 acc[4];
+  f32x4 acc[NJ2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  mma_rows<F, 4>(acc, hs + rw * 16 * LDH, wb + ch * 64 * LDH, lane);
+  for (int j = 0; j < NJ2; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  mma_rows<F, NJ2>(acc, hs + rw * 16 * LDH, wb + ch * NC2 * LDH, lane);
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NJ2; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[j][r] += b2v[j] + xres[j][r];
   __syncthreads();
   RB_MARK(4);
-  float* stage_w = reinterpret_cast<float*>(smem) + wave * 16 * 68;
-  f32x4 y[4];
+  float* stage_w = reinterpret_cast<float*>(smem) + wave * 16 * PW;
+  f32x4 y[NJ2];
   float rstd[4];
-  layer_norm_rows_split(acc, y, gam, bet, p.eps, rstd, lnred, rw, ch, lane);
-  store_rows64(y, stage_w, p.y, D, m0 + rw * 16, p.M, ch * 64, D, lane);
+  layer_norm_rows_split<NJ2, CH, RBT>(acc, y, gam, bet, p.eps, rstd, lnred, rw * 16, ch, lane);
+  store_rows_w<NJ2>(y, stage_w, p.y, D, m0 + rw * 16, p.M, ch * NC2, D, lane);
   if (p.xhat) {
-    store_rows64(acc, stage_w, p.xhat, D, m0 + rw * 16, p.M, ch * 64, D, lane);
+    store_rows_w<NJ2>(acc, stage_w, p.xhat, D, m0 + rw * 16, p.M, ch * NC2, D, lane);
     if (fr == 0 && ch == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -465,19 +482,20 @@ __device__ __forceinline__ float quad_sumf(float v) {
 // WAVES = 8: two waves per SIMD share a row block (wave = 4 * column-half + row-group).  These kernels are
 // instruction-issue bound at one wave per SIMD (tools/rb_phase_probe.py: the GELU' epilogue alone was 15k of
 // 44k cycles), so the second wave per SIMD is close to a 2x on every phase; LDS use is unchanged.
-template <int KC, int NOUT, bool LNBWD, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void rb_nn_kernel(NnP p) {
+template <int KC, int NOUT, bool LNBWD, int RBT>
+__global__ __launch_bounds__(NT8) void rb_nn_kernel(NnP p) {
   static_assert(!LNBWD || KC == 128, "the LayerNorm-backward prologue works on 128-wide rows");
-  constexpr int NTH = 64 * WAVES, CH = WAVES / 4, NCOL = NOUT / CH;  // threads, column groups, columns per wave
+  // 8 waves, wave = RG * column-group + row-group; RBT = 64 rows per workgroup (2 column groups) or 32 (4)
+  constexpr int WAVES = 8, NTH = 64 * WAVES, RG = RBT / 16, CH = WAVES / RG, NCOL = NOUT / CH;
   constexpr int LD = KC + 8, NJ = NCOL / 16, SPW = NCOL + 4;
   constexpr int W_EL = NOUT * LD, STAGE_EL = WAVES * 16 * SPW * 2;
-  __shared__ __attribute__((aligned(16))) __bf16 smem[(W_EL > STAGE_EL ? W_EL : STAGE_EL) + RB * LD];
+  __shared__ __attribute__((aligned(16))) __bf16 smem[(W_EL > STAGE_EL ? W_EL : STAGE_EL) + RBT * LD];
   __shared__ float red[2 * (NTH / 128)][128];
   __bf16* ws = smem;
   __bf16* as = smem + (W_EL > STAGE_EL ? W_EL : STAGE_EL);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-  const int rw = wave & 3, ch = wave >> 2;
-  const int m0 = blockIdx.x * RB;
+  const int rw = wave % RG, ch = wave / RG;
+  const int m0 = blockIdx.x * RBT;
   RB_MARK(0);
 
   // Transposed weight staging, a wave covers a 16 (k) x 32 (n) patch per trip: lane = (k pair) + 8 * (n / 4)
@@ -511,7 +529,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb_nn_kernel(NnP p) {
 
   // ---- A operand ----
   if constexpr (LNBWD) {
-    constexpr int LPR = NTH / 64, CPL = 128 / LPR, V4 = CPL / 4;  // lanes per row, columns / float4 per lane
+    constexpr int LPR = NTH / RBT, CPL = 128 / LPR, V4 = CPL / 4;  // lanes per row, columns / float4 per lane
     const int r = tid / LPR, c0 = (tid % LPR) * CPL, m = m0 + r;
     float g[CPL], xh[CPL];
     float s1 = 0.f, s2 = 0.f;
@@ -530,7 +548,8 @@ __global__ __launch_bounds__(64 * WAVES) void rb_nn_kernel(NnP p) {
 #pragma unroll
     for (int i = 0; i < CPL; ++i) { s1 += g[i]; s2 += g[i] * xh[i]; }
     s1 = quad_sumf(s1); s2 = quad_sumf(s2);
-    if constexpr (LPR == 8) { s1 += dpp_move<0x141>(s1); s2 += dpp_move<0x141>(s2); }  // the other quad of the row
+    if constexpr (LPR >= 8) { s1 += dpp_move<0x141>(s1); s2 += dpp_move<0x141>(s2); }   // the other quad
+    if constexpr (LPR == 16) { s1 += dpp_move<0x140>(s1); s2 += dpp_move<0x140>(s2); }  // the other half row
     const float m1 = s1 * (1.f / 128.f), m2 = s2 * (1.f / 128.f);
 #pragma unroll
     for (int v4 = 0; v4 < V4; ++v4) {
@@ -543,7 +562,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb_nn_kernel(NnP p) {
       st_bf16x4(as + r * LD + c0 + v4 * 4, o);
     }
   } else {
-    Tile<RB, KC, NTH> ta;
+    Tile<RBT, KC, NTH> ta;
     ta.load(p.a, p.lda, m0, p.M, tid);
     ta.store(as, tid);
   }
@@ -562,7 +581,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb_nn_kernel(NnP p) {
 
   if constexpr (LNBWD) {
     // d gamma / d beta: column sums over this block's rows (dy, x-hat re-read from L2, column-major work split)
-    constexpr int GR = NTH / 128, RPG = RB / GR;  // row groups, rows per group
+    constexpr int GR = NTH / 128, RPG = RBT / GR;  // row groups, rows per group
     const int c = tid & 127, grp = tid >> 7;
     float sb = 0.f, sg = 0.f;
 #pragma unroll 1
@@ -668,15 +687,18 @@ extern "C" int rf_rowblock_linear(const float* x, int64_t ldx, const float* w, c
   RF_REQUIRE(al16(x) && al16(w) && al16(y) && ldx % 4 == 0 && ldy % 4 == 0);
   RF_REQUIRE(!ln || (ln_beta && (!xhat || (rstd && al16(xhat)))));
   LinP p{x, ldx, w, bias, residual, ldr, y, ldy, M, N, ln_gamma, ln_beta, xhat, rstd, eps};
-  dim3 grid((N + 127) / 128, (M + RB - 1) / RB);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (K == 128) {
-    if (ln) hipLaunchKernelGGL((rb_linear_kernel<128, true>), grid, dim3(NT8), 0, st, p);
-    else hipLaunchKernelGGL((rb_linear_kernel<128, false>), grid, dim3(NT8), 0, st, p);
-  } else {
-    if (ln) hipLaunchKernelGGL((rb_linear_kernel<256, true>), grid, dim3(NT8), 0, st, p);
-    else hipLaunchKernelGGL((rb_linear_kernel<256, false>), grid, dim3(NT8), 0, st, p);
-  }
+  const bool small = M <= 2048;  // few row blocks: 32-row blocks (shorter per-workgroup chain, 2x the workgroups)
+  const int rbt = small ? 32 : RB;
+  dim3 grid((N + 127) / 128, (M + rbt - 1) / rbt);
+#define RF_RB_LIN(KC_, LN_) \
+  do { \
+    if (small) hipLaunchKernelGGL((rb_linear_kernel<KC_, LN_, 32>), grid, dim3(NT8), 0, st, p); \
+    else hipLaunchKernelGGL((rb_linear_kernel<KC_, LN_, RB>), grid, dim3(NT8), 0, st, p); \
+  } while (0)
+  if (K == 128) { if (ln) RF_RB_LIN(128, true); else RF_RB_LIN(128, false); }
+  else { if (ln) RF_RB_LIN(256, true); else RF_RB_LIN(256, false); }
+#undef RF_RB_LIN
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
@@ -688,7 +710,10 @@ extern "C" int rf_rowblock_ffn_ln(const float* x, const float* w1, const float* 
   RF_REQUIRE(x && w1 && b1 && w2 && b2 && y && ln_gamma && ln_beta && M > 0 && d_model == 128 && d_ff == 256);
   RF_REQUIRE(al16(x) && al16(w1) && al16(w2) && al16(y) && (!xhat || (rstd && al16(xhat))));
   FfnP p{x, w1, b1, w2, b2, h, z, y, M, act, ln_gamma, ln_beta, xhat, rstd, eps};
-  hipLaunchKernelGGL(rb_ffn_ln_kernel, dim3((M + RB - 1) / RB), dim3(NT8), 0, static_cast<hipStream_t>(stream), p);
+  if (M <= 2048)  // few row blocks: 32-row blocks, 2x the workgroups
+    hipLaunchKernelGGL(rb_ffn_ln_kernel<32>, dim3((M + 31) / 32), dim3(NT8), 0, static_cast<hipStream_t>(stream), p);
+  else
+    hipLaunchKernelGGL(rb_ffn_ln_kernel<RB>, dim3((M + RB - 1) / RB), dim3(NT8), 0, static_cast<hipStream_t>(stream), p);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
@@ -712,14 +737,20 @@ extern "C" int rf_rowblock_linear_nn(const float* a, int64_t lda, const float* l
   RF_REQUIRE(!dact_mode || (dact_src && al16(dact_src) && ldd % 4 == 0));
   NnP p{a, lda, ln_dy, ln_xhat, ln_rstd, ln_gamma, dpre, dgamma, dbeta, w, residual, ldr,
         dact_mode ? dact_src : nullptr, ldd, dact_mode, y, ldy, M};
-  dim3 grid((M + RB - 1) / RB);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  constexpr int W = 8;  // waves per workgroup
-  if (ln && NOUT == 128) hipLaunchKernelGGL((rb_nn_kernel<128, 128, true, W>), grid, dim3(64 * W), 0, st, p);
-  else if (ln) hipLaunchKernelGGL((rb_nn_kernel<128, 256, true, W>), grid, dim3(64 * W), 0, st, p);
-  else if (KC == 128) hipLaunchKernelGGL((rb_nn_kernel<128, 128, false, W>), grid, dim3(64 * W), 0, st, p);
-  else if (KC == 256) hipLaunchKernelGGL((rb_nn_kernel<256, 128, false, W>), grid, dim3(64 * W), 0, st, p);
-  else hipLaunchKernelGGL((rb_nn_kernel<384, 128, false, W>), grid, dim3(64 * W), 0, st, p);
+  const bool small = M <= 2048;  // few row blocks: 32-row blocks, 2x the workgroups
+  dim3 grid(small ? (M + 31) / 32 : (M + RB - 1) / RB);
+#define RF_RB_NN(KC_, NOUT_, LN_) \
+  do { \
+    if (small) hipLaunchKernelGGL((rb_nn_kernel<KC_, NOUT_, LN_, 32>), grid, dim3(NT8), 0, st, p); \
+    else hipLaunchKernelGGL((rb_nn_kernel<KC_, NOUT_, LN_, RB>), grid, dim3(NT8), 0, st, p); \
+  } while (0)
+  if (ln && NOUT == 128) RF_RB_NN(128, 128, true);
+  else if (ln) RF_RB_NN(128, 256, true);
+  else if (KC == 128) RF_RB_NN(128, 128, false);
+  else if (KC == 256) RF_RB_NN(256, 128, false);
+  else RF_RB_NN(384, 128, false);
+#undef RF_RB_NN
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

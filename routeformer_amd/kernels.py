@@ -397,7 +397,7 @@ def _rowblock_linear(x2, w, b, r2, y, M, N, K, ln=None, xhat=None, rstd=None, ep
     check(_hip.lib().rf_rowblock_linear(*args, _stream()), "rf_rowblock_linear")
     if ev is not None:
         keep = (x2, w, b, r2, y, ln, xhat, rstd)
-        PROFILE.end(f"rb_linear_kernel<{K}, {'true' if ln else 'false'}>", ev, 2.0 * M * N * K,
+        PROFILE.end(f"rb_linear_kernel<{K}, {'true' if ln else 'false'}, {32 if M <= 2048 else 64}>", ev, 2.0 * M * N * K,
                     4.0 * (M * K + N * K + M * N * (1 + (r2 is not None) + (xhat is not None))),
                     replay=lambda a=args, k=keep: _hip.lib().rf_rowblock_linear(*a, _stream()))
 
@@ -422,7 +422,7 @@ def _rowblock_nn(w2d, M, *, a=None, ln=None, dpre=None, dgam=None, dbet=None, re
     if ev is not None:
         keep = (a, ln, dpre, dgam, dbet, w2d, res, dsrc, y)
         lnbwd = "true" if ln else "false"
-        PROFILE.end(f"rb_nn_kernel<{KC}, {NOUT}, {lnbwd}, 8>", ev, 2.0 * M * KC * NOUT,
+        PROFILE.end(f"rb_nn_kernel<{KC}, {NOUT}, {lnbwd}, {32 if M <= 2048 else 64}>", ev, 2.0 * M * KC * NOUT,
                     4.0 * (M * KC * (3 if ln else 1) + KC * NOUT + M * NOUT * (1 + (res is not None) + (dsrc is not None))))
     return y
 
@@ -727,7 +727,7 @@ class _FFNAddLN(torch.autograd.Function):
         check(_hip.lib().rf_rowblock_ffn_ln(*args, _stream()), "rf_rowblock_ffn_ln")
         if ev is not None:
             keep = (x2, w1, b1, w2, b2, h, z, y, gamma, beta, xhat, rstd)
-            PROFILE.end("rb_ffn_ln_kernel", ev, 4.0 * M * D * F,
+            PROFILE.end(f"rb_ffn_ln_kernel<{32 if M <= 2048 else 64}>", ev, 4.0 * M * D * F,
                         4.0 * (M * D * (2 + (xhat is not None)) + 2 * D * F + M * F * ((h is not None) + (z is not None))),
                         replay=lambda a=args, k=keep: _hip.lib().rf_rowblock_ffn_ln(*a, _stream()))
         if need_grad:
