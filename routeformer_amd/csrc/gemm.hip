@@ -326,6 +326,71 @@ __device__ __forceinline__ void gload(float4 (&r)[NV], const float* __restrict__
   }
 }
 
+// The same tile fetch with everything loop-invariant hoisted: per slot the address of its float4 at k = 0
+// (NULL when the slot lies outside the tile / the matrix) and its k offset are computed once, a K-step then
+// costs one add and one compare per load instead of the index arithmetic (the 64x64 kernels run one wave per
+// SIMD and are instruction-issue bound: ~250 instructions per wave and K-step before this).
+template <int ROWS, int BKV, int MODE, int NV>
+struct GLoader {
+  const float* base[NV];
+  int kofs[NV];
+  bool edge[NV];
+  long kstep;  // elements per unit of k
+  int nrows_, row0_;
+  __device__ __forceinline__ void init(const float* __restrict__ G, long ld_row, long ld_k, int row0, int nrows, int tid) {
+    kstep = MODE == 0 ? 1 : ld_k;
+    nrows_ = nrows; row0_ = row0;
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
+      const int i = tid + s * NT;
+      if constexpr (MODE == 0) {
+        constexpr int VPR = BKV / 4;
+        const int rr = i / VPR, kv = (i % VPR) * 4, gr = row0 + rr;
+        kofs[s] = kv;
+        edge[s] = false;
+        base[s] = (i < ROWS * VPR && gr < nrows) ? G + (long)gr * ld_row + kv : nullptr;
+      } else {
+        constexpr int VPK = ROWS / 4;
+        const int k = i / VPK, rv = (i % VPK) * 4, gr = row0 + rv;
+        kofs[s] = k;
+        edge[s] = gr + 3 >= nrows;
+        base[s] = (i < BKV * VPK && gr < nrows) ? G + (long)k * ld_k + gr : nullptr;
+      }
+    }
+  }
+  __device__ __forceinline__ void load(float4 (&r)[NV], int k0, int kend) const {
+    const long adv = (long)k0 * kstep;
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int gk = k0 + kofs[s];
+      if (base[s] && gk < kend) {
+        const float* p = base[s] + adv;
+        if constexpr (MODE == 0) {
+          if (gk + 3 < kend) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (gk + 1 < kend) v.y = p[1];
+            if (gk + 2 < kend) v.z = p[2];
+          }
+        } else {
+          if (!edge[s]) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            const int gr = row0_ + ((tid_of(s)) % (ROWS / 4)) * 4;
+            v.x = p[0];
+            if (gr + 1 < nrows_) v.y = p[1];
+            if (gr + 2 < nrows_) v.z = p[2];
+          }
+        }
+      }
+      r[s] = v;
+    }
+  }
+  __device__ __forceinline__ int tid_of(int s) const { return (int)threadIdx.x + s * NT; }
+};
+
 // registers -> LDS stage ([row][k], pitch LD)
 template <int ROWS, int BKV, int MODE, int NV, typename T, int LD>
 __device__ __forceinline__ void lstore(T* __restrict__ S, const float4 (&r)[NV], int tid) {
@@ -395,6 +460,10 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
     }
   }
 
+  GLoader<BM, BKV, (AM == 3 ? 0 : AM), NA> la;
+  GLoader<BN, BKV, BMODE, NB> lb;
+  if constexpr (AM != 3) la.init(p.A, p.lda_m, p.lda_k, m0, p.M, tid);
+  lb.init(p.B, p.ldb_n, p.ldb_k, n0, p.N, tid);
   float4 ra[NA], rb[NB];
   float4 rsum[NA];  // per-thread partial row sums of A (bias-gradient side product, AM == 1 only)
   if constexpr (AM == 1) {
@@ -417,7 +486,7 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
         ra[s] = v;
       }
     } else {
-      gload<BM, BKV, AM, NA>(ra, p.A, p.lda_m, p.lda_k, m0, p.M, k0, kend, tid);
+      la.load(ra, k0, kend);
       if constexpr (AM == 1) {
         if (p.a_rowsum) {
 #pragma unroll
@@ -434,7 +503,7 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
   };
 
   load_a(kbeg);
-  gload<BN, BKV, BMODE, NB>(rb, p.B, p.ldb_n, p.ldb_k, n0, p.N, kbeg, kend, tid);
+  lb.load(rb, kbeg, kend);
   store_a(As0);
   lstore<BN, BKV, BMODE, NB, T, LD>(Bs0, rb, tid);
   __syncthreads();
@@ -444,7 +513,7 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
     const bool more = k0 + BKV < kend;
     if (more) {  // next stage's global loads go out before this stage's matrix work
       load_a(k0 + BKV);
-      gload<BN, BKV, BMODE, NB>(rb, p.B, p.ldb_n, p.ldb_k, n0, p.N, k0 + BKV, kend, tid);
+      lb.load(rb, k0 + BKV, kend);
     }
     const T* As = As0 + cur * BM * LD;
     const T* Bs = Bs0 + cur * BN * LD;
