@@ -150,7 +150,7 @@ int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const float* x, c
  * `grad_weight = grad_out^T @ input`): for each entry  dw[N,K] += dy[M,N]^T x[M,K]  and, if db != NULL,
  * db[N] += column sums of dy -- fp32 atomics into gradient slots that were zeroed at the start of the step.
  * Up to RF_WGRAD_MAX_GROUP problems per launch; `entries` is a HOST array (copied into the kernel arguments).
- * dy / x: 16-B aligned, unit column stride, row pitches ld_dy / ld_x multiples of 4; dw contiguous (N,K).
+ * dy / x: 16-B aligned, unit column stride, row pitches ld_dy / ld_x and N, K multiples of 4; dw contiguous (N,K).
  * `splits` = requested split of the reduction dimension M (clamped); `kchunk` is filled in by the library.
  * `exclusive` != 0: the caller guarantees that nothing else writes dw during this launch and that dw holds
  * zeros; if the problem also ends up with a single K slice the tile is then written with plain stores

@@ -330,16 +330,20 @@ __device__ __forceinline__ void gload(float4 (&r)[NV], const float* __restrict__
 // (NULL when the slot lies outside the tile / the matrix) and its k offset are computed once, a K-step then
 // costs one add and one compare per load instead of the index arithmetic (the 64x64 kernels run one wave per
 // SIMD and are instruction-issue bound: ~250 instructions per wave and K-step before this).
+__device__ const float4 rf_zero16 = {0.f, 0.f, 0.f, 0.f};  // what out-of-range tile slots read
+
 template <int ROWS, int BKV, int MODE, int NV>
 struct GLoader {
+  // Branch-free: every slot issues its 16-B load unconditionally; slots outside the tile / matrix / K range
+  // read a 16-B block of zeros instead (no select on the loaded value, so nothing waits for the data).  The predicated form cost ~8 exec-mask
+  // branches per load -- 1.5k of the 2.5k cycles of a K-step (tools/gemm_phase_probe.py).  Requires whole
+  // float4s: K % 4 == 0 (MODE 0) / rows % 4 == 0 (MODE 1), which rf_gemm checks before choosing this kernel.
   const float* base[NV];
   int kofs[NV];
-  bool edge[NV];
+  bool ok[NV];
   long kstep;  // elements per unit of k
-  int nrows_, row0_;
   __device__ __forceinline__ void init(const float* __restrict__ G, long ld_row, long ld_k, int row0, int nrows, int tid) {
     kstep = MODE == 0 ? 1 : ld_k;
-    nrows_ = nrows; row0_ = row0;
 #pragma unroll
     for (int s = 0; s < NV; ++s) {
       const int i = tid + s * NT;
@@ -347,14 +351,14 @@ struct GLoader {
         constexpr int VPR = BKV / 4;
         const int rr = i / VPR, kv = (i % VPR) * 4, gr = row0 + rr;
         kofs[s] = kv;
-        edge[s] = false;
-        base[s] = (i < ROWS * VPR && gr < nrows) ? G + (long)gr * ld_row + kv : nullptr;
+        ok[s] = i < ROWS * VPR && gr < nrows;
+        base[s] = G + (ok[s] ? (long)gr * ld_row + kv : 0);
       } else {
         constexpr int VPK = ROWS / 4;
         const int k = i / VPK, rv = (i % VPK) * 4, gr = row0 + rv;
         kofs[s] = k;
-        edge[s] = gr + 3 >= nrows;
-        base[s] = (i < BKV * VPK && gr < nrows) ? G + (long)k * ld_k + gr : nullptr;
+        ok[s] = i < BKV * VPK && gr < nrows;
+        base[s] = G + (ok[s] ? (long)k * ld_k + gr : 0);
       }
     }
   }
@@ -362,33 +366,11 @@ struct GLoader {
     const long adv = (long)k0 * kstep;
 #pragma unroll
     for (int s = 0; s < NV; ++s) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int gk = k0 + kofs[s];
-      if (base[s] && gk < kend) {
-        const float* p = base[s] + adv;
-        if constexpr (MODE == 0) {
-          if (gk + 3 < kend) {
-            v = *reinterpret_cast<const float4*>(p);
-          } else {
-            v.x = p[0];
-            if (gk + 1 < kend) v.y = p[1];
-            if (gk + 2 < kend) v.z = p[2];
-          }
-        } else {
-          if (!edge[s]) {
-            v = *reinterpret_cast<const float4*>(p);
-          } else {
-            const int gr = row0_ + ((tid_of(s)) % (ROWS / 4)) * 4;
-            v.x = p[0];
-            if (gr + 1 < nrows_) v.y = p[1];
-            if (gr + 2 < nrows_) v.z = p[2];
-          }
-        }
-      }
-      r[s] = v;
+      const bool in = ok[s] && (k0 + kofs[s] < kend);
+      const float* p = in ? base[s] + adv : reinterpret_cast<const float*>(&rf_zero16);
+      r[s] = *reinterpret_cast<const float4*>(p);
     }
   }
-  __device__ __forceinline__ int tid_of(int s) const { return (int)threadIdx.x + s * NT; }
 };
 
 // registers -> LDS stage ([row][k], pitch LD)
@@ -409,6 +391,14 @@ __device__ __forceinline__ void lstore(T* __restrict__ S, const float4 (&r)[NV],
     }
   }
 }
+
+// Phase timing aid (tools/gemm_phase_probe.py builds a private copy with -DRF_GEMM_TIMING)
+#ifdef RF_GEMM_TIMING
+__device__ unsigned long long rf_gemm_timing[16 * 1024];
+#define GM_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.z == 0) rf_gemm_timing[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GM_MARK(k) do {} while (0)
+#endif
 
 struct BlockId { int x, y, z, gx, gz; };  // position of this workgroup inside ITS problem's grid
 
@@ -502,19 +492,24 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
     else lstore<BM, BKV, AM, NA, T, LD>(As, ra, tid);
   };
 
+  GM_MARK(0);
   load_a(kbeg);
   lb.load(rb, kbeg, kend);
   store_a(As0);
   lstore<BN, BKV, BMODE, NB, T, LD>(Bs0, rb, tid);
   __syncthreads();
+  GM_MARK(1);
 
   int cur = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BKV) {
     const bool more = k0 + BKV < kend;
+    const bool probe = k0 == kbeg + BKV;  // second trip
+    if (probe) GM_MARK(2);
     if (more) {  // next stage's global loads go out before this stage's matrix work
       load_a(k0 + BKV);
       lb.load(rb, k0 + BKV, kend);
     }
+    if (probe) GM_MARK(3);
     const T* As = As0 + cur * BM * LD;
     const T* Bs = Bs0 + cur * BN * LD;
     if constexpr (PREC == 0) {
@@ -548,13 +543,17 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
+    if (probe) GM_MARK(4);
     if (more) {
       store_a(As0 + (cur ^ 1) * BM * LD);
       lstore<BN, BKV, BMODE, NB, T, LD>(Bs0 + (cur ^ 1) * BN * LD, rb, tid);
     }
+    if (probe) GM_MARK(5);
     __syncthreads();
+    if (probe) GM_MARK(6);
     cur ^= 1;
   }
+  GM_MARK(7);
 
   if constexpr (AM == 1) {
     // bias-gradient side product: only the first column tile of each row panel contributes (the other
@@ -663,7 +662,47 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
       p.C[(long)m * p.ldc + ecol] = t;
     }
   };
-  if (mode == 0) {
+  const bool simple = !p.preact && !p.res_before_act && (p.act == 0 || p.act == RF_ACT_RELU) &&
+                      (p.dact == 0 || p.dact == RF_ACT_RELU) && (!p.res || p.res_rows >= p.M);
+  if (mode == 0 && simple) {
+    // y = [relu](acc + bias) [* (src > 0)] [+ residual]: most forward and dX launches.  One column predicate
+    // around the whole epilogue, a row count instead of per-element bounds tests, pointers advanced by constant
+    // strides, flags applied by selects -- the per-element guarded form spent 8.4k cycles here
+    // (tools/gemm_phase_probe.py), more than 4 K-steps
+    if (ecol < p.N) {
+      const int kmax = min(EPT, (p.M - m0 - er0 + RSTEP - 1) / RSTEP);
+      const long row = m0 + er0;
+      float* cp = p.C + row * p.ldc + ecol;
+      const float* rp = p.res ? p.res + row * p.ldr + ecol : nullptr;
+      const float* dp = p.dact ? p.dsrc + row * p.ldd + ecol : nullptr;
+      const float* lp = ct + er0 * CP + tid % BN;
+      const bool relu = p.act == RF_ACT_RELU;
+#pragma unroll 1
+      for (int k0 = 0; k0 < kmax; k0 += 4) {
+        float v[4], rs[4] = {0.f, 0.f, 0.f, 0.f}, ds[4] = {1.f, 1.f, 1.f, 1.f};
+        if (rp) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (k0 + u < kmax) rs[u] = rp[(long)(k0 + u) * RSTEP * p.ldr];
+        }
+        if (dp) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (k0 + u < kmax) ds[u] = dp[(long)(k0 + u) * RSTEP * p.ldd];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float t = lp[(k0 + u) * RSTEP * CP] + bias_v;  // (reads stay inside the tile)
+          t = relu ? fmaxf(t, 0.f) : t;
+          t = ds[u] > 0.f ? t : 0.f;
+          v[u] = t + rs[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (k0 + u < kmax) cp[(long)(k0 + u) * RSTEP * p.ldc] = v[u];
+      }
+    }
+  } else if (mode == 0) {
     float rs[4], ds[4], nrs[4] = {0.f, 0.f, 0.f, 0.f}, nds[4] = {0.f, 0.f, 0.f, 0.f};
     epi_inputs(0, rs, ds);
 #pragma unroll 1
@@ -717,6 +756,7 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
       }
     }
   }
+  GM_MARK(8);
 }
 
 // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order and each XCD has its
@@ -856,11 +896,12 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
   p.atomic = atomic_accumulate; p.a_rowsum = a_rowsum;
   p.tile_cnt = nullptr;
 
+  // vector layouts (pipelined kernel): 16-B addressable rows made of whole float4s, else the scalar kernel
   int am = 2, bm = 2;
-  if (lda_k == 1 && (lda_m % 4) == 0 && aligned16(A)) am = 0;
-  else if (lda_m == 1 && (lda_k % 4) == 0 && aligned16(A)) am = 1;
-  if (ldb_k == 1 && (ldb_n % 4) == 0 && aligned16(B)) bm = 0;
-  else if (ldb_n == 1 && (ldb_k % 4) == 0 && aligned16(B)) bm = 1;
+  if (lda_k == 1 && (lda_m % 4) == 0 && (K % 4) == 0 && aligned16(A)) am = 0;
+  else if (lda_m == 1 && (lda_k % 4) == 0 && (M % 4) == 0 && aligned16(A)) am = 1;
+  if (ldb_k == 1 && (ldb_n % 4) == 0 && (K % 4) == 0 && aligned16(B)) bm = 0;
+  else if (ldb_n == 1 && (ldb_k % 4) == 0 && (N % 4) == 0 && aligned16(B)) bm = 1;
 
   if (atomic_accumulate && !(am <= 1 && bm <= 1)) {
     rf_g_last_error = "atomic_accumulate needs 16-B vectorizable operands";
@@ -954,6 +995,14 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int parts, i
 }
 }  // namespace
 
+#ifdef RF_GEMM_TIMING
+extern "C" void* rf_gemm_timing_address() {
+  void* a = nullptr;
+  (void)hipGetSymbolAddress(&a, HIP_SYMBOL(rf_gemm_timing));
+  return a;
+}
+#endif
+
 extern "C" int rf_wgrad_grouped(const RfWgradEntry* entries, int count, int prec, void* stream) {
   RF_REQUIRE(entries && count >= 1 && count <= RF_WGRAD_MAX_GROUP && (prec == 0 || prec == 1));
   WgradTable t{};
@@ -963,7 +1012,7 @@ extern "C" int rf_wgrad_grouped(const RfWgradEntry* entries, int count, int prec
   for (int i = 0; i < count; ++i) {
     RfWgradEntry e = entries[i];
     RF_REQUIRE(e.dy && e.x && e.dw && e.M > 0 && e.N > 0 && e.K > 0 && e.splits >= 1);
-    RF_REQUIRE(aligned16(e.dy) && aligned16(e.x) && e.ld_dy % 4 == 0 && e.ld_x % 4 == 0);
+    RF_REQUIRE(aligned16(e.dy) && aligned16(e.x) && e.ld_dy % 4 == 0 && e.ld_x % 4 == 0 && e.N % 4 == 0 && e.K % 4 == 0);
     const int ktiles = (e.M + KQ - 1) / KQ;
     int splits = e.splits > ktiles ? ktiles : e.splits;
     e.kchunk = ((ktiles + splits - 1) / splits) * KQ;

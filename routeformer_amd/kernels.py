@@ -253,7 +253,8 @@ def _weight_grad(dy2: torch.Tensor, x2: torch.Tensor, into: Optional[torch.Tenso
     M, N = dy2.shape
     K = x2.shape[1]
     tiles = -(-N // 64) * -(-K // 64)
-    if into is not None and not DETERMINISTIC and _vec_ok(dy2) and _vec_ok(x2) and into.data_ptr() % 16 == 0:
+    if (into is not None and not DETERMINISTIC and _vec_ok(dy2) and _vec_ok(x2) and into.data_ptr() % 16 == 0
+            and N % 4 == 0 and K % 4 == 0):
         if WGRAD.active and into.is_contiguous():
             WGRAD.push(dy2, x2, into, bias_into, M, N, K, _splits(tiles, M))
             return bias_into is not None
