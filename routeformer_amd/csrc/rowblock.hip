@@ -27,6 +27,8 @@ __device__ __forceinline__ void st_bf16x4(__bf16* s, const float4& v) {
   *reinterpret_cast<bf16x4*>(s) = o;
 }
 
+__device__ const float4 rb_zero16 = {0.f, 0.f, 0.f, 0.f};  // what rows beyond the matrix read (branch-free loads)
+
 // ROWS x KC fp32 (k contiguous, row pitch ld) -> registers; rows >= nrows read as zero
 template <int ROWS, int KC, int NTH = NT>
 struct Tile {
@@ -36,8 +38,10 @@ struct Tile {
 #pragma unroll
     for (int s = 0; s < NV; ++s) {
       const int i = tid + s * NTH, rr = i / VPR, kv = (i % VPR) * 4;
-      r[s] = (row0 + rr < nrows) ? *reinterpret_cast<const float4*>(g + (long)(row0 + rr) * ld + kv)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      // unconditional 16-B load (a predicated one costs an exec-mask branch per load): out-of-range rows
+      // read a block of zeros
+      const float* src = (row0 + rr < nrows) ? g + (long)(row0 + rr) * ld + kv : reinterpret_cast<const float*>(&rb_zero16);
+      r[s] = *reinterpret_cast<const float4*>(src);
     }
   }
   __device__ __forceinline__ void store(__bf16* __restrict__ lds, int tid) const {  // [row][k], pitch KC + 8
