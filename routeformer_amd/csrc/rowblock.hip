@@ -263,12 +263,15 @@ __global__ __launch_bounds__(NT8) void rb_linear_kernel(LinP p) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int cl = ch * NCOL + j * 16 + fr, n = n0 + cl;
-    bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    // unconditional loads at clamped indices (a predicated load is an exec-mask branch each; rows / columns
+    // outside the matrix are never stored, so what they read does not matter)
+    const int nc = min(n, p.N - 1);
+    bv[j] = p.bias ? p.bias[nc] : 0.f;
     if constexpr (LN) { gam[j] = p.gamma[cl]; bet[j] = p.beta[cl]; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = m0 + rw * 16 + fq * 4 + r;
-      rv[j][r] = (p.res && m < p.M && n < p.N) ? p.res[(long)m * p.ldr + n] : 0.f;
+      const int mc = min(m0 + rw * 16 + fq * 4 + r, p.M - 1);
+      rv[j][r] = p.res ? p.res[(long)mc * p.ldr + nc] : 0.f;
     }
   }
 
@@ -421,8 +424,8 @@ __global__ __launch_bounds__(NT8) void rb_ffn_ln_kernel(FfnP p) {
     b2v[j] = p.b2[n]; gam[j] = p.gamma[n]; bet[j] = p.beta[n];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = m0 + rw * 16 + fq * 4 + r;
-      xres[j][r] = m < p.M ? p.x[(long)m * D + n] : 0.f;
+      const int mc = min(m0 + rw * 16 + fq * 4 + r, p.M - 1);  // clamped, unconditional (never stored beyond M)
+      xres[j][r] = p.x[(long)mc * D + n];
     }
   }
   __syncthreads();
@@ -537,14 +540,13 @@ __global__ __launch_bounds__(NT8) void rb_nn_kernel(NnP p) {
     const int r = tid / LPR, c0 = (tid % LPR) * CPL, m = m0 + r;
     float g[CPL], xh[CPL];
     float s1 = 0.f, s2 = 0.f;
-    const float rs = m < p.M ? p.rstd[m] : 0.f;
+    const float rs = p.rstd[min(m, p.M - 1)];
 #pragma unroll
     for (int v4 = 0; v4 < V4; ++v4) {
-      float4 d = make_float4(0.f, 0.f, 0.f, 0.f), x = d;
-      if (m < p.M) {
-        d = *reinterpret_cast<const float4*>(p.dy + (long)m * 128 + c0 + v4 * 4);
-        x = *reinterpret_cast<const float4*>(p.xhat + (long)m * 128 + c0 + v4 * 4);
-      }
+      // rows beyond M: unconditional loads of a zero block (no exec-mask branch per load)
+      const float* dsrc_ = m < p.M ? p.dy + (long)m * 128 + c0 + v4 * 4 : reinterpret_cast<const float*>(&rb_zero16);
+      const float* xsrc_ = m < p.M ? p.xhat + (long)m * 128 + c0 + v4 * 4 : reinterpret_cast<const float*>(&rb_zero16);
+      const float4 d = *reinterpret_cast<const float4*>(dsrc_), x = *reinterpret_cast<const float4*>(xsrc_);
       const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c0 + v4 * 4);
       g[v4 * 4 + 0] = d.x * gm.x; g[v4 * 4 + 1] = d.y * gm.y; g[v4 * 4 + 2] = d.z * gm.z; g[v4 * 4 + 3] = d.w * gm.w;
       xh[v4 * 4 + 0] = x.x; xh[v4 * 4 + 1] = x.y; xh[v4 * 4 + 2] = x.z; xh[v4 * 4 + 3] = x.w;
@@ -594,8 +596,10 @@ __global__ __launch_bounds__(NT8) void rb_nn_kernel(NnP p) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int m = m0 + r0 + u;
-        d[u] = m < p.M ? p.dy[(long)m * 128 + c] : 0.f;
-        x[u] = m < p.M ? p.xhat[(long)m * 128 + c] : 0.f;
+        const float keep = m < p.M ? 1.f : 0.f;
+        const long mc = min(m, p.M - 1);
+        d[u] = p.dy[mc * 128 + c] * keep;
+        x[u] = p.xhat[mc * 128 + c];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) { sb += d[u]; sg += d[u] * x[u]; }
@@ -639,11 +643,10 @@ __global__ __launch_bounds__(NT8) void rb_nn_kernel(NnP p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int i = (it + u) * 64 + lane, rr = i / V4R, col = ch * NCOL + (i % V4R) * 4, m = m0 + rw * 16 + rr;
+      const long mc = min(m, p.M - 1);  // clamped rows: loaded unconditionally, never stored
       rz[u] = dz[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < p.M) {
-        if (p.res) rz[u] = *reinterpret_cast<const float4*>(p.res + (long)m * p.ldr + col);
-        if (p.dact) dz[u] = *reinterpret_cast<const float4*>(p.dsrc + (long)m * p.ldd + col);
-      }
+      if (p.res) rz[u] = *reinterpret_cast<const float4*>(p.res + mc * p.ldr + col);
+      if (p.dact) dz[u] = *reinterpret_cast<const float4*>(p.dsrc + mc * p.ldd + col);
     }
   };
   float4 rz[2], dz[2], nrz[2], ndz[2];
