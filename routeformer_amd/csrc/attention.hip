@@ -123,14 +123,14 @@ __device__ __forceinline__ void load_qkv(float* Qs, float* Ks, float* Vs, const 
       RowCol it(tid, nt, E4);
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
-        const int i = tid + u * nt, l = it.r, e = it.c << 2;
+        const int l = it.r, e = it.c << 2;
         ls[u] = l; es[u] = e;
         it.next();
-        if (i < nq) rq[u] = *reinterpret_cast<const float4*>(qb + (long)l * p.q_ld + e);
-        if (i < nk) {
-          rk[u] = *reinterpret_cast<const float4*>(kb + (long)l * p.k_ld + e);
-          rv[u] = *reinterpret_cast<const float4*>(vb + (long)l * p.v_ld + e);
-        }
+        // unconditional loads at clamped rows (a predicated load is an exec-mask branch); the stores are guarded
+        const int lq = min(l, max(p.Qs_rows, 1) - 1), lk = min(l, p.LK - 1);
+        rq[u] = *reinterpret_cast<const float4*>((p.Qs_rows ? qb : kb) + (long)lq * (p.Qs_rows ? p.q_ld : p.k_ld) + e);
+        rk[u] = *reinterpret_cast<const float4*>(kb + (long)lk * p.k_ld + e);
+        rv[u] = *reinterpret_cast<const float4*>(vb + (long)lk * p.v_ld + e);
       }
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
