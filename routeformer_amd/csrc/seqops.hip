@@ -22,11 +22,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = i * 64 + lane;
+    // unconditional loads at a clamped column, masked by a select (a predicated load is an exec-mask branch)
+    const int c = i * 64 + lane, cc = min(c, cols - 1);
     float t = 0.f;
-    if (c < cols) {
-      t = x[off + c];
-      if (res) t += res[off + c];
+    if (i * 64 < cols) {  // wave-uniform (scalar branch): skip the 64-column groups beyond the row
+      t = x[off + cc];
+      if (res) t += res[off + cc];
+      t = c < cols ? t : 0.f;
     }
     v[i] = t;
     s += t;
@@ -69,9 +71,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = i * 64 + lane;
+      const int c = i * 64 + lane, cc = min(c, cols - 1);  // clamped, unconditional; masked below
       float d = 0.f, hh = 0.f, gm = 0.f;
-      if (c < cols) { d = dy[off + c]; hh = xhat[off + c]; gm = gamma[c]; }
+      if (i * 64 < cols) {  // wave-uniform (scalar branch): skip the 64-column groups beyond the row
+        d = dy[off + cc]; hh = xhat[off + cc]; gm = gamma[cc];
+        d = c < cols ? d : 0.f;
+        hh = c < cols ? hh : 0.f;
+      }
       dg[i] += d * hh;
       db[i] += d;
       g[i] = d * gm;
