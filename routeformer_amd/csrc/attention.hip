@@ -108,43 +108,54 @@ struct RowCol {
 };
 
 // Q, K and V head slices in one go: every global load of the three slices is issued before the first LDS
-// store (one memory round trip for the whole prologue instead of one per slice and loop trip).
-template <bool V4>
+// store (one memory round trip for the whole prologue instead of one per slice and loop trip).  TRIPS =
+// loads per thread and slice, a launch-uniform count: the body is branch-free (a branch around a load makes
+// the compiler drain the memory counter at the join, which serialises the round trips -- measured 2.3x on this
+// prologue), and an all-clamped trip would still cost the CU's address unit 16 cycles per wave and slice.
+template <int TRIPS, bool HAS_Q>
+__device__ __forceinline__ void load_qkv_trips(float* Qs, float* Ks, float* Vs, const AttnP& p, int b, int h, int EP,
+                                               int tid, int nq, int nk) {
+  const int nt = blockDim.x, E4 = p.E >> 2;
+  const float* qb = p.q + (long)b * p.LQ * p.q_ld + (long)h * p.E;
+  const float* kb = p.k + (long)b * p.LK * p.k_ld + (long)h * p.E;
+  const float* vb = p.v + (long)b * p.LK * p.v_ld + (long)h * p.E;
+  float4 rq[TRIPS], rk[TRIPS], rv[TRIPS];
+  int ls[TRIPS], es[TRIPS];
+  RowCol it(tid, nt, E4);
+#pragma unroll
+  for (int u = 0; u < TRIPS; ++u) {
+    const int l = it.r, e = it.c << 2;
+    ls[u] = l; es[u] = e;
+    it.next();
+    // unconditional loads at clamped rows (a predicated load is an exec-mask branch); the stores are guarded
+    const int lk = min(l, p.LK - 1);
+    if constexpr (HAS_Q) rq[u] = *reinterpret_cast<const float4*>(qb + (long)min(l, p.Qs_rows - 1) * p.q_ld + e);
+    rk[u] = *reinterpret_cast<const float4*>(kb + (long)lk * p.k_ld + e);
+    rv[u] = *reinterpret_cast<const float4*>(vb + (long)lk * p.v_ld + e);
+  }
+#pragma unroll
+  for (int u = 0; u < TRIPS; ++u) {
+    const int i = tid + u * nt, l = ls[u], e = es[u];
+    if constexpr (HAS_Q)
+      if (i < nq) *reinterpret_cast<float4*>(Qs + l * EP + e) = rq[u];
+    if (i < nk) {
+      *reinterpret_cast<float4*>(Ks + l * EP + e) = rk[u];
+      *reinterpret_cast<float4*>(Vs + l * EP + e) = rv[u];
+    }
+  }
+}
+
+template <bool V4, bool HAS_Q>
 __device__ __forceinline__ void load_qkv(float* Qs, float* Ks, float* Vs, const AttnP& p, int b, int h, int EP, int tid) {
   const int nt = blockDim.x;
   if constexpr (V4) {
-    const int E4 = p.E >> 2, nq = p.Qs_rows * E4, nk = p.LK * E4;
-    if (nq <= 3 * nt && nk <= 3 * nt) {
-      const float* qb = p.q + (long)b * p.LQ * p.q_ld + (long)h * p.E;
-      const float* kb = p.k + (long)b * p.LK * p.k_ld + (long)h * p.E;
-      const float* vb = p.v + (long)b * p.LK * p.v_ld + (long)h * p.E;
-      float4 rq[3], rk[3], rv[3];
-      int ls[3], es[3];
-      RowCol it(tid, nt, E4);
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const int l = it.r, e = it.c << 2;
-        ls[u] = l; es[u] = e;
-        it.next();
-        // unconditional loads at clamped rows (a predicated load is an exec-mask branch); the stores are guarded
-        const int lq = min(l, max(p.Qs_rows, 1) - 1), lk = min(l, p.LK - 1);
-        rq[u] = *reinterpret_cast<const float4*>((p.Qs_rows ? qb : kb) + (long)lq * (p.Qs_rows ? p.q_ld : p.k_ld) + e);
-        rk[u] = *reinterpret_cast<const float4*>(kb + (long)lk * p.k_ld + e);
-        rv[u] = *reinterpret_cast<const float4*>(vb + (long)lk * p.v_ld + e);
-      }
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const int i = tid + u * nt, l = ls[u], e = es[u];
-        if (i < nq) *reinterpret_cast<float4*>(Qs + l * EP + e) = rq[u];
-        if (i < nk) {
-          *reinterpret_cast<float4*>(Ks + l * EP + e) = rk[u];
-          *reinterpret_cast<float4*>(Vs + l * EP + e) = rv[u];
-        }
-      }
-      return;
-    }
+    const int E4 = p.E >> 2, nq = HAS_Q ? p.Qs_rows * E4 : 0, nk = p.LK * E4;
+    const int trips = (max(nq, nk) + nt - 1) / nt;
+    if (trips == 1) { load_qkv_trips<1, HAS_Q>(Qs, Ks, Vs, p, b, h, EP, tid, nq, nk); return; }
+    if (trips == 2) { load_qkv_trips<2, HAS_Q>(Qs, Ks, Vs, p, b, h, EP, tid, nq, nk); return; }
+    if (trips == 3) { load_qkv_trips<3, HAS_Q>(Qs, Ks, Vs, p, b, h, EP, tid, nq, nk); return; }
   }
-  if (p.Qs_rows) load_head<V4>(Qs, p.q, p.q_ld, b, h, p.LQ, p.E, EP, tid);
+  if constexpr (HAS_Q) load_head<V4>(Qs, p.q, p.q_ld, b, h, p.LQ, p.E, EP, tid);
   load_head<V4>(Ks, p.k, p.k_ld, b, h, p.LK, p.E, EP, tid);
   load_head<V4>(Vs, p.v, p.v_ld, b, h, p.LK, p.E, EP, tid);
 }
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
     const int32_t* idx = p.idx + (long)(b / p.idx_group) * p.idx_stride;
     for (int i = tid; i < LQ * p.sample_k; i += (int)blockDim.x) Sidx[i] = idx[i];
   }
-  load_qkv<V4>(Qs, Ks, Vs, p, b, h, EP, tid);
+  load_qkv<V4, true>(Qs, Ks, Vs, p, b, h, EP, tid);
   for (int i = tid; i < (LKP - LK) * EP; i += (int)blockDim.x) { Ks[LK * EP + i] = 0.f; Vs[LK * EP + i] = 0.f; }
   __syncthreads();
   RF_MARK(1);
@@ -439,7 +450,12 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   int* sel = top_list + n_sel;
 
   RF_MARK(9);
-  load_qkv<V4>(nullptr, Ks, Vs, p, b, h, EP, tid);
+  // the selection list rides along with the K/V loads (one memory round trip instead of two)
+  const int32_t* gtop = p.mode != 0 ? p.top + ((long)b * p.H + h) * p.n_top : nullptr;
+  const bool top_in_regs = n_sel <= (int)blockDim.x;
+  int my_top = tid;
+  if (p.mode != 0 && top_in_regs) my_top = gtop[min(tid, n_sel - 1)];
+  load_qkv<V4, false>(nullptr, Ks, Vs, p, b, h, EP, tid);
   for (int i = tid; i < (LKP - LK) * EP; i += (int)blockDim.x) { Ks[LK * EP + i] = 0.f; Vs[LK * EP + i] = 0.f; }
   for (int i = tid; i < (NSP - n_sel) * EP; i += (int)blockDim.x) { Qsel[n_sel * EP + i] = 0.f; dCsel[n_sel * EP + i] = 0.f; }
   for (int i = tid; i < (NSP - n_sel) * LKP; i += (int)blockDim.x) { P[n_sel * LKP + i] = 0.f; dS[n_sel * LKP + i] = 0.f; }
@@ -447,20 +463,33 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   __syncthreads();
   if (p.mode == 0) {
     for (int i = tid; i < n_sel; i += (int)blockDim.x) top_list[i] = i;
+  } else if (top_in_regs) {
+    if (tid < n_sel) { top_list[tid] = my_top; sel[my_top] = tid; }
   } else {
-    const int32_t* gtop = p.top + ((long)b * p.H + h) * p.n_top;
     for (int i = tid; i < n_sel; i += (int)blockDim.x) { top_list[i] = gtop[i]; sel[gtop[i]] = i; }
   }
   __syncthreads();
   const float* qbase = p.q + (long)b * LQ * p.q_ld + (long)h * E;
   {
-    RowCol rc(tid, blockDim.x, E);
     const long row_step = p.out_layout == 0 ? (long)p.H * E : (long)E;
     const float* dbase = p.dctx + ctx_off(p, b, h, 0);
-    for (int i = tid; i < n_sel * E; i += (int)blockDim.x, rc.next()) {
-      const int q = top_list[rc.r];
-      Qsel[rc.r * EP + rc.c] = qbase[(long)q * p.q_ld + rc.c];
-      dCsel[rc.r * EP + rc.c] = dbase[q * row_step + rc.c];
+    if constexpr (V4) {
+      const int E4 = E >> 2;
+      RowCol rc(tid, blockDim.x, E4);
+      for (int i = tid; i < n_sel * E4; i += (int)blockDim.x, rc.next()) {
+        const int q = top_list[rc.r], e = rc.c << 2;
+        const float4 a = *reinterpret_cast<const float4*>(qbase + (long)q * p.q_ld + e);
+        const float4 d = *reinterpret_cast<const float4*>(dbase + q * row_step + e);
+        *reinterpret_cast<float4*>(Qsel + rc.r * EP + e) = a;
+        *reinterpret_cast<float4*>(dCsel + rc.r * EP + e) = d;
+      }
+    } else {
+      RowCol rc(tid, blockDim.x, E);
+      for (int i = tid; i < n_sel * E; i += (int)blockDim.x, rc.next()) {
+        const int q = top_list[rc.r];
+        Qsel[rc.r * EP + rc.c] = qbase[(long)q * p.q_ld + rc.c];
+        dCsel[rc.r * EP + rc.c] = dbase[q * row_step + rc.c];
+      }
     }
   }
   __syncthreads();
@@ -691,7 +720,7 @@ extern "C" int rf_attn_bwd(const float* q, const float* k, const float* v, int64
   RF_REQUIRE(mode == 0 || (top_idx && n_top > 0 && n_top <= LQ));
   RF_REQUIRE(mode != 2 || LQ == LK);
   const int n_sel = mode == 0 ? LQ : n_top;
-  const bool v4 = (E % 4 == 0) && al16(q) && al16(k) && al16(v) && al16(dq) && al16(dk) && al16(dv) &&
+  const bool v4 = (E % 4 == 0) && al16(q) && al16(k) && al16(v) && al16(dq) && al16(dk) && al16(dv) && al16(dctx) &&
                   q_ld % 4 == 0 && k_ld % 4 == 0 && v_ld % 4 == 0 && dq_ld % 4 == 0 && dk_ld % 4 == 0 && dv_ld % 4 == 0;
   const size_t lds = bwd_lds(LQ, LK, E, n_sel, v4);
   if (lds > 160 * 1024) { rf_g_last_error = "attention backward exceeds 160 KB LDS"; return RF_EUNSUPPORTED; }
