@@ -22,6 +22,15 @@ from routeformer_amd.losses import FutureDiscountedLoss
 from routeformer_amd.score import ade, fde
 
 
+def _capture_kw() -> dict:
+    """Stream-capture options.  In a multi-rank job the process group's watchdog thread polls its events with
+    hipEventQuery at arbitrary moments; under the default "global" capture mode such a call from ANOTHER thread
+    invalidates a capture in progress.  "thread_local" keeps the checks for this thread (the one capturing)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return {"capture_error_mode": "thread_local"}
+    return {}
+
+
 def train_step_losses(model, item, epoch: int = 0, trajectory_loss: Optional[FutureDiscountedLoss] = None,
                       dense_loss: Optional[FutureDiscountedLoss] = None,
                       tokens_ready: bool = False) -> Dict[str, torch.Tensor]:
@@ -469,7 +478,7 @@ class GraphedTrainEngine(TrainEngine):
             self.model.video_backbone.encode_clips(clips, out=self._tok_next)  # warm (weight folding, caches)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **_capture_kw()):
                 self.model.video_backbone.encode_clips(clips, out=self._tok_next)
             self._trunk_graphs[key] = (g, clips)  # keep the clip tensors alive: the graph reads them
             g = self._trunk_graphs[key]
@@ -538,7 +547,7 @@ class GraphedTrainEngine(TrainEngine):
         SAMPLER.rewind_static()
         g = torch.cuda.CUDAGraph()
         if not self.split:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **_capture_kw()):
                 cur = torch.cuda.current_stream()
                 if key is not None:
                     self._tstream.wait_stream(cur)
@@ -553,7 +562,7 @@ class GraphedTrainEngine(TrainEngine):
             g2 = torch.cuda.CUDAGraph()
             self._enter()
             try:
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, **_capture_kw()):
                     cur = torch.cuda.current_stream()
                     if key is not None:
                         self._tstream.wait_stream(cur)
@@ -562,7 +571,7 @@ class GraphedTrainEngine(TrainEngine):
                     out, carry = self._stage1(self._static_item, self._epoch, tokens_ready=self._pipelined)
                     if key is not None:
                         cur.wait_stream(self._tstream)
-                with torch.cuda.graph(g2, pool=g.pool()):
+                with torch.cuda.graph(g2, pool=g.pool(), **_capture_kw()):
                     self._stage2(carry)
             finally:
                 self._leave()
