@@ -108,11 +108,29 @@ def main():
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    # RF_REHEARSE_COLLECTIVES=1 at N=1: a one-rank RCCL group and the engine's whole N>1 code path (bucketed
+    # all-reduce launches, two-graph step) on a single GPU -- a rehearsal, never the reported N=1 line
+    rehearse = world == 1 and os.environ.get("RF_REHEARSE_COLLECTIVES") == "1"
+    multi = world > 1 or rehearse
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        # RCCL prints a version banner on STDOUT when it builds its communicator; stdout is reserved for the one
+        # JSON line, so file descriptor 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from routeformer_amd import kernels as K
     from routeformer_amd.engine import GraphedTrainEngine, TrainEngine
@@ -150,7 +168,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -176,7 +194,7 @@ def main():
         K.PROFILE.enable()
         engine._eager_fwd_bwd(item, 10)
         K.PROFILE.disable()
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
@@ -232,10 +250,12 @@ def main():
                        "launch": "hipGraph replay of fwd+bwd" if use_graph else "eager launches"},
             "loss": float(res["loss"]), "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if rehearse:
+            out["config"]["rehearsal"] = "one-rank RCCL group, N>1 code path (RF_REHEARSE_COLLECTIVES=1)"
+        if world == 1 and not args.no_cpu_baseline and not rehearse:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, c, args.cpu_steps)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

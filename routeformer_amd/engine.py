@@ -26,7 +26,7 @@ def _capture_kw() -> dict:
     """Stream-capture options.  In a multi-rank job the process group's watchdog thread polls its events with
     hipEventQuery at arbitrary moments; under the default "global" capture mode such a call from ANOTHER thread
     invalidates a capture in progress.  "thread_local" keeps the checks for this thread (the one capturing)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         return {"capture_error_mode": "thread_local"}
     return {}
 
@@ -158,6 +158,10 @@ class GradReducer:
         self.params = laid
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # RF_REHEARSE_COLLECTIVES=1: run the exchange step even in a one-rank group (tools/rccl_rehearsal.py: the
+        # whole N>1 code path -- RCCL launches, stream ordering, split graphs -- on a single GPU)
+        import os
+        self.exchange = self.world > 1 or (os.environ.get("RF_REHEARSE_COLLECTIVES") == "1" and dist.is_initialized())
         dev = self.params[0].device
         ALIGN = 64  # floats: every parameter starts on a 256-B boundary (16-B vector loads in the GEMMs)
         total = sum(-(-p.numel() // ALIGN) * ALIGN for p in self.params)
@@ -190,7 +194,7 @@ class GradReducer:
         self._works: List = []
         self._starts = sorted((self.offset[id(p)], id(p)) for p in self.params)
         self.hooks_enabled = True  # False: no in-backward launches (HIP-graph capture); finish() sends all
-        if self.world > 1:
+        if self.exchange:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -253,7 +257,7 @@ class GradReducer:
         """All-reduce, now, every bucket made up ONLY of parameters whose name starts with ``prefix`` (their
         gradients are final).  Returns how many were launched."""
         n = 0
-        if self.world > 1:
+        if self.exchange:
             for b in range(len(self.buckets)):
                 if not self._launched[b] and self._bucket_prefix_ok(b, names_of, prefix):
                     self._launch(b)
@@ -272,7 +276,7 @@ class GradReducer:
         """Flush buckets whose parameters got no gradient this step (e.g. gaze branch dropped), then
         make the compute stream wait for all reductions.  Gradients hold the SUM over ranks; the
         1/world factor is folded into the optimizer kernel (``grad_scale``)."""
-        if self.world > 1:
+        if self.exchange:
             for b in range(len(self.buckets)):
                 if not self._launched[b]:
                     self._launch(b)
@@ -281,7 +285,7 @@ class GradReducer:
         return 1.0 / self.world
 
     def broadcast_parameters(self, src: int = 0):
-        if self.world > 1:
+        if self.exchange:
             dist.broadcast(self.flat_param, src=src, group=self.group)
 
 
@@ -454,7 +458,7 @@ class GraphedTrainEngine(TrainEngine):
         # N > 1: capture the step as two graphs so that the gradient all-reduce of the GPS backbone overlaps the
         # rest of the backward pass (RF_SPLIT_BWD=1 forces it at N = 1, =0 disables it)
         env = __import__("os").environ.get("RF_SPLIT_BWD")
-        self.split = (self.reducer.world > 1) if env is None else env == "1"
+        self.split = self.reducer.exchange if env is None else env == "1"
         self._names = {id(p): n for n, p in model.named_parameters()}
         c = model.configs
         if c.view_dropout > 0 or c.gaze_dropout > 0 or c.motion_noise > 0 or c.feature_dropout > 0:
@@ -489,6 +493,7 @@ class GraphedTrainEngine(TrainEngine):
         from routeformer_amd.models.blocks import SAMPLER
         self.reducer.hooks_enabled = False  # no collective inside the captured region
         self.model.train()
+        SAMPLER.drop_static()  # a previous capture in this process (another engine / shape) planned its own draws
         dev = self.reducer.flat_param.device
         # static inputs of the main graph: private copies of the small tensors (gps, gaze); the video
         # tensors are only consulted for shapes / cache keys while capturing (the trunk has its own graphs)
