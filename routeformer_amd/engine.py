@@ -256,12 +256,27 @@ class GradReducer:
     def launch_complete_prefix(self, names_of: Dict[int, str], prefix: str) -> int:
         """All-reduce, now, every bucket made up ONLY of parameters whose name starts with ``prefix`` (their
         gradients are final).  Returns how many were launched."""
-        n = 0
-        if self.exchange:
-            for b in range(len(self.buckets)):
-                if not self._launched[b] and self._bucket_prefix_ok(b, names_of, prefix):
-                    self._launch(b)
-                    n += 1
+        if not self.exchange:
+            return 0
+        return self._launch_runs([b for b in range(len(self.buckets))
+                                  if not self._launched[b] and self._bucket_prefix_ok(b, names_of, prefix)])
+
+    def _launch_runs(self, ready: List[int]) -> int:
+        """All-reduce the given buckets, every run of neighbours as ONE collective over their joint slice of the flat
+        buffer: when many buckets become final at the same moment (end of a replayed graph) there is nothing to
+        overlap bucket by bucket, and xGMI's point-to-point rings are per-link bound -- fewer, larger messages."""
+        i, n = 0, 0
+        while i < len(ready):
+            j = i
+            while j + 1 < len(ready) and ready[j + 1] == ready[j] + 1:
+                j += 1
+            s, e = self.buckets[ready[i]][0], self.buckets[ready[j]][1]
+            self._works.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                               async_op=True))
+            for b in ready[i:j + 1]:
+                self._launched[b] = True
+            n += j + 1 - i
+            i = j + 1
         return n
 
     def _bucket_prefix_ok(self, b, names_of, prefix):
@@ -277,9 +292,7 @@ class GradReducer:
         make the compute stream wait for all reductions.  Gradients hold the SUM over ranks; the
         1/world factor is folded into the optimizer kernel (``grad_scale``)."""
         if self.exchange:
-            for b in range(len(self.buckets)):
-                if not self._launched[b]:
-                    self._launch(b)
+            self._launch_runs([b for b in range(len(self.buckets)) if not self._launched[b]])
             for w in self._works:
                 w.wait()
         return 1.0 / self.world
