@@ -190,13 +190,16 @@ def _tile_counters(device):
 
 
 def _auto_split(M: int, N: int, K: int) -> int:
-    """Split-K for launches that would leave most of the 256 CUs idle (small-M Informer GEMMs): aim for
-    ~512 workgroups with >= 128 of reduction depth each."""
+    """Split-K for launches that would leave most of the 256 CUs idle (small-M Informer GEMMs).  Measured on the
+    step's shapes (tools/splitk_sweep.py): a reduction depth >= 1024 wants ~512 workgroups (the slices are long
+    enough to pay for the extra reduction pass), a shallower one only enough slices to reach ~256, and in
+    either case >= 128 of depth per slice."""
     tm = -(-M // (128 if M >= 4096 and N >= 64 else 64))
     tiles = tm * -(-N // 64)
     if tiles >= 256 or K < 256:
         return 1
-    return max(1, min(16, K // 128, -(-512 // tiles)))
+    want = -(-512 // tiles) if K >= 1024 else 256 // tiles
+    return max(1, min(16, K // 128, want))
 
 
 def gemm(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, *, bias=None, residual=None, ldr=0,
