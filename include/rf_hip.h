@@ -65,14 +65,21 @@ int rf_colsum_parts(int M, int N);
 int rf_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, float* workspace,
               void* stream);
 
+/* Activation storage of the trunk's NHWC maps (`act_dtype` below): RF_ACT_F32 = fp32, RF_ACT_BF16 = bf16.  The bf16
+ * matrix-core mode rounds every convolution input to bf16 anyway; keeping the maps themselves in bf16 halves the
+ * HBM traffic of this bandwidth-bound stack.  Arithmetic between load and store is fp32 in both forms; pointers
+ * typed `void*` below are float* or bf16* accordingly, pitches are in elements. */
+#define RF_ACT_F32 0
+#define RF_ACT_BF16 1
+
 /* ---- conv2d as implicit GEMM over NHWC (frozen HRNet-16 trunk, inference only) -------------
  * y[n,ho,wo,co] = act( sum_{kh,kw,ci} x[n,ho*s-p+kh,wo*s-p+kw,ci] * w[co,kh,kw,ci] + bias[co]
  *                      (+ residual[n,ho,wo,co]) )
  * BatchNorm2d(eval) is folded into w/bias by the host.  x has row pitch `cin` (channels innermost),
  * y is written with channel pitch ldy at channel offset 0 of the given pointer.
  * Replaces Conv2d+BN+ReLU(+add) of inverse_form_layers/hrnetv2.py:45-61,79-99,434-440. */
-int rf_conv2d_nhwc(const float* x, const float* w, const float* bias, const float* residual,
-                   float* y, int N, int H, int W, int cin, int cout, int ksize, int stride, int pad,
+int rf_conv2d_nhwc(const void* x, const float* w, const float* bias, const void* residual,
+                   void* y, int act_dtype, int N, int H, int W, int cin, int cout, int ksize, int stride, int pad,
                    int Ho, int Wo, int64_t ldy, int64_t ldres, int relu, int prec, void* stream);
 
 /* 3x3 / stride 1 / pad 1 fast path on the bf16 matrix cores ("raster window": the contiguous NHWC span a
@@ -81,30 +88,30 @@ int rf_conv2d_nhwc(const float* x, const float* w, const float* bias, const floa
  * (128,128) (256,16) -- the BasicBlock / Bottleneck / transition convs of hrnetv2.py:45-61,79-99,310-330.
  * Same arithmetic contract as rf_conv2d_nhwc(prec = 1). */
 int rf_conv3x3_bf16_supported(int cin, int cout);
-int rf_conv3x3_bf16(const float* x, const void* w_bf16, const float* bias, const float* residual, float* y,
-                    int N, int H, int W, int cin, int cout, int relu, void* stream);
+int rf_conv3x3_bf16(const void* x, const void* w_bf16, const float* bias, const void* residual, void* y,
+                    int act_dtype, int N, int H, int W, int cin, int cout, int relu, void* stream);
 
 /* Stem: frame gather + cast + conv0 (3->3, k2 s2, no BN; hrnetv2.py:292-293,432-433).
  * video: (B,T,3,H,W), video_dtype 0 = fp16 in [0,1] (what the dataset emits), 1 = fp32, 2 = raw uint8 camera
  * bytes -- the dataset's `astype(float16) / 255` (io/dataset.py:1506-1523) is then applied on the fly, bit for
  * bit, so clips can stay uint8 in HBM; frame_idx[F] picks frames (routeformer.py:418-421);
- * y: (B*F, H/2, W/2, 4) fp32 NHWC with a zero 4th channel. w: (3,3,2,2) as in the state dict. */
+ * y: (B*F, H/2, W/2, 4) NHWC (act_dtype) with a zero 4th channel. w: (3,3,2,2) as in the state dict. */
 int rf_stem_conv0(const void* video, int video_dtype, const int32_t* frame_idx, const float* w,
-                  float* y, int B, int T, int F, int H, int W, void* stream);
+                  void* y, int act_dtype, int B, int T, int F, int H, int W, void* stream);
 
 /* y[n,ho,wo,c] = (accumulate ? y : 0) + (addend ? addend[n,ho,wo,c] : 0) + bilinear(x)[n,ho,wo,c]
  * (align_corners=False), optional ReLU afterwards; y has channel pitch ldy, addend is dense (pitch C).
- * hrnetv2.py:266-271,453-498. */
-int rf_upsample_bilinear_nhwc(const float* x, const float* addend, float* y, int N, int Hi, int Wi,
+ * hrnetv2.py:266-271,453-498.  C % 4 == 0, ldy % 4 == 0 (four channels per access). */
+int rf_upsample_bilinear_nhwc(const void* x, const void* addend, void* y, int act_dtype, int N, int Hi, int Wi,
                               int C, int Ho, int Wo, int64_t ldy, int accumulate, int relu,
                               void* stream);
 
-/* out = relu?(a + b) elementwise over n floats (fuse-layer identity terms). */
-int rf_add_relu(const float* a, const float* b, float* out, int64_t n, int relu, void* stream);
+/* out = relu?(a + b) elementwise over n elements (fuse-layer identity terms). */
+int rf_add_relu(const void* a, const void* b, void* out, int act_dtype, int64_t n, int relu, void* stream);
 
 /* AdaptiveAvgPool2d((8,8)) on NHWC + token layout + the constant -1 row:
- * x (N,H,W,C) -> tokens (N,65,C); InverseForm.py:66-67 + routeformer.py:478-487. */
-int rf_avgpool8_tokens(const float* x, float* tokens, int N, int H, int W, int C, void* stream);
+ * x (N,H,W,C) (act_dtype) -> tokens (N,65,C) fp32; InverseForm.py:66-67 + routeformer.py:478-487.  C % 4 == 0. */
+int rf_avgpool8_tokens(const void* x, int act_dtype, float* tokens, int N, int H, int W, int C, void* stream);
 
 /* ---- sequence ops ---------------------------------------------------------------------------
  * Circular unfold for Conv1d(k=3, padding_mode="circular"): x (B,L,C) -> cols (B,Lout,3C),
@@ -248,6 +255,12 @@ int rf_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
 int rf_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, int sumsq_parts,
                   float max_norm, float lr, float beta1, float beta2, float eps, float wd, int step,
                   float grad_scale, void* stream);
+/* Same update with the scalars read from device memory, for a launch replayed from a HIP graph:
+ * hyper[10] = {pending (0: leave everything untouched), max_norm, lr, beta1, beta2, eps, wd, 1-beta1^t,
+ * sqrt(1-beta2^t), grad_scale}.  `sumsq` may cover a larger buffer than [p, p+n): the clip coefficient is global. */
+#define RF_ADAMW_HYPER 10
+int rf_adamw_clip_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, int sumsq_parts,
+                      const float* hyper, void* stream);
 
 #ifdef __cplusplus
 }

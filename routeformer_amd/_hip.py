@@ -20,13 +20,13 @@ SIGNATURES = {
                 _I, _I, _I, _P, _I, _P, _P, _P],
     "rf_colsum_parts": [_I, _I],
     "rf_colsum": [_P, _L, _I, _I, _P, _I, _P, _P],
-    "rf_conv2d_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _I, _I, _P],
+    "rf_conv2d_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _I, _I, _P],
     "rf_conv3x3_bf16_supported": [_I, _I],
-    "rf_conv3x3_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "rf_stem_conv0": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "rf_upsample_bilinear_nhwc": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _I, _I, _P],
-    "rf_add_relu": [_P, _P, _P, _L, _I, _P],
-    "rf_avgpool8_tokens": [_P, _P, _I, _I, _I, _I, _P],
+    "rf_conv3x3_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "rf_stem_conv0": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "rf_upsample_bilinear_nhwc": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _P],
+    "rf_add_relu": [_P, _P, _P, _I, _L, _I, _P],
+    "rf_avgpool8_tokens": [_P, _I, _P, _I, _I, _I, _I, _P],
     "rf_unfold3_circular": [_P, _P, _I, _I, _I, _I, _P],
     "rf_fold3_circular": [_P, _P, _I, _I, _I, _I, _P],
     "rf_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
@@ -51,6 +51,7 @@ SIGNATURES = {
     "rf_sumsq_parts": [_L],
     "rf_sumsq": [_P, _L, _P, _P],
     "rf_adamw_clip": [_P, _P, _P, _P, _L, _P, _I, _F, _F, _F, _F, _F, _F, _I, _F, _P],
+    "rf_adamw_clip_dev": [_P, _P, _P, _P, _L, _P, _I, _P, _P],
     "rf_version": [],
 }
 

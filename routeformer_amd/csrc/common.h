@@ -26,6 +26,26 @@ extern thread_local const char* rf_g_last_error;
     }                                                      \
   } while (0)
 
+// Activation storage of the frozen conv trunk: fp32, or bf16 in the bf16 matrix-core mode (the convolutions round
+// their inputs to bf16 anyway, so keeping the maps in bf16 halves the HBM traffic of an HBM-bound stack).  These
+// helpers move 4 consecutive channels (16 B / 8 B); arithmetic between load and store is always fp32.
+__device__ __forceinline__ float4 act_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 act_ld4(const __bf16* p) {
+  const uint2 r = *reinterpret_cast<const uint2*>(p);  // bf16 -> fp32 is a 16-bit shift
+  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                     __uint_as_float(r.y & 0xffff0000u));
+}
+__device__ __forceinline__ void act_st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void act_st4(__bf16* p, const float4& v) {
+  typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+  const bf16x4_ o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};  // round to nearest even
+  *reinterpret_cast<bf16x4_*>(p) = o;
+}
+__device__ __forceinline__ float act_ld(const float* p) { return *p; }
+__device__ __forceinline__ float act_ld(const __bf16* p) { return (float)*p; }
+__device__ __forceinline__ void act_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void act_st(__bf16* p, float v) { *p = (__bf16)v; }
+
 // Cross-lane reductions on the DPP path (data-parallel primitives: the operand of a VALU instruction is
 // taken from another lane of the same 16-lane row, no LDS round trip) -- __shfl_xor lowers to
 // ds_bpermute_b32, ~100+ cycles per step, which made the 6-step butterflies the slowest part of the

@@ -1,4 +1,4 @@
-// 3x3 / stride 1 / pad 1 convolution over NHWC fp32 activations on the bf16 matrix cores, for the
+// 3x3 / stride 1 / pad 1 convolution over NHWC (fp32 or bf16) activations on the bf16 matrix cores, for the
 // residual blocks of the frozen HRNet-16 trunk (C_in = C_out in {16,32,64,128}; 256->16 transition).
 //
 // "Raster window" formulation.  NHWC makes the (n,h,w) raster order of pixels contiguous in memory, and a
@@ -10,7 +10,7 @@
 // per-tap constant offset; image borders (and tiles that straddle two images) are handled by a per-lane
 // validity mask.  Weights are tiny ([C_out][9][C_in] bf16, pre-folded with BatchNorm) and shared by every
 // workgroup, so B fragments come straight from global memory (L1/L2 hits), software-prefetched one
-// k-step ahead.  Epilogue: + bias (+ residual) -> ReLU -> fp32 NHWC.
+// k-step ahead.  Epilogue: + bias (+ residual) -> ReLU -> NHWC in the maps' storage type.
 //
 // v_mfma_f32_16x16x32_bf16: a k-step covers 32 input channels of one tap, or (C_in = 16) both halves of
 // two taps (the weight tensor then carries a zero 10th tap).
@@ -25,10 +25,10 @@ namespace {
 constexpr int NT = 256;
 constexpr int TILE = 128;  // output pixels per workgroup (4 waves x 2 MFMA row tiles)
 
-template <int CIN, int COUT>
-__global__ __launch_bounds__(NT) void conv3x3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wt,
+template <int CIN, int COUT, typename AT>
+__global__ __launch_bounds__(NT) void conv3x3_kernel(const AT* __restrict__ x, const __bf16* __restrict__ wt,
                                                       const float* __restrict__ bias,
-                                                      const float* __restrict__ residual, float* __restrict__ y,
+                                                      const AT* __restrict__ residual, AT* __restrict__ y,
                                                       int total, int H, int W, int relu) {
   constexpr int LDC = CIN + 8;                       // LDS pixel pitch (bf16): odd multiple of 16 B
   constexpr int TAPS = (CIN == 16) ? 10 : 9;         // taps stored per output channel
@@ -48,10 +48,16 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(const float* __restrict__ x
     for (long i = tid; i < nvec; i += NT) {
       const int px = (int)(i / (CIN / 4)), c = (int)(i % (CIN / 4)) * 4;
       const long g = s0 + px;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g >= 0 && g < total) v = *reinterpret_cast<const float4*>(x + g * CIN + c);
-      bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-      *reinterpret_cast<bf16x4*>(win + px * LDC + c) = o;
+      if constexpr (sizeof(AT) == 2) {  // bf16 maps: the window is a plain copy
+        uint2 raw = make_uint2(0u, 0u);
+        if (g >= 0 && g < total) raw = *reinterpret_cast<const uint2*>(x + g * CIN + c);
+        *reinterpret_cast<uint2*>(win + px * LDC + c) = raw;
+      } else {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g >= 0 && g < total) v = act_ld4(x + g * CIN + c);
+        bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<bf16x4*>(win + px * LDC + c) = o;
+      }
     }
   }
 
@@ -132,30 +138,38 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(const float* __restrict__ x
       for (int j = 0; j < NTL; ++j) {
         const int n = j * 16 + fr;
         float v = acc[i][j][r] + bias[n];
-        if (residual) v += residual[m * COUT + n];
+        if (residual) v += act_ld(residual + m * COUT + n);
         if (relu) v = v > 0.f ? v : 0.f;
-        y[m * COUT + n] = v;
+        act_st(y + m * COUT + n, v);
       }
     }
   }
 }
 
-template <int CIN, int COUT>
-int launch(const float* x, const void* wt, const float* bias, const float* residual, float* y, long total, int H,
-           int W, int relu, hipStream_t st) {
+template <int CIN, int COUT, typename AT>
+int launch_t(const void* x, const void* wt, const float* bias, const void* residual, void* y, long total, int H,
+             int W, int relu, hipStream_t st) {
   const size_t lds = (size_t)(TILE + 2 * W + 2) * (CIN + 8) * sizeof(__bf16);
   if (lds > 160 * 1024) { rf_g_last_error = "conv3x3 window exceeds LDS"; return RF_EUNSUPPORTED; }
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_kernel<CIN, COUT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_kernel<CIN, COUT, AT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const int blocks = (int)((total + TILE - 1) / TILE);
-  hipLaunchKernelGGL((conv3x3_kernel<CIN, COUT>), dim3(blocks), dim3(NT), lds, st, x,
-                     static_cast<const __bf16*>(wt), bias, residual, y, (int)total, H, W, relu);
+  hipLaunchKernelGGL((conv3x3_kernel<CIN, COUT, AT>), dim3(blocks), dim3(NT), lds, st, static_cast<const AT*>(x),
+                     static_cast<const __bf16*>(wt), bias, static_cast<const AT*>(residual), static_cast<AT*>(y),
+                     (int)total, H, W, relu);
   RF_CHECK_LAUNCH();
   return RF_OK;
+}
+
+template <int CIN, int COUT>
+int launch(const void* x, const void* wt, const float* bias, const void* residual, void* y, int act_dtype, long total,
+           int H, int W, int relu, hipStream_t st) {
+  if (act_dtype == RF_ACT_BF16) return launch_t<CIN, COUT, __bf16>(x, wt, bias, residual, y, total, H, W, relu, st);
+  return launch_t<CIN, COUT, float>(x, wt, bias, residual, y, total, H, W, relu, st);
 }
 
 }  // namespace
@@ -165,16 +179,18 @@ extern "C" int rf_conv3x3_bf16_supported(int cin, int cout) {
          (cin == 128 && cout == 128) || (cin == 256 && cout == 16);
 }
 
-extern "C" int rf_conv3x3_bf16(const float* x, const void* w_bf16, const float* bias, const float* residual,
-                               float* y, int N, int H, int W, int cin, int cout, int relu, void* stream) {
+extern "C" int rf_conv3x3_bf16(const void* x, const void* w_bf16, const float* bias, const void* residual,
+                               void* y, int act_dtype, int N, int H, int W, int cin, int cout, int relu,
+                               void* stream) {
   RF_REQUIRE(x && w_bf16 && bias && y && N > 0 && H > 0 && W > 0);
+  RF_REQUIRE(act_dtype == RF_ACT_F32 || act_dtype == RF_ACT_BF16);
   RF_REQUIRE(rf_conv3x3_bf16_supported(cin, cout));
   const long total = (long)N * H * W;
   RF_REQUIRE(total < (1L << 31));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (cin == 16) return launch<16, 16>(x, w_bf16, bias, residual, y, total, H, W, relu, st);
-  if (cin == 32) return launch<32, 32>(x, w_bf16, bias, residual, y, total, H, W, relu, st);
-  if (cin == 64) return launch<64, 64>(x, w_bf16, bias, residual, y, total, H, W, relu, st);
-  if (cin == 128) return launch<128, 128>(x, w_bf16, bias, residual, y, total, H, W, relu, st);
-  return launch<256, 16>(x, w_bf16, bias, residual, y, total, H, W, relu, st);
+  if (cin == 16) return launch<16, 16>(x, w_bf16, bias, residual, y, act_dtype, total, H, W, relu, st);
+  if (cin == 32) return launch<32, 32>(x, w_bf16, bias, residual, y, act_dtype, total, H, W, relu, st);
+  if (cin == 64) return launch<64, 64>(x, w_bf16, bias, residual, y, act_dtype, total, H, W, relu, st);
+  if (cin == 128) return launch<128, 128>(x, w_bf16, bias, residual, y, act_dtype, total, H, W, relu, st);
+  return launch<256, 16>(x, w_bf16, bias, residual, y, act_dtype, total, H, W, relu, st);
 }

@@ -39,6 +39,7 @@ struct GemmP {
   float* a_rowsum;  // optional: a_rowsum[m] += sum_k A[m,k] (A row-contiguous)
   // implicit-GEMM conv (A mode 3): A is the NHWC input, row m = output pixel
   int cH, cW, cCin, cKs, cStride, cPad, cHo, cWo;
+  int act_bf16;  // implicit-GEMM conv only: A, res and C are bf16 maps (rf_conv2d_nhwc, RF_ACT_BF16)
 };
 
 template <int CFG> struct Cfg;
@@ -432,14 +433,21 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
 #pragma unroll
     for (int j = 0; j < C_::TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // implicit-GEMM (AM == 3): decode this thread's output pixels once
+  // implicit-GEMM (AM == 3): decode this thread's output pixels once.  bf16 maps with C_in % 8 == 0 ("wide"): a
+  // slot is 8 channels = one 16-B load that goes to the bf16 LDS stage as it is (half the load instructions of
+  // the 4-channel slots, no convert); the first NA/2 slots of a thread then cover the tile.
   constexpr int VPR = BKV / 4;
+  bool wide = false;
+  if constexpr (AM == 3 && PREC == 1) wide = p.act_bf16 && (p.cCin & 7) == 0;
+  constexpr int SH4 = VPR == 16 ? 4 : (VPR == 8 ? 3 : 2);  // log2(slots per row)
+  static_assert((1 << SH4) == VPR, "slots per row must be a power of two");
+  const int vshift = wide ? SH4 - 1 : SH4;
   long c_img[NA]; int c_h[NA], c_w[NA];
   if constexpr (AM == 3) {
 #pragma unroll
     for (int s = 0; s < NA; ++s) {
-      const int gm = m0 + (tid + s * NT) / VPR;
-      if (gm < p.M && (tid + s * NT) < BM * VPR) {
+      const int gm = m0 + ((tid + s * NT) >> vshift);
+      if (gm < p.M && (tid + s * NT) < (BM << vshift)) {
         const int wo = gm % p.cWo, t = gm / p.cWo, ho = t % p.cHo, n = t / p.cHo;
         c_img[s] = (long)n * p.cH * p.cW * p.cCin;
         c_h[s] = ho * p.cStride - p.cPad;
@@ -462,6 +470,25 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
   }
   auto load_a = [&](int k0) {
     if constexpr (AM == 3) {
+      if constexpr (PREC == 1) {
+        if (wide) {
+#pragma unroll
+          for (int s = 0; s < (NA + 1) / 2; ++s) {
+            const int gk = k0 + ((tid + s * NT) % (BKV / 8)) * 8;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);  // (eight bf16 zeros)
+            if (c_img[s] >= 0 && gk < kend) {
+              const int tap = gk / p.cCin, c = gk - tap * p.cCin;
+              const int kh = tap / p.cKs, kw = tap - kh * p.cKs;
+              const int hi = c_h[s] + kh, wi = c_w[s] + kw;
+              if (hi >= 0 && hi < p.cH && wi >= 0 && wi < p.cW)
+                v = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(p.A) + c_img[s] +
+                                                     ((long)hi * p.cW + wi) * p.cCin + c);
+            }
+            ra[s] = v;
+          }
+          return;
+        }
+      }
 #pragma unroll
       for (int s = 0; s < NA; ++s) {
         const int gk = k0 + ((tid + s * NT) % VPR) * 4;
@@ -470,8 +497,10 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
           const int tap = gk / p.cCin, c = gk - tap * p.cCin;
           const int kh = tap / p.cKs, kw = tap - kh * p.cKs;
           const int hi = c_h[s] + kh, wi = c_w[s] + kw;
-          if (hi >= 0 && hi < p.cH && wi >= 0 && wi < p.cW)
-            v = *reinterpret_cast<const float4*>(p.A + c_img[s] + ((long)hi * p.cW + wi) * p.cCin + c);
+          if (hi >= 0 && hi < p.cH && wi >= 0 && wi < p.cW) {
+            const long at = c_img[s] + ((long)hi * p.cW + wi) * p.cCin + c;
+            v = p.act_bf16 ? act_ld4(reinterpret_cast<const __bf16*>(p.A) + at) : act_ld4(p.A + at);
+          }
         }
         ra[s] = v;
       }
@@ -488,6 +517,16 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
     }
   };
   auto store_a = [&](T* As) {
+    if constexpr (AM == 3 && PREC == 1) {
+      if (wide) {
+#pragma unroll
+        for (int s = 0; s < (NA + 1) / 2; ++s) {
+          const int i = tid + s * NT;
+          if (i < BM * (BKV / 8)) *reinterpret_cast<float4*>(As + (i / (BKV / 8)) * LD + (i % (BKV / 8)) * 8) = ra[s];
+        }
+        return;
+      }
+    }
     if constexpr (AM == 3) lstore<BM, BKV, 0, NA, T, LD>(As, ra, tid);
     else lstore<BM, BKV, AM, NA, T, LD>(As, ra, tid);
   };
@@ -632,7 +671,12 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
     for (int u = 0; u < 4; ++u) {
       const int m = m0 + er0 + (k0 + u) * RSTEP;
       const bool ok = m < p.M && ecol < p.N;
-      rs[u] = (ok && p.res) ? p.res[(long)(m % p.res_rows) * p.ldr + ecol] : 0.f;
+      if constexpr (AM == 3) {
+        const long at = (long)(m % p.res_rows) * p.ldr + ecol;
+        rs[u] = (ok && p.res) ? (p.act_bf16 ? act_ld(reinterpret_cast<const __bf16*>(p.res) + at) : p.res[at]) : 0.f;
+      } else {
+        rs[u] = (ok && p.res) ? p.res[(long)(m % p.res_rows) * p.ldr + ecol] : 0.f;
+      }
       ds[u] = (ok && p.dact) ? p.dsrc[(long)m * p.ldd + ecol] : 0.f;
     }
   };
@@ -645,7 +689,10 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int m = m0 + er0 + (k0 + u) * RSTEP;
-        if (m < p.M && ecol < p.N) p.C[(long)m * p.ldc + ecol] = t[u];
+        if (m < p.M && ecol < p.N) {
+          if (AM == 3 && p.act_bf16) act_st(reinterpret_cast<__bf16*>(p.C) + (long)m * p.ldc + ecol, t[u]);
+          else p.C[(long)m * p.ldc + ecol] = t[u];
+        }
       }
       return;
     }
@@ -659,12 +706,44 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
       t = apply_act(t, p.act);
       if (p.dact) t *= act_grad(ds[u], p.dact);
       if (!p.res_before_act) t += rs[u];
-      p.C[(long)m * p.ldc + ecol] = t;
+      if (AM == 3 && p.act_bf16) act_st(reinterpret_cast<__bf16*>(p.C) + (long)m * p.ldc + ecol, t);
+      else p.C[(long)m * p.ldc + ecol] = t;
     }
   };
   const bool simple = !p.preact && !p.res_before_act && (p.act == 0 || p.act == RF_ACT_RELU) &&
                       (p.dact == 0 || p.dact == RF_ACT_RELU) && (!p.res || p.res_rows >= p.M);
-  if (mode == 0 && simple) {
+  bool maps_done = false;
+  if constexpr (AM == 3) {
+    if (p.act_bf16) {
+      // conv epilogue on bf16 maps: y = [relu](acc + bias [+ residual]); four channels per thread and trip --
+      // one 16-B LDS read, one 8-B residual load, one 8-B store (rf_conv2d_nhwc checks N, ldc, ldr % 4 == 0)
+      constexpr int TPR = BN / 4, ROWS_PER_TRIP = NT / TPR;
+      const int c4 = (tid % TPR) * 4, col = n0 + c4;
+      if (col < p.N) {
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) b4 = make_float4(p.bias[col], p.bias[col + 1], p.bias[col + 2], p.bias[col + 3]);
+        __bf16* cb = reinterpret_cast<__bf16*>(p.C);
+        const __bf16* rb = reinterpret_cast<const __bf16*>(p.res);
+        const bool relu = p.act == RF_ACT_RELU;
+#pragma unroll 2
+        for (int r = tid / TPR; r < BM; r += ROWS_PER_TRIP) {
+          const int m = m0 + r;
+          if (m >= p.M) break;
+          float4 v = *reinterpret_cast<const float4*>(ct + r * CP + c4);
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          if (rb) {
+            const float4 q = act_ld4(rb + (long)m * p.ldr + col);
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+          }
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          act_st4(cb + (long)m * p.ldc + col, v);
+        }
+      }
+      maps_done = true;
+    }
+  }
+  if (maps_done) {
+  } else if (mode == 0 && simple) {
     // y = [relu](acc + bias) [* (src > 0)] [+ residual]: most forward and dX launches.  One column predicate
     // around the whole epilogue, a row count instead of per-element bounds tests, pointers advanced by constant
     // strides, flags applied by selects -- the per-element guarded form spent 8.4k cycles here
@@ -937,12 +1016,19 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
   return RF_OK;
 }
 
-extern "C" int rf_conv2d_nhwc(const float* x, const float* w, const float* bias, const float* residual,
-                              float* y, int N, int H, int W, int cin, int cout, int ksize, int stride,
+extern "C" int rf_conv2d_nhwc(const void* x_, const float* w, const float* bias, const void* residual_,
+                              void* y_, int act_dtype, int N, int H, int W, int cin, int cout, int ksize, int stride,
                               int pad, int Ho, int Wo, int64_t ldy, int64_t ldres, int relu, int prec,
                               void* stream) {
+  // bf16 maps travel through the fp32-typed GemmP fields; the implicit-GEMM loader / epilogue reinterpret them
+  const float* x = static_cast<const float*>(x_);
+  const float* residual = static_cast<const float*>(residual_);
+  float* y = static_cast<float*>(y_);
   RF_REQUIRE(x && w && y && N > 0 && cin > 0 && cout > 0);
-  RF_REQUIRE(cin % 4 == 0 && aligned16(x) && aligned16(w));
+  RF_REQUIRE(act_dtype == RF_ACT_F32 || act_dtype == RF_ACT_BF16);
+  RF_REQUIRE(act_dtype == RF_ACT_F32 || prec == 1);  // bf16 maps only with the bf16 matrix-core path
+  RF_REQUIRE(cin % 4 == 0 && aligned16(w) &&
+             (reinterpret_cast<uintptr_t>(x) & ((act_dtype == RF_ACT_BF16 && cin % 8 != 0) ? 7 : 15)) == 0);
   RF_REQUIRE(prec == 0 || prec == 1);
   RF_REQUIRE(Ho == (H + 2 * pad - ksize) / stride + 1 && Wo == (W + 2 * pad - ksize) / stride + 1);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -954,6 +1040,10 @@ extern "C" int rf_conv2d_nhwc(const float* x, const float* w, const float* bias,
   p.act = relu ? RF_ACT_RELU : RF_ACT_NONE;
   p.kchunk = ((K + 63) / 64) * 64; p.ws = nullptr;
   p.cH = H; p.cW = W; p.cCin = cin; p.cKs = ksize; p.cStride = stride; p.cPad = pad; p.cHo = Ho; p.cWo = Wo;
+  p.act_bf16 = act_dtype == RF_ACT_BF16;
+  if (p.act_bf16)  // the bf16-map epilogue moves four channels at a time
+    RF_REQUIRE(cout % 4 == 0 && ldy % 4 == 0 && (!residual || ldres % 4 == 0) &&
+               (reinterpret_cast<uintptr_t>(y) & 7) == 0 && (reinterpret_cast<uintptr_t>(residual) & 7) == 0);
   const int cfg = cout <= 16 ? 1 : (cout <= 32 ? 2 : 0);
   if (prec == 0) {
     if (cfg == 1) launch2<0, 3, 0, 1>(p, 1, st);

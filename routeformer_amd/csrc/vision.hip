@@ -19,9 +19,9 @@ __device__ __forceinline__ float ldf(const float* p) { return *p; }
 // quotient rounded to fp16 exactly as numpy's half division does (computed in fp32, stored as fp16)
 __device__ __forceinline__ float ldf(const uint8_t* p) { return __half2float(__float2half((float)*p / 255.0f)); }
 
-template <typename TIn>
+template <typename TIn, typename AT>
 __global__ void stem_conv0_kernel(const TIn* __restrict__ video, const int32_t* __restrict__ fidx,
-                                  const float* __restrict__ w, float* __restrict__ y, int B, int T, int F, int H,
+                                  const float* __restrict__ w, AT* __restrict__ y, int B, int T, int F, int H,
                                   int W) {
   __shared__ float ws[36];
   if (threadIdx.x < 36) ws[threadIdx.x] = w[threadIdx.x];  // [co][ci][kh][kw]
@@ -48,17 +48,20 @@ __global__ void stem_conv0_kernel(const TIn* __restrict__ video, const int32_t* 
         for (int co = 0; co < 3; ++co)
           acc[co] = fmaf(x1, ws[(co * 3 + ci) * 4 + kh * 2 + 1], fmaf(x0, ws[(co * 3 + ci) * 4 + kh * 2], acc[co]));
       }
-    *reinterpret_cast<float4*>(y + i * 4) = make_float4(acc[0], acc[1], acc[2], 0.f);
+    act_st4(y + i * 4, make_float4(acc[0], acc[1], acc[2], 0.f));
   }
 }
 
-__global__ void upsample_kernel(const float* __restrict__ x, const float* __restrict__ addend, float* __restrict__ y,
+// Four channels per thread (C % 4 == 0 everywhere in the trunk): 16-B / 8-B accesses instead of scalar ones.
+template <typename AT>
+__global__ void upsample_kernel(const AT* __restrict__ x, const AT* __restrict__ addend, AT* __restrict__ y,
                                 int N, int Hi, int Wi, int C, int Ho, int Wo, long ldy, int accumulate, int relu) {
-  const long total = (long)N * Ho * Wo * C;
+  const int C4 = C >> 2;
+  const long total = (long)N * Ho * Wo * C4;
   const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    long r = i / C;
+    const int c = (int)(i % C4) << 2;
+    long r = i / C4;
     const int wo = (int)(r % Wo); r /= Wo;
     const int ho = (int)(r % Ho);
     const int n = (int)(r / Ho);
@@ -68,43 +71,65 @@ __global__ void upsample_kernel(const float* __restrict__ x, const float* __rest
     const int h0 = (int)fh, w0 = (int)fw;
     const int h1 = h0 + (h0 < Hi - 1 ? 1 : 0), w1 = w0 + (w0 < Wi - 1 ? 1 : 0);
     const float lh = fh - (float)h0, lw = fw - (float)w0;
-    const float* xb = x + (long)n * Hi * Wi * C + c;
-    const float v = (1.f - lh) * ((1.f - lw) * xb[((long)h0 * Wi + w0) * C] + lw * xb[((long)h0 * Wi + w1) * C]) +
-                    lh * ((1.f - lw) * xb[((long)h1 * Wi + w0) * C] + lw * xb[((long)h1 * Wi + w1) * C]);
-    float* yp = y + (((long)n * Ho + ho) * Wo + wo) * ldy + c;
-    float o = accumulate ? *yp : 0.f;
-    if (addend) o += addend[i];
-    o += v;
-    if (relu) o = o > 0.f ? o : 0.f;
-    *yp = o;
+    const AT* xb = x + (long)n * Hi * Wi * C + c;
+    const float4 a00 = act_ld4(xb + ((long)h0 * Wi + w0) * C), a01 = act_ld4(xb + ((long)h0 * Wi + w1) * C);
+    const float4 a10 = act_ld4(xb + ((long)h1 * Wi + w0) * C), a11 = act_ld4(xb + ((long)h1 * Wi + w1) * C);
+    AT* yp = y + (((long)n * Ho + ho) * Wo + wo) * ldy + c;
+    float4 o = accumulate ? act_ld4(yp) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (addend) {
+      const float4 ad = act_ld4(addend + i * 4);
+      o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+    }
+    auto lerp = [&](float v00, float v01, float v10, float v11) {
+      return (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+    };
+    o.x += lerp(a00.x, a01.x, a10.x, a11.x); o.y += lerp(a00.y, a01.y, a10.y, a11.y);
+    o.z += lerp(a00.z, a01.z, a10.z, a11.z); o.w += lerp(a00.w, a01.w, a10.w, a11.w);
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    act_st4(yp, o);
   }
 }
 
-__global__ void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-                                long n, int relu) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float v = a[i] + b[i];
+template <typename AT>
+__global__ void add_relu_kernel(const AT* __restrict__ a, const AT* __restrict__ b, AT* __restrict__ out, long n,
+                                int relu) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 u = act_ld4(a + 4 * i), w = act_ld4(b + 4 * i);
+    float4 v = make_float4(u.x + w.x, u.y + w.y, u.z + w.z, u.w + w.w);
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    act_st4(out + 4 * i, v);
+  }
+  for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = act_ld(a + i) + act_ld(b + i);
     if (relu) v = v > 0.f ? v : 0.f;
-    out[i] = v;
+    act_st(out + i, v);
   }
 }
 
-__global__ void avgpool8_tokens_kernel(const float* __restrict__ x, float* __restrict__ tok, int N, int H, int W,
+template <typename AT>
+__global__ void avgpool8_tokens_kernel(const AT* __restrict__ x, float* __restrict__ tok, int N, int H, int W,
                                        int C) {
-  const long total = (long)N * 65 * C;
+  const int C4 = C >> 2;
+  const long total = (long)N * 65 * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const long r = i / C;
+    const int c = (int)(i % C4) << 2;
+    const long r = i / C4;
     const int t = (int)(r % 65);
     const int n = (int)(r / 65);
-    if (t == 64) { tok[i] = -1.f; continue; }
+    float* tp = tok + r * C + c;
+    if (t == 64) { *reinterpret_cast<float4*>(tp) = make_float4(-1.f, -1.f, -1.f, -1.f); continue; }
     const int bh = t / 8, bw = t % 8;
     const int h0 = (bh * H) / 8, h1 = ((bh + 1) * H + 7) / 8;
     const int w0 = (bw * W) / 8, w1 = ((bw + 1) * W + 7) / 8;
-    float s = 0.f;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int h = h0; h < h1; ++h)
-      for (int w = w0; w < w1; ++w) s += x[(((long)n * H + h) * W + w) * C + c];
-    tok[i] = s / (float)((h1 - h0) * (w1 - w0));
+      for (int w = w0; w < w1; ++w) {
+        const float4 v = act_ld4(x + (((long)n * H + h) * W + w) * C + c);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    const float inv = (float)((h1 - h0) * (w1 - w0));
+    *reinterpret_cast<float4*>(tp) = make_float4(s.x / inv, s.y / inv, s.z / inv, s.w / inv);
   }
 }
 
@@ -130,10 +155,18 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// HYPER: the scalars come from a device array (rf_adamw_clip_dev) -- a launch replayed from a HIP graph cannot
+// take new by-value arguments, and the bias corrections / learning rate change every step.
+template <bool HYPER>
 __global__ void adamw_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                   float* __restrict__ v, long n, const float* __restrict__ sumsq, float max_norm,
                                   float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                  float grad_scale, int sumsq_parts) {
+                                  float grad_scale, int sumsq_parts, const float* __restrict__ hyper) {
+  if constexpr (HYPER) {
+    if (hyper[0] == 0.f) return;  // no update pending (first replay after a capture / after a flush)
+    max_norm = hyper[1]; lr = hyper[2]; b1 = hyper[3]; b2 = hyper[4]; eps = hyper[5]; wd = hyper[6];
+    bc1 = hyper[7]; bc2_sqrt = hyper[8]; grad_scale = hyper[9];
+  }
   float coef = grad_scale;
   if (max_norm > 0.f) {
     float ss = 0.f;
@@ -171,45 +204,85 @@ __global__ void adamw_clip_kernel(float* __restrict__ p, const float* __restrict
 
 }  // namespace
 
-extern "C" int rf_stem_conv0(const void* video, int video_dtype, const int32_t* frame_idx, const float* w, float* y,
-                             int B, int T, int F, int H, int W, void* stream) {
+namespace {
+template <typename TIn>
+void launch_stem(const void* video, const int32_t* frame_idx, const float* w, void* y, int act_dtype, int B, int T,
+                 int F, int H, int W, hipStream_t st) {
+  const long total = (long)B * F * (H / 2) * (W / 2);
+  if (act_dtype == 1)
+    hipLaunchKernelGGL((stem_conv0_kernel<TIn, __bf16>), dim3(grid_for(total)), dim3(256), 0, st,
+                       static_cast<const TIn*>(video), frame_idx, w, static_cast<__bf16*>(y), B, T, F, H, W);
+  else
+    hipLaunchKernelGGL((stem_conv0_kernel<TIn, float>), dim3(grid_for(total)), dim3(256), 0, st,
+                       static_cast<const TIn*>(video), frame_idx, w, static_cast<float*>(y), B, T, F, H, W);
+}
+inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+inline bool al16v(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// 4 consecutive channels must be one aligned vector access in the given storage type
+inline bool act_aligned(const void* p, int act_dtype) { return !p || (act_dtype == 1 ? al8(p) : al16v(p)); }
+}  // namespace
+
+extern "C" int rf_stem_conv0(const void* video, int video_dtype, const int32_t* frame_idx, const float* w, void* y,
+                             int act_dtype, int B, int T, int F, int H, int W, void* stream) {
   RF_REQUIRE(video && frame_idx && w && y && B > 0 && T > 0 && F > 0 && H > 1 && W > 1);
   RF_REQUIRE(H % 2 == 0 && W % 2 == 0 && video_dtype >= 0 && video_dtype <= 2);
-  const long total = (long)B * F * (H / 2) * (W / 2);
-  if (video_dtype == 2)
-    hipLaunchKernelGGL(stem_conv0_kernel<uint8_t>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const uint8_t*>(video), frame_idx, w, y, B, T, F, H, W);
-  else if (video_dtype == 1)
-    hipLaunchKernelGGL(stem_conv0_kernel<float>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const float*>(video), frame_idx, w, y, B, T, F, H, W);
-  else
-    hipLaunchKernelGGL(stem_conv0_kernel<__half>, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const __half*>(video), frame_idx, w, y, B, T, F, H, W);
+  RF_REQUIRE((act_dtype == 0 || act_dtype == 1) && act_aligned(y, act_dtype));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (video_dtype == 2) launch_stem<uint8_t>(video, frame_idx, w, y, act_dtype, B, T, F, H, W, st);
+  else if (video_dtype == 1) launch_stem<float>(video, frame_idx, w, y, act_dtype, B, T, F, H, W, st);
+  else launch_stem<__half>(video, frame_idx, w, y, act_dtype, B, T, F, H, W, st);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
 
-extern "C" int rf_upsample_bilinear_nhwc(const float* x, const float* addend, float* y, int N, int Hi, int Wi, int C,
-                                         int Ho, int Wo, int64_t ldy, int accumulate, int relu, void* stream) {
+extern "C" int rf_upsample_bilinear_nhwc(const void* x, const void* addend, void* y, int act_dtype, int N, int Hi,
+                                         int Wi, int C, int Ho, int Wo, int64_t ldy, int accumulate, int relu,
+                                         void* stream) {
   RF_REQUIRE(x && y && N > 0 && Hi > 0 && Wi > 0 && C > 0 && Ho > 0 && Wo > 0 && ldy >= C);
-  hipLaunchKernelGGL(upsample_kernel, dim3(grid_for((long)N * Ho * Wo * C)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, addend, y, N, Hi, Wi, C, Ho, Wo, (long)ldy, accumulate, relu);
+  RF_REQUIRE(act_dtype == 0 || act_dtype == 1);
+  RF_REQUIRE(C % 4 == 0 && ldy % 4 == 0 && act_aligned(x, act_dtype) && act_aligned(addend, act_dtype) &&
+             act_aligned(y, act_dtype));
+  const int grid = grid_for((long)N * Ho * Wo * (C / 4));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (act_dtype == 1)
+    hipLaunchKernelGGL(upsample_kernel<__bf16>, dim3(grid), dim3(256), 0, st, static_cast<const __bf16*>(x),
+                       static_cast<const __bf16*>(addend), static_cast<__bf16*>(y), N, Hi, Wi, C, Ho, Wo, (long)ldy,
+                       accumulate, relu);
+  else
+    hipLaunchKernelGGL(upsample_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(x),
+                       static_cast<const float*>(addend), static_cast<float*>(y), N, Hi, Wi, C, Ho, Wo, (long)ldy,
+                       accumulate, relu);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
 
-extern "C" int rf_add_relu(const float* a, const float* b, float* out, int64_t n, int relu, void* stream) {
-  RF_REQUIRE(a && b && out && n > 0);
-  hipLaunchKernelGGL(add_relu_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out,
-                     (long)n, relu);
+extern "C" int rf_add_relu(const void* a, const void* b, void* out, int act_dtype, int64_t n, int relu, void* stream) {
+  RF_REQUIRE(a && b && out && n > 0 && (act_dtype == 0 || act_dtype == 1));
+  RF_REQUIRE(act_aligned(a, act_dtype) && act_aligned(b, act_dtype) && act_aligned(out, act_dtype));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = grid_for((n + 3) / 4);
+  if (act_dtype == 1)
+    hipLaunchKernelGGL(add_relu_kernel<__bf16>, dim3(grid), dim3(256), 0, st, static_cast<const __bf16*>(a),
+                       static_cast<const __bf16*>(b), static_cast<__bf16*>(out), (long)n, relu);
+  else
+    hipLaunchKernelGGL(add_relu_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(a),
+                       static_cast<const float*>(b), static_cast<float*>(out), (long)n, relu);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
 
-extern "C" int rf_avgpool8_tokens(const float* x, float* tokens, int N, int H, int W, int C, void* stream) {
-  RF_REQUIRE(x && tokens && N > 0 && H > 0 && W > 0 && C > 0);
-  hipLaunchKernelGGL(avgpool8_tokens_kernel, dim3(grid_for((long)N * 65 * C)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, tokens, N, H, W, C);
+extern "C" int rf_avgpool8_tokens(const void* x, int act_dtype, float* tokens, int N, int H, int W, int C,
+                                  void* stream) {
+  RF_REQUIRE(x && tokens && N > 0 && H > 0 && W > 0 && C > 0 && (act_dtype == 0 || act_dtype == 1));
+  RF_REQUIRE(C % 4 == 0 && act_aligned(x, act_dtype) && al16v(tokens));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = grid_for((long)N * 65 * (C / 4));
+  if (act_dtype == 1)
+    hipLaunchKernelGGL(avgpool8_tokens_kernel<__bf16>, dim3(grid), dim3(256), 0, st, static_cast<const __bf16*>(x),
+                       tokens, N, H, W, C);
+  else
+    hipLaunchKernelGGL(avgpool8_tokens_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(x),
+                       tokens, N, H, W, C);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
@@ -230,9 +303,19 @@ extern "C" int rf_adamw_clip(float* p, const float* g, float* m, float* v, int64
   RF_REQUIRE(p && g && m && v && n > 0 && step >= 1 && (max_norm <= 0.f || (sumsq && sumsq_parts >= 1)));
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
-  hipLaunchKernelGGL(adamw_clip_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     p, g, m, v, (long)n, sumsq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, grad_scale,
-                     sumsq_parts);
+  hipLaunchKernelGGL(adamw_clip_kernel<false>, dim3(grid_for(n, 256, 4096)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p, g, m, v, (long)n, sumsq, max_norm, lr, beta1, beta2, eps, wd,
+                     bc1, bc2_sqrt, grad_scale, sumsq_parts, static_cast<const float*>(nullptr));
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_adamw_clip_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
+                                 int sumsq_parts, const float* hyper, void* stream) {
+  RF_REQUIRE(p && g && m && v && n > 0 && hyper && sumsq && sumsq_parts >= 1);
+  hipLaunchKernelGGL(adamw_clip_kernel<true>, dim3(grid_for(n, 256, 4096)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p, g, m, v, (long)n, sumsq, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f,
+                     1.f, sumsq_parts, hyper);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

@@ -325,6 +325,27 @@ class FusedAdamW:
     def lr(self, value: float):
         self.param_groups[0]["lr"] = value
 
+    def hyper(self, grad_scale: float, pending: bool = True) -> List[float]:
+        """The scalar arguments of update number ``self.t`` as rf_adamw_clip_dev reads them from device memory."""
+        t = max(self.t, 1)
+        return [1.0 if pending else 0.0, self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                1.0 - self.betas[0] ** t, (1.0 - self.betas[1] ** t) ** 0.5, grad_scale]
+
+    def launch_sumsq(self):
+        from routeformer_amd import _hip, kernels as K
+        _hip.check(_hip.lib().rf_sumsq(self.g.data_ptr(), self.p.numel(), self.sumsq.data_ptr(), K._stream()), "rf_sumsq")
+
+    def launch_update_dev(self, lo: int, hi: int, hyper_dev: torch.Tensor):
+        """AdamW over the slice [lo, hi) of the flat buffers on the current stream, scalars from ``hyper_dev``
+        (the clip coefficient still comes from the norm of the WHOLE gradient buffer: launch_sumsq first)."""
+        from routeformer_amd import _hip, kernels as K
+        if hi <= lo:
+            return
+        o = 4 * lo
+        _hip.check(_hip.lib().rf_adamw_clip_dev(self.p.data_ptr() + o, self.g.data_ptr() + o, self.m.data_ptr() + o,
+                                                self.v.data_ptr() + o, hi - lo, self.sumsq.data_ptr(), self.parts,
+                                                hyper_dev.data_ptr(), K._stream()), "rf_adamw_clip_dev")
+
     def step(self, grad_scale: float = 1.0):
         from routeformer_amd import _hip, kernels as K
         self.t += 1
@@ -369,14 +390,18 @@ class TrainEngine:
         self.tl = FutureDiscountedLoss(cfg.discount_factor, cfg.epsilon, loss_function="smooth_l1")
         self.dl = FutureDiscountedLoss(cfg.discount_factor, cfg.visual_epsilon, loss_function="smooth_l1")
 
+    def _begin_step_kernels(self):
+        """First launches of a step: zero the flat gradient buffer (GraphedTrainEngine may add the deferred update)."""
+        self.reducer.zero()
+
     def _fwd_bwd(self, item, epoch, tokens_ready: bool = False):
         from routeformer_amd import kernels as K
-        self.reducer.zero()
         K.OVERLAP = self.overlap
         K.SINK.active = True  # kernels accumulate parameter gradients straight into the flat buffer
         K.SINK.on_write = None
         K.WGRAD.active = self.group_wgrad
         try:
+            self._begin_step_kernels()
             res = train_step_losses(self.model, item, epoch, self.tl, self.dl, tokens_ready=tokens_ready)
             res["loss"].backward()
             K.flush_weight_grads()  # queued dW / db launches, each on the stream its operands were produced on
@@ -384,6 +409,7 @@ class TrainEngine:
                 K.join_side_streams()
         finally:
             K.SINK.active, K.SINK.on_write, K.OVERLAP, K.WGRAD.active = False, None, False, False
+            self.model.__dict__.pop("_before_gps_backbone", None)
         return res
 
     # -- the same step in two stages (GraphedTrainEngine with N > 1): stage 1 = forward + the backward of the
@@ -399,10 +425,11 @@ class TrainEngine:
     def _leave(self):
         from routeformer_amd import kernels as K
         K.SINK.active, K.SINK.on_write, K.OVERLAP, K.WGRAD.active = False, None, False, False
+        self.model.__dict__.pop("_before_gps_backbone", None)
 
     def _stage1(self, item, epoch, tokens_ready: bool = False):
         from routeformer_amd import kernels as K
-        self.reducer.zero()
+        self._begin_step_kernels()
         self.model._keep_gps_input = True
         try:
             res = train_step_losses(self.model, item, epoch, self.tl, self.dl, tokens_ready=tokens_ready)
@@ -460,8 +487,17 @@ class GraphedTrainEngine(TrainEngine):
     Requires a step whose control flow does not depend on random draws (view / gaze dropout 0) and fixed
     batch shapes."""
 
-    def __init__(self, model, **kw):
+    def __init__(self, model, defer_update: bool = False, **kw):
         super().__init__(model, **kw)
+        # defer_update: the clip + AdamW of step k is replayed at the START of step k+1's graph, and the 95 % of it
+        # that belongs to the GPS backbone runs on a side stream underneath step k+1's camera / gaze / fusion encoders
+        # (which do not read those parameters); the backbone's forward waits for it.  Same arithmetic in the same
+        # order -- the bandwidth-bound update just no longer sits alone on the critical path.  ``flush()`` applies a
+        # still-pending update (call it before reading parameters or saving a checkpoint).
+        self.defer_update = defer_update
+        self._pending = None          # hyper-parameters of the update the next replay has to apply
+        self._hyper = self._hyper_pinned = None
+        self._gps_range = None
         self.graph = None
         self._static_item = None
         self._out = None
@@ -479,6 +515,69 @@ class GraphedTrainEngine(TrainEngine):
 
     def _eager_fwd_bwd(self, item, epoch):
         return self._fwd_bwd(item, epoch)
+
+    # -- deferred update ---------------------------------------------------------------------------
+    def _backbone_range(self):
+        """[lo, hi) of the flat buffers holding exactly the GPS backbone's parameters, or None."""
+        r = self.reducer
+        mine = [p for p in r.params if self._names[id(p)].startswith("gps_backbone.")]
+        if not mine:
+            return None
+        lo = min(r.offset[id(p)] for p in mine)
+        hi = max(r.offset[id(p)] + p.numel() for p in mine)
+        inside = [p for p in r.params if lo <= r.offset[id(p)] < hi]
+        if len(inside) != len(mine):
+            return None
+        hi = min([r.offset[id(p)] for p in r.params if r.offset[id(p)] >= hi] + [r.flat_param.numel()])  # + padding
+        return lo, hi
+
+    def _begin_step_kernels(self):
+        """First launches of a step.  Plain engine: zero the gradient buffer.  Deferred update: the pending clip +
+        AdamW (scalars from ``self._hyper``, a no-op while nothing is pending), the backbone's share on a side stream
+        that the backbone forward joins (``model._before_gps_backbone``), each slice zeroed once it has been used."""
+        from routeformer_amd import kernels as K
+        if not self.defer_update:
+            self.reducer.zero()
+            return
+        r, opt = self.reducer, self.opt
+        n = r.flat_param.numel()
+        opt.launch_sumsq()
+        rng = self._gps_range if (self.overlap and __import__("os").environ.get("RF_DEFER_SIDE", "1") != "0") else None
+        cur = torch.cuda.current_stream()
+        if rng is not None:
+            lo, hi = rng
+            side = K.side_stream("update")
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                opt.launch_update_dev(lo, hi, self._hyper)
+                r.flat_grad[lo:hi].zero_()
+            for a, b in ((0, lo), (hi, n)):
+                if b > a:
+                    opt.launch_update_dev(a, b, self._hyper)
+                    r.flat_grad[a:b].zero_()
+            self.model.__dict__["_before_gps_backbone"] = lambda: torch.cuda.current_stream().wait_stream(side)
+        else:
+            opt.launch_update_dev(0, n, self._hyper)
+            r.flat_grad.zero_()
+        r.begin_step()
+        K.WGRAD.begin_step()
+
+    def _set_hyper(self):
+        """Ship the pending update's scalars (or "nothing pending") ahead of the replay."""
+        vals = self._pending if self._pending is not None else self.opt.hyper(1.0, pending=False)
+        self._hyper_pinned[:len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
+        self._hyper.copy_(self._hyper_pinned, non_blocking=True)
+
+    def flush(self):
+        """Apply a still-pending optimizer update now (eagerly, on the current stream)."""
+        if self._pending is not None:
+            vals, self._pending = self._pending, None
+            self.opt.launch_sumsq()
+            self._hyper_pinned[:len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
+            self._hyper.copy_(self._hyper_pinned, non_blocking=True)
+            self.opt.launch_update_dev(0, self.reducer.flat_param.numel(), self._hyper)
+            self.reducer.flat_grad.zero_()
+        return self
 
     # -- conv-trunk side ---------------------------------------------------------------------------
     def _vkey(self, item):
@@ -508,6 +607,12 @@ class GraphedTrainEngine(TrainEngine):
         self.model.train()
         SAMPLER.drop_static()  # a previous capture in this process (another engine / shape) planned its own draws
         dev = self.reducer.flat_param.device
+        if self.defer_update:
+            self.flush()
+            from routeformer_amd._hip import lib as _lib  # noqa: F401  (fail loudly without the extension)
+            self._hyper = torch.zeros(16, device=dev, dtype=torch.float32)  # "nothing pending" during the warm-up passes
+            self._hyper_pinned = torch.zeros(16, dtype=torch.float32).pin_memory()
+            self._gps_range = self._backbone_range()
         # static inputs of the main graph: private copies of the small tensors (gps, gaze); the video
         # tensors are only consulted for shapes / cache keys while capturing (the trunk has its own graphs)
         self._static_item = {part: {n: (v if v.dim() == 5 else v.clone()) for n, v in d.items()}
@@ -619,6 +724,8 @@ class GraphedTrainEngine(TrainEngine):
                     dst.copy_(v, non_blocking=True)
         SAMPLER.refill_static()
         self.reducer.begin_step()  # the replay does not run the Python bookkeeping of zero()
+        if self.defer_update:
+            self._set_hyper()  # scalars of the update this replay starts with (or "nothing pending")
         if isinstance(g, tuple):
             g[0].replay()
             # 95 % of the gradient bytes (the GPS backbone's) are final here: reduce them underneath stage 2
@@ -629,5 +736,9 @@ class GraphedTrainEngine(TrainEngine):
         if self._pipelined and next_item is not None:
             self._ready_key = self._vkey(next_item)
         scale = self.reducer.finish()
-        self.opt.step(scale)
+        if self.defer_update:
+            self.opt.t += 1
+            self._pending = self.opt.hyper(scale)  # applied at the start of the next replay (or by flush())
+        else:
+            self.opt.step(scale)
         return out

@@ -137,6 +137,9 @@ class Routeformer(nn.Module):
         x = torch.cat(feats, dim=-1)
         if getattr(self, "_keep_gps_input", False):
             self._gps_input = x  # cut point of the engine's two-stage backward (GPS backbone first)
+        hook = self.__dict__.get("_before_gps_backbone")
+        if hook is not None:  # engine: the backbone's parameters may still be in flight on another stream
+            hook()
         out = self.gps_backbone(x)
         if c.decoder_mode == "recursive":
             out = out + (x[:, -1:, :] if c.dense_prediction else x[:, -1:, :2])

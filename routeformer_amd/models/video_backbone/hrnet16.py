@@ -170,47 +170,64 @@ class HRNet16Backbone(VideoBackboneModule):
         return folded
 
     # ---- execution --------------------------------------------------------------------------------
+    @staticmethod
+    def _act_dtype():
+        """Storage type of the trunk's activation maps: bf16 in the bf16 matrix-core mode (every convolution rounds
+        its input to bf16 there anyway -- the maps just stop carrying the other 16 bits through HBM), else fp32."""
+        return torch.bfloat16 if K._PRECISION == 1 else torch.float32
+
+    @staticmethod
+    def _act_code(t):
+        return 1 if (t.dtype if isinstance(t, torch.Tensor) else t) == torch.bfloat16 else 0
+
     def _conv(self, W, unit, x, stride=1, relu=False, residual=None):
         w, b, cin, cout, k, wb = W[unit]
         N, H, Wd, C = x.shape
         assert C == cin, (unit, C, cin)
         pad = 1 if k == 3 else 0
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
-        y = torch.empty(N, Ho, Wo, cout, device=x.device, dtype=torch.float32)
+        y = torch.empty(N, Ho, Wo, cout, device=x.device, dtype=x.dtype)
+        act = self._act_code(x)
+        assert residual is None or residual.dtype == x.dtype
         ev = K.PROFILE.begin() if K.PROFILE.on else None
         fast = wb is not None and stride == 1 and K._PRECISION == 1
         if fast:  # 3x3/s1 on the bf16 matrix cores straight out of an LDS raster window
-            check(_hip.lib().rf_conv3x3_bf16(ptr(x), ptr(wb), ptr(b), ptr(residual), ptr(y), N, H, Wd, cin, cout,
+            check(_hip.lib().rf_conv3x3_bf16(ptr(x), ptr(wb), ptr(b), ptr(residual), ptr(y), act, N, H, Wd, cin, cout,
                                              1 if relu else 0, K._stream()), "rf_conv3x3_bf16")
         else:
-            check(_hip.lib().rf_conv2d_nhwc(ptr(x), ptr(w), ptr(b), ptr(residual), ptr(y), N, H, Wd, cin, cout, k,
+            check(_hip.lib().rf_conv2d_nhwc(ptr(x), ptr(w), ptr(b), ptr(residual), ptr(y), act, N, H, Wd, cin, cout, k,
                                             stride, pad, Ho, Wo, cout, cout, 1 if relu else 0, K._PRECISION,
                                             K._stream()), "rf_conv2d_nhwc")
         if ev is not None:  # algorithmic work: one read of x / w (/ residual), one write of y
             M = N * Ho * Wo
-            tag = f"conv3x3_kernel<{cin}, {cout}>" if fast else \
+            tag = f"conv3x3_kernel<{cin}, {cout}, {'__bf16' if act else 'float'}>" if fast else \
                 f"gemm2_kernel<{K._PRECISION}, 3, 0, {1 if cout <= 16 else (2 if cout <= 32 else 0)}>"
+            es = x.element_size()
             K.PROFILE.end(tag, ev, 2.0 * M * cout * k * k * cin,
-                          4.0 * (x.numel() + w.numel() + M * cout * (2 if residual is not None else 1)))
+                          es * (x.numel() + M * cout * (2 if residual is not None else 1)) + 4.0 * w.numel())
         return y
 
-    @staticmethod
-    def _upsample(x, size, *, addend=None, out=None, ldy=None, accumulate=False, relu=False):
+    @classmethod
+    def _upsample(cls, x, size, *, addend=None, out=None, ldy=None, accumulate=False, relu=False):
+        """``out``: tensor, or a raw device address of maps stored in x's dtype."""
         N, Hi, Wi, C = x.shape
         Ho, Wo = size
         if out is None:
-            out = torch.empty(N, Ho, Wo, C, device=x.device, dtype=torch.float32)
+            out = torch.empty(N, Ho, Wo, C, device=x.device, dtype=x.dtype)
             ldy = C
+        assert (addend is None or addend.dtype == x.dtype) and (not isinstance(out, torch.Tensor) or out.dtype == x.dtype)
         check(_hip.lib().rf_upsample_bilinear_nhwc(ptr(x), ptr(addend), out.data_ptr() if isinstance(out, torch.Tensor)
-                                                   else out, N, Hi, Wi, C, Ho, Wo, ldy, 1 if accumulate else 0,
-                                                   1 if relu else 0, K._stream()), "rf_upsample_bilinear_nhwc")
+                                                   else out, cls._act_code(x), N, Hi, Wi, C, Ho, Wo, ldy,
+                                                   1 if accumulate else 0, 1 if relu else 0, K._stream()),
+              "rf_upsample_bilinear_nhwc")
         return out
 
-    @staticmethod
-    def _add(a, b, relu):
+    @classmethod
+    def _add(cls, a, b, relu):
         out = torch.empty_like(a)
-        check(_hip.lib().rf_add_relu(ptr(a), ptr(b), ptr(out), a.numel(), 1 if relu else 0, K._stream()),
-              "rf_add_relu")
+        assert a.dtype == b.dtype
+        check(_hip.lib().rf_add_relu(ptr(a), ptr(b), ptr(out), cls._act_code(a), a.numel(), 1 if relu else 0,
+                                     K._stream()), "rf_add_relu")
         return out
 
     def _basic(self, W, p, x):
@@ -290,11 +307,13 @@ class HRNet16Backbone(VideoBackboneModule):
         dev = vids[0].device
         N = sum(counts)
         W = self._prepare(dev)
-        x = torch.empty(N, H // 2, Wd // 2, 4, device=dev, dtype=torch.float32)
+        adt = self._act_dtype()
+        act, es = self._act_code(adt), (2 if adt == torch.bfloat16 else 4)
+        x = torch.empty(N, H // 2, Wd // 2, 4, device=dev, dtype=adt)
         off = 0
         for v, fi, n in zip(vids, fidx, counts):
             check(_hip.lib().rf_stem_conv0(ptr(v), {torch.float16: 0, torch.float32: 1, torch.uint8: 2}[v.dtype], ptr(fi), ptr(W["conv0"][0]),
-                                           x.data_ptr() + 4 * off * (H // 2) * (Wd // 2) * 4, v.shape[0], v.shape[1],
+                                           x.data_ptr() + es * off * (H // 2) * (Wd // 2) * 4, act, v.shape[0], v.shape[1],
                                            fi.numel(), H, Wd, K._stream()), "rf_stem_conv0")
             off += n
         x = self._conv(W, "conv1", x, stride=2, relu=True)
@@ -309,14 +328,14 @@ class HRNet16Backbone(VideoBackboneModule):
             for m in range(nmod):
                 xs = self._module(W, f"{stage}.{m}", xs)
         Hf, Wf = xs[0].shape[1:3]
-        feats = torch.empty(N, Hf, Wf, 240, device=dev, dtype=torch.float32)
+        feats = torch.empty(N, Hf, Wf, 240, device=dev, dtype=adt)
         off = 0
         for t in xs:  # concat along channels; identity-scale "upsample" copies branch 0
             c = t.shape[-1]
-            self._upsample(t, (Hf, Wf), out=feats.data_ptr() + 4 * off, ldy=240)
+            self._upsample(t, (Hf, Wf), out=feats.data_ptr() + es * off, ldy=240)
             off += c
         tokens = out if out is not None else torch.empty(N, 65, 240, device=dev, dtype=torch.float32)
         assert tuple(tokens.shape) == (N, 65, 240) and tokens.is_contiguous()
-        check(_hip.lib().rf_avgpool8_tokens(ptr(feats), ptr(tokens), N, Hf, Wf, 240, K._stream()),
+        check(_hip.lib().rf_avgpool8_tokens(ptr(feats), act, ptr(tokens), N, Hf, Wf, 240, K._stream()),
               "rf_avgpool8_tokens")
         return tokens

@@ -323,26 +323,40 @@ def _nhwc(x):
                                                 (5, 7, 7, 64, 64, 3, 1), (3, 4, 4, 128, 128, 3, 1),
                                                 (2, 14, 14, 32, 64, 3, 2), (2, 4, 4, 128, 16, 1, 1),
                                                 (1, 1, 1, 128, 128, 3, 1), (2, 2, 2, 64, 128, 3, 2)])
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 2e-2), ("bf16_maps", 2e-2)])
 def test_conv2d_nhwc(N, H, W, cin, cout, k, s, prec, tol):
+    """prec "bf16_maps": input, residual and output maps stored in bf16 (RF_ACT_BF16), as the trunk keeps them in the
+    bf16 matrix-core mode; must agree with the fp32-map launch on the same (bf16-representable) data to rounding."""
     from routeformer_amd import _hip, kernels as Kn
-    Kn.set_precision(prec)
+    maps_bf16 = prec == "bf16_maps"
+    Kn.set_precision("bf16" if maps_bf16 else prec)
     g = _g(H + cin + cout)
     x = torch.randn(N, cin, H, W, generator=g)
     w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
     b = torch.randn(cout, generator=g)
     pad = 1 if k == 3 else 0
-    ref = F.conv2d(x, w, b, stride=s, padding=pad)
-    res = torch.randn(ref.shape, generator=g)
-    ref = F.relu(ref + res)
+    res = torch.randn(F.conv2d(x, w, b, stride=s, padding=pad).shape, generator=g)
+    if maps_bf16:
+        x, res = x.bfloat16().float(), res.bfloat16().float()
+    ref = F.relu(F.conv2d(x, w, b, stride=s, padding=pad) + res)
     Ho, Wo = ref.shape[-2:]
     xd, rd, bd = _nhwc(x).to(DEV), _nhwc(res).to(DEV), b.to(DEV)  # keep every operand alive across the launch
     wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
     y = torch.empty(N, Ho, Wo, cout, device=DEV)
     _hip.check(_hip.lib().rf_conv2d_nhwc(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr(),
-                                         y.data_ptr(), N, H, W, cin, cout, k, s, pad, Ho, Wo, cout, cout, 1,
+                                         y.data_ptr(), 0, N, H, W, cin, cout, k, s, pad, Ho, Wo, cout, cout, 1,
                                          Kn._PRECISION, Kn._stream()), "conv")
     assert rel_err(y, _nhwc(ref)) < tol
+    if maps_bf16:
+        xb, rb = xd.bfloat16(), rd.bfloat16()
+        yb = torch.empty(N, Ho, Wo, cout, device=DEV, dtype=torch.bfloat16)
+        _hip.check(_hip.lib().rf_conv2d_nhwc(xb.data_ptr(), wd.data_ptr(), bd.data_ptr(), rb.data_ptr(),
+                                             yb.data_ptr(), 1, N, H, W, cin, cout, k, s, pad, Ho, Wo, cout, cout, 1,
+                                             Kn._PRECISION, Kn._stream()), "conv bf16 maps")
+        assert torch.equal(yb, y.bfloat16())  # same accumulation, one rounding at the store
+        # bf16 maps need the bf16 matrix-core path
+        assert _hip.lib().rf_conv2d_nhwc(xb.data_ptr(), wd.data_ptr(), bd.data_ptr(), rb.data_ptr(), yb.data_ptr(), 1,
+                                         N, H, W, cin, cout, k, s, pad, Ho, Wo, cout, cout, 1, 0, Kn._stream()) != 0
 
 
 @pytest.mark.parametrize("N,H,W,cin,cout", [(3, 28, 28, 16, 16), (5, 14, 14, 32, 32), (7, 7, 7, 64, 64), (9, 4, 4, 128, 128),
@@ -366,11 +380,19 @@ def test_conv3x3_raster_window(N, H, W, cin, cout):
     y = torch.empty(N, H, W, cout, device=DEV)
     assert _hip.lib().rf_conv3x3_bf16_supported(cin, cout) == 1
     _hip.check(_hip.lib().rf_conv3x3_bf16(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr(), y.data_ptr(),
-                                          N, H, W, cin, cout, 1, Kn._stream()), "conv3x3")
+                                          0, N, H, W, cin, cout, 1, Kn._stream()), "conv3x3")
     assert rel_err(y, _nhwc(ref)) < 2e-5  # identical operands (bf16-rounded), fp32 accumulate
     _hip.check(_hip.lib().rf_conv3x3_bf16(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, y.data_ptr(),
-                                          N, H, W, cin, cout, 0, Kn._stream()), "conv3x3")
+                                          0, N, H, W, cin, cout, 0, Kn._stream()), "conv3x3")
     assert rel_err(y, _nhwc(F.conv2d(xb, wb_, b, padding=1))) < 2e-5
+    # bf16 maps (RF_ACT_BF16): same sums from a bf16 input / residual, one rounding at the store
+    xh, rh = xd.bfloat16(), rd.bfloat16()
+    yh = torch.empty(N, H, W, cout, device=DEV, dtype=torch.bfloat16)
+    _hip.check(_hip.lib().rf_conv3x3_bf16(xh.data_ptr(), wd.data_ptr(), bd.data_ptr(), rh.data_ptr(), yh.data_ptr(),
+                                          1, N, H, W, cin, cout, 1, Kn._stream()), "conv3x3 bf16 maps")
+    _hip.check(_hip.lib().rf_conv3x3_bf16(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rh.float().data_ptr(), y.data_ptr(),
+                                          0, N, H, W, cin, cout, 1, Kn._stream()), "conv3x3")
+    assert torch.equal(yh, y.bfloat16())
 
 
 def test_vision_helpers():
@@ -388,13 +410,27 @@ def test_vision_helpers():
         y2 = ad.clone()
         HRNet16Backbone._upsample(xd, (ho, ho), out=y2, ldy=16, accumulate=True)
         assert rel_err(y2, _nhwc(add + F.interpolate(x, size=(ho, ho), mode="bilinear", align_corners=False))) < 1e-5
+        # bf16 maps: fp32 arithmetic on the bf16 values, one rounding at the store
+        xh, ah = xd.bfloat16(), ad.bfloat16()
+        yh = HRNet16Backbone._upsample(xh, (ho, ho), addend=ah, relu=True)
+        assert yh.dtype == torch.bfloat16
+        # (a last-bit difference in the fp32 sum can flip a round-to-even tie: compare to one bf16 ulp)
+        assert torch.allclose(yh.float(), HRNet16Backbone._upsample(xh.float(), (ho, ho), addend=ah.float(), relu=True),
+                              rtol=2.0 ** -7, atol=1e-6)
+        assert torch.equal(HRNet16Backbone._add(xh, xh, True), F.relu(xh.float() + xh.float()).bfloat16())
+    a5, b5 = torch.randn(1031, generator=g).to(DEV), torch.randn(1031, generator=g).to(DEV)  # odd length: scalar tail
+    assert torch.equal(HRNet16Backbone._add(a5, b5, True), F.relu(a5 + b5))
     # adaptive avg pool -> tokens with the -1 row, for 28x28 / 8x8 / 12x12 / 56x56 / 3x5 maps
     for (h, w) in ((28, 28), (8, 8), (12, 12), (56, 56), (3, 5)):
         x = torch.randn(2, 24, h, w, generator=g)
         tok, xd = torch.empty(2, 65, 24, device=DEV), _nhwc(x).to(DEV)
-        _hip.check(_hip.lib().rf_avgpool8_tokens(xd.data_ptr(), tok.data_ptr(), 2, h, w, 24, Kn._stream()), "pool")
+        _hip.check(_hip.lib().rf_avgpool8_tokens(xd.data_ptr(), 0, tok.data_ptr(), 2, h, w, 24, Kn._stream()), "pool")
         ref = F.adaptive_avg_pool2d(x, (8, 8)).permute(0, 2, 3, 1).reshape(2, 64, 24)
         assert rel_err(tok[:, :64], ref) < 1e-5 and torch.all(tok[:, 64] == -1)
+        xh, tok2 = xd.bfloat16(), torch.empty_like(tok)
+        _hip.check(_hip.lib().rf_avgpool8_tokens(xh.data_ptr(), 1, tok2.data_ptr(), 2, h, w, 24, Kn._stream()), "pool bf16")
+        ref2 = F.adaptive_avg_pool2d(xh.float().cpu().permute(0, 3, 1, 2), (8, 8)).permute(0, 2, 3, 1).reshape(2, 64, 24)
+        assert rel_err(tok2[:, :64], ref2) < 1e-5 and torch.all(tok2[:, 64] == -1)
     # stem: frame gather + fp16 cast + conv0
     video = torch.rand(2, 5, 3, 16, 20, generator=g).half()
     w0 = torch.randn(3, 3, 2, 2, generator=g)
@@ -402,9 +438,13 @@ def test_vision_helpers():
     ref = F.conv2d(video[:, idx].flatten(0, 1).float(), w0, stride=2)
     y, idx_d, w0_d = torch.empty(6, 8, 10, 4, device=DEV), idx.int().to(DEV), w0.to(DEV)
     for vid, is32 in ((video.to(DEV), 0), (video.float().to(DEV), 1)):
-        _hip.check(_hip.lib().rf_stem_conv0(vid.data_ptr(), is32, idx_d.data_ptr(), w0_d.data_ptr(), y.data_ptr(),
+        _hip.check(_hip.lib().rf_stem_conv0(vid.data_ptr(), is32, idx_d.data_ptr(), w0_d.data_ptr(), y.data_ptr(), 0,
                                             2, 5, 3, 16, 20, Kn._stream()), "stem")
         assert rel_err(y[..., :3], _nhwc(ref)) < 1e-5 and torch.all(y[..., 3] == 0)
+        yh = torch.empty(6, 8, 10, 4, device=DEV, dtype=torch.bfloat16)
+        _hip.check(_hip.lib().rf_stem_conv0(vid.data_ptr(), is32, idx_d.data_ptr(), w0_d.data_ptr(), yh.data_ptr(), 1,
+                                            2, 5, 3, 16, 20, Kn._stream()), "stem bf16 maps")
+        assert torch.equal(yh, y.bfloat16())
     # raw uint8 camera bytes: the dataset's `astype(np.float16) / 255.0` (io/dataset.py:1506-1523) fused into the
     # stem must give EXACTLY what the fp16 path gives on the numpy-converted clip
     raw = torch.randint(0, 256, (2, 5, 3, 16, 20), generator=g, dtype=torch.uint8)
@@ -412,9 +452,9 @@ def test_vision_helpers():
     assert as_f16.dtype == torch.float16
     y8, y16 = torch.empty_like(y), torch.empty_like(y)
     raw_d, f16_d = raw.to(DEV), as_f16.to(DEV)
-    _hip.check(_hip.lib().rf_stem_conv0(raw_d.data_ptr(), 2, idx_d.data_ptr(), w0_d.data_ptr(), y8.data_ptr(), 2, 5, 3, 16,
+    _hip.check(_hip.lib().rf_stem_conv0(raw_d.data_ptr(), 2, idx_d.data_ptr(), w0_d.data_ptr(), y8.data_ptr(), 0, 2, 5, 3, 16,
                                         20, Kn._stream()), "stem u8")
-    _hip.check(_hip.lib().rf_stem_conv0(f16_d.data_ptr(), 0, idx_d.data_ptr(), w0_d.data_ptr(), y16.data_ptr(), 2, 5, 3, 16,
+    _hip.check(_hip.lib().rf_stem_conv0(f16_d.data_ptr(), 0, idx_d.data_ptr(), w0_d.data_ptr(), y16.data_ptr(), 0, 2, 5, 3, 16,
                                         20, Kn._stream()), "stem f16")
     assert torch.equal(y8, y16)
 

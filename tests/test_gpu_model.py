@@ -279,29 +279,39 @@ def test_graphed_step_matches_eager():
     from routeformer_amd.engine import GraphedTrainEngine, TrainEngine
     from routeformer_amd.models.blocks import SAMPLER
     results = {}
-    for mode in ("eager", "graph", "graph_nolookahead"):
+    for mode in ("eager", "graph", "graph_nolookahead", "graph_deferred", "graph_deferred_split"):
         model, cfg, sd, c = build_product_model("c2_small", DEV)
         items = []
         for seed in (11, 12):
             it = synthetic.synth_item(c["B"], c["T"], c["P"], seed, c["H"], c["W"], streams=c["streams"], gaze=c["gaze"])
             items.append({"train": _to_dev(it["train"]), "target": _to_dev(it["target"])})
-        eng = (TrainEngine if mode == "eager" else GraphedTrainEngine)(model, lr=1e-3)
-        if mode != "eager":
+        if mode == "eager":
+            eng = TrainEngine(model, lr=1e-3)
+        else:
+            # deferred: clip + AdamW of step k replayed at the start of step k+1 (backbone share on a side stream)
+            eng = GraphedTrainEngine(model, lr=1e-3, defer_update=mode.startswith("graph_deferred"))
+            eng.split = mode.endswith("_split")  # two-graph step (the N > 1 form)
             eng.capture(items[0], epoch=10)
         torch.manual_seed(99)
         SAMPLER.log = []
         losses = []
         for i in range(4):
-            nxt = items[(i + 1) % 2] if mode == "graph" else None
+            nxt = items[(i + 1) % 2] if mode in ("graph", "graph_deferred") else None
             losses.append(float(eng.step(items[i % 2], epoch=10, next_item=nxt)["loss"]))
         torch.cuda.synchronize()
+        grads = eng.reducer.flat_grad.clone()
+        if mode.startswith("graph_deferred"):
+            assert eng._pending is not None
+            eng.flush()  # the last step's update is still pending
+            torch.cuda.synchronize()
+            assert eng._pending is None and eng.opt.t == 4
         results[mode] = (losses, eng.reducer.flat_param.clone(), [t_.clone() for t_ in SAMPLER.log],
-                         torch.get_rng_state(), eng.reducer.flat_grad.clone())
+                         torch.get_rng_state(), grads)
         SAMPLER.log = None
         SAMPLER.drop_static()
     le, pe, de, re_, ge = results["eager"]
     assert abs(le[0] - le[1]) > 1e-6, "the two batches should differ"
-    for mode in ("graph", "graph_nolookahead"):
+    for mode in ("graph", "graph_nolookahead", "graph_deferred", "graph_deferred_split"):
         lg, pg, dg, rg, gg = results[mode]
         assert len(de) == len(dg) and all(torch.equal(a, b) for a, b in zip(de, dg)), mode
         assert torch.equal(re_, rg), "host RNG state diverged between eager and graph mode"
