@@ -83,12 +83,15 @@ int rf_conv2d_nhwc(const void* x, const float* w, const float* bias, const void*
                    int Ho, int Wo, int64_t ldy, int64_t ldres, int relu, int prec, void* stream);
 
 /* 3x3 / stride 1 / pad 1 fast path on the bf16 matrix cores ("raster window": the contiguous NHWC span a
- * 128-pixel tile needs is staged into LDS once; no im2col).  w_bf16: [cout][9][cin] bf16 (cin == 16:
- * [cout][10][16] with a zero 10th tap), BatchNorm folded.  Supported (cin,cout): (16,16) (32,32) (64,64)
+ * 128-pixel tile needs is staged into LDS once; no im2col).  Supported (cin,cout): (16,16) (32,32) (64,64)
  * (128,128) (256,16) -- the BasicBlock / Bottleneck / transition convs of hrnetv2.py:45-61,79-99,310-330.
+ * Weights (BatchNorm folded) are consumed in MFMA fragment order: rf_conv3x3_pack_bf16 turns the fp32 device tensor
+ * w[cout][3][3][cin] into that form once (rf_conv3x3_packed_elems bf16 elements).
  * Same arithmetic contract as rf_conv2d_nhwc(prec = 1). */
 int rf_conv3x3_bf16_supported(int cin, int cout);
-int rf_conv3x3_bf16(const void* x, const void* w_bf16, const float* bias, const void* residual, void* y,
+int64_t rf_conv3x3_packed_elems(int cin, int cout);
+int rf_conv3x3_pack_bf16(const float* w, void* w_packed, int cin, int cout, void* stream);
+int rf_conv3x3_bf16(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,
                     int act_dtype, int N, int H, int W, int cin, int cout, int relu, void* stream);
 
 /* Stem: frame gather + cast + conv0 (3->3, k2 s2, no BN; hrnetv2.py:292-293,432-433).

@@ -22,6 +22,8 @@ SIGNATURES = {
     "rf_colsum": [_P, _L, _I, _I, _P, _I, _P, _P],
     "rf_conv2d_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _I, _I, _P],
     "rf_conv3x3_bf16_supported": [_I, _I],
+    "rf_conv3x3_packed_elems": [_I, _I],
+    "rf_conv3x3_pack_bf16": [_P, _P, _I, _I, _P],
     "rf_conv3x3_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "rf_stem_conv0": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "rf_upsample_bilinear_nhwc": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _P],
@@ -86,6 +88,7 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = c_int
+        handle.rf_conv3x3_packed_elems.restype = c_int64
         handle.rf_last_error.restype = ctypes.c_char_p
         handle.rf_last_error.argtypes = []
         _lib = handle

@@ -9,16 +9,28 @@
 // fragment (16 pixels x 8 channels per lane group) is a single ds_read_b128 out of that window at a
 // per-tap constant offset; image borders (and tiles that straddle two images) are handled by a per-lane
 // validity mask.  Weights are tiny ([C_out][9][C_in] bf16, pre-folded with BatchNorm) and shared by every
-// workgroup, so B fragments come straight from global memory (L1/L2 hits), software-prefetched one
-// k-step ahead.  Epilogue: + bias (+ residual) -> ReLU -> NHWC in the maps' storage type.
+// workgroup, so B fragments come straight from global memory (L1/L2 hits) in fragment order, software-prefetched
+// a few k-steps ahead.  Epilogue: + bias (+ residual) -> ReLU -> NHWC in the maps' storage type.
 //
 // v_mfma_f32_16x16x32_bf16: a k-step covers 32 input channels of one tap, or (C_in = 16) both halves of
-// two taps (the weight tensor then carries a zero 10th tap).
+// two taps (the packed weights then carry a zero 10th tap).
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef RF_CONV_TIMING
+__device__ unsigned long long rf_conv_timing[8 * 4096];
+#define CV_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) rf_conv_timing[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+extern "C" void* rf_conv_timing_address() {
+  void* a = nullptr;
+  (void)hipGetSymbolAddress(&a, HIP_SYMBOL(rf_conv_timing));
+  return a;
+}
+#else
+#define CV_MARK(k) do {} while (0)
+#endif
 
 namespace {
 
@@ -31,7 +43,6 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(const AT* __restrict__ x, c
                                                       const AT* __restrict__ residual, AT* __restrict__ y,
                                                       int total, int H, int W, int relu) {
   constexpr int LDC = CIN + 8;                       // LDS pixel pitch (bf16): odd multiple of 16 B
-  constexpr int TAPS = (CIN == 16) ? 10 : 9;         // taps stored per output channel
   constexpr int KSTEPS = (CIN == 16) ? 5 : 9 * (CIN / 32);
   constexpr int NTL = COUT / 16;                     // MFMA column tiles
   extern __shared__ __attribute__((aligned(16))) __bf16 win[];
@@ -42,21 +53,34 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(const AT* __restrict__ x, c
   const int span = TILE + 2 * W + 2;                 // staged pixels
   const long s0 = m0 - W - 1;                        // raster index of window pixel 0
 
+  CV_MARK(0);
   // ---- stage the input window (contiguous in memory) ----
+  // 16-B loads (8 bf16 / 4 fp32 channels), four per thread in flight before the first LDS store: the plain
+  // load -> store loop paid one memory round trip per iteration (49 of them for the 256-channel window)
   {
-    const long nvec = (long)span * (CIN / 4);
-    for (long i = tid; i < nvec; i += NT) {
-      const int px = (int)(i / (CIN / 4)), c = (int)(i % (CIN / 4)) * 4;
-      const long g = s0 + px;
-      if constexpr (sizeof(AT) == 2) {  // bf16 maps: the window is a plain copy
-        uint2 raw = make_uint2(0u, 0u);
-        if (g >= 0 && g < total) raw = *reinterpret_cast<const uint2*>(x + g * CIN + c);
-        *reinterpret_cast<uint2*>(win + px * LDC + c) = raw;
-      } else {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g >= 0 && g < total) v = act_ld4(x + g * CIN + c);
-        bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-        *reinterpret_cast<bf16x4*>(win + px * LDC + c) = o;
+    constexpr int VEC = sizeof(AT) == 2 ? 8 : 4, VPP = CIN / VEC, U = 4;
+    const int nvec = span * VPP;
+    for (int base = 0; base < nvec; base += NT * U) {
+      float4 raw[U];
+      int at[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + tid + u * NT;
+        const int px = i / VPP, c = (i % VPP) * VEC;
+        const long g = s0 + px;
+        at[u] = i < nvec ? px * LDC + c : -1;
+        raw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nvec && g >= 0 && g < total) raw[u] = *reinterpret_cast<const float4*>(x + g * CIN + c);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (at[u] < 0) continue;
+        if constexpr (sizeof(AT) == 2) {  // bf16 maps: the window is a plain copy
+          *reinterpret_cast<float4*>(win + at[u]) = raw[u];
+        } else {
+          bf16x4 o = {(__bf16)raw[u].x, (__bf16)raw[u].y, (__bf16)raw[u].z, (__bf16)raw[u].w};
+          *reinterpret_cast<bf16x4*>(win + at[u]) = o;
+        }
       }
     }
   }
@@ -87,69 +111,108 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(const AT* __restrict__ x, c
 #pragma unroll
     for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // B fragment of k-step s, column tile j: wt[(j*16+fr)][tap][c0 .. c0+7]
+  // B fragment of k-step s, column tile j.  The weights arrive in FRAGMENT ORDER (rf_conv3x3_pack_bf16): the 64
+  // lanes of a wave read one contiguous 1-KB block.  Read from the [cout][tap][cin] tensor, the same fragment is 16
+  // rows 2*9*CIN bytes apart -- 64 cache-line look-ups per load instruction, and with eight such loads per wave and
+  // k-step the L1 tag pipe, not the matrix cores, set the pace of the loop (1.9k cycles per step measured).
   auto ldb = [&](int s, int j) -> bf16x8 {
-    int tap, c0;
-    if constexpr (CIN == 16) { tap = 2 * s + (fq >> 1); c0 = (fq & 1) * 8; }
-    else { tap = s / (CIN / 32); c0 = (s % (CIN / 32)) * 32 + fq * 8; }
-    return *reinterpret_cast<const bf16x8*>(wt + ((long)(j * 16 + fr) * TAPS + tap) * CIN + c0);
+    return *reinterpret_cast<const bf16x8*>(wt + ((long)(s * NTL + j) * 64 + lane) * 8);
   };
 
-  bf16x8 bcur[NTL], bnext[NTL];
+  // Weight fragments run PF k-steps ahead of the MFMAs in a register ring: every step's fragments come from L2
+  // (~1 us away when little else is in flight) and the small maps (4x4, 7x7: a few dozen workgroups, one per CU)
+  // have nothing else to hide that behind -- with a distance of one the loop ran at one memory round trip per step.
+  constexpr int PF = KSTEPS < 4 ? KSTEPS : 4;
+  bf16x8 bq[PF][NTL];
 #pragma unroll
-  for (int j = 0; j < NTL; ++j) bcur[j] = ldb(0, j);
+  for (int d = 0; d < PF; ++d)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) bq[d][j] = ldb(d, j);
+  CV_MARK(1);
   __syncthreads();  // window staged
+  CV_MARK(2);
 
 #pragma unroll 1
-  for (int s = 0; s < KSTEPS; ++s) {
-    if (s + 1 < KSTEPS) {
+  for (int s0 = 0; s0 < KSTEPS; s0 += PF) {
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) bnext[j] = ldb(s + 1, j);
-    }
-    int tap, c0;
-    if constexpr (CIN == 16) { tap = 2 * s + (fq >> 1); c0 = (fq & 1) * 8; }
-    else { tap = s / (CIN / 32); c0 = (s % (CIN / 32)) * 32 + fq * 8; }
-    const int toff = (tap < 9) ? (tap / 3 - 1) * W + (tap % 3 - 1) : 0;
-    bf16x8 a[2];
+    for (int d = 0; d < PF; ++d) {
+      const int s = s0 + d;
+      if (s < KSTEPS) {
+        int tap, c0;
+        if constexpr (CIN == 16) { tap = 2 * s + (fq >> 1); c0 = (fq & 1) * 8; }
+        else { tap = s / (CIN / 32); c0 = (s % (CIN / 32)) * 32 + fq * 8; }
+        const int toff = (tap < 9) ? (tap / 3 - 1) * W + (tap % 3 - 1) : 0;
+        bf16x8 a[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool ok = tap < 9 && ((vmask[i] >> tap) & 1u);
-      bf16x8 v = *reinterpret_cast<const bf16x8*>(win + (pl[i] + (ok ? toff : 0)) * LDC + c0);
-      if (!ok) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      a[i] = v;
-    }
+        for (int i = 0; i < 2; ++i) {
+          const bool ok = tap < 9 && ((vmask[i] >> tap) & 1u);
+          bf16x8 v = *reinterpret_cast<const bf16x8*>(win + (pl[i] + (ok ? toff : 0)) * LDC + c0);
+          if (!ok) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          a[i] = v;
+        }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < NTL; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bcur[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NTL; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[d][j], acc[i][j], 0, 0, 0);
+        if (s + PF < KSTEPS) {
 #pragma unroll
-    for (int j = 0; j < NTL; ++j) bcur[j] = bnext[j];
-  }
-
-  // ---- epilogue: C/D fragment col = lane&15 (channel), row = 4*(lane>>4)+r (pixel) ----
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long m = m0 + wave * 32 + i * 16 + fq * 4 + r;
-      if (m >= total) continue;
-#pragma unroll
-      for (int j = 0; j < NTL; ++j) {
-        const int n = j * 16 + fr;
-        float v = acc[i][j][r] + bias[n];
-        if (residual) v += act_ld(residual + m * COUT + n);
-        if (relu) v = v > 0.f ? v : 0.f;
-        act_st(y + m * COUT + n, v);
+          for (int j = 0; j < NTL; ++j) bq[d][j] = ldb(s + PF, j);
+        }
       }
     }
   }
+
+  CV_MARK(3);
+  // ---- epilogue ----
+  // The C/D fragment holds (4 pixels x 1 channel) per lane and tile: finishing it from the registers meant one
+  // 2- or 4-byte residual load and store per element (and a bias load each) -- a quarter to a third of the kernel
+  // (tools/conv_phase_probe.py).  Each wave instead drops one 16-pixel row tile at a time into its own fp32 patch
+  // of the (now dead) window and finishes it 8 channels per lane: 16-B residual loads, 16-B (bf16) / 2x16-B stores.
+  constexpr int SP = COUT + 4;                       // patch pitch (floats)
+  float* patch = reinterpret_cast<float*>(win) + wave * 16 * SP;
+  __syncthreads();  // every wave is done reading the window
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) patch[(fq * 4 + r) * SP + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    constexpr int VPP = COUT / 8;                    // 8-channel vectors per pixel
+    for (int v = lane; v < 16 * VPP; v += 64) {
+      const int px = v / VPP, c = (v % VPP) * 8;
+      const long m = m0 + wave * 32 + i * 16 + px;
+      if (m < total) {
+        float4 lo = *reinterpret_cast<const float4*>(patch + px * SP + c);
+        float4 hi = *reinterpret_cast<const float4*>(patch + px * SP + c + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + c), b1 = *reinterpret_cast<const float4*>(bias + c + 4);
+        lo.x += b0.x; lo.y += b0.y; lo.z += b0.z; lo.w += b0.w;
+        hi.x += b1.x; hi.y += b1.y; hi.z += b1.z; hi.w += b1.w;
+        if (residual) {
+          const float4 r0 = act_ld4(residual + m * COUT + c), r1 = act_ld4(residual + m * COUT + c + 4);
+          lo.x += r0.x; lo.y += r0.y; lo.z += r0.z; lo.w += r0.w;
+          hi.x += r1.x; hi.y += r1.y; hi.z += r1.z; hi.w += r1.w;
+        }
+        if (relu) {
+          lo.x = fmaxf(lo.x, 0.f); lo.y = fmaxf(lo.y, 0.f); lo.z = fmaxf(lo.z, 0.f); lo.w = fmaxf(lo.w, 0.f);
+          hi.x = fmaxf(hi.x, 0.f); hi.y = fmaxf(hi.y, 0.f); hi.z = fmaxf(hi.z, 0.f); hi.w = fmaxf(hi.w, 0.f);
+        }
+        act_st4(y + m * COUT + c, lo);
+        act_st4(y + m * COUT + c + 4, hi);
+      }
+    }
+    if (i == 0) __syncthreads();  // the patch is rewritten by the second row tile
+  }
+  CV_MARK(4);
 }
 
 template <int CIN, int COUT, typename AT>
 int launch_t(const void* x, const void* wt, const float* bias, const void* residual, void* y, long total, int H,
              int W, int relu, hipStream_t st) {
-  const size_t lds = (size_t)(TILE + 2 * W + 2) * (CIN + 8) * sizeof(__bf16);
+  size_t lds = (size_t)(TILE + 2 * W + 2) * (CIN + 8) * sizeof(__bf16);
+  const size_t patches = (size_t)(NT / 64) * 16 * (COUT + 4) * sizeof(float);  // epilogue staging, one per wave
+  if (lds < patches) lds = patches;
   if (lds > 160 * 1024) { rf_g_last_error = "conv3x3 window exceeds LDS"; return RF_EUNSUPPORTED; }
   static bool attr = false;
   if (!attr) {
@@ -172,7 +235,37 @@ int launch(const void* x, const void* wt, const float* bias, const void* residua
   return launch_t<CIN, COUT, float>(x, wt, bias, residual, y, total, H, W, relu, st);
 }
 
+// fragment-order packing: out[((s*NTL + j)*64 + lane)*8 + e] = w[j*16 + (lane&15)][tap(s, lane>>4)][c0(s, lane>>4) + e]
+__global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int cin, int cout) {
+  const int ntl = cout / 16, ksteps = cin == 16 ? 5 : 9 * (cin / 32);
+  const long total = (long)ksteps * ntl * 64 * 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const int sj = (int)(i >> 9), j = sj % ntl, s = sj / ntl;
+    const int fr = lane & 15, fq = lane >> 4;
+    int tap, c0;
+    if (cin == 16) { tap = 2 * s + (fq >> 1); c0 = (fq & 1) * 8; }
+    else { tap = s / (cin / 32); c0 = (s % (cin / 32)) * 32 + fq * 8; }
+    const float v = tap < 9 ? w[((long)(j * 16 + fr) * 9 + tap) * cin + c0 + e] : 0.f;
+    out[i] = (__bf16)v;
+  }
+}
+
 }  // namespace
+
+extern "C" int64_t rf_conv3x3_packed_elems(int cin, int cout) {
+  if (!rf_conv3x3_bf16_supported(cin, cout)) return 0;
+  return (int64_t)(cin == 16 ? 5 : 9 * (cin / 32)) * (cout / 16) * 64 * 8;
+}
+
+extern "C" int rf_conv3x3_pack_bf16(const float* w, void* w_packed, int cin, int cout, void* stream) {
+  RF_REQUIRE(w && w_packed && rf_conv3x3_bf16_supported(cin, cout));
+  const long total = rf_conv3x3_packed_elems(cin, cout);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     w, static_cast<__bf16*>(w_packed), cin, cout);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
 
 extern "C" int rf_conv3x3_bf16_supported(int cin, int cout) {
   return (cin == 16 && cout == 16) || (cin == 32 && cout == 32) || (cin == 64 && cout == 64) ||

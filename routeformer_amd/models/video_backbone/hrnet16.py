@@ -83,6 +83,15 @@ def _conv_units() -> List[Tuple[str, Optional[str], int, int, int]]:
 UNITS = _conv_units()
 
 
+def pack_conv3x3_weights(w_khwc: torch.Tensor) -> torch.Tensor:
+    """(cout, 3, 3, cin) fp32 device tensor -> the bf16 fragment-order buffer rf_conv3x3_bf16 consumes."""
+    cout, _, _, cin = w_khwc.shape
+    out = torch.empty(int(_hip.lib().rf_conv3x3_packed_elems(cin, cout)), device=w_khwc.device, dtype=torch.bfloat16)
+    w = w_khwc.contiguous().float()
+    check(_hip.lib().rf_conv3x3_pack_bf16(ptr(w), ptr(out), cin, cout, K._stream()), "rf_conv3x3_pack_bf16")
+    return out
+
+
 class HRNet16Backbone(VideoBackboneModule):
     def __init__(self, configs: Optional[VideoBackboneConfig] = None):
         super().__init__()
@@ -159,12 +168,9 @@ class HRNet16Backbone(VideoBackboneModule):
                 cin_p = (cin + 3) // 4 * 4  # conv1 reads the 4-channel (zero-padded) stem output
                 wk = torch.zeros(cout, k, k, cin_p, device=device, dtype=torch.float32)
                 wk[..., :cin] = w.permute(0, 2, 3, 1)
-                wb = None  # bf16 [cout][taps][cin] copy for the raster-window 3x3 kernel
+                wb = None  # bf16 copy in MFMA fragment order for the raster-window 3x3 kernel
                 if k == 3 and bias is not None and _hip.lib().rf_conv3x3_bf16_supported(cin_p, cout):
-                    taps = wk.view(cout, 9, cin_p)
-                    if cin_p == 16:  # one k-step spans two taps: zero 10th tap
-                        taps = torch.cat([taps, torch.zeros(cout, 1, cin_p, device=device)], dim=1)
-                    wb = taps.to(torch.bfloat16).contiguous()
+                    wb = pack_conv3x3_weights(wk)
                 folded[conv] = (wk.contiguous(), bias, cin_p, cout, k, wb)
         self._folded, self._folded_key = folded, key
         return folded

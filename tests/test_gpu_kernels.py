@@ -373,10 +373,8 @@ def test_conv3x3_raster_window(N, H, W, cin, cout):
     xb, wb_ = x.bfloat16().float(), w.bfloat16().float()
     ref = F.relu(F.conv2d(xb, wb_, b, padding=1) + res)
     xd, rd, bd = _nhwc(x).to(DEV), _nhwc(res).to(DEV), b.to(DEV)
-    taps = w.permute(0, 2, 3, 1).reshape(cout, 9, cin)
-    if cin == 16:
-        taps = torch.cat([taps, torch.zeros(cout, 1, cin)], dim=1)
-    wd = taps.bfloat16().contiguous().to(DEV)
+    from routeformer_amd.models.video_backbone.hrnet16 import pack_conv3x3_weights
+    wd = pack_conv3x3_weights(w.permute(0, 2, 3, 1).contiguous().to(DEV))  # MFMA fragment order, bf16
     y = torch.empty(N, H, W, cout, device=DEV)
     assert _hip.lib().rf_conv3x3_bf16_supported(cin, cout) == 1
     _hip.check(_hip.lib().rf_conv3x3_bf16(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr(), y.data_ptr(),
