@@ -94,6 +94,17 @@ int rf_conv3x3_pack_bf16(const float* w, void* w_packed, int cin, int cout, void
 int rf_conv3x3_bf16(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,
                     int act_dtype, int N, int H, int W, int cin, int cout, int relu, void* stream);
 
+/* 1x1 convolution over bf16 maps as a streaming GEMM with the layer's weights held in registers (the Bottleneck
+ * stage, hrnetv2.py:79-99): y[M,cout] = relu?(x[M,cin] W^T + bias (+ residual[M,cout])), x / residual / y bf16,
+ * dense rows.  Supported (cin,cout): (64,64) (64,256) (256,64).  Weights (BatchNorm folded) in fragment order:
+ * rf_pointwise_pack_bf16 converts the fp32 device tensor w[cout][cin] once (rf_pointwise_packed_elems bf16
+ * elements).  Same arithmetic contract as rf_conv2d_nhwc(prec = 1, RF_ACT_BF16) with ksize 1. */
+int rf_pointwise_bf16_supported(int cin, int cout);
+int64_t rf_pointwise_packed_elems(int cin, int cout);
+int rf_pointwise_pack_bf16(const float* w, void* w_packed, int cin, int cout, void* stream);
+int rf_pointwise_bf16(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,
+                      int64_t M, int cin, int cout, int relu, void* stream);
+
 /* Stem: frame gather + cast + conv0 (3->3, k2 s2, no BN; hrnetv2.py:292-293,432-433).
  * video: (B,T,3,H,W), video_dtype 0 = fp16 in [0,1] (what the dataset emits), 1 = fp32, 2 = raw uint8 camera
  * bytes -- the dataset's `astype(float16) / 255` (io/dataset.py:1506-1523) is then applied on the fly, bit for

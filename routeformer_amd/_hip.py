@@ -25,6 +25,10 @@ SIGNATURES = {
     "rf_conv3x3_packed_elems": [_I, _I],
     "rf_conv3x3_pack_bf16": [_P, _P, _I, _I, _P],
     "rf_conv3x3_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "rf_pointwise_bf16_supported": [_I, _I],
+    "rf_pointwise_packed_elems": [_I, _I],
+    "rf_pointwise_pack_bf16": [_P, _P, _I, _I, _P],
+    "rf_pointwise_bf16": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "rf_stem_conv0": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "rf_upsample_bilinear_nhwc": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _P],
     "rf_add_relu": [_P, _P, _P, _I, _L, _I, _P],
@@ -89,6 +93,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = c_int
         handle.rf_conv3x3_packed_elems.restype = c_int64
+        handle.rf_pointwise_packed_elems.restype = c_int64
         handle.rf_last_error.restype = ctypes.c_char_p
         handle.rf_last_error.argtypes = []
         _lib = handle

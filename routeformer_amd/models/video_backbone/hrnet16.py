@@ -92,6 +92,15 @@ def pack_conv3x3_weights(w_khwc: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_pointwise_weights(w: torch.Tensor) -> torch.Tensor:
+    """(cout, cin) fp32 device tensor -> the bf16 fragment-order buffer rf_pointwise_bf16 keeps in registers."""
+    cout, cin = w.shape
+    out = torch.empty(int(_hip.lib().rf_pointwise_packed_elems(cin, cout)), device=w.device, dtype=torch.bfloat16)
+    w = w.contiguous().float()
+    check(_hip.lib().rf_pointwise_pack_bf16(ptr(w), ptr(out), cin, cout, K._stream()), "rf_pointwise_pack_bf16")
+    return out
+
+
 class HRNet16Backbone(VideoBackboneModule):
     def __init__(self, configs: Optional[VideoBackboneConfig] = None):
         super().__init__()
@@ -171,6 +180,8 @@ class HRNet16Backbone(VideoBackboneModule):
                 wb = None  # bf16 copy in MFMA fragment order for the raster-window 3x3 kernel
                 if k == 3 and bias is not None and _hip.lib().rf_conv3x3_bf16_supported(cin_p, cout):
                     wb = pack_conv3x3_weights(wk)
+                elif k == 1 and bias is not None and _hip.lib().rf_pointwise_bf16_supported(cin_p, cout):
+                    wb = pack_pointwise_weights(wk.view(cout, cin_p))  # streaming 1x1 kernel (bf16 maps)
                 folded[conv] = (wk.contiguous(), bias, cin_p, cout, k, wb)
         self._folded, self._folded_key = folded, key
         return folded
@@ -196,8 +207,12 @@ class HRNet16Backbone(VideoBackboneModule):
         act = self._act_code(x)
         assert residual is None or residual.dtype == x.dtype
         ev = K.PROFILE.begin() if K.PROFILE.on else None
-        fast = wb is not None and stride == 1 and K._PRECISION == 1
-        if fast:  # 3x3/s1 on the bf16 matrix cores straight out of an LDS raster window
+        fast = wb is not None and k == 3 and stride == 1 and K._PRECISION == 1
+        pw = wb is not None and k == 1 and stride == 1 and K._PRECISION == 1 and act == 1
+        if pw:  # 1x1 over bf16 maps: streaming GEMM, weights in registers
+            check(_hip.lib().rf_pointwise_bf16(ptr(x), ptr(wb), ptr(b), ptr(residual), ptr(y), N * H * Wd, cin, cout,
+                                               1 if relu else 0, K._stream()), "rf_pointwise_bf16")
+        elif fast:  # 3x3/s1 on the bf16 matrix cores straight out of an LDS raster window
             check(_hip.lib().rf_conv3x3_bf16(ptr(x), ptr(wb), ptr(b), ptr(residual), ptr(y), act, N, H, Wd, cin, cout,
                                              1 if relu else 0, K._stream()), "rf_conv3x3_bf16")
         else:
@@ -206,7 +221,8 @@ class HRNet16Backbone(VideoBackboneModule):
                                             K._stream()), "rf_conv2d_nhwc")
         if ev is not None:  # algorithmic work: one read of x / w (/ residual), one write of y
             M = N * Ho * Wo
-            tag = f"conv3x3_kernel<{cin}, {cout}, {'__bf16' if act else 'float'}>" if fast else \
+            tag = f"pointwise_kernel<{cin}, {cout}>" if pw else \
+                f"conv3x3_kernel<{cin}, {cout}, {'__bf16' if act else 'float'}>" if fast else \
                 f"gemm2_kernel<{K._PRECISION}, 3, 0, {1 if cout <= 16 else (2 if cout <= 32 else 0)}>"
             es = x.element_size()
             K.PROFILE.end(tag, ev, 2.0 * M * cout * k * k * cin,

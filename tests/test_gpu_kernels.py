@@ -393,6 +393,33 @@ def test_conv3x3_raster_window(N, H, W, cin, cout):
     assert torch.equal(yh, y.bfloat16())
 
 
+@pytest.mark.parametrize("M,cin,cout,res", [(263424, 64, 256, True), (1000, 64, 256, False), (777, 256, 64, False),
+                                            (16, 64, 64, True), (5, 64, 64, False), (4097, 256, 64, True)])
+def test_pointwise_bf16(M, cin, cout, res):
+    """Streaming 1x1 convolution over bf16 maps (weights in registers) against F.linear on the same bf16-rounded
+    operands, including ragged tails (M not a multiple of the 16-pixel tile / of the 64-pixel workgroup group)."""
+    from routeformer_amd import _hip, kernels as Kn
+    from routeformer_amd.models.video_backbone.hrnet16 import pack_pointwise_weights
+    g = _g(M + cin + cout)
+    x = torch.randn(M, cin, generator=g).bfloat16()
+    w = (torch.randn(cout, cin, generator=g) / math.sqrt(cin))
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(M, cout, generator=g).bfloat16() if res else None
+    ref = F.linear(x.float(), w.bfloat16().float(), b)
+    if res:
+        ref = ref + r.float()
+    ref = F.relu(ref)
+    assert _hip.lib().rf_pointwise_bf16_supported(cin, cout) == 1 and _hip.lib().rf_pointwise_bf16_supported(128, 128) == 0
+    xd, bd, rd = x.to(DEV), b.to(DEV), (r.to(DEV) if res else None)
+    wp = pack_pointwise_weights(w.to(DEV))
+    y = torch.full((M + 3, cout), 7.0, device=DEV, dtype=torch.bfloat16)  # 3 guard rows: nothing past M is written
+    _hip.check(_hip.lib().rf_pointwise_bf16(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), _hip.ptr(rd), y.data_ptr(), M,
+                                            cin, cout, 1, Kn._stream()), "pointwise")
+    assert torch.all(y[M:] == 7.0)
+    assert torch.allclose(y[:M].float().cpu(), ref, rtol=2.0 ** -7, atol=2e-2)  # one bf16 rounding of the result
+    assert rel_err(y[:M].float(), ref) < 6e-3
+
+
 def test_vision_helpers():
     from routeformer_amd import _hip, kernels as Kn
     from routeformer_amd.models.video_backbone.hrnet16 import HRNet16Backbone
