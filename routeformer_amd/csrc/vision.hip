@@ -187,12 +187,17 @@ __global__ void adamw_clip_kernel(float* __restrict__ p, const float* __restrict
   const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                     reinterpret_cast<uintptr_t>(v)) & 15) == 0;
   const long n4 = al ? n >> 2 : 0;
+  // RF_ADAMW_NT: the moments and gradients are touched once per step and are far larger than the caches --
+  // nontemporal accesses keep them from evicting what the next forward is about to read
+  typedef float f4 __attribute__((ext_vector_type(4)));
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
-    const float4 gg = reinterpret_cast<const float4*>(g)[i];
-    upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
-    reinterpret_cast<float4*>(m)[i] = mm;
-    reinterpret_cast<float4*>(v)[i] = vv;
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const f4 m_ = __builtin_nontemporal_load(reinterpret_cast<f4*>(m) + i), v_ = __builtin_nontemporal_load(reinterpret_cast<f4*>(v) + i);
+    const f4 gg = __builtin_nontemporal_load(reinterpret_cast<const f4*>(g) + i);
+    float4 mm = make_float4(m_[0], m_[1], m_[2], m_[3]), vv = make_float4(v_[0], v_[1], v_[2], v_[3]);
+    upd(pp.x, gg[0], mm.x, vv.x); upd(pp.y, gg[1], mm.y, vv.y); upd(pp.z, gg[2], mm.z, vv.z); upd(pp.w, gg[3], mm.w, vv.w);
+    __builtin_nontemporal_store(f4{mm.x, mm.y, mm.z, mm.w}, reinterpret_cast<f4*>(m) + i);
+    __builtin_nontemporal_store(f4{vv.x, vv.y, vv.z, vv.w}, reinterpret_cast<f4*>(v) + i);
     reinterpret_cast<float4*>(p)[i] = pp;
   }
   for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
