@@ -254,6 +254,10 @@ int rf_attn_fwd(const float* q, const float* k, const float* v, int64_t q_ld, in
                 int64_t v_ld, float* ctx, int out_layout, const int32_t* index_sample, int idx_group,
                 int64_t idx_group_stride, int32_t* top_idx, int force_top, int B, int H, int LQ, int LK, int E,
                 int sample_k, int n_top, int mode, float scale, void* stream);
+/* 1 when rf_attn_fwd runs the ProbSparse forward in its whole-score-matrix form for this shape (the full Q K^T
+ * fits the LDS budget of the launch): same results, fewer passes; exported so that a profile can name the kernel
+ * variant a launch maps to. */
+int rf_attn_fwd_full_scores(int B, int H, int LQ, int LK, int E, int sample_k, int n_top, int mode);
 int rf_attn_bwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
                 int64_t v_ld, const float* dctx, int out_layout, const int32_t* top_idx, float* dq,
                 float* dk, float* dv, int64_t dq_ld, int64_t dk_ld, int64_t dv_ld, int B, int H,

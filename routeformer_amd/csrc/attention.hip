@@ -166,6 +166,27 @@ __device__ __forceinline__ int quad_sum(int v) {  // all-reduce over each aligne
   return v;
 }
 
+// Sparsity measure M[q] = max_j s(q,j) - sum_j s(q,j) / LK over the sampled scores of query q; four lanes
+// share one query.  gather == nullptr: s(q,j) = S[q*sample_k + j]; else s(q,j) = S[q*ld + gather[q*sample_k + j]].
+__device__ __forceinline__ void sparsity_measure(const float* S, int ld, const int* gather, float* Ms, int LQ,
+                                                 int sample_k, int LK, int tid) {
+  const int quads = blockDim.x >> 2, sub = tid & 3;
+  for (int q0 = 0; q0 < LQ; q0 += quads) {
+    const int q = q0 + (tid >> 2), qq = min(q, LQ - 1);
+    float mx = -INFINITY, sm = 0.f;
+    for (int j = sub; j < sample_k; j += 4) {
+      const float d = gather ? S[qq * ld + gather[qq * sample_k + j]] : S[qq * sample_k + j];
+      mx = fmaxf(mx, d);
+      sm += d;
+    }
+    mx = fmaxf(mx, dpp_move<0xB1>(mx));
+    mx = fmaxf(mx, dpp_move<0x4E>(mx));
+    sm += dpp_move<0xB1>(sm);
+    sm += dpp_move<0x4E>(sm);
+    if (q < LQ && sub == 0) Ms[q] = mx - sm / (float)LK;
+  }
+}
+
 // Select the n_top rows of M (size LQ): sel[q] = position among the selected (ascending q) or -1.
 __device__ void select_top(float* Ms, int* sel, int* top_list, int LQ, int n_top, int tid) {
   // four lanes share one query: each counts a quarter of the competitors, a quad DPP add combines them
@@ -270,7 +291,11 @@ __device__ unsigned long long rf_attn_timing[16 * 4096];
 #define RF_MARK(k) do {} while (0)
 #endif
 
-template <bool V4>
+// FULLS (chosen by rf_attn_fwd_full_scores: the whole score matrix fits next to Q, K, V): Q K^T is formed once
+// on the matrix cores; the sampled scores of the sparsity measure are gathers from it and the rows of the selected
+// queries are already there for the softmax -- the scalar sampling stage and the second score pass disappear, and
+// so do four of the eleven block barriers.
+template <bool V4, bool FULLS>
 __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -279,7 +304,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
   const int LQ = p.LQ, LK = p.LK, E = p.E, EP = pitch<V4>(E);
   const int n_sel = (p.mode == 0) ? LQ : p.n_top;
   const int LKP = V4 ? ((LK + 3) & ~3) : LK;  // key rows / score columns padded to the MFMA k granule
-  const int s_elems = (max(LQ * p.sample_k, n_sel * LKP) + 3) & ~3;
+  const int s_elems = FULLS ? ((LQ * LKP + 3) & ~3) : ((max(LQ * p.sample_k, n_sel * LKP) + 3) & ~3);
   float* Qs = smem;
   float* Ks = Qs + LQ * EP;
   float* Vs = Ks + LKP * EP;
@@ -293,7 +318,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
   // the key-sample table rides along with the head loads: its entries wait in the score buffer, each
   // later overwritten by the dot product it selects (same thread, same slot)
   const bool sampling = p.mode != 0 && !p.force_top;
-  int* Sidx = reinterpret_cast<int*>(S);
+  int* Sidx = FULLS ? top_list + n_sel : reinterpret_cast<int*>(S);  // FULLS: own region (S holds Q K^T)
+  float* vpart = reinterpret_cast<float*>(Sidx + LQ * p.sample_k);     // FULLS: partial column sums of V
   if (sampling) {
     const int32_t* idx = p.idx + (long)(b / p.idx_group) * p.idx_stride;
     for (int i = tid; i < LQ * p.sample_k; i += (int)blockDim.x) Sidx[i] = idx[i];
@@ -302,6 +328,104 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
   for (int i = tid; i < (LKP - LK) * EP; i += (int)blockDim.x) { Ks[LK * EP + i] = 0.f; Vs[LK * EP + i] = 0.f; }
   __syncthreads();
   RF_MARK(1);
+
+  if constexpr (FULLS) {
+    // ---- (a) S = Q K^T (all rows), and the partial column sums of V for the lazy rows, one phase ----
+    mm_tiles((LQ + 15) >> 4, (LK + 15) >> 4, E >> 2, lane, wave,
+             [&](int q) { return Qs + min(q, LQ - 1) * EP; }, 1,
+             [&](int s_) { return Ks + min(s_, LK - 1) * EP; }, 1,
+             [&](int q, int s_, float v) {
+               if (q < LQ && s_ < LKP) S[q * LKP + s_] = s_ < LK ? v : 0.f;
+             });
+    const int parts = max(1, min((int)blockDim.x / E, 16));
+    if (p.mode == 1) {
+      for (int i = tid; i < parts * E; i += (int)blockDim.x) {
+        const int part = i / E, d = i - part * E;
+        float a = 0.f;
+        for (int l = part; l < LK; l += parts) a += Vs[l * EP + d];
+        vpart[i] = a;
+      }
+    }
+    __syncthreads();
+    RF_MARK(2);
+    // ---- (b) sparsity measure from the sampled entries of S; column means of V ----
+    int32_t* gtop = p.top + ((long)b * p.H + h) * p.n_top;
+    if (sampling) {
+      sparsity_measure(S, LKP, Sidx, Ms, LQ, p.sample_k, LK, tid);
+    } else {
+      for (int q = tid; q < LQ; q += (int)blockDim.x) sel[q] = -1;
+    }
+    if (p.mode == 1) {
+      for (int d = tid; d < E; d += (int)blockDim.x) {
+        float a = 0.f;
+        for (int part = 0; part < parts; ++part) a += vpart[part * E + d];
+        vmean[d] = a / (float)LK;
+      }
+    }
+    __syncthreads();
+    RF_MARK(3);
+    // ---- (c) top-u queries ----
+    if (sampling) {
+      select_top(Ms, sel, top_list, LQ, n_sel, tid);
+      for (int i = tid; i < n_sel; i += (int)blockDim.x) gtop[i] = top_list[i];
+    } else {
+      for (int i = tid; i < n_sel; i += (int)blockDim.x) { top_list[i] = gtop[i]; sel[gtop[i]] = i; }
+      __syncthreads();
+    }
+    RF_MARK(4);
+    // ---- (d) lazy rows out; softmax of the selected rows in place (scale and mask folded in) ----
+    if (p.mode == 1) {
+      RowCol rc(tid, blockDim.x, E);
+      const long row_step = p.out_layout == 0 ? (long)p.H * E : (long)E;
+      float* base = p.ctx + ctx_off(p, b, h, 0);
+      for (int i = tid; i < LQ * E; i += (int)blockDim.x, rc.next())
+        if (sel[rc.r] < 0) base[rc.r * row_step + rc.c] = vmean[rc.c];
+    } else {
+      for (int d = tid; d < E; d += (int)blockDim.x) {
+        float a = 0.f;
+        for (int ql = 0; ql < LQ; ++ql) {
+          a += Vs[ql * EP + d];
+          if (sel[ql] < 0) p.ctx[ctx_off(p, b, h, ql) + d] = a;
+        }
+      }
+    }
+    RF_MARK(5);
+    RF_MARK(6);
+    {
+      const int l16 = tid & 15;
+      for (int base_ = 0; base_ < n_sel; base_ += rows_per_trip()) {
+        const int si = row_of(base_);
+        const bool live = si < n_sel;
+        const int q = live ? top_list[si] : 0;
+        float* row = S + q * LKP;
+        const int kmax = live ? (p.mode == 2 ? q + 1 : LK) : 0;
+        float mx = -INFINITY;
+        for (int s_ = l16; s_ < kmax; s_ += 16) mx = fmaxf(mx, row[s_]);
+        mx = row16_max(mx);
+        float sum = 0.f;
+        for (int s_ = l16; s_ < kmax; s_ += 16) {
+          const float e_ = __expf((row[s_] - mx) * p.scale);  // scale > 0: the row maximum is the same
+          row[s_] = e_;
+          sum += e_;
+        }
+        sum = row16_sum(sum);
+        const float inv = 1.f / sum;
+        if (live)
+          for (int s_ = l16; s_ < LKP; s_ += 16) row[s_] = s_ < kmax ? row[s_] * inv : 0.f;
+      }
+    }
+    __syncthreads();
+    RF_MARK(7);
+    // ---- (e) P V for the selected rows ----
+    mm_tiles((n_sel + 15) >> 4, (E + 15) >> 4, LKP >> 2, lane, wave,
+             [&](int si) { return S + top_list[min(si, n_sel - 1)] * LKP; }, 1,
+             [&](int d) { return Vs + min(d, E - 1); }, EP,
+             [&](int si, int d, float v) {
+               if (si < n_sel && d < E) p.ctx[ctx_off(p, b, h, top_list[si]) + d] = v;
+             });
+    RF_MARK(8);
+    return;
+  }
 
   if (p.mode == 0) {
     for (int q = tid; q < LQ; q += (int)blockDim.x) { sel[q] = q; top_list[q] = q; }
@@ -320,15 +444,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
         S[i] = dot_rows<V4>(Qs + qs.r * EP, Ks + Sidx[i] * EP, E);
       __syncthreads();
       RF_MARK(2);
-      for (int q = tid; q < LQ; q += (int)blockDim.x) {
-        float mx = -INFINITY, sm = 0.f;
-        for (int j = 0; j < p.sample_k; ++j) {
-          const float d = S[q * p.sample_k + j];
-          mx = fmaxf(mx, d);
-          sm += d;
-        }
-        Ms[q] = mx - sm / (float)LK;
-      }
+      sparsity_measure(S, 0, nullptr, Ms, LQ, p.sample_k, LK, tid);
       __syncthreads();
       RF_MARK(3);
       // (2) top-u queries
@@ -653,11 +769,13 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   RF_MARK(14);
 }
 
-size_t fwd_lds(int LQ, int LK, int E, int n_sel, int sample_k, bool v4) {
+size_t fwd_lds(int LQ, int LK, int E, int n_sel, int sample_k, bool v4, bool fulls = false) {
   const size_t EP = v4 ? E + 4 : E + 1;
   const size_t LKP = v4 ? ((LK + 3) & ~3) : LK;
-  const size_t s_elems = (max((size_t)LQ * sample_k, (size_t)n_sel * LKP) + 3) & ~(size_t)3;
-  return sizeof(float) * (LQ * EP + 2 * LKP * EP + s_elems + LQ + E) + sizeof(int) * ((size_t)LQ + n_sel) + 16;
+  const size_t s_elems = fulls ? (((size_t)LQ * LKP + 3) & ~(size_t)3)
+                               : ((max((size_t)LQ * sample_k, (size_t)n_sel * LKP) + 3) & ~(size_t)3);
+  const size_t extra = fulls ? sizeof(int) * (size_t)LQ * sample_k + sizeof(float) * 16 * (size_t)E : 0;
+  return sizeof(float) * (LQ * EP + 2 * LKP * EP + s_elems + LQ + E) + sizeof(int) * ((size_t)LQ + n_sel) + extra + 16;
 }
 size_t bwd_lds(int LQ, int LK, int E, int n_sel, bool v4) {
   const size_t EP = v4 ? E + 4 : E + 1;
@@ -668,6 +786,8 @@ size_t bwd_lds(int LQ, int LK, int E, int n_sel, bool v4) {
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+extern "C" int rf_attn_fwd_full_scores(int B, int H, int LQ, int LK, int E, int sample_k, int n_top, int mode);
 
 extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
                            int64_t v_ld, float* ctx, int out_layout, const int32_t* index_sample,
@@ -681,7 +801,9 @@ extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64
   RF_REQUIRE(mode != 2 || LQ == LK);
   const bool v4 = (E % 4 == 0) && al16(q) && al16(k) && al16(v) && al16(ctx) && q_ld % 4 == 0 && k_ld % 4 == 0 &&
                   v_ld % 4 == 0;
-  const size_t lds = fwd_lds(LQ, LK, E, mode == 0 ? LQ : n_top, mode == 0 ? 0 : sample_k, v4);
+  const int threads = threads_for(B * H);
+  const bool fulls = v4 && rf_attn_fwd_full_scores(B, H, LQ, LK, E, sample_k, n_top, mode);
+  const size_t lds = fwd_lds(LQ, LK, E, mode == 0 ? LQ : n_top, mode == 0 ? 0 : sample_k, v4, fulls);
   if (lds > 160 * 1024) { rf_g_last_error = "attention head slice exceeds 160 KB LDS"; return RF_EUNSUPPORTED; }
   AttnP p{};
   p.q = q; p.k = k; p.v = v; p.q_ld = q_ld; p.k_ld = k_ld; p.v_ld = v_ld; p.ctx = ctx;
@@ -692,14 +814,25 @@ extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64
   p.idx_stride = idx_group_stride > 0 ? idx_group_stride : (long)LQ * sample_k;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  if (v4) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(B * H), dim3(threads_for(B * H)), lds, static_cast<hipStream_t>(stream), p);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(B * H), dim3(threads_for(B * H)), lds, static_cast<hipStream_t>(stream), p);
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  if (fulls) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), dim3(B * H), dim3(threads), lds, st, p);
+  else if (v4) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), dim3(B * H), dim3(threads), lds, st, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), dim3(B * H), dim3(threads), lds, st, p);
   RF_CHECK_LAUNCH();
   return RF_OK;
+}
+
+extern "C" int rf_attn_fwd_full_scores(int B, int H, int LQ, int LK, int E, int sample_k, int n_top, int mode) {
+  if (E % 4 != 0 || mode == 0) return 0;
+  const size_t full = fwd_lds(LQ, LK, E, n_top, sample_k, true, true);
+  // a workgroup alone on its CU (<= 128 problems) may use the whole LDS; a chip-filling launch must keep four
+  // workgroups per CU resident (at 48 KB -- three per CU -- the frame-encoder launch went from 53 to 75 us)
+  return full <= (threads_for(B * H) == 1024 ? 160 * 1024 : 32 * 1024);
 }
 
 #ifdef RF_ATTN_TIMING

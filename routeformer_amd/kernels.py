@@ -956,7 +956,8 @@ class _Attention(torch.autograd.Function):
         if ev is not None:
             u = LQ if mode == 0 else n_top  # sample stage + active rows (QK^T and AV)
             keep = (a, b, out, index_sample, top)
-            PROFILE.end("attn_fwd_kernel<true>", ev, B * H * (2.0 * LQ * sample_k * E + 4.0 * u * LK * E),
+            full = _hip.lib().rf_attn_fwd_full_scores(B, H, LQ, LK, E, sample_k, n_top, mode)
+            PROFILE.end("attn_fwd_kernel<true, true>" if full else "attn_fwd_kernel<true, false>", ev, B * H * (2.0 * LQ * sample_k * E + 4.0 * u * LK * E),
                         4.0 * B * H * E * (2 * LQ + 2 * LK) + 4.0 * LQ * sample_k,
                         replay=lambda fa=fargs, k=keep: _hip.lib().rf_attn_fwd(*fa, _stream()))
         if top is not None and TOPS.record is not None:

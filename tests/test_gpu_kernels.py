@@ -313,6 +313,33 @@ def test_attention_packed_self_and_forced_top():
     assert rel_err(ctx2, exp) < 3e-5
 
 
+@pytest.mark.parametrize("L,E,masked", [(40, 104, False), (42, 104, True), (160, 16, False), (105, 104, True)])
+def test_attention_full_score_form_matches_compact_form(L, E, masked):
+    """rf_attn_fwd keeps the whole Q K^T in LDS when the launch's LDS budget allows (always for <= 128 (batch, head)
+    problems that fit 160 KB; up to 32 KB per problem for chip-filling launches) and streams the sampled scores
+    otherwise: both forms must select the same queries and produce the same context."""
+    from routeformer_amd import _hip, kernels as Kn
+    B, H, factor = 20, 8, 5
+    g = _g(L + E)
+    sample_k, n_top = O.prob_sizes(L, L, factor)
+    mode = 2 if masked else 1
+    small, big = (_hip.lib().rf_attn_fwd_full_scores(b, H, L, L, E, sample_k, n_top, mode) for b in (B // 2, B))
+    if (small, big) == (0, 0) or (small, big) == (1, 1):
+        pytest.skip(f"one form for both launch sizes at L={L}, E={E} (full-score form: {small})")
+    qkv = torch.randn(B * L, 3 * H * E, generator=g).to(DEV)
+    idx = torch.randint(L, (L, sample_k), generator=g).to(torch.int32).to(DEV)
+    offs, tops = (0, H * E, 2 * H * E), []
+    Kn.TOPS.record = tops
+    try:
+        whole = Kn.attention(qkv, qkv, offs, (B, H, L, L, E), mode, index_sample=idx, n_top=n_top)
+        halves = [Kn.attention(part, part, offs, (B // 2, H, L, L, E), mode, index_sample=idx, n_top=n_top)
+                  for part in (qkv[:B // 2 * L], qkv[B // 2 * L:])]
+    finally:
+        Kn.TOPS.record = None
+    assert torch.equal(tops[0], torch.cat(tops[1:]))
+    assert rel_err(torch.cat(halves), whole) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
