@@ -280,6 +280,16 @@ int rf_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const
 int rf_adamw_clip_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, int sumsq_parts,
                       const float* hyper, void* stream);
 
+/* ---- measurement -----------------------------------------------------------------------------
+ * rf_kernel_timer_arm(): the NEXT kernel this thread launches through the library carries a start / stop event
+ * pair bracketing exactly its dispatch (hipExtLaunchKernelGGL) -- the kernel's own execution time, what rocprofv3's
+ * kernel trace reports.  Up to 4096 arms may be outstanding (launches keep queueing: no synchronisation, so the
+ * timed kernels run in a busy stream at load clocks).  rf_kernel_timer_collect(us, capacity): waits, writes the
+ * durations in microseconds in arm order (< 0: nothing was launched for that arm), resets, returns the count.
+ * Not for use inside stream capture. */
+int rf_kernel_timer_arm(void);
+int rf_kernel_timer_collect(float* us, int capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -820,9 +820,9 @@ extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64
     attr_set = true;
   }
   const hipStream_t st = static_cast<hipStream_t>(stream);
-  if (fulls) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), dim3(B * H), dim3(threads), lds, st, p);
-  else if (v4) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), dim3(B * H), dim3(threads), lds, st, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), dim3(B * H), dim3(threads), lds, st, p);
+  if (fulls) RF_LAUNCH((attn_fwd_kernel<true, true>), dim3(B * H), dim3(threads), lds, st, p);
+  else if (v4) RF_LAUNCH((attn_fwd_kernel<true, false>), dim3(B * H), dim3(threads), lds, st, p);
+  else RF_LAUNCH((attn_fwd_kernel<false, false>), dim3(B * H), dim3(threads), lds, st, p);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
@@ -868,8 +868,8 @@ extern "C" int rf_attn_bwd(const float* q, const float* k, const float* v, int64
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  if (v4) hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(B * H), dim3(threads_for(B * H)), lds, static_cast<hipStream_t>(stream), p);
-  else hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(B * H), dim3(threads_for(B * H)), lds, static_cast<hipStream_t>(stream), p);
+  if (v4) RF_LAUNCH(attn_bwd_kernel<true>, dim3(B * H), dim3(threads_for(B * H)), lds, static_cast<hipStream_t>(stream), p);
+  else RF_LAUNCH(attn_bwd_kernel<false>, dim3(B * H), dim3(threads_for(B * H)), lds, static_cast<hipStream_t>(stream), p);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels (wave = 64 lanes everywhere).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "rf_hip.h"
@@ -16,6 +17,22 @@ extern thread_local const char* rf_g_last_error;
       rf_g_last_error = hipGetErrorString(e__);            \
       return RF_ELAUNCH;                                   \
     }                                                      \
+  } while (0)
+
+// Every kernel launch of the library goes through RF_LAUNCH.  While the calling thread has armed the kernel timer
+// (rf_kernel_timer_arm), the launch carries a start / stop event pair that brackets exactly the dispatch -- the
+// execution time of the kernel itself, the quantity rocprofv3's kernel trace reports -- instead of whatever else a
+// pair of stream events around the call would include (dispatch turnaround, host launch path).
+extern thread_local hipEvent_t rf_g_timer_start, rf_g_timer_stop;
+extern thread_local bool rf_g_timer_armed;
+#define RF_LAUNCH(kernel, grid, block, lds, stream, ...)                                                      \
+  do {                                                                                                        \
+    if (rf_g_timer_armed) {                                                                                   \
+      rf_g_timer_armed = false; /* one kernel per arm: the first one of the call */                           \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, rf_g_timer_start, rf_g_timer_stop, 0, __VA_ARGS__); \
+    } else {                                                                                                  \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                      \
+    }                                                                                                         \
   } while (0)
 
 #define RF_REQUIRE(cond)                                   \

@@ -221,7 +221,7 @@ int launch_t(const void* x, const void* wt, const float* bias, const void* resid
     attr = true;
   }
   const int blocks = (int)((total + TILE - 1) / TILE);
-  hipLaunchKernelGGL((conv3x3_kernel<CIN, COUT, AT>), dim3(blocks), dim3(NT), lds, st, static_cast<const AT*>(x),
+  RF_LAUNCH((conv3x3_kernel<CIN, COUT, AT>), dim3(blocks), dim3(NT), lds, st, static_cast<const AT*>(x),
                      static_cast<const __bf16*>(wt), bias, static_cast<const AT*>(residual), static_cast<AT*>(y),
                      (int)total, H, W, relu);
   RF_CHECK_LAUNCH();
@@ -261,7 +261,7 @@ extern "C" int64_t rf_conv3x3_packed_elems(int cin, int cout) {
 extern "C" int rf_conv3x3_pack_bf16(const float* w, void* w_packed, int cin, int cout, void* stream) {
   RF_REQUIRE(w && w_packed && rf_conv3x3_bf16_supported(cin, cout));
   const long total = rf_conv3x3_packed_elems(cin, cout);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  RF_LAUNCH(pack_weights_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      w, static_cast<__bf16*>(w_packed), cin, cout);
   RF_CHECK_LAUNCH();
   return RF_OK;

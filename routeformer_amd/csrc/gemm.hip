@@ -908,7 +908,7 @@ void launch2(const GemmP& p, int splits, hipStream_t st) {
   // which operand is worth keeping on one XCD?  the one whose panel is re-read by the other dimension's tiles
   q.share = (q.gx >= 2 && q.gy >= 2) ? (q.gy <= q.gx ? 1 : 2) : 0;
   const int blocks = q.share == 1 ? 8 * q.gy * ((q.gx + 7) / 8) : (q.share == 2 ? 8 * q.gx * ((q.gy + 7) / 8) : q.gx * q.gy);
-  hipLaunchKernelGGL((gemm2_kernel<PREC, AM, BMODE, CFG>), dim3(blocks, 1, splits), dim3(NT), 0, st, q);
+  RF_LAUNCH((gemm2_kernel<PREC, AM, BMODE, CFG>), dim3(blocks, 1, splits), dim3(NT), 0, st, q);
 }
 
 template <int PREC>
@@ -931,7 +931,7 @@ void launch(const GemmP& p, int splits, hipStream_t st) {
   using C_ = Cfg<CFG>;
   constexpr int BM = C_::WM * C_::TM * 16, BN = C_::WN * C_::TN * 16;
   dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, splits);
-  hipLaunchKernelGGL((gemm_kernel<PREC, AM, BMODE, CFG>), grid, dim3(NT), 0, st, p);
+  RF_LAUNCH((gemm_kernel<PREC, AM, BMODE, CFG>), grid, dim3(NT), 0, st, p);
 }
 
 template <int PREC, int AM>
@@ -1010,7 +1010,7 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
     const long total = (long)M * N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, splitk);
+    RF_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, splitk);
     RF_CHECK_LAUNCH();
   }
   return RF_OK;
@@ -1113,8 +1113,8 @@ extern "C" int rf_wgrad_grouped(const RfWgradEntry* entries, int count, int prec
   }
   t.first_block[count] = blocks;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (prec == 1) hipLaunchKernelGGL(wgrad_grouped_kernel<1>, dim3(blocks), dim3(NT), 0, st, t);
-  else hipLaunchKernelGGL(wgrad_grouped_kernel<0>, dim3(blocks), dim3(NT), 0, st, t);
+  if (prec == 1) RF_LAUNCH(wgrad_grouped_kernel<1>, dim3(blocks), dim3(NT), 0, st, t);
+  else RF_LAUNCH(wgrad_grouped_kernel<0>, dim3(blocks), dim3(NT), 0, st, t);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
@@ -1126,10 +1126,10 @@ extern "C" int rf_colsum(const float* X, int64_t ldx, int M, int N, float* out, 
   RF_REQUIRE(X && out && workspace && M > 0 && N > 0);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int parts = rf_colsum_parts(M, N);
-  hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 63) / 64, parts), dim3(256), 0, st, X, (long)ldx, M, N,
+  RF_LAUNCH(colsum_part_kernel, dim3((N + 63) / 64, parts), dim3(256), 0, st, X, (long)ldx, M, N,
                      workspace);
   RF_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, workspace, parts, N, out, accumulate);
+  RF_LAUNCH(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, workspace, parts, N, out, accumulate);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

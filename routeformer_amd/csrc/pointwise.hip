@@ -130,7 +130,7 @@ int launch(const void* x, const void* wt, const float* bias, const void* residua
   const int groups = ((M + 15) / 16 + 3) / 4;
   const int per_cu = (int)(160 * 1024 / lds) < 4 ? (int)(160 * 1024 / lds) : 4;  // co-resident workgroups per CU
   const int grid = groups < 256 * per_cu ? groups : 256 * per_cu;              // persistent: every wave streams tiles
-  hipLaunchKernelGGL((pointwise_kernel<CIN, COUT>), dim3(grid), dim3(NT), lds, st, static_cast<const __bf16*>(x),
+  RF_LAUNCH((pointwise_kernel<CIN, COUT>), dim3(grid), dim3(NT), lds, st, static_cast<const __bf16*>(x),
                      static_cast<const __bf16*>(wt), bias, static_cast<const __bf16*>(residual),
                      static_cast<__bf16*>(y), M, relu);
   RF_CHECK_LAUNCH();
@@ -152,7 +152,7 @@ extern "C" int64_t rf_pointwise_packed_elems(int cin, int cout) {
 extern "C" int rf_pointwise_pack_bf16(const float* w, void* w_packed, int cin, int cout, void* stream) {
   RF_REQUIRE(w && w_packed && rf_pointwise_bf16_supported(cin, cout));
   const long total = rf_pointwise_packed_elems(cin, cout);
-  hipLaunchKernelGGL(pointwise_pack_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0,
+  RF_LAUNCH(pointwise_pack_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, static_cast<__bf16*>(w_packed), cin, cout);
   RF_CHECK_LAUNCH();
   return RF_OK;

@@ -700,8 +700,8 @@ extern "C" int rf_rowblock_linear(const float* x, int64_t ldx, const float* w, c
   dim3 grid((N + 127) / 128, (M + rbt - 1) / rbt);
 #define RF_RB_LIN(KC_, LN_) \
   do { \
-    if (small) hipLaunchKernelGGL((rb_linear_kernel<KC_, LN_, 32>), grid, dim3(NT8), 0, st, p); \
-    else hipLaunchKernelGGL((rb_linear_kernel<KC_, LN_, RB>), grid, dim3(NT8), 0, st, p); \
+    if (small) RF_LAUNCH((rb_linear_kernel<KC_, LN_, 32>), grid, dim3(NT8), 0, st, p); \
+    else RF_LAUNCH((rb_linear_kernel<KC_, LN_, RB>), grid, dim3(NT8), 0, st, p); \
   } while (0)
   if (K == 128) { if (ln) RF_RB_LIN(128, true); else RF_RB_LIN(128, false); }
   else { if (ln) RF_RB_LIN(256, true); else RF_RB_LIN(256, false); }
@@ -718,9 +718,9 @@ extern "C" int rf_rowblock_ffn_ln(const float* x, const float* w1, const float* 
   RF_REQUIRE(al16(x) && al16(w1) && al16(w2) && al16(y) && (!xhat || (rstd && al16(xhat))));
   FfnP p{x, w1, b1, w2, b2, h, z, y, M, act, ln_gamma, ln_beta, xhat, rstd, eps};
   if (M <= 2048)  // few row blocks: 32-row blocks, 2x the workgroups
-    hipLaunchKernelGGL(rb_ffn_ln_kernel<32>, dim3((M + 31) / 32), dim3(NT8), 0, static_cast<hipStream_t>(stream), p);
+    RF_LAUNCH(rb_ffn_ln_kernel<32>, dim3((M + 31) / 32), dim3(NT8), 0, static_cast<hipStream_t>(stream), p);
   else
-    hipLaunchKernelGGL(rb_ffn_ln_kernel<RB>, dim3((M + RB - 1) / RB), dim3(NT8), 0, static_cast<hipStream_t>(stream), p);
+    RF_LAUNCH(rb_ffn_ln_kernel<RB>, dim3((M + RB - 1) / RB), dim3(NT8), 0, static_cast<hipStream_t>(stream), p);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
@@ -749,8 +749,8 @@ extern "C" int rf_rowblock_linear_nn(const float* a, int64_t lda, const float* l
   dim3 grid(small ? (M + 31) / 32 : (M + RB - 1) / RB);
 #define RF_RB_NN(KC_, NOUT_, LN_) \
   do { \
-    if (small) hipLaunchKernelGGL((rb_nn_kernel<KC_, NOUT_, LN_, 32>), grid, dim3(NT8), 0, st, p); \
-    else hipLaunchKernelGGL((rb_nn_kernel<KC_, NOUT_, LN_, RB>), grid, dim3(NT8), 0, st, p); \
+    if (small) RF_LAUNCH((rb_nn_kernel<KC_, NOUT_, LN_, 32>), grid, dim3(NT8), 0, st, p); \
+    else RF_LAUNCH((rb_nn_kernel<KC_, NOUT_, LN_, RB>), grid, dim3(NT8), 0, st, p); \
   } while (0)
   if (ln && NOUT == 128) RF_RB_NN(128, 128, true);
   else if (ln) RF_RB_NN(128, 256, true);

@@ -301,7 +301,7 @@ inline int grid_for(long total, int block = 256, int cap = 4096) {
 extern "C" int rf_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
                                 float* y, float* xhat, float* rstd, int rows, int cols, float eps, void* stream) {
   RF_REQUIRE(x && gamma && beta && y && rows > 0 && cols > 0 && cols <= 64 * LN_MAXV);
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + LN_WAVES - 1) / LN_WAVES), dim3(256), 0,
+  RF_LAUNCH(layernorm_fwd_kernel, dim3((rows + LN_WAVES - 1) / LN_WAVES), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, residual, gamma, beta, y, xhat, rstd, rows, cols, eps);
   RF_CHECK_LAUNCH();
   return RF_OK;
@@ -324,16 +324,16 @@ extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float*
     // launches are latency-bound), then grid-stride
     int blocks = (rows + LN_WAVES - 1) / LN_WAVES;
     blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, xhat, rstd, gamma, dx,
+    RF_LAUNCH(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, xhat, rstd, gamma, dx,
                        static_cast<float*>(nullptr), rows, cols, dgamma, dbeta);
     RF_CHECK_LAUNCH();
     return RF_OK;
   }
   const int parts = rf_layernorm_bwd_parts(rows);
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, st, dy, xhat, rstd, gamma, dx, workspace, rows,
+  RF_LAUNCH(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, st, dy, xhat, rstd, gamma, dx, workspace, rows,
                      cols, static_cast<float*>(nullptr), static_cast<float*>(nullptr));
   RF_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, workspace, parts, cols,
+  RF_LAUNCH(ln_param_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, workspace, parts, cols,
                      dgamma, dbeta, accumulate);
   RF_CHECK_LAUNCH();
   return RF_OK;
@@ -342,7 +342,7 @@ extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float*
 extern "C" int rf_unfold3_circular(const float* x, float* cols, int B, int L, int C, int pad, void* stream) {
   RF_REQUIRE(x && cols && B > 0 && L > 0 && C > 0 && pad >= 1 && pad <= 2);
   const int Lout = L + 2 * pad - 2;
-  hipLaunchKernelGGL(unfold3_kernel, dim3(grid_for((long)B * Lout * 3 * C)), dim3(256), 0,
+  RF_LAUNCH(unfold3_kernel, dim3(grid_for((long)B * Lout * 3 * C)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, cols, B, L, C, pad, Lout);
   RF_CHECK_LAUNCH();
   return RF_OK;
@@ -351,7 +351,7 @@ extern "C" int rf_unfold3_circular(const float* x, float* cols, int B, int L, in
 extern "C" int rf_fold3_circular(const float* dcols, float* dx, int B, int L, int C, int pad, void* stream) {
   RF_REQUIRE(dcols && dx && B > 0 && L > 0 && C > 0 && pad >= 1 && pad <= 2);
   const int Lout = L + 2 * pad - 2;
-  hipLaunchKernelGGL(fold3_kernel, dim3(grid_for((long)B * L * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  RF_LAUNCH(fold3_kernel, dim3(grid_for((long)B * L * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      dcols, dx, B, L, C, pad, Lout);
   RF_CHECK_LAUNCH();
   return RF_OK;
@@ -360,7 +360,7 @@ extern "C" int rf_fold3_circular(const float* dcols, float* dx, int B, int L, in
 extern "C" int rf_bn_stats(const float* x, float* mean, float* var, int rows, int C, float* running_mean,
                            float* running_var, int64_t* num_batches_tracked, float momentum, void* stream) {
   RF_REQUIRE(x && mean && var && rows > 0 && C > 0 && (!running_mean == !running_var));
-  hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), x, mean,
+  RF_LAUNCH(bn_stats_kernel, dim3((C + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), x, mean,
                      var, rows, C, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked),
                      momentum);
   RF_CHECK_LAUNCH();
@@ -372,7 +372,7 @@ extern "C" int rf_bn_elu_pool_fwd(const float* x, const float* mean, const float
                                   void* stream) {
   RF_REQUIRE(x && mean && var && gamma && beta && y && B > 0 && L > 0 && C > 0);
   const int Lout = (L - 1) / 2 + 1;
-  hipLaunchKernelGGL(bn_elu_pool_fwd_kernel, dim3(grid_for((long)B * Lout * C)), dim3(256), 0,
+  RF_LAUNCH(bn_elu_pool_fwd_kernel, dim3(grid_for((long)B * Lout * C)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, mean, var, gamma, beta, y, argmax, B, L, C, Lout, eps);
   RF_CHECK_LAUNCH();
   return RF_OK;
@@ -384,7 +384,7 @@ extern "C" int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const 
                                   void* stream) {
   RF_REQUIRE(dy && argmax && x && mean && var && gamma && beta && dx && dgamma && dbeta && B > 0 && L > 0 && C > 0);
   const int Lout = (L - 1) / 2 + 1;
-  hipLaunchKernelGGL(bn_elu_pool_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), dy,
+  RF_LAUNCH(bn_elu_pool_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), dy,
                      argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, B, L, C, Lout, eps, training, accumulate);
   RF_CHECK_LAUNCH();
   return RF_OK;
@@ -493,7 +493,7 @@ extern "C" int rf_traj_head_fwd(const float* out, const float* last_gps, const f
                                 float motion_mean, void* stream) {
   RF_REQUIRE(out && last_gps && target_gps && positions && gpos && scalars && B > 0 && P > 0 && C >= 2);
   RF_REQUIRE(!target_vis || C >= 2 + E);
-  hipLaunchKernelGGL(traj_head_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), out, last_gps,
+  RF_LAUNCH(traj_head_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), out, last_gps,
                      target_gps, target_vis, positions, gpos, scalars, B, P, C, E, gamma, dense_ratio, dense_on,
                      motion_std, motion_mean);
   RF_CHECK_LAUNCH();
@@ -504,7 +504,7 @@ extern "C" int rf_traj_head_bwd(const float* out, const float* target_vis, const
                                 const float* grad_loss, float* dout, int B, int P, int C, int E, float gamma,
                                 float motion_std, void* stream) {
   RF_REQUIRE(out && gpos && scalars && dout && B > 0 && P > 0 && C >= 2);
-  hipLaunchKernelGGL(traj_head_bwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), out, target_vis,
+  RF_LAUNCH(traj_head_bwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), out, target_vis,
                      gpos, scalars, grad_loss, dout, B, P, C, E, gamma, motion_std);
   RF_CHECK_LAUNCH();
   return RF_OK;
@@ -568,7 +568,7 @@ extern "C" int rf_assemble_streams_fwd(const float* const* streams, const float*
   AsmP p{};
   for (int s = 0; s < S; ++s) { p.stream[s] = streams[s]; p.emb[s] = embeddings[s]; RF_REQUIRE(embeddings[s]); }
   p.out = out; p.B = B; p.T = T; p.E = E; p.S = S;
-  hipLaunchKernelGGL(assemble_fwd_kernel, dim3(grid_for((long)B * S * T * (E / 4))), dim3(256), 0,
+  RF_LAUNCH(assemble_fwd_kernel, dim3(grid_for((long)B * S * T * (E / 4))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p);
   RF_CHECK_LAUNCH();
   return RF_OK;
@@ -579,7 +579,7 @@ extern "C" int rf_assemble_streams_bwd(const float* dout, float* const* demb, in
   AsmP p{};
   for (int s = 0; s < S; ++s) p.demb[s] = demb[s];
   p.dout = dout; p.B = B; p.T = T; p.E = E; p.S = S;
-  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  RF_LAUNCH(assemble_bwd_kernel, dim3(S), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

@@ -215,10 +215,10 @@ void launch_stem(const void* video, const int32_t* frame_idx, const float* w, vo
                  int F, int H, int W, hipStream_t st) {
   const long total = (long)B * F * (H / 2) * (W / 2);
   if (act_dtype == 1)
-    hipLaunchKernelGGL((stem_conv0_kernel<TIn, __bf16>), dim3(grid_for(total)), dim3(256), 0, st,
+    RF_LAUNCH((stem_conv0_kernel<TIn, __bf16>), dim3(grid_for(total)), dim3(256), 0, st,
                        static_cast<const TIn*>(video), frame_idx, w, static_cast<__bf16*>(y), B, T, F, H, W);
   else
-    hipLaunchKernelGGL((stem_conv0_kernel<TIn, float>), dim3(grid_for(total)), dim3(256), 0, st,
+    RF_LAUNCH((stem_conv0_kernel<TIn, float>), dim3(grid_for(total)), dim3(256), 0, st,
                        static_cast<const TIn*>(video), frame_idx, w, static_cast<float*>(y), B, T, F, H, W);
 }
 inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
@@ -250,11 +250,11 @@ extern "C" int rf_upsample_bilinear_nhwc(const void* x, const void* addend, void
   const int grid = grid_for((long)N * Ho * Wo * (C / 4));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (act_dtype == 1)
-    hipLaunchKernelGGL(upsample_kernel<__bf16>, dim3(grid), dim3(256), 0, st, static_cast<const __bf16*>(x),
+    RF_LAUNCH(upsample_kernel<__bf16>, dim3(grid), dim3(256), 0, st, static_cast<const __bf16*>(x),
                        static_cast<const __bf16*>(addend), static_cast<__bf16*>(y), N, Hi, Wi, C, Ho, Wo, (long)ldy,
                        accumulate, relu);
   else
-    hipLaunchKernelGGL(upsample_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(x),
+    RF_LAUNCH(upsample_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(x),
                        static_cast<const float*>(addend), static_cast<float*>(y), N, Hi, Wi, C, Ho, Wo, (long)ldy,
                        accumulate, relu);
   RF_CHECK_LAUNCH();
@@ -267,10 +267,10 @@ extern "C" int rf_add_relu(const void* a, const void* b, void* out, int act_dtyp
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int grid = grid_for((n + 3) / 4);
   if (act_dtype == 1)
-    hipLaunchKernelGGL(add_relu_kernel<__bf16>, dim3(grid), dim3(256), 0, st, static_cast<const __bf16*>(a),
+    RF_LAUNCH(add_relu_kernel<__bf16>, dim3(grid), dim3(256), 0, st, static_cast<const __bf16*>(a),
                        static_cast<const __bf16*>(b), static_cast<__bf16*>(out), (long)n, relu);
   else
-    hipLaunchKernelGGL(add_relu_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(a),
+    RF_LAUNCH(add_relu_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(a),
                        static_cast<const float*>(b), static_cast<float*>(out), (long)n, relu);
   RF_CHECK_LAUNCH();
   return RF_OK;
@@ -283,10 +283,10 @@ extern "C" int rf_avgpool8_tokens(const void* x, int act_dtype, float* tokens, i
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int grid = grid_for((long)N * 65 * (C / 4));
   if (act_dtype == 1)
-    hipLaunchKernelGGL(avgpool8_tokens_kernel<__bf16>, dim3(grid), dim3(256), 0, st, static_cast<const __bf16*>(x),
+    RF_LAUNCH(avgpool8_tokens_kernel<__bf16>, dim3(grid), dim3(256), 0, st, static_cast<const __bf16*>(x),
                        tokens, N, H, W, C);
   else
-    hipLaunchKernelGGL(avgpool8_tokens_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(x),
+    RF_LAUNCH(avgpool8_tokens_kernel<float>, dim3(grid), dim3(256), 0, st, static_cast<const float*>(x),
                        tokens, N, H, W, C);
   RF_CHECK_LAUNCH();
   return RF_OK;
@@ -296,7 +296,7 @@ extern "C" int rf_sumsq_parts(int64_t n) { return grid_for(n, 256, 1024); }
 
 extern "C" int rf_sumsq(const float* g, int64_t n, float* sumsq, void* stream) {
   RF_REQUIRE(g && sumsq && n > 0);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(rf_sumsq_parts(n)), dim3(256), 0, static_cast<hipStream_t>(stream), g,
+  RF_LAUNCH(sumsq_kernel, dim3(rf_sumsq_parts(n)), dim3(256), 0, static_cast<hipStream_t>(stream), g,
                      (long)n, sumsq);
   RF_CHECK_LAUNCH();
   return RF_OK;
@@ -308,7 +308,7 @@ extern "C" int rf_adamw_clip(float* p, const float* g, float* m, float* v, int64
   RF_REQUIRE(p && g && m && v && n > 0 && step >= 1 && (max_norm <= 0.f || (sumsq && sumsq_parts >= 1)));
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
-  hipLaunchKernelGGL(adamw_clip_kernel<false>, dim3(grid_for(n, 256, 4096)), dim3(256), 0,
+  RF_LAUNCH(adamw_clip_kernel<false>, dim3(grid_for(n, 256, 4096)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p, g, m, v, (long)n, sumsq, max_norm, lr, beta1, beta2, eps, wd,
                      bc1, bc2_sqrt, grad_scale, sumsq_parts, static_cast<const float*>(nullptr));
   RF_CHECK_LAUNCH();
@@ -318,7 +318,7 @@ extern "C" int rf_adamw_clip(float* p, const float* g, float* m, float* v, int64
 extern "C" int rf_adamw_clip_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
                                  int sumsq_parts, const float* hyper, void* stream) {
   RF_REQUIRE(p && g && m && v && n > 0 && hyper && sumsq && sumsq_parts >= 1);
-  hipLaunchKernelGGL(adamw_clip_kernel<true>, dim3(grid_for(n, 256, 4096)), dim3(256), 0,
+  RF_LAUNCH(adamw_clip_kernel<true>, dim3(grid_for(n, 256, 4096)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p, g, m, v, (long)n, sumsq, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f,
                      1.f, sumsq_parts, hyper);
   RF_CHECK_LAUNCH();
@@ -326,5 +326,47 @@ extern "C" int rf_adamw_clip_dev(float* p, const float* g, float* m, float* v, i
 }
 
 thread_local const char* rf_g_last_error = "";
+thread_local hipEvent_t rf_g_timer_start = nullptr, rf_g_timer_stop = nullptr;
+thread_local bool rf_g_timer_armed = false;
+namespace {
+constexpr int TIMER_PAIRS = 4096;
+thread_local hipEvent_t timer_ev[2 * TIMER_PAIRS];
+thread_local int timer_created = 0, timer_used = 0;
+}  // namespace
+
+extern "C" int rf_kernel_timer_arm(void) {
+  if (timer_used >= TIMER_PAIRS) { rf_g_last_error = "kernel timer: collect before arming more"; return RF_EINVAL; }
+  if (timer_used >= timer_created) {
+    if (hipEventCreate(&timer_ev[2 * timer_created]) != hipSuccess ||
+        hipEventCreate(&timer_ev[2 * timer_created + 1]) != hipSuccess) {
+      rf_g_last_error = "hipEventCreate failed";
+      return RF_ELAUNCH;
+    }
+    ++timer_created;
+  }
+  rf_g_timer_start = timer_ev[2 * timer_used];
+  rf_g_timer_stop = timer_ev[2 * timer_used + 1];
+  ++timer_used;
+  rf_g_timer_armed = true;
+  return RF_OK;
+}
+
+extern "C" int rf_kernel_timer_collect(float* us, int capacity) {
+  const int n = timer_used < capacity ? timer_used : capacity;
+  if (rf_g_timer_armed) { rf_g_timer_armed = false; }  // armed but nothing was launched: that slot reads < 0
+  for (int i = 0; i < n; ++i) {
+    float ms = -1.f;
+    if (us) {
+      if (hipEventSynchronize(timer_ev[2 * i + 1]) != hipSuccess ||
+          hipEventElapsedTime(&ms, timer_ev[2 * i], timer_ev[2 * i + 1]) != hipSuccess)
+        ms = -1.f;
+      us[i] = ms < 0.f ? -1.f : ms * 1000.f;
+    }
+  }
+  (void)hipGetLastError();  // an unrecorded pair is an expected, reported (< 0) condition
+  timer_used = 0;
+  return n;
+}
+
 extern "C" int rf_version(void) { return 1; }
 extern "C" const char* rf_last_error(void) { return rf_g_last_error; }

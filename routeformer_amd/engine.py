@@ -565,16 +565,26 @@ class GraphedTrainEngine(TrainEngine):
     def _set_hyper(self):
         """Ship the pending update's scalars (or "nothing pending") ahead of the replay."""
         vals = self._pending if self._pending is not None else self.opt.hyper(1.0, pending=False)
+        ev = self.__dict__.get("_hyper_copied")
+        if ev is not None:
+            ev.synchronize()  # the previous copy must have left the pinned buffer before it is rewritten
         self._hyper_pinned[:len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
         self._hyper.copy_(self._hyper_pinned, non_blocking=True)
+        self._hyper_copied = torch.cuda.Event()
+        self._hyper_copied.record()
 
     def flush(self):
         """Apply a still-pending optimizer update now (eagerly, on the current stream)."""
         if self._pending is not None:
             vals, self._pending = self._pending, None
             self.opt.launch_sumsq()
+            ev = self.__dict__.get("_hyper_copied")
+            if ev is not None:
+                ev.synchronize()
             self._hyper_pinned[:len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
             self._hyper.copy_(self._hyper_pinned, non_blocking=True)
+            self._hyper_copied = torch.cuda.Event()
+            self._hyper_copied.record()
             self.opt.launch_update_dev(0, self.reducer.flat_param.numel(), self._hyper)
             self.reducer.flat_grad.zero_()
         return self

@@ -119,26 +119,37 @@ class _Profiler:
         e.record()
         self.events.append((tag, start, e, flops, nbytes, replay))
 
-    def refine(self, tag, reps: int = 10):
-        """Per-launch duration of kernel ``tag`` without the eager launch gaps: every recorded launch of it
-        is re-issued ``reps`` times back to back between two HIP events on the launch stream (same
-        operands, same shapes).  Returns (launches, total_us_per_step, flops, bytes) or None."""
+    def refine(self, tag, reps: int = 5):
+        """Per-launch EXECUTION time of kernel ``tag``: the step's launches of it are re-issued (same operands, same
+        shapes) as one uninterrupted stream of work -- a few untimed rounds first, so the timed ones run at load
+        clocks like the step itself (an isolated launch after an idle gap reads ~30 % longer) -- each timed launch
+        carrying a start / stop event pair that brackets exactly its dispatch (rf_kernel_timer_arm,
+        hipExtLaunchKernelGGL): the duration rocprofv3's kernel trace reports, without dispatch turnaround or host
+        launch path.  For a call that launches two kernels the first one is timed.
+        Returns (launches, total_us_per_step, flops, bytes) or None."""
+        import ctypes
         todo = [(fl, by, rp) for t, _, _, fl, by, rp in self.events if t == tag and rp is not None]
-        if not todo:
+        if not todo or len(todo) * reps > 4096:
             return None
-        total_us = fl_sum = by_sum = 0.0
-        for fl, by, rp in todo:
-            rp()  # warm
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(reps):
+        lib = _hip.lib()
+        for _ in range(int(os.environ.get("RF_REFINE_WARM", "3"))):  # clocks up, caches as in the step
+            for _, _, rp in todo:
                 rp()
-            e.record()
-            e.synchronize()
-            total_us += s.elapsed_time(e) * 1e3 / reps
-            fl_sum += fl
-            by_sum += by
-        return len(todo), total_us, fl_sum, by_sum
+        for _ in range(reps):
+            for _, _, rp in todo:
+                check(lib.rf_kernel_timer_arm(), "rf_kernel_timer_arm")
+                rp()
+        buf = (ctypes.c_float * (len(todo) * reps))()
+        n = lib.rf_kernel_timer_collect(buf, len(buf))
+        vals = [buf[i] for i in range(n)]
+        if n != len(buf) or any(v < 0 for v in vals):
+            return None
+        total_us = sum(vals) / reps
+        if os.environ.get("RF_REFINE_DEBUG"):
+            import sys
+            per = [sum(vals[i::len(todo)]) / reps for i in range(len(todo))]
+            print(f"[refine] {tag}: " + " ".join(f"{v:.1f}" for v in per), file=sys.stderr)
+        return len(todo), total_us, sum(fl for fl, _, _ in todo), sum(by for _, by, _ in todo)
 
     def summary(self):
         """tag -> {launches, total_ms, flops, bytes} (algorithmic flops / bytes summed over launches)."""
@@ -226,6 +237,8 @@ def gemm(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, *, bias=None, residu
             tag = f"gemm2_kernel<{_PRECISION}, {am}, {bm}, {3 if (M >= 4096 and N >= 64) else 0}>"
         else:
             tag = f"gemm_kernel<{_PRECISION}, {am}, {bm}, 0>"
+        if splitk > 1 and not atomic:  # two kernels per call: kept apart from the single-kernel launches of the symbol
+            tag += " + splitk_reduce_kernel"
         keep = (A, B, C, bias, residual, preact, dact_src, ws, a_rowsum)  # operands stay alive for the replay
         PROFILE.end(tag, ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N),
                     replay=lambda a=args, k=keep: _hip.lib().rf_gemm(*a, _stream()))
@@ -974,15 +987,18 @@ class _Attention(torch.autograd.Function):
         da = torch.empty(a.shape, device=dout.device, dtype=torch.float32)
         db = da if same else torch.empty(b.shape, device=dout.device, dtype=torch.float32)
         ev = PROFILE.begin() if PROFILE.on else None
-        check(_hip.lib().rf_attn_bwd(a.data_ptr() + 4 * q_off, b.data_ptr() + 4 * k_off,
-                                     b.data_ptr() + 4 * v_off, a.stride(0), b.stride(0), b.stride(0),
-                                     ptr(dout), out_layout, ptr(top) if mode != 0 else None,
-                                     da.data_ptr() + 4 * q_off, db.data_ptr() + 4 * k_off,
-                                     db.data_ptr() + 4 * v_off, da.stride(0), db.stride(0), db.stride(0),
-                                     B, H, LQ, LK, E, n_top, mode, scale, _stream()), "rf_attn_bwd")
+        bargs = (a.data_ptr() + 4 * q_off, b.data_ptr() + 4 * k_off,
+                 b.data_ptr() + 4 * v_off, a.stride(0), b.stride(0), b.stride(0),
+                 ptr(dout), out_layout, ptr(top) if mode != 0 else None,
+                 da.data_ptr() + 4 * q_off, db.data_ptr() + 4 * k_off,
+                 db.data_ptr() + 4 * v_off, da.stride(0), db.stride(0), db.stride(0),
+                 B, H, LQ, LK, E, n_top, mode, scale)
+        check(_hip.lib().rf_attn_bwd(*bargs, _stream()), "rf_attn_bwd")
         if ev is not None:
             u = LQ if mode == 0 else n_top
-            PROFILE.end("attn_bwd_kernel<true>", ev, B * H * 10.0 * u * LK * E, 4.0 * B * H * E * (4 * LQ + 4 * LK))
+            keep = (a, b, dout, top, da, db)  # operands stay alive for the replay
+            PROFILE.end("attn_bwd_kernel<true>", ev, B * H * 10.0 * u * LK * E, 4.0 * B * H * E * (4 * LQ + 4 * LK),
+                        replay=lambda fa=bargs, k=keep: _hip.lib().rf_attn_bwd(*fa, _stream()))
         return da, (None if same else db), None, None, None, None, None, None, None, None, None
 
 

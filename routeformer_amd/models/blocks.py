@@ -84,9 +84,15 @@ class IndexSampler:
     def refill_static(self):
         """Host side of one step: the reference's draws in order, then ONE async H2D copy."""
         dev_buf, pinned, slots = self._static
+        ev = self.__dict__.get("_copied")
+        if ev is not None:
+            ev.synchronize()  # the previous step's copy must have left the pinned buffer before it is rewritten
         for off, lk, lq, k in slots:
             pinned[off:off + lq * k].copy_(self.draw_host(lk, lq, k).view(-1))
         dev_buf.copy_(pinned, non_blocking=True)
+        if dev_buf.is_cuda:
+            self._copied = torch.cuda.Event()
+            self._copied.record()
         self._cursor = 0
 
     def rewind_static(self):

@@ -14,7 +14,7 @@ def _declared():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int64_t|int|const char\*)\s+(rf_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int64_t|int|float|const char\*)\s+(rf_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = [a.strip() for a in m.group(2).replace("\n", " ").split(",") if a.strip() and a.strip() != "void"]
         out[m.group(1)] = args
     return out
