@@ -326,7 +326,14 @@ class _WgradQueue:
         uses = {}
         for item in q:
             uses[item[2].data_ptr()] = uses.get(item[2].data_ptr(), 0) + 1
+        # Split-K was sized per problem (>= 512 workgroups each); a group that fills the chip on its own tiles needs
+        # it only to bound the reduction depth a single workgroup walks.  Every split of a d=832 weight is another
+        # read-modify-write pass of fp32 atomics over it: PMC showed 3 GB of HBM traffic per step here against 0.3 GB
+        # of gradients, and an unsplit tile may use plain exclusive stores.
+        total_tiles = sum(-(-i[5] // 64) * -(-i[6] // 64) for i in q)
         for e, (dy2, x2, into, bias_into, M, N, K, splits) in zip(arr, q):
+            if total_tiles >= _WGRAD_GROUP_TILES:
+                splits = max(1, min(splits, -(-M // 1024)))
             e.dy, e.x, e.dw, e.db = ptr(dy2), ptr(x2), ptr(into), ptr(bias_into)
             e.M, e.N, e.K, e.ld_dy, e.ld_x, e.splits = M, N, K, dy2.stride(0), x2.stride(0), splits
             e.exclusive = 1 if (uses[into.data_ptr()] == 1 and into.data_ptr() not in self.written) else 0
@@ -353,6 +360,7 @@ class _WgradQueue:
         self.pending.clear()
 
 
+_WGRAD_GROUP_TILES = int(os.environ.get("RF_WGRAD_GROUP_TILES", "1024"))
 WGRAD = _WgradQueue()
 
 
