@@ -354,6 +354,15 @@ struct GLoader {
         kofs[s] = kv;
         ok[s] = i < ROWS * VPR && gr < nrows;
         base[s] = G + (ok[s] ? (long)gr * ld_row + kv : 0);
+      } else if constexpr (NV % 2 == 0) {
+        // slots come in pairs (2p, 2p+1) holding the SAME four rows at two adjacent k: the transposing LDS store
+        // then writes (k, k+1) pairs -- half the ds_write instructions, which were 58 % of a weight-gradient K trip
+        constexpr int VPK = ROWS / 4;
+        const int ip = tid + (s >> 1) * NT;
+        const int k = 2 * (ip / VPK) + (s & 1), rv = (ip % VPK) * 4, gr = row0 + rv;
+        kofs[s] = k;
+        ok[s] = ip < BKV * VPK / 2 && gr < nrows;
+        base[s] = G + (ok[s] ? (long)k * ld_k + gr : 0);
       } else {
         constexpr int VPK = ROWS / 4;
         const int k = i / VPK, rv = (i % VPK) * 4, gr = row0 + rv;
@@ -375,8 +384,33 @@ struct GLoader {
 };
 
 // registers -> LDS stage ([row][k], pitch LD)
+template <typename T> __device__ __forceinline__ void st2(T* s, float a, float b);
+template <> __device__ __forceinline__ void st2<float>(float* s, float a, float b) {
+  *reinterpret_cast<float2*>(s) = make_float2(a, b);
+}
+template <> __device__ __forceinline__ void st2<__bf16>(__bf16* s, float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 o = {(__bf16)a, (__bf16)b};
+  *reinterpret_cast<bf16x2*>(s) = o;
+}
+
 template <int ROWS, int BKV, int MODE, int NV, typename T, int LD>
 __device__ __forceinline__ void lstore(T* __restrict__ S, const float4 (&r)[NV], int tid) {
+  if constexpr (MODE == 1 && NV % 2 == 0) {  // paired slots (see GLoader::init): (k, k+1) pairs of four rows
+    constexpr int VPK = ROWS / 4;
+#pragma unroll
+    for (int p = 0; p < NV / 2; ++p) {
+      const int ip = tid + p * NT;
+      if (ip < BKV * VPK / 2) {
+        T* sp = S + ((ip % VPK) * 4) * LD + 2 * (ip / VPK);
+        st2<T>(sp, r[2 * p].x, r[2 * p + 1].x);
+        st2<T>(sp + LD, r[2 * p].y, r[2 * p + 1].y);
+        st2<T>(sp + 2 * LD, r[2 * p].z, r[2 * p + 1].z);
+        st2<T>(sp + 3 * LD, r[2 * p].w, r[2 * p + 1].w);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < NV; ++s) {
     const int i = tid + s * NT;

@@ -11,16 +11,21 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-sh
                        f"-I{root}/include", f"-I{src}", os.path.join(src, "gemm.hip"), os.path.join(src, "vision.hip"), "-o", out])
 lib = ctypes.CDLL(out); hip = ctypes.CDLL("libamdhip64.so")
 M, N, K = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (320, 3328, 832)
+WGRAD = len(sys.argv) > 4 and sys.argv[4] == "wgrad"  # weight-gradient form: dW[M,N] += dY[K,M]^T X[K,N] (fp32 atomics)
 P, L = ctypes.c_void_p, ctypes.c_int64
 x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda"); b = torch.randn(N, device="cuda"); y = torch.empty(M, N, device="cuda")
+dyw = torch.randn(K, M, device="cuda"); xw = torch.randn(K, N, device="cuda"); dw = torch.zeros(M, N, device="cuda")
 def call():
+    if WGRAD:
+        return lib.rf_gemm(P(dyw.data_ptr()), L(1), L(M), P(xw.data_ptr()), L(N), L(1), P(dw.data_ptr()), L(N), M, N, K, None, None, L(0), 0,
+                           0, 0, None, L(0), None, L(0), 0, 1, 1, None, 1, None, None, P(torch.cuda.current_stream().cuda_stream))
     return lib.rf_gemm(P(x.data_ptr()), L(K), L(1), P(w.data_ptr()), L(1), L(K), P(y.data_ptr()), L(N), M, N, K, P(b.data_ptr()), None, L(0), 0,
                        0, 0, None, L(0), None, L(0), 0, 1, 1, None, 0, None, None, P(torch.cuda.current_stream().cuda_stream))
 for _ in range(3): assert call() == 0
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record(); [call() for _ in range(20)]; e.record(); torch.cuda.synchronize()
-print(f"launch: {s.elapsed_time(e) / 20 * 1e3:.1f} us for {M} x {N} x {K} (bf16 inputs, no split-K)")
+print(f"launch: {s.elapsed_time(e) / 20 * 1e3:.1f} us for {M} x {N} x {K} (bf16 inputs, no split-K{', weight-gradient layouts' if WGRAD else ''})")
 lib.rf_gemm_timing_address.restype = ctypes.c_void_p
 buf = torch.zeros(16 * 1024, device="cuda", dtype=torch.int64)
 hip.hipMemcpy(P(buf.data_ptr()), P(lib.rf_gemm_timing_address()), ctypes.c_size_t(8 * 16 * 1024), 3)
