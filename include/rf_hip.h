@@ -280,6 +280,17 @@ int rf_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const
 int rf_adamw_clip_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, int sumsq_parts,
                       const float* hyper, void* stream);
 
+/* ---- backbone input / output head (routeformer.py:210-233,279-292) ------------------------------
+ * rf_motion_input: x[b,t,:] = [R(-origin_b) motion | (angle - origin_b)/pi | |motion| | |motion|_t - |motion|_{t-1}
+ * | visual[b,t,:]] with origin_b = the angle of the last step (rotate_motion) or the first; without rotate_motion the
+ * motion channels are copied unrotated.  x: (B,T,5+E), origin: (B) (kept for the output rotation), zero_visual
+ * writes zeros instead of `visual` (the `_only_motion` ablation).  Motion carries no gradient; d visual = dx[..., 5:].
+ * rf_rotate_head: out = in with channels 0,1 rotated by sign * origin_b, other channels copied (sign = +1: the
+ * un-rotation of the predicted motion; -1: its backward). */
+int rf_motion_input(const float* motion, const float* visual, float* x, float* origin, int B, int T, int E,
+                    int rotate_motion, int zero_visual, void* stream);
+int rf_rotate_head(const float* in, const float* origin, float* out, int B, int P, int C, float sign, void* stream);
+
 /* ---- measurement -----------------------------------------------------------------------------
  * rf_kernel_timer_arm(): the NEXT kernel this thread launches through the library carries a start / stop event
  * pair bracketing exactly its dispatch (hipExtLaunchKernelGGL) -- the kernel's own execution time, what rocprofv3's

@@ -55,6 +55,8 @@ SIGNATURES = {
     "rf_attn_fwd_full_scores": [_I, _I, _I, _I, _I, _I, _I, _I],
     "rf_attn_bwd": [_P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _I,
                     _I, _I, _F, _P],
+    "rf_motion_input": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "rf_rotate_head": [_P, _P, _P, _I, _I, _I, _F, _P],
     "rf_kernel_timer_arm": [],
     "rf_kernel_timer_collect": [_P, _I],
     "rf_sumsq_parts": [_L],

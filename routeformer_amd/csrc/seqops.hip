@@ -583,3 +583,80 @@ extern "C" int rf_assemble_streams_bwd(const float* dout, float* const* demb, in
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
+
+// ---- backbone input / output head (routeformer.py:279-292, 210-233) ---------------------
+// x[b,t,:] = [rotate(motion, -origin) | (angle - origin)/pi | |motion| | d|motion|/dt | visual]: ~20 elementwise
+// ATen launches (atan2, norm, slices, pad, cos, sin, stack, two cats) in one pass; the motion inputs carry no
+// gradient, so the backward of this op is just the slice of dX that belongs to `visual`.
+namespace {
+__global__ void motion_input_kernel(const float* __restrict__ motion, const float* __restrict__ visual,
+                                    float* __restrict__ x, float* __restrict__ origin_out, int B, int T, int E,
+                                    int rotate_motion, int zero_visual) {
+  const int C = 5 + E;
+  const long total = (long)B * T * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const int t = (int)(r % T), b = (int)(r / T);
+    if (c >= 5) {
+      x[i] = zero_visual ? 0.f : visual[r * E + (c - 5)];
+      continue;
+    }
+    const float* mb = motion + (long)b * T * 2;
+    const int to = rotate_motion ? T - 1 : 0;
+    const float origin = atan2f(mb[2 * to + 1], mb[2 * to]);
+    if (t == 0 && c == 0) origin_out[b] = origin;
+    const float mx = mb[2 * t], my = mb[2 * t + 1];
+    float v;
+    if (c < 2) {
+      if (rotate_motion) {  // R(-origin) [mx, my]
+        const float cs = cosf(-origin), sn = sinf(-origin);
+        v = c == 0 ? cs * mx - sn * my : sn * mx + cs * my;
+      } else {
+        v = c == 0 ? mx : my;
+      }
+    } else if (c == 2) {
+      v = (atan2f(my, mx) - origin) / 3.14159265358979323846f;
+    } else {
+      const float n = sqrtf(mx * mx + my * my);
+      if (c == 3) v = n;
+      else v = t > 0 ? n - sqrtf(mb[2 * t - 2] * mb[2 * t - 2] + mb[2 * t - 1] * mb[2 * t - 1]) : 0.f;
+    }
+    x[i] = v;
+  }
+}
+
+// y = out with channels 0,1 rotated by sign * origin[b] (R = [[c,-s],[s,c]]); sign = +1 forward, -1 backward
+__global__ void rotate_head_kernel(const float* __restrict__ in, const float* __restrict__ origin,
+                                   float* __restrict__ out, int B, int P, int C, float sign) {
+  const long total = (long)B * P * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    if (c >= 2) { out[i] = in[i]; continue; }
+    const int b = (int)(r / P);
+    const float a = sign * origin[b];
+    const float cs = cosf(a), sn = sinf(a);
+    const float vx = in[r * C], vy = in[r * C + 1];
+    out[i] = c == 0 ? cs * vx - sn * vy : sn * vx + cs * vy;
+  }
+}
+}  // namespace
+
+extern "C" int rf_motion_input(const float* motion, const float* visual, float* x, float* origin, int B, int T, int E,
+                               int rotate_motion, int zero_visual, void* stream) {
+  RF_REQUIRE(motion && x && origin && B > 0 && T > 0 && E >= 0 && (E == 0 || visual || zero_visual));
+  RF_LAUNCH(motion_input_kernel, dim3(grid_for((long)B * T * (5 + E))), dim3(256), 0, static_cast<hipStream_t>(stream),
+            motion, visual, x, origin, B, T, E, rotate_motion, zero_visual);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_rotate_head(const float* in, const float* origin, float* out, int B, int P, int C, float sign,
+                              void* stream) {
+  RF_REQUIRE(in && origin && out && B > 0 && P > 0 && C >= 2 && (sign == 1.f || sign == -1.f));
+  RF_LAUNCH(rotate_head_kernel, dim3(grid_for((long)B * P * C)), dim3(256), 0, static_cast<hipStream_t>(stream), in,
+            origin, out, B, P, C, sign);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}

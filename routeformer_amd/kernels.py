@@ -1073,6 +1073,62 @@ def traj_head(out, last_gps, target_gps, target_vis, gamma: float, ratio: float,
                            float(motion_std), float(motion_mean))
 
 
+class _MotionInput(torch.autograd.Function):
+    """x = [R(-origin) motion | (angle - origin)/pi | |motion| | d|motion| | visual] in one launch (rf_motion_input);
+    the motion inputs carry no gradient, d visual is the matching slice of dX."""
+
+    @staticmethod
+    def forward(ctx, motion, visual, rotate_motion: bool, zero_visual: bool):
+        B, T, _ = motion.shape
+        E = 0 if visual is None else visual.shape[-1]
+        motion = motion.contiguous().float()
+        vis = None if visual is None else visual.contiguous().float()
+        x = torch.empty(B, T, 5 + E, device=motion.device, dtype=torch.float32)
+        origin = torch.empty(B, device=motion.device, dtype=torch.float32)
+        check(_hip.lib().rf_motion_input(ptr(motion), ptr(vis), ptr(x), ptr(origin), B, T, E, 1 if rotate_motion else 0,
+                                         1 if zero_visual else 0, _stream()), "rf_motion_input")
+        ctx.E, ctx.zero_visual = E, zero_visual
+        ctx.mark_non_differentiable(origin)
+        return x, origin
+
+    @staticmethod
+    def backward(ctx, dx, _dorigin):
+        dvis = None
+        if ctx.E and not ctx.zero_visual and ctx.needs_input_grad[1]:
+            dvis = dx[..., 5:]
+        return None, dvis, None, None
+
+
+class _RotateHead(torch.autograd.Function):
+    """Channels 0,1 of the backbone output rotated back by +origin (rf_rotate_head); backward rotates by -origin."""
+
+    @staticmethod
+    def forward(ctx, out, origin):
+        out = out.contiguous().float()
+        B, P, C = out.shape
+        y = torch.empty_like(out)
+        check(_hip.lib().rf_rotate_head(ptr(out), ptr(origin), ptr(y), B, P, C, 1.0, _stream()), "rf_rotate_head")
+        ctx.save_for_backward(origin)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (origin,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, P, C = dy.shape
+        dout = torch.empty_like(dy)
+        check(_hip.lib().rf_rotate_head(ptr(dy), ptr(origin), ptr(dout), B, P, C, -1.0, _stream()), "rf_rotate_head")
+        return dout, None
+
+
+def motion_input(motion, visual, rotate_motion: bool, zero_visual: bool = False):
+    return _MotionInput.apply(motion, visual, rotate_motion, zero_visual)
+
+
+def rotate_head(out, origin):
+    return _RotateHead.apply(out, origin)
+
+
 class _AssembleStreams(torch.autograd.Function):
     """cat([stream_s + emb_s for s], dim=1) with ``None`` streams standing for zeros -- one launch each way."""
 

@@ -123,6 +123,8 @@ class Routeformer(nn.Module):
 
     def _forward(self, motion, visual):
         c = self.configs
+        if motion.is_cuda:
+            return self._forward_fused(motion, visual)
         angle, norm = estimate_angle_and_norm(motion)
         origin = angle[:, -1:, :] if c.rotate_motion else angle[:, :1, :]
         rel_angle = (angle - origin) / torch.pi
@@ -145,6 +147,26 @@ class Routeformer(nn.Module):
             out = out + (x[:, -1:, :] if c.dense_prediction else x[:, -1:, :2])
         if c.rotate_motion:
             out = torch.cat([rotate(out[:, :, :2], origin), out[:, :, 2:]], dim=-1)
+        return out, None
+
+    def _forward_fused(self, motion, visual):
+        """``_forward`` with the motion featurisation + concat and the output un-rotation as one launch each
+        (rf_motion_input / rf_rotate_head instead of ~35 elementwise ATen launches; same arithmetic)."""
+        c = self.configs
+        x, origin = K.motion_input(motion, visual if self.with_video else None, c.rotate_motion,
+                                   zero_visual=bool(c._only_motion and self.with_video))
+        if c._only_motion and not self.with_video:  # the ablation zeroes the LAST feature group: here the motion itself
+            x = torch.zeros_like(x)
+        if getattr(self, "_keep_gps_input", False):
+            self._gps_input = x  # cut point of the engine's two-stage backward (GPS backbone first)
+        hook = self.__dict__.get("_before_gps_backbone")
+        if hook is not None:  # engine: the backbone's parameters may still be in flight on another stream
+            hook()
+        out = self.gps_backbone(x)
+        if c.decoder_mode == "recursive":
+            out = out + (x[:, -1:, :] if c.dense_prediction else x[:, -1:, :2])
+        if c.rotate_motion:
+            out = K.rotate_head(out, origin)
         return out, None
 
     # ------------------------------------------------------------------------------------------

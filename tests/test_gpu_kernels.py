@@ -447,6 +447,42 @@ def test_pointwise_bf16(M, cin, cout, res):
     assert rel_err(y[:M].float(), ref) < 6e-3
 
 
+@pytest.mark.parametrize("B,T,P,E,rot", [(8, 40, 30, 64, True), (3, 7, 5, 0, True), (2, 40, 30, 16, False)])
+def test_motion_input_and_rotate_head(B, T, P, E, rot):
+    """rf_motion_input / rf_rotate_head against the elementwise formulation of routeformer.py:210-233 (angle, norm,
+    acceleration, rotation by -origin, concat; output un-rotation), values and gradients."""
+    from routeformer_amd import kernels as Kn
+    from routeformer_amd.utils.tensor import estimate_angle_and_norm, rotate
+    g = _g(B * T + E)
+    motion = torch.randn(B, T, 2, generator=g).to(DEV)
+    vis = torch.randn(B, T, E, generator=g).to(DEV).requires_grad_() if E else None
+    angle, norm = estimate_angle_and_norm(motion)
+    origin = angle[:, -1:, :] if rot else angle[:, :1, :]
+    feats = [torch.cat([rotate(motion, -origin) if rot else motion, (angle - origin) / torch.pi, norm,
+                        F.pad(norm[:, 1:, :] - norm[:, :-1, :], (0, 0, 1, 0))], dim=-1)]
+    if E:
+        feats.append(vis)
+    ref = torch.cat(feats, dim=-1)
+    vis2 = vis.detach().clone().requires_grad_() if E else None
+    x, org = Kn.motion_input(motion, vis2, rot)
+    assert torch.allclose(x, ref, rtol=1e-5, atol=1e-6) and torch.allclose(org, origin.reshape(B), rtol=1e-6, atol=1e-6)
+    if E:
+        w = torch.randn(ref.shape, generator=g).to(DEV)
+        (ref * w).sum().backward()
+        (x * w).sum().backward()
+        assert torch.equal(vis2.grad, vis.grad)
+        assert torch.equal(Kn.motion_input(motion, vis2, rot, True)[0][..., 5:], torch.zeros_like(vis2))  # _only_motion
+    out = torch.randn(B, P, 2 + E, generator=g).to(DEV).requires_grad_()
+    out2 = out.detach().clone().requires_grad_()
+    ref_y = torch.cat([rotate(out[:, :, :2], origin), out[:, :, 2:]], dim=-1)
+    y = Kn.rotate_head(out2, org)
+    assert torch.allclose(y, ref_y, rtol=1e-5, atol=1e-6)
+    w = torch.randn(ref_y.shape, generator=g).to(DEV)
+    (ref_y * w).sum().backward()
+    (y * w).sum().backward()
+    assert torch.allclose(out2.grad, out.grad, rtol=1e-5, atol=1e-6)
+
+
 def test_vision_helpers():
     from routeformer_amd import _hip, kernels as Kn
     from routeformer_amd.models.video_backbone.hrnet16 import HRNet16Backbone
