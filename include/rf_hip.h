@@ -91,6 +91,13 @@ int rf_conv2d_nhwc(const void* x, const float* w, const float* bias, const void*
 int rf_conv3x3_bf16_supported(int cin, int cout);
 int64_t rf_conv3x3_packed_elems(int cin, int cout);
 int rf_conv3x3_pack_bf16(const float* w, void* w_packed, int cin, int cout, void* stream);
+/* The same convolution step of up to four independent maps in ONE launch (the branches of an HRNet module, cin ==
+ * cout in {16,32,64,128}); entries as for rf_conv3x3_bf16, all maps in the same act_dtype. */
+typedef struct RfConvEntry {
+  const void* x; const void* w_packed; const float* bias; const void* residual; void* y;
+  int N, H, W, cin, cout, relu;
+} RfConvEntry;
+int rf_conv3x3_group_bf16(const RfConvEntry* entries, int count, int act_dtype, void* stream);
 int rf_conv3x3_bf16(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,
                     int act_dtype, int N, int H, int W, int cin, int cout, int relu, void* stream);
 

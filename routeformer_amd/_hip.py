@@ -24,6 +24,7 @@ SIGNATURES = {
     "rf_conv3x3_bf16_supported": [_I, _I],
     "rf_conv3x3_packed_elems": [_I, _I],
     "rf_conv3x3_pack_bf16": [_P, _P, _I, _I, _P],
+    "rf_conv3x3_group_bf16": [_P, _I, _I, _P],
     "rf_conv3x3_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "rf_pointwise_bf16_supported": [_I, _I],
     "rf_pointwise_packed_elems": [_I, _I],
@@ -77,6 +78,12 @@ class WgradEntry(ctypes.Structure):
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("db", c_void_p), ("M", c_int), ("N", c_int),
                 ("K", c_int), ("ld_dy", c_int), ("ld_x", c_int), ("splits", c_int), ("kchunk", c_int),
                 ("exclusive", c_int)]
+
+
+class ConvEntry(ctypes.Structure):
+    """RfConvEntry of include/rf_hip.h."""
+    _fields_ = [("x", c_void_p), ("w_packed", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("y", c_void_p),
+                ("N", c_int), ("H", c_int), ("W", c_int), ("cin", c_int), ("cout", c_int), ("relu", c_int)]
 
 
 class HipLibraryError(RuntimeError):

@@ -37,19 +37,21 @@ namespace {
 constexpr int NT = 256;
 constexpr int TILE = 128;  // output pixels per workgroup (4 waves x 2 MFMA row tiles)
 
+extern __shared__ __attribute__((aligned(16))) __bf16 rf_conv_win[];
+
+// One 128-pixel tile (`tile`) of one convolution; all threads of the workgroup take the same path.
 template <int CIN, int COUT, typename AT>
-__global__ __launch_bounds__(NT) void conv3x3_kernel(const AT* __restrict__ x, const __bf16* __restrict__ wt,
-                                                      const float* __restrict__ bias,
-                                                      const AT* __restrict__ residual, AT* __restrict__ y,
-                                                      int total, int H, int W, int relu) {
+__device__ __forceinline__ void conv3x3_body(const AT* __restrict__ x, const __bf16* __restrict__ wt,
+                                             const float* __restrict__ bias, const AT* __restrict__ residual,
+                                             AT* __restrict__ y, int total, int H, int W, int relu, int tile) {
   constexpr int LDC = CIN + 8;                       // LDS pixel pitch (bf16): odd multiple of 16 B
   constexpr int KSTEPS = (CIN == 16) ? 5 : 9 * (CIN / 32);
   constexpr int NTL = COUT / 16;                     // MFMA column tiles
-  extern __shared__ __attribute__((aligned(16))) __bf16 win[];
+  __bf16* win = rf_conv_win;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const long m0 = (long)blockIdx.x * TILE;
+  const long m0 = (long)tile * TILE;
   const int span = TILE + 2 * W + 2;                 // staged pixels
   const long s0 = m0 - W - 1;                        // raster index of window pixel 0
 
@@ -208,6 +210,44 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(const AT* __restrict__ x, c
 }
 
 template <int CIN, int COUT, typename AT>
+__global__ __launch_bounds__(NT) void conv3x3_kernel(const AT* __restrict__ x, const __bf16* __restrict__ wt,
+                                                      const float* __restrict__ bias,
+                                                      const AT* __restrict__ residual, AT* __restrict__ y,
+                                                      int total, int H, int W, int relu) {
+  conv3x3_body<CIN, COUT, AT>(x, wt, bias, residual, y, total, H, W, relu, (int)blockIdx.x);
+}
+
+// Grouped launch: the same convolution step of up to four INDEPENDENT maps (the branches of an HRNet module:
+// 16 ch @ 28x28, 32 @ 14x14, 64 @ 7x7, 128 @ 4x4) in one launch.  The low-resolution branches are a few dozen
+// workgroups walking a long k-loop (17 us for 42 workgroups at 4x4): launched one after the other they leave the
+// chip idle four times per block, launched together they disappear underneath the 28x28 branch.  Entries are
+// ordered by the host so that the longest-running workgroups (most channels) are dispatched first.
+struct ConvGroup {
+  int count, pad;
+  struct Item {
+    const void* x; const void* w; const float* bias; const void* res; void* y;
+    int total, H, W, relu, cin, first_block;
+  } e[4];
+};
+
+template <typename AT>
+__global__ __launch_bounds__(NT) void conv3x3_group_kernel(const ConvGroup g) {
+  int k = 0;
+  for (int i = 1; i < g.count; ++i)
+    if ((int)blockIdx.x >= g.e[i].first_block) k = i;
+  const ConvGroup::Item& e = g.e[k];
+  const int tile = (int)blockIdx.x - e.first_block;
+  const AT* x = static_cast<const AT*>(e.x);
+  const AT* res = static_cast<const AT*>(e.res);
+  AT* y = static_cast<AT*>(e.y);
+  const __bf16* w = static_cast<const __bf16*>(e.w);
+  if (e.cin == 16) conv3x3_body<16, 16, AT>(x, w, e.bias, res, y, e.total, e.H, e.W, e.relu, tile);
+  else if (e.cin == 32) conv3x3_body<32, 32, AT>(x, w, e.bias, res, y, e.total, e.H, e.W, e.relu, tile);
+  else if (e.cin == 64) conv3x3_body<64, 64, AT>(x, w, e.bias, res, y, e.total, e.H, e.W, e.relu, tile);
+  else conv3x3_body<128, 128, AT>(x, w, e.bias, res, y, e.total, e.H, e.W, e.relu, tile);
+}
+
+template <int CIN, int COUT, typename AT>
 int launch_t(const void* x, const void* wt, const float* bias, const void* residual, void* y, long total, int H,
              int W, int relu, hipStream_t st) {
   size_t lds = (size_t)(TILE + 2 * W + 2) * (CIN + 8) * sizeof(__bf16);
@@ -263,6 +303,45 @@ extern "C" int rf_conv3x3_pack_bf16(const float* w, void* w_packed, int cin, int
   const long total = rf_conv3x3_packed_elems(cin, cout);
   RF_LAUNCH(pack_weights_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      w, static_cast<__bf16*>(w_packed), cin, cout);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_conv3x3_group_bf16(const RfConvEntry* entries, int count, int act_dtype, void* stream) {
+  RF_REQUIRE(entries && count >= 1 && count <= 4 && (act_dtype == RF_ACT_F32 || act_dtype == RF_ACT_BF16));
+  ConvGroup g{};
+  g.count = count;
+  // longest-running workgroups first: more channels = longer k-loop
+  int order[4] = {0, 1, 2, 3};
+  for (int i = 1; i < count; ++i)
+    for (int j = i; j > 0 && entries[order[j]].cin > entries[order[j - 1]].cin; --j) { const int v = order[j]; order[j] = order[j - 1]; order[j - 1] = v; }
+  int blocks = 0;
+  size_t lds = 0;
+  for (int k = 0; k < count; ++k) {
+    const RfConvEntry& e = entries[order[k]];
+    RF_REQUIRE(e.x && e.w_packed && e.bias && e.y && e.N > 0 && e.H > 0 && e.W > 0);
+    RF_REQUIRE(e.cin == e.cout && (e.cin == 16 || e.cin == 32 || e.cin == 64 || e.cin == 128));
+    const long total = (long)e.N * e.H * e.W;
+    RF_REQUIRE(total < (1L << 31));
+    g.e[k].x = e.x; g.e[k].w = e.w_packed; g.e[k].bias = e.bias; g.e[k].res = e.residual; g.e[k].y = e.y;
+    g.e[k].total = (int)total; g.e[k].H = e.H; g.e[k].W = e.W; g.e[k].relu = e.relu; g.e[k].cin = e.cin;
+    g.e[k].first_block = blocks;
+    blocks += (int)((total + TILE - 1) / TILE);
+    size_t need = (size_t)(TILE + 2 * e.W + 2) * (e.cin + 8) * sizeof(__bf16);
+    const size_t patches = (size_t)(NT / 64) * 16 * (e.cout + 4) * sizeof(float);
+    if (need < patches) need = patches;
+    if (lds < need) lds = need;
+  }
+  if (lds > 160 * 1024) { rf_g_last_error = "conv3x3 window exceeds LDS"; return RF_EUNSUPPORTED; }
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_group_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_group_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (act_dtype == RF_ACT_BF16) RF_LAUNCH(conv3x3_group_kernel<__bf16>, dim3(blocks), dim3(NT), lds, st, g);
+  else RF_LAUNCH(conv3x3_group_kernel<float>, dim3(blocks), dim3(NT), lds, st, g);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

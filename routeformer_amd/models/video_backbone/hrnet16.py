@@ -83,6 +83,10 @@ def _conv_units() -> List[Tuple[str, Optional[str], int, int, int]]:
 UNITS = _conv_units()
 
 
+import os as _os
+GROUP_BRANCHES = _os.environ.get("RF_CONV_GROUP", "1") != "0"  # one launch per conv step of an HRNet module's branches
+
+
 def pack_conv3x3_weights(w_khwc: torch.Tensor) -> torch.Tensor:
     """(cout, 3, 3, cin) fp32 device tensor -> the bf16 fragment-order buffer rf_conv3x3_bf16 consumes."""
     cout, _, _, cin = w_khwc.shape
@@ -229,6 +233,25 @@ class HRNet16Backbone(VideoBackboneModule):
                           es * (x.numel() + M * cout * (2 if residual is not None else 1)) + 4.0 * w.numel())
         return y
 
+    def _conv_group(self, W, units, xs, residuals):
+        """relu(conv3x3(x_b) + bias_b [+ residual_b]) for every branch b in one launch."""
+        n = len(units)
+        arr = (_hip.ConvEntry * n)()
+        ys = []
+        for i, (unit, x) in enumerate(zip(units, xs)):
+            w, b, cin, cout, k, wb = W[unit]
+            N, H, Wd, C = x.shape
+            assert C == cin and k == 3 and wb is not None and x.is_contiguous()
+            y = torch.empty(N, H, Wd, cout, device=x.device, dtype=x.dtype)
+            r = None if residuals is None else residuals[i]
+            assert r is None or (r.dtype == x.dtype and r.shape == y.shape and r.is_contiguous())
+            e = arr[i]
+            e.x, e.w_packed, e.bias, e.residual, e.y = ptr(x), ptr(wb), ptr(b), ptr(r), ptr(y)
+            e.N, e.H, e.W, e.cin, e.cout, e.relu = N, H, Wd, cin, cout, 1
+            ys.append(y)
+        check(_hip.lib().rf_conv3x3_group_bf16(arr, n, self._act_code(xs[0]), K._stream()), "rf_conv3x3_group_bf16")
+        return ys
+
     @classmethod
     def _upsample(cls, x, size, *, addend=None, out=None, ldy=None, accumulate=False, relu=False):
         """``out``: tensor, or a raw device address of maps stored in x's dtype."""
@@ -267,9 +290,22 @@ class HRNet16Backbone(VideoBackboneModule):
         (hrnetv2.py:250-277), summing terms in the reference's order j = 0..nb-1, ReLU on the last."""
         nb = len(xs)
         xs = list(xs)
-        for b in range(nb):
+        if GROUP_BRANCHES and nb > 2 and K._PRECISION == 1 and all(W[f"{p}.branches.{b}.0.conv1"][5] is not None for b in range(nb)):
+            # the same conv step of the LOW-RESOLUTION branches in one launch (rf_conv3x3_group_bf16): each is a few
+            # dozen latency-bound workgroups (17 us for 42 workgroups at 4x4) that would otherwise leave the chip idle
+            # one after the other.  The 28x28 branch keeps its own launch: a group shares one LDS size and one
+            # register budget, and with the 128-channel window every 16-channel workgroup loses half its occupancy
+            # (all four together: trunk 2.66 -> 3.00 ms).
+            lo = list(range(1, nb))
             for k in range(BLOCKS_PER_BRANCH):
-                xs[b] = self._basic(W, f"{p}.branches.{b}.{k}", xs[b])
+                y0 = self._conv(W, f"{p}.branches.0.{k}.conv1", xs[0], relu=True)
+                ys = self._conv_group(W, [f"{p}.branches.{b}.{k}.conv1" for b in lo], [xs[b] for b in lo], None)
+                x0 = self._conv(W, f"{p}.branches.0.{k}.conv2", y0, relu=True, residual=xs[0])
+                xs = [x0] + self._conv_group(W, [f"{p}.branches.{b}.{k}.conv2" for b in lo], ys, [xs[b] for b in lo])
+        else:
+            for b in range(nb):
+                for k in range(BLOCKS_PER_BRANCH):
+                    xs[b] = self._basic(W, f"{p}.branches.{b}.{k}", xs[b])
         outs = []
         for i in range(nb):
             size = tuple(xs[i].shape[1:3])
