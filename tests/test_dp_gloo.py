@@ -72,6 +72,64 @@ def test_bucketed_allreduce_matches_replica_mean():
     assert torch.allclose(g0, (grads[0] + grads[1]) / 2, atol=1e-6)
 
 
+def _worker_prefix(rank, world, port, out):
+    """The graph-replay protocol: no hooks; after "stage 1" the buckets made up only of one sub-module's parameters go
+    out early (launch_complete_prefix), the rest in finish(); neighbouring buckets leave as ONE collective."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from routeformer_amd.engine import GradReducer
+    torch.manual_seed(0)
+    net = _Net()
+    red = GradReducer(list(net.parameters()), bucket_mb=0.0001)
+    red.hooks_enabled = False
+    red.broadcast_parameters(0)
+    names = {id(p): n for n, p in net.named_parameters()}
+    calls = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **kw):
+        calls.append(t.numel())
+        return real(t, *a, **kw)
+
+    dist.all_reduce = counting
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        x = torch.randn(5, 8, generator=g)
+        red.zero()
+        net(x).square().sum().backward()
+        assert not calls, "no collective may go out from hooks in this mode"
+        early = red.launch_complete_prefix(names, "c.")  # the last layer's gradients are final first
+        n_early = len(calls)
+        scale = red.finish()
+    finally:
+        dist.all_reduce = real
+    out[rank] = (torch.cat([(p.grad * scale).reshape(-1) for p in net.parameters()]), early, n_early, len(calls),
+                 len(red.buckets), sum(calls), red.flat_grad.numel())
+    dist.destroy_process_group()
+
+
+def test_prefix_launch_and_run_coalescing():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_prefix, args=(world, port, out), nprocs=world, join=True)
+        r0, r1 = out[0], out[1]
+    assert torch.equal(r0[0], r1[0]), "ranks disagree after all-reduce"
+    _, early, n_early, n_calls, n_buckets, elems, total = r0
+    assert early >= 1 and n_early == 1, "the prefix buckets are neighbours: one collective"
+    assert n_calls == 2 and n_buckets >= 3, "the remaining buckets are neighbours too: one more collective"
+    assert elems == total, "every element reduced exactly once"
+    torch.manual_seed(0)
+    ref = _Net()
+    grads = []
+    for rank in range(world):
+        x = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + rank))
+        ref.zero_grad()
+        ref(x).square().sum().backward()
+        grads.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ref.parameters()]))
+    assert torch.allclose(r0[0], (grads[0] + grads[1]) / 2, atol=1e-6)
+
+
 def test_single_process_reducer_is_a_noop():
     from routeformer_amd.engine import GradReducer
     net = _Net()

@@ -139,3 +139,29 @@ def test_product_refuses_cpu_execution():
     model, cfg, sd, c = build_product_model("c1_default")
     with pytest.raises(_hip.HipLibraryError):
         model({"gps": torch.zeros(4, 10, 2)})
+
+
+def test_split_k_heuristics():
+    """Split-K choices for the step's small-M GEMMs (tools/splitk_sweep.py picked them on the GPU): no split once the
+    tiles alone reach ~half the chip, ~256 workgroups for a one-d_model-deep reduction, ~512 for a deep one."""
+    from routeformer_amd import kernels as K
+    assert K._auto_split(12480, 128, 128) == 1            # plenty of tiles
+    assert K._auto_split(320, 2496, 832) == 1             # 195 tiles
+    assert K._auto_split(320, 832, 832) == 3              # 65 tiles, shallow
+    assert K._auto_split(320, 832, 3328) == 8             # 65 tiles, deep
+    assert K._auto_split(40, 2496, 832) == 6              # capped by >= 128 of depth per slice
+    assert K._auto_split(560, 66, 832) in (6,)            # skinny output
+    assert all(1 <= K._auto_split(m, n, k) <= 16 for m in (5, 40, 320, 560) for n in (64, 832, 3328) for k in (128, 832, 3328))
+    assert K._splits(4, 12480) == 64 and K._splits(169, 560) == 4 and K._splits(1000, 560) == 1
+
+
+def test_fused_adamw_hyper_vector():
+    """The device-side hyper-parameter vector of the graph-replayed update (rf_adamw_clip_dev layout)."""
+    import torch
+    from routeformer_amd.engine import FusedAdamW
+    opt = FusedAdamW.__new__(FusedAdamW)
+    opt.betas, opt.eps, opt.wd, opt.max_norm, opt.param_groups, opt.t = (0.9, 0.999), 1e-8, 1e-4, 2.5, [{"lr": 3e-4}], 7
+    h = opt.hyper(0.125)
+    assert len(h) == 10 and h[0] == 1.0 and h[1] == 2.5 and h[2] == 3e-4 and h[9] == 0.125
+    assert abs(h[7] - (1 - 0.9 ** 7)) < 1e-12 and abs(h[8] - (1 - 0.999 ** 7) ** 0.5) < 1e-12
+    assert opt.hyper(1.0, pending=False)[0] == 0.0
