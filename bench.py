@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- samples/s of one full Routeformer train step on synthetic GEM-shaped batches.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -57,10 +57,10 @@ def make_item(c, rank, device=None, case_id=2):
     return item
 
 
-def cpu_baseline(cfg, sd, c, steps=2):
+def cpu_baseline(cfg, sd, c, steps=10, warm=3):
     """The CPU oracle (kind "port": our restatement of the reference, pinned to the reference's golden
-    vectors) doing the SAME full train step on the host cores.  Bounded sample: `steps` steps of the B=8
-    workload after one warm-up step is skipped (first step is included in no average)."""
+    vectors) doing the SAME full train step on the host cores.  Bounded sample: `warm` untimed
+    steps, then `steps` timed steps of the B=8 workload; the MEDIAN step time is reported."""
     from oracle import routeformer_oracle as O
     # the GPU box gives a 16-core share per GPU (cpu_count() reports the whole host): oversubscribing stalls
     cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
@@ -71,7 +71,7 @@ def cpu_baseline(cfg, sd, c, steps=2):
     train = [p for p in params.values() if p.requires_grad]
     opt = torch.optim.AdamW(train, lr=cfg.lr, weight_decay=cfg.wd)
     times = []
-    for i in range(steps + 1):
+    for i in range(warm + steps):
         t0 = time.perf_counter()
         torch.manual_seed(i)
         orc = O.OracleRouteformer(cfg, params, training=True)
@@ -81,11 +81,95 @@ def cpu_baseline(cfg, sd, c, steps=2):
         torch.nn.utils.clip_grad_norm_(train, 2.5)
         opt.step()
         times.append(time.perf_counter() - t0)
-        print(f"[cpu_baseline] step {i}: {times[-1]:.2f} s on {cores} threads", file=sys.stderr, flush=True)
-    dt = sum(times[1:]) / steps
+        print(f"[cpu_baseline] step {i}{' (warm-up)' if i < warm else ''}: {times[-1]:.2f} s on {cores} threads",
+              file=sys.stderr, flush=True)
+    timed = sorted(times[warm:])
+    dt = timed[len(timed) // 2] if len(timed) % 2 else 0.5 * (timed[len(timed) // 2 - 1] + timed[len(timed) // 2])
     return {"value": c["B"] / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} full train steps (after 1 warm-up) of the same C2 batch-{c['B']} workload, "
-                      f"fp32, torch CPU oracle, {dt:.2f} s/step"}
+            "sample": f"median of {steps} full train steps (after {warm} warm-up steps) of the same C2 batch-{c['B']} "
+                      f"workload, fp32, torch CPU oracle, {dt:.2f} s/step (min {timed[0]:.2f}, max {timed[-1]:.2f})"}
+
+
+def ade_vs_cpu_ref(model, cfg, item, precision, n=2, seed=1234):
+    """BASELINE.json's second metric, "ADE vs CPU ref": the mean L2 distance in METRES between the trajectories this
+    model (HIP kernels, its current weights) and the CPU oracle (same weights, same seed -> same host-RNG key
+    samples) predict for the first `n` samples of the bench batch, eval mode.  Per arithmetic mode (fp32 MFMA /
+    bf16 MFMA) with the ProbSparse top-u selections free-running and with the oracle's selections imposed (the
+    selection is discontinuous: DESIGN.md section 2).  Outside the timed region."""
+    from oracle import routeformer_oracle as O
+    from routeformer_amd import kernels as K
+    sub = {k: v[:n] for k, v in item["train"].items()}
+    sd = {k: v.detach().float().cpu().clone() if v.is_floating_point() else v.detach().cpu().clone()
+          for k, v in model.state_dict().items()}
+    src = O.IndexSource()
+    torch.manual_seed(seed)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = O.OracleRouteformer(cfg, sd, training=False, idx=src).forward({k: v.cpu() for k, v in sub.items()})
+    pos_o = (out[0] if isinstance(out, tuple) else out).double()
+    cpu_s = time.perf_counter() - t0
+    was_training = model.training
+    model.eval()
+    res = {"samples": n, "unit": "m", "trajectory_scale_m": float(pos_o.abs().max()), "cpu_forward_s": round(cpu_s, 2)}
+    try:
+        for prec in ("f32", "bf16"):
+            K.set_precision(prec)
+            for forced in (False, True):
+                K.TOPS.forced = [t.clone() for t in src.tops] if forced else None
+                torch.manual_seed(seed)
+                with torch.no_grad():
+                    o = model(sub)
+                pos = (o[0] if isinstance(o, tuple) else o).double().cpu()
+                d = (pos - pos_o).norm(dim=-1)
+                res[f"{prec}_{'imposed' if forced else 'free'}"] = {"ade": float(d.mean()), "max": float(d.max())}
+    finally:
+        K.TOPS.forced = None
+        K.set_precision(precision)
+        model.train(was_training)
+    return res
+
+
+def batch_independence(model, item, seed=4321):
+    """Eval-mode `future_gps` of sample 0 of the bench batch vs the same sample forwarded alone with the same seed
+    (per-sample ops, BatchNorm on running statistics, one shared key-sample table per call as in the reference):
+    max |difference| relative to the trajectory scale.  The timed weights, the timed batch."""
+    was_training = model.training
+    model.eval()
+    try:
+        outs = []
+        for bt in (item["train"], {k: v[:1] for k, v in item["train"].items()}):
+            torch.manual_seed(seed)
+            with torch.no_grad():
+                o = model(bt)
+            outs.append((o[0] if isinstance(o, tuple) else o)[0].double())
+    finally:
+        model.train(was_training)
+    return float((outs[0] - outs[1]).abs().max() / max(1.0, float(outs[0].abs().max())))
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start N rank processes of this script
+    through torch.distributed.run (fresh children -- this parent has not touched the GPU and never does), relay
+    rank 0's JSON line, return the children's status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 else (0 if line is not None else 1)
 
 
 def main():
@@ -97,9 +181,12 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (N=1)")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--no-ade", action="store_true", help="skip the ADE-vs-CPU-reference leg (N=1, rank 0)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -142,6 +229,8 @@ def main():
     # two different synthetic batches, used alternately: the engine's look-ahead (conv trunk of the NEXT
     # batch under the current step) then always works on data it has not seen in this step
     items = [make_item(c, rank, device), make_item(c, rank + 500, device)]
+    for i, it in enumerate(items):
+        it["id"] = i  # explicit batch ids: the engine's look-ahead never keys on tensor addresses
     item = items[0]
     note("model + 2 synthetic batches resident in HBM")
     use_graph = not args.no_graph
@@ -151,24 +240,38 @@ def main():
     defer = os.environ.get("RF_DEFER_UPDATE", "0") == "1"
     engine = GraphedTrainEngine(model, defer_update=defer) if use_graph else TrainEngine(model)
     if use_graph:
-        # capture once up front; fall back step by step (same arithmetic and the same collective order in every
-        # mode): two-graph step (N > 1) -> one graph -> eager launches
+        # capture once up front; fall back step by step: two-graph step (N > 1) -> one graph -> eager launches.
+        # The decision is COLLECTIVE (a rank that failed alone would otherwise issue a different sequence of
+        # collectives than its peers: engine construction broadcasts the parameters): every rank reports, the MAX
+        # is all-reduced, and all ranks switch mode together.
         from routeformer_amd.models.blocks import SAMPLER
+
+        def any_rank_failed(failed: bool) -> bool:
+            if not multi:
+                return failed
+            flag = torch.tensor([1.0 if failed else 0.0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            return bool(flag.item() > 0)
+
         for attempt in ("as configured", "single graph"):
+            failed = False
             try:
                 engine.capture(item, epoch=10)
-                break
             except Exception as exc:  # noqa: BLE001
-                print(f"[bench] HIP-graph capture failed ({attempt}; {type(exc).__name__}: {exc})", file=sys.stderr, flush=True)
-                SAMPLER.drop_static()
-                if attempt == "as configured" and engine.split:
-                    engine = GraphedTrainEngine(model, defer_update=defer)
-                    engine.split = False
-                else:
-                    print("[bench] using eager launches", file=sys.stderr, flush=True)
-                    use_graph = False
-                    engine = TrainEngine(model)
-                    break
+                failed = True
+                print(f"[bench r{rank}] HIP-graph capture failed ({attempt}; {type(exc).__name__}: {exc})", file=sys.stderr,
+                      flush=True)
+            if not any_rank_failed(failed):
+                break
+            SAMPLER.drop_static()
+            if attempt == "as configured" and engine.split:
+                engine = GraphedTrainEngine(model, defer_update=defer)
+                engine.split = False
+            else:
+                print(f"[bench r{rank}] using eager launches", file=sys.stderr, flush=True)
+                use_graph = False
+                engine = TrainEngine(model)
+                break
 
     def sync():
         torch.cuda.synchronize()
@@ -199,13 +302,20 @@ def main():
         from routeformer_amd.models.blocks import SAMPLER
         SAMPLER.rewind_static()
         K.PROFILE.enable()
-        engine._eager_fwd_bwd(item, 10)
+        engine._eager_fwd_bwd(engine._static_item, 10)
         K.PROFILE.disable()
     if multi:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
     assert torch.isfinite(res["loss"]).item(), "loss is not finite"
+    for k in ("ade", "fde"):
+        assert torch.isfinite(res[k]).all().item(), f"{k} is not finite"
+    rccl_ranks = dist.get_world_size() if multi else 1
+    # more than "finite": the timed model must treat the samples of its batch independently (eval forward of sample
+    # 0 inside the batch == the same sample alone, same seed) -- bound: the bf16 tolerance north_star states
+    indep = batch_independence(model, item)
+    assert indep < 1e-2, f"sample 0 of the bench batch depends on its batch mates: rel diff {indep:.3e}"
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -239,17 +349,23 @@ def main():
             mfma_bound = (flops / max(nbytes, 1)) > (peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9))
             # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
             # separately, gfx950 x2 read correction applied; bench.py itself cannot collect counters)
-            traffic = None
+            traffic, traffic_src = None, None
             try:
-                with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
-                    traffic = json.load(fh)["kernels"].get(name, {}).get("hbm_bytes_per_launch")
+                for rnd in ("r02", "r01"):  # the newest committed PMC pass that knows this kernel
+                    path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+                    if os.path.exists(path):
+                        with open(path) as fh:
+                            traffic = json.load(fh)["kernels"].get(name, {}).get("hbm_bytes_per_launch")
+                        if traffic is not None:
+                            traffic_src = f"profiles/{rnd}/pmc_traffic.json"
+                            break
             except (OSError, ValueError, KeyError):
                 pass
             roof = {"kernel": name + " (librf_hip.so, anonymous namespace)", "bound": "mfma" if mfma_bound else "hbm",
                     "achieved": tfl if mfma_bound else gbs, "peak": peak_tf if mfma_bound else HBM_PEAK_GBS,
                     "unit": "TFLOP/s" if mfma_bound else "GB/s",
                     "frac": (tfl / peak_tf) if mfma_bound else (gbs / HBM_PEAK_GBS), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r01/pmc_traffic.json)",
+                    "traffic_unit": f"HBM bytes per launch (PMC, {traffic_src})",
                     "algorithmic_bytes_per_launch": nbytes / launches, "launches_per_step": launches, "avg_us": avg_s * 1e6,
                     "flop_per_byte": flops / max(nbytes, 1), "alt_tflops": tfl, "alt_gbs": gbs,
                     "eager_event_ms_by_kernel": {k: round(v["total_ms"], 3) for k, v in ranked[:12]}}
@@ -265,10 +381,13 @@ def main():
                        "step": "fwd + target-feature fwd + losses + bwd + grad all-reduce + clip + AdamW",
                        "launch": ("hipGraph replay of fwd+bwd" + (" (+ the previous step's clip/AdamW at its head)" if defer else ""))
                        if use_graph else "eager launches"},
-            "loss": float(res["loss"]), "roofline": roof,
+            "loss": float(res["loss"].detach()), "rccl_ranks": rccl_ranks, "batch_independence_rel": indep,
+            "roofline": roof,
         }
         if rehearse:
             out["config"]["rehearsal"] = "one-rank RCCL group, N>1 code path (RF_REHEARSE_COLLECTIVES=1)"
+        if world == 1 and not rehearse and not args.no_ade and cfg.with_video:
+            out["ade_vs_cpu_ref"] = ade_vs_cpu_ref(model, cfg, item, args.precision)
         if world == 1 and not args.no_cpu_baseline and not rehearse:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, c, args.cpu_steps)
         print(json.dumps(out))

@@ -501,8 +501,10 @@ class GraphedTrainEngine(TrainEngine):
         self.graph = None
         self._static_item = None
         self._out = None
-        self._trunk_graphs = {}
-        self._ready_key = None
+        self._trunk_g = None
+        self._ready_id = None
+        self._clip_stage = self._clip_idx = None
+        self._recipe = None
         self._tstream = None
         # N > 1: capture the step as two graphs so that the gradient all-reduce of the GPS backbone overlaps the
         # rest of the backward pass (RF_SPLIT_BWD=1 forces it at N = 1, =0 disables it)
@@ -590,25 +592,47 @@ class GraphedTrainEngine(TrainEngine):
         return self
 
     # -- conv-trunk side ---------------------------------------------------------------------------
-    def _vkey(self, item):
+    # The trunk graphs never read a caller's tensors: the frames a pass needs (the sub-sampled ones, 8 of 40 per
+    # clip) are gathered into staging buffers the engine owns, and every graph is captured on those.  A loader
+    # may therefore hand over freshly allocated device tensors every step, or refill its own buffers as soon as
+    # ``step`` returns: the number of captured graphs stays at three (trunk alone, step, step + look-ahead trunk)
+    # and nothing is keyed by ``data_ptr``.  The copy is ~100 MB per step at C2 (0.03 ms).
+    def _alloc_clip_stage(self, item):
         clips, _ = self.model.video_clips([item["train"], item["target"]])
-        return tuple(v.data_ptr() for v, _ in clips)
+        self._clip_stage = [torch.empty((v.shape[0], idx.numel()) + tuple(v.shape[2:]), device=v.device, dtype=v.dtype)
+                            for v, idx in clips]
+        self._clip_idx = [idx.to(v.device) for v, idx in clips]
 
-    def _trunk_graph(self, item):
-        """Graph of one trunk pass over ``item``'s frames into ``self._tok_next`` (captured once per set of
-        input buffers: a data pipeline that rotates a few pinned device buffers hits the cache)."""
-        key = self._vkey(item)
-        g = self._trunk_graphs.get(key)
-        if g is None:
-            clips, _ = self.model.video_clips([item["train"], item["target"]])
-            self.model.video_backbone.encode_clips(clips, out=self._tok_next)  # warm (weight folding, caches)
+    def _stage_clips(self, item):
+        """Gather the frames of ``item`` the trunk reads into the engine's staging buffers (current stream)."""
+        clips, _ = self.model.video_clips([item["train"], item["target"]])
+        assert len(clips) == len(self._clip_stage), "the batch has a different set of camera streams than the captured one"
+        for (v, _), dst, idx in zip(clips, self._clip_stage, self._clip_idx):
+            if v.dtype != dst.dtype or v.shape[0] != dst.shape[0] or v.shape[2:] != dst.shape[2:]:
+                raise ValueError(f"clip {tuple(v.shape)} {v.dtype} does not match the captured step "
+                                 f"({tuple(dst.shape)} {dst.dtype}): capture() again for a new batch shape")
+            torch.index_select(v, 1, idx, out=dst)
+
+    def _staged(self):
+        return [(t, None) for t in self._clip_stage]  # frame index None = every staged frame
+
+    def _trunk_graph(self):
+        """Graph of one trunk pass over the staged frames into ``self._tok_next`` (cold start / no look-ahead)."""
+        if self._trunk_g is None:
+            self.model.video_backbone.encode_clips(self._staged(), out=self._tok_next)  # warm (weight folding, caches)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, **_capture_kw()):
-                self.model.video_backbone.encode_clips(clips, out=self._tok_next)
-            self._trunk_graphs[key] = (g, clips)  # keep the clip tensors alive: the graph reads them
-            g = self._trunk_graphs[key]
-        return g[0]
+                self.model.video_backbone.encode_clips(self._staged(), out=self._tok_next)
+            self._trunk_g = g
+        return self._trunk_g
+
+    def _recipe_for(self, epoch: int):
+        """What the captured loss arithmetic depends on besides the tensors: the dense-loss switch (epoch >= 10,
+        full_comparison.py:500-505) and the discount in force at ``epoch`` (losses/future_discounted_mse.py:71-74;
+        rf_traj_head takes gamma by value, so it is baked into the graph)."""
+        self.tl.current_epoch = self.dl.current_epoch = epoch
+        return (epoch >= 10, float(self.tl.discount()), float(self.dl.discount()))
 
     def capture(self, item, epoch: int = 0, warmup: int = 2):
         from routeformer_amd import kernels as K
@@ -623,11 +647,13 @@ class GraphedTrainEngine(TrainEngine):
             self._hyper = torch.zeros(16, device=dev, dtype=torch.float32)  # "nothing pending" during the warm-up passes
             self._hyper_pinned = torch.zeros(16, dtype=torch.float32).pin_memory()
             self._gps_range = self._backbone_range()
-        # static inputs of the main graph: private copies of the small tensors (gps, gaze); the video
-        # tensors are only consulted for shapes / cache keys while capturing (the trunk has its own graphs)
-        self._static_item = {part: {n: (v if v.dim() == 5 else v.clone()) for n, v in d.items()}
-                             for part, d in item.items()}
         self._pipelined = self.overlap and bool(self.model.video_clips([item["train"], item["target"]])[0])
+        # static inputs of the main graph: private copies of every tensor.  Pipelined engine: the video tensors are
+        # only consulted for shapes / cache keys inside the main graph (the trunk reads the staging buffers), so
+        # they are kept by reference; otherwise the captured trunk reads them and they are copied like gps / gaze.
+        self._static_item = {part: {n: (v if (v.dim() == 5 and self._pipelined) else v.clone()) for n, v in item[part].items()}
+                             for part in ("train", "target")}
+        self._trunk_g = None
         # plan: which draws does one step make?
         plan = None
         side = torch.cuda.Stream()
@@ -649,28 +675,31 @@ class GraphedTrainEngine(TrainEngine):
             self._tok_cur = torch.empty(n, 65, 240, device=dev, dtype=torch.float32)
             self._tok_next = torch.empty_like(self._tok_cur)
             self._tstream = torch.cuda.Stream()
-            self._trunk_graph(item).replay()
+            self._alloc_clip_stage(item)
+            self._stage_clips(item)
+            self._trunk_graph().replay()
             self._tok_cur.copy_(self._tok_next)
             self.model.set_video_tokens(self._tok_cur, clips, keys)
             torch.cuda.synchronize()
         self._epoch = epoch
+        self._recipe = self._recipe_for(epoch)
         self._graphs = {}
-        self.graph, self._out = self._main_graph(None)
-        self._ready_key = None
+        self.graph, self._out = self._main_graph(False)
+        self._ready_id = None
         return self
 
-    def _main_graph(self, next_item):
-        """Graph of forward + backward on the static inputs.  With ``next_item`` the conv-trunk pass of that
-        batch is a parallel branch of the SAME graph (forked stream, writes ``_tok_next``): two separate
-        graphs launched on two streams do not overlap on ROCm 7.2 (measured: 14.2 + 5.4 = 19.5 ms), branches
-        of one graph do."""
-        key = None if (next_item is None or not self._pipelined) else self._vkey(next_item)
+    def _main_graph(self, lookahead: bool):
+        """Graph of forward + backward on the static inputs.  With ``lookahead`` the conv-trunk pass over the
+        staged frames of the NEXT batch is a parallel branch of the SAME graph (forked stream, writes
+        ``_tok_next``): two separate graphs launched on two streams do not overlap on ROCm 7.2 (measured:
+        14.2 + 5.4 = 19.5 ms), branches of one graph do."""
+        key = True if (lookahead and self._pipelined) else None
         hit = self._graphs.get(key)
         if hit is not None:
             return hit[0], hit[1]
         clips = None
         if key is not None:
-            clips, _ = self.model.video_clips([next_item["train"], next_item["target"]])
+            clips = self._staged()
             self.model.video_backbone.encode_clips(clips)  # warm caches outside capture (scratch output)
         if self._pipelined:
             c0, k0 = self.model.video_clips([self._static_item["train"], self._static_item["target"]])
@@ -711,26 +740,43 @@ class GraphedTrainEngine(TrainEngine):
             del carry
             g = (g, g2)
         self.model.clear_video_tokens()
-        self._graphs[key] = (g, out, clips)
+        self._graphs[key] = (g, out)
         return g, out
 
     def step(self, item, epoch: int = 0, next_item=None):
         """One train step on ``item``; ``next_item`` (optional) = the batch of the following step, whose
-        conv-trunk pass runs underneath this step (a parallel branch of the replayed graph)."""
+        conv-trunk pass runs underneath this step (a parallel branch of the replayed graph).
+
+        Batches are told apart by an explicit ``item["id"]`` (any hashable), never by tensor addresses: the trunk
+        tokens computed ahead for ``next_item`` are used by the following call only if its ``item`` carries the same
+        id; without ids every step runs its own trunk pass first (correct, just not pipelined)."""
         from routeformer_amd.models.blocks import SAMPLER
         if self.graph is None:
             self.capture(item, epoch)
-        assert epoch == self._epoch or (epoch >= 10) == (self._epoch >= 10), "re-capture when the loss recipe changes"
-        g, out = self._main_graph(next_item)  # (captures on first use of a new look-ahead buffer set)
+        recipe = self._recipe_for(epoch)
+        if recipe != self._recipe:
+            # dense-loss switch (epoch 10) or a new discount (a key of ``discount_factor``): the loss arithmetic in
+            # the captured graphs is stale -- capture the main graphs again on the same static buffers
+            torch.cuda.synchronize()
+            self._graphs.clear()
+            self._epoch, self._recipe = epoch, recipe
+            self.graph, self._out = self._main_graph(False)
+        g, out = self._main_graph(next_item is not None)
         if self._pipelined:
-            if not (self._ready_key is not None and self._ready_key == self._vkey(item)):
-                self._trunk_graph(item).replay()         # cold start / no look-ahead: run this batch's trunk now
+            iid = item.get("id")
+            if not (self._ready_id is not None and iid is not None and iid == self._ready_id):
+                self._stage_clips(item)                   # cold start / no look-ahead: run this batch's trunk now
+                self._trunk_graph().replay()
             self._tok_cur.copy_(self._tok_next)
-            self._ready_key = None
+            self._ready_id = None
+            if next_item is not None:
+                self._stage_clips(next_item)
         for part in ("train", "target"):
             for n, v in item[part].items():
                 dst = self._static_item[part][n]
-                if v.dim() != 5 and v.data_ptr() != dst.data_ptr():
+                if v.dim() == 5 and self._pipelined:
+                    continue  # the main graph reads trunk tokens, not clips
+                if v.data_ptr() != dst.data_ptr():
                     dst.copy_(v, non_blocking=True)
         SAMPLER.refill_static()
         self.reducer.begin_step()  # the replay does not run the Python bookkeeping of zero()
@@ -744,7 +790,7 @@ class GraphedTrainEngine(TrainEngine):
         else:
             g.replay()
         if self._pipelined and next_item is not None:
-            self._ready_key = self._vkey(next_item)
+            self._ready_id = next_item.get("id")
         scale = self.reducer.finish()
         if self.defer_update:
             self.opt.t += 1

@@ -34,3 +34,19 @@ def test_two_rank_engines_agree(tmp_path):
         d = (res[m]["flat"] - ref).abs()
         assert float(d.max() / ref.abs().max()) < 5e-3, (m, float(d.max()))   # <= a few Adam steps of lr
         assert float(d.mean() / ref.abs().mean()) < 1e-4, (m, float(d.mean()))  # ... on a handful of parameters
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment starts its two rank processes itself (fresh children;
+    the parent never touches the GPU), prints exactly one JSON line and reports the size of the process group.
+    Here the two ranks share the one GPU over gloo (RF_DIST_BACKEND); on a node the same path runs over RCCL."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--case", "c2_small", "--precision", "f32"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0 and out["config"]["global_batch"] == 4

@@ -313,6 +313,41 @@ def test_attention_packed_self_and_forced_top():
     assert rel_err(ctx2, exp) < 3e-5
 
 
+@pytest.mark.parametrize("B,groups,L,E,masked,factor", [
+    (192, 3, 65, 16, False, 5),   # 1 536 problems: the frame encoder of the bench step (256-thread form, XCD order)
+    (336, 3, 65, 16, False, 5),   # 2 688 problems: history + target frames in one pass (256-thread form)
+    (96, 2, 65, 16, False, 5),    # 768 problems: 256-thread form, B % 8 == 0
+    (40, 1, 40, 8, True, 5),      # 320 problems: 512-thread form, masked (decoder self-attention shape), XCD order
+    (36, 2, 65, 16, False, 5),    # 288 problems: 512-thread form, B % 8 != 0 (plain problem order)
+    (67, 1, 40, 16, False, 5),    # 536 problems: 256-thread form, plain problem order
+])
+def test_attention_launch_shapes_vs_oracle(B, groups, L, E, masked, factor):
+    """Every workgroup size rf_attn_fwd / rf_attn_bwd choose (attention.hip threads_for: 1024 / 512 / 256 threads by
+    problem count) and both problem orders (XCD-aware when B % 8 == 0), at the chip-filling launch shapes bench.py
+    times -- ctx, dq, dk, dv against the CPU oracle, with grouped key-sample tables as the stream-batched frame
+    encoder passes them (cross_modal_transformer.py:88-166)."""
+    from routeformer_amd import kernels as Kn
+    H = 8
+    g = _g(B + L + E)
+    q, k, v = (torch.randn(B, L, H, E, generator=g).requires_grad_() for _ in range(3))
+    sample_k, n_top = O.prob_sizes(L, L, factor)
+    per = B // groups
+    assert per * groups == B
+    idx = torch.randint(L, (groups, L, sample_k), generator=g)
+    refs = [O.prob_attention(q[i * per:(i + 1) * per], k[i * per:(i + 1) * per], v[i * per:(i + 1) * per], idx[i], factor,
+                             masked) for i in range(groups)]
+    ref = torch.cat(refs)
+    qkv = torch.cat([a.detach().reshape(B * L, H * E) for a in (q, k, v)], dim=1).to(DEV).requires_grad_()
+    ctx = Kn.attention(qkv, qkv, (0, H * E, 2 * H * E), (B, H, L, L, E), 2 if masked else 1,
+                       index_sample=idx.to(torch.int32).to(DEV), n_top=n_top, idx_group=per)
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    (ctx * w.to(DEV)).sum().backward()
+    assert rel_err(ctx, ref) < 3e-5
+    packed_ref = torch.cat([a.grad.reshape(B * L, H * E) for a in (q, k, v)], dim=1)
+    assert rel_err(qkv.grad, packed_ref) < 3e-5
+
+
 @pytest.mark.parametrize("L,E,masked", [(40, 104, False), (42, 104, True), (160, 16, False), (105, 104, True)])
 def test_attention_full_score_form_matches_compact_form(L, E, masked):
     """rf_attn_fwd keeps the whole Q K^T in LDS when the launch's LDS budget allows (always for <= 128 (batch, head)
