@@ -304,6 +304,7 @@ def main():
         K.PROFILE.enable()
         engine._eager_fwd_bwd(engine._static_item, 10)
         K.PROFILE.disable()
+        SAMPLER.drop_static()  # the legs below run the model outside the engine: ordinary host draws again
     if multi:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -270,6 +270,34 @@ int rf_attn_bwd(const float* q, const float* k, const float* v, int64_t q_ld, in
                 float* dk, float* dv, int64_t dq_ld, int64_t dk_ld, int64_t dv_ld, int B, int H,
                 int LQ, int LK, int E, int n_top, int mode, float scale, void* stream);
 
+/* ---- dropout on the trainable path -------------------------------------------------------------
+ * nn.Dropout of cross_modal_transformer.py:49,63,220-231,285-299, gps_backbone/layers/Embedding.py:122-126,
+ * layers/TransformerEncoderDecoder.py:41-50,102-113.  Masks are never stored: the keep-bit of element e of dropout
+ * site `site` in training step `step` is Philox4x32-10(counter = (e/4, site, step), key = seed)[e % 4] >= p * 2^32,
+ * so a backward kernel regenerates the mask its forward drew.  rng_state = two uint64 in DEVICE memory
+ * {seed, step}: rf_rng_seed sets them, rf_rng_advance does step += 1 (one launch at the head of every training
+ * step, also when the step is replayed from a HIP graph).  `mask_in` (one byte per element, non-zero = keep)
+ * replaces the generator: the parity tests feed the masks the reference run recorded.
+ * rf_dropout: y = x * keep / (1 - p) over n contiguous floats (x == y allowed; the same call is its own backward);
+ * x == y == NULL with mask_out: only materialise the keep-mask of that site (tests).
+ * rf_attn_fwd_drop / rf_attn_bwd_drop: rf_attn_fwd / rf_attn_bwd with dropout on the softmax probabilities
+ * A[b,h,q,s] (element index ((b*H + h)*LQ + q)*LK + s) -- FullAttention only: mode 0, or mode 2 with every query
+ * row imposed (the causal form); drop_p == 0 is exactly rf_attn_fwd / rf_attn_bwd. */
+int rf_rng_seed(void* rng_state, int64_t seed, int64_t step, void* stream);
+int rf_rng_advance(void* rng_state, void* stream);
+int rf_dropout(const float* x, float* y, int64_t n, float p, const void* rng_state, int site, const uint8_t* mask_in,
+               uint8_t* mask_out, void* stream);
+int rf_attn_fwd_drop(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld, int64_t v_ld,
+                     float* ctx, int out_layout, const int32_t* index_sample, int idx_group, int64_t idx_group_stride,
+                     int32_t* top_idx, int force_top, int B, int H, int LQ, int LK, int E, int sample_k, int n_top,
+                     int mode, float scale, float drop_p, const void* rng_state, int drop_site,
+                     const uint8_t* drop_mask, void* stream);
+int rf_attn_bwd_drop(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld, int64_t v_ld,
+                     const float* dctx, int out_layout, const int32_t* top_idx, float* dq, float* dk, float* dv,
+                     int64_t dq_ld, int64_t dk_ld, int64_t dv_ld, int B, int H, int LQ, int LK, int E, int n_top,
+                     int mode, float scale, float drop_p, const void* rng_state, int drop_site,
+                     const uint8_t* drop_mask, void* stream);
+
 /* ---- optimizer (experiments/full_comparison.py:694-702,829-830) -------------------------------
  * sumsq[k] = partial sum of g^2 of workgroup k, k < rf_sumsq_parts(n) (no atomics: the consumer adds the
  * partials in ascending order, so the global norm is reproducible bit for bit across runs and ranks). */

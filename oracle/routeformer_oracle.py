@@ -62,6 +62,39 @@ class IndexSource:
         return t
 
 
+class DropoutSource:
+    """``nn.Dropout`` masks (train mode, p > 0), one per dropout call in the reference's call order.
+
+    ``replay=[keep-masks]`` -> pop recorded masks (fixtures recorded from the reference run, or masks materialised
+    from the product's Philox generator); else draw ``bernoulli(1 - p)`` from a PRIVATE generator, so the global CPU
+    generator -- the ProbSparse key samples -- is consumed exactly as on a GPU run of the reference, where dropout
+    draws from the device generator.  ``log`` keeps every mask used.
+    A mask is stored in the layout of the tensor the reference drops (the FFN's hidden activation is dropped in its
+    (B, d_ff, L) Conv1d layout, cross_modal_transformer.py:298)."""
+
+    def __init__(self, replay: Optional[Sequence[torch.Tensor]] = None, seed: int = 0):
+        self.replay = list(replay) if replay is not None else None
+        self.gen = torch.Generator().manual_seed(seed)
+        self.log: List[torch.Tensor] = []
+
+    def keep(self, shape, p: float) -> torch.Tensor:
+        if self.replay is not None:
+            m = self.replay.pop(0).to(torch.bool)
+            assert tuple(m.shape) == tuple(shape), (tuple(m.shape), tuple(shape))
+        else:
+            m = torch.empty(tuple(shape)).bernoulli_(1.0 - p, generator=self.gen).to(torch.bool)
+        self.log.append(m)
+        return m
+
+
+def _drop(x, p: float, src: Optional[DropoutSource]):
+    """F.dropout(x, p, training=True): x * keep / (1 - p).  p == 0 (or eval: callers pass 0) is the identity."""
+    if p <= 0.0:
+        return x
+    assert src is not None, "dropout > 0 in train mode needs a DropoutSource"
+    return x * (src.keep(x.shape, p).to(x.dtype) / (1.0 - p))
+
+
 # ---------------------------------------------------------------------------------------------
 # attention (cross_modal_transformer.py:36-198, layers/SelfAttentionFamily.py:35-194)
 # ---------------------------------------------------------------------------------------------
@@ -72,8 +105,9 @@ def prob_sizes(L_Q: int, L_K: int, factor: int):
     return (U_part if U_part < L_K else L_K), (u if u < L_Q else L_Q)
 
 
-def full_attention(q, k, v, scale=None, masked: bool = False):
-    """softmax(scale * Q K^T) V -- cross_modal_transformer.py:51-69; ``masked`` = the TriangularCausalMask
+def full_attention(q, k, v, scale=None, masked: bool = False, dropout: float = 0.0,
+                   drop: Optional[DropoutSource] = None):
+    """dropout(softmax(scale * Q K^T)) V -- cross_modal_transformer.py:51-69; ``masked`` = the TriangularCausalMask
     branch of the GPS copy (layers/SelfAttentionFamily.py:9-17,53-57).  (B,L,H,E) in/out."""
     E = q.shape[-1]
     scale = scale or 1.0 / math.sqrt(E)
@@ -81,7 +115,7 @@ def full_attention(q, k, v, scale=None, masked: bool = False):
     if masked:
         L = q.shape[1]
         s = s.masked_fill(torch.triu(torch.ones(L, s.shape[-1], dtype=torch.bool), diagonal=1), float("-inf"))
-    a = torch.softmax(scale * s, dim=-1)
+    a = _drop(torch.softmax(scale * s, dim=-1), dropout, drop)  # (:63) on the (B,H,L,S) probabilities
     return torch.einsum("bhls,bshd->blhd", a, v).contiguous()
 
 
@@ -127,7 +161,8 @@ def _linear(sd: SD, p: str, x):
 
 
 def attention_layer(sd: SD, p: str, xq, xk, xv, n_heads: int, kind: str, idx: IndexSource,
-                    factor: int = 5, gps_variant: bool = False, mix: bool = False):
+                    factor: int = 5, gps_variant: bool = False, mix: bool = False, dropout: float = 0.0,
+                    drop: Optional[DropoutSource] = None):
     """AttentionLayer -- cross_modal_transformer.py:169-198 / SelfAttentionFamily.py:168-194.
     kind in {"prob", "prob_masked", "full", "full_masked"}."""
     B, L, _ = xq.shape
@@ -136,8 +171,8 @@ def attention_layer(sd: SD, p: str, xq, xk, xv, n_heads: int, kind: str, idx: In
     k = _linear(sd, p + ".key_projection", xk).view(B, S, n_heads, -1)
     v = _linear(sd, p + ".value_projection", xv).view(B, S, n_heads, -1)
     if kind in ("full", "full_masked"):
-        out = full_attention(q, k, v, masked=kind == "full_masked")
-    else:
+        out = full_attention(q, k, v, masked=kind == "full_masked", dropout=dropout, drop=drop)
+    else:  # ProbAttention defines a Dropout it never applies (cross_modal_transformer.py:86)
         sample_k, _ = prob_sizes(L, S, factor)
         index_sample = idx.randint(S, (L, sample_k))
         out = prob_attention(q, k, v, index_sample, factor, kind == "prob_masked",
@@ -157,31 +192,35 @@ def _ln(sd: SD, p: str, x):
     return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
 
 
-def _ffn(sd: SD, p: str, x, activation: str):
-    """Conv1d(k=1) -> act -> Conv1d(k=1) on (B,L,C) -- cross_modal_transformer.py:298-299."""
+def _ffn(sd: SD, p: str, x, activation: str, dropout: float = 0.0, drop: Optional[DropoutSource] = None):
+    """dropout(Conv1d(k=1)(dropout(act(Conv1d(k=1)(x))))) on (B,L,C) -- cross_modal_transformer.py:298-299: the
+    first dropout acts on the (B, d_ff, L) Conv1d layout, the second after the transpose back."""
     w1, w2 = sd[p + ".conv1.weight"].squeeze(-1), sd[p + ".conv2.weight"].squeeze(-1)
     y = _act(activation)(F.linear(x, w1, sd[p + ".conv1.bias"]))
-    return F.linear(y, w2, sd[p + ".conv2.bias"])
+    y = _drop(y.transpose(-1, 1), dropout, drop).transpose(-1, 1)
+    return _drop(F.linear(y, w2, sd[p + ".conv2.bias"]), dropout, drop)
 
 
-def encoder_layer(sd: SD, p: str, x, n_heads, idx, factor, activation, gps_variant, kind: str = "prob"):
-    """Post-LN encoder block -- cross_modal_transformer.py:288-301."""
-    x = x + attention_layer(sd, p + ".attention", x, x, x, n_heads, kind, idx, factor,
-                            gps_variant)
+def encoder_layer(sd: SD, p: str, x, n_heads, idx, factor, activation, gps_variant, kind: str = "prob",
+                  dropout: float = 0.0, drop: Optional[DropoutSource] = None):
+    """Post-LN encoder block -- cross_modal_transformer.py:288-301 (dropout sites :295,298,299)."""
+    x = x + _drop(attention_layer(sd, p + ".attention", x, x, x, n_heads, kind, idx, factor,
+                                  gps_variant, dropout=dropout, drop=drop), dropout, drop)
     x = _ln(sd, p + ".norm1", x)
-    return _tap(p, _ln(sd, p + ".norm2", x + _ffn(sd, p, x, activation)))
+    return _tap(p, _ln(sd, p + ".norm2", x + _ffn(sd, p, x, activation, dropout, drop)))
 
 
 def decoder_layer(sd: SD, p: str, x, cross, n_heads, idx, factor, activation, gps_variant,
-                  cross_kind: str, mix: bool = False, self_kind: str = "prob_masked"):
+                  cross_kind: str, mix: bool = False, self_kind: str = "prob_masked", dropout: float = 0.0,
+                  drop: Optional[DropoutSource] = None):
     """Decoder block -- cross_modal_transformer.py:223-233 / TransformerEncoderDecoder.py:106-115."""
-    x = x + attention_layer(sd, p + ".self_attention", x, x, x, n_heads, self_kind, idx, factor,
-                            gps_variant, mix=mix)
+    x = x + _drop(attention_layer(sd, p + ".self_attention", x, x, x, n_heads, self_kind, idx, factor,
+                                  gps_variant, mix=mix, dropout=dropout, drop=drop), dropout, drop)
     x = _ln(sd, p + ".norm1", x)
-    x = x + attention_layer(sd, p + ".cross_attention", x, cross, cross, n_heads, cross_kind, idx,
-                            factor, gps_variant)
+    x = x + _drop(attention_layer(sd, p + ".cross_attention", x, cross, cross, n_heads, cross_kind, idx,
+                                  factor, gps_variant, dropout=dropout, drop=drop), dropout, drop)
     x = _ln(sd, p + ".norm2", x)
-    return _tap(p, _ln(sd, p + ".norm3", x + _ffn(sd, p, x, activation)))
+    return _tap(p, _ln(sd, p + ".norm3", x + _ffn(sd, p, x, activation, dropout, drop)))
 
 
 def _count(sd: SD, prefix: str) -> int:
@@ -205,7 +244,8 @@ def circular_conv3(x, weight, bias=None, padding: int = 1):
 
 
 def perceive_encoder(sd: SD, p: str, x, n_heads: int, out_len: int, idx: IndexSource,
-                     factor: int = 5, activation: str = "gelu"):
+                     factor: int = 5, activation: str = "gelu", dropout: float = 0.0,
+                     drop: Optional[DropoutSource] = None):
     """PerceiveEncoder.forward -- cross_modal_transformer.py:425-433."""
     L = x.shape[1]
     h = circular_conv3(x, sd[p + ".value_embedding.tokenConv.weight"],
@@ -213,13 +253,14 @@ def perceive_encoder(sd: SD, p: str, x, n_heads: int, out_len: int, idx: IndexSo
     h = h + sd[p + ".position_embedding.pe"][:, :L]
     for i in range(_count(sd, p + ".encoder.attn_layers")):
         h = encoder_layer(sd, f"{p}.encoder.attn_layers.{i}", h, n_heads, idx, factor, activation,
-                          gps_variant=False)
+                          gps_variant=False, dropout=dropout, drop=drop)
     h = _ln(sd, p + ".encoder.norm", h)
     return _tap(p, _linear(sd, p + ".projection", h)[:, -out_len:, :])
 
 
 def perceive_decoder(sd: SD, p: str, x_enc, x_dec, n_heads: int, out_len: int, idx: IndexSource,
-                     factor: int = 5, activation: str = "gelu", mix: bool = False):
+                     factor: int = 5, activation: str = "gelu", mix: bool = False, dropout: float = 0.0,
+                     drop: Optional[DropoutSource] = None):
     """PerceiveDecoder.forward -- cross_modal_transformer.py:498-503 (cross attention = FullAttention)."""
     L = x_dec.shape[1]
     h = circular_conv3(x_dec, sd[p + ".value_embedding.tokenConv.weight"],
@@ -227,7 +268,7 @@ def perceive_decoder(sd: SD, p: str, x_enc, x_dec, n_heads: int, out_len: int, i
     h = h + sd[p + ".position_embedding.pe"][:, :L]
     for i in range(_count(sd, p + ".decoder.layers")):
         h = decoder_layer(sd, f"{p}.decoder.layers.{i}", h, x_enc, n_heads, idx, factor, activation,
-                          gps_variant=False, cross_kind="full", mix=mix)
+                          gps_variant=False, cross_kind="full", mix=mix, dropout=dropout, drop=drop)
     h = _ln(sd, p + ".decoder.norm", h)
     return _tap(p, _linear(sd, p + ".projection", h)[:, -out_len:, :])
 
@@ -235,14 +276,14 @@ def perceive_decoder(sd: SD, p: str, x_enc, x_dec, n_heads: int, out_len: int, i
 # ---------------------------------------------------------------------------------------------
 # Informer GPS backbone (gps_backbone/Informer.py:105-167 + layers/*)
 # ---------------------------------------------------------------------------------------------
-def data_embedding(sd: SD, p: str, x):
-    """DataEmbedding (timeF): circular conv (no bias) + Linear(1->d)(position as float) + PE.
+def data_embedding(sd: SD, p: str, x, dropout: float = 0.0, drop: Optional[DropoutSource] = None):
+    """DataEmbedding (timeF): dropout(circular conv (no bias) + Linear(1->d)(position as float) + PE).
     layers/Embedding.py:111-126; x_mark = arange(L) (Informer.py:119-123,152-156)."""
     B, L, _ = x.shape
     mark = torch.arange(L, dtype=torch.float32).view(1, L, 1).expand(B, L, 1)
-    return (circular_conv3(x, sd[p + ".value_embedding.tokenConv.weight"])
-            + F.linear(mark, sd[p + ".temporal_embedding.embed.weight"])
-            + sd[p + ".position_embedding.pe"][:, :L])
+    return _drop(circular_conv3(x, sd[p + ".value_embedding.tokenConv.weight"])
+                 + F.linear(mark, sd[p + ".temporal_embedding.embed.weight"])
+                 + sd[p + ".position_embedding.pe"][:, :L], dropout, drop)
 
 
 def distil_conv(sd: SD, p: str, x, training: bool, bn_state: Optional[dict] = None):
@@ -267,47 +308,50 @@ def distil_conv(sd: SD, p: str, x, training: bool, bn_state: Optional[dict] = No
 
 def informer(sd: SD, p: str, x, *, pred_len: int, n_heads: int, factor: int, activation: str,
              smart_decoder: bool, training: bool, idx: IndexSource,
-             bn_state: Optional[dict] = None):
-    """Informer.forward -- gps_backbone/Informer.py:105-167."""
+             bn_state: Optional[dict] = None, dropout: float = 0.0, drop: Optional[DropoutSource] = None):
+    """Informer.forward -- gps_backbone/Informer.py:105-167 (``dropout``: the active probability, 0 in eval)."""
+    dk = dict(dropout=dropout, drop=drop)
     tail = x[:, -1:, :].repeat(1, pred_len, 1) if smart_decoder else \
         torch.zeros(x.shape[0], pred_len, x.shape[-1])
     x_dec = torch.cat([x, tail], dim=1)
-    h = data_embedding(sd, p + ".enc_embedding", x)
+    h = data_embedding(sd, p + ".enc_embedding", x, **dk)
     n_attn = _count(sd, p + ".encoder.attn_layers")
     n_conv = _count(sd, p + ".encoder.conv_layers")
     if n_conv:  # distilling: zip(attn, conv) then one last attn layer (TransformerEncoderDecoder.py:66-71)
         for i in range(n_conv):
             h = encoder_layer(sd, f"{p}.encoder.attn_layers.{i}", h, n_heads, idx, factor,
-                              activation, gps_variant=True)
+                              activation, gps_variant=True, **dk)
             h = distil_conv(sd, f"{p}.encoder.conv_layers.{i}", h, training, bn_state)
         h = encoder_layer(sd, f"{p}.encoder.attn_layers.{n_attn - 1}", h, n_heads, idx, factor,
-                          activation, gps_variant=True)
+                          activation, gps_variant=True, **dk)
     else:
         for i in range(n_attn):
             h = encoder_layer(sd, f"{p}.encoder.attn_layers.{i}", h, n_heads, idx, factor,
-                              activation, gps_variant=True)
+                              activation, gps_variant=True, **dk)
     enc = _ln(sd, p + ".encoder.norm", h)
-    d = data_embedding(sd, p + ".dec_embedding", x_dec)
+    d = data_embedding(sd, p + ".dec_embedding", x_dec, **dk)
     for i in range(_count(sd, p + ".decoder.layers")):
         d = decoder_layer(sd, f"{p}.decoder.layers.{i}", d, enc, n_heads, idx, factor, activation,
-                          gps_variant=True, cross_kind="prob")
+                          gps_variant=True, cross_kind="prob", **dk)
     d = _ln(sd, p + ".decoder.norm", d)
     return _tap(p, _linear(sd, p + ".decoder.projection", d)[:, -pred_len:, :])
 
 
-def transformer_gps(sd: SD, p: str, x, *, pred_len: int, n_heads: int, activation: str):
+def transformer_gps(sd: SD, p: str, x, *, pred_len: int, n_heads: int, activation: str, dropout: float = 0.0,
+                    drop: Optional[DropoutSource] = None):
     """The vanilla ``Transformer`` GPS backbone -- gps_backbone/Transformer.py:98-141:
     FullAttention encoder, causal FullAttention + cross FullAttention decoder, decoder input = history
     followed by ``pred_len`` zero rows, no distilling, no host RNG."""
+    dk = dict(dropout=dropout, drop=drop)
     x_dec = torch.cat([x, torch.zeros(x.shape[0], pred_len, x.shape[-1])], dim=1)
-    h = data_embedding(sd, p + ".enc_embedding", x)
+    h = data_embedding(sd, p + ".enc_embedding", x, **dk)
     for i in range(_count(sd, p + ".encoder.attn_layers")):
-        h = encoder_layer(sd, f"{p}.encoder.attn_layers.{i}", h, n_heads, None, 0, activation, False, kind="full")
+        h = encoder_layer(sd, f"{p}.encoder.attn_layers.{i}", h, n_heads, None, 0, activation, False, kind="full", **dk)
     enc = _ln(sd, p + ".encoder.norm", h)
-    d = data_embedding(sd, p + ".dec_embedding", x_dec)
+    d = data_embedding(sd, p + ".dec_embedding", x_dec, **dk)
     for i in range(_count(sd, p + ".decoder.layers")):
         d = decoder_layer(sd, f"{p}.decoder.layers.{i}", d, enc, n_heads, None, 0, activation, False,
-                          cross_kind="full", self_kind="full_masked")
+                          cross_kind="full", self_kind="full_masked", **dk)
     d = _ln(sd, p + ".decoder.norm", d)
     return _linear(sd, p + ".decoder.projection", d)[:, -pred_len:, :]
 
@@ -500,9 +544,15 @@ class OracleRouteformer:
     """Functional Routeformer over a state dict.  ``cfg`` is any object exposing the
     RouteformerConfig fields (reference's or this repo's)."""
 
-    def __init__(self, cfg, sd: SD, *, training: bool = False, idx: Optional[IndexSource] = None):
+    def __init__(self, cfg, sd: SD, *, training: bool = False, idx: Optional[IndexSource] = None,
+                 drop: Optional[DropoutSource] = None):
         self.cfg, self.sd, self.training = cfg, sd, training
         self.idx = idx or IndexSource()
+        # nn.Dropout follows the MODULE's train/eval state (so it is also active in the target-side feature pass of
+        # a train step, preprocess_batch(target, training=False) -- full_comparison.py:482), not the `training` argument
+        self.drop = drop or DropoutSource()
+        self.p_feat = float(getattr(cfg, "feature_dropout", 0.0)) if training else 0.0
+        self.p_gps = float(getattr(cfg.gps_backbone_config, "dropout", 0.0)) if training else 0.0
         self.bn_state: dict = {}
         g = cfg.gps_backbone_config
         self.gps_kw = dict(n_heads=g.n_heads, factor=g.factor, activation=g.activation,
@@ -523,7 +573,8 @@ class OracleRouteformer:
         f = hrnet16_features(self.sd, "video_backbone._Backbone", frames)
         tok = f.permute(0, 2, 3, 1).reshape(f.shape[0], -1, f.shape[1])
         tok = torch.cat([tok, -torch.ones_like(tok[:, :1])], dim=1)
-        out = perceive_encoder(self.sd, "frame_encoder", tok, self.cfg.encoder_heads, 1, self.idx)
+        out = perceive_encoder(self.sd, "frame_encoder", tok, self.cfg.encoder_heads, 1, self.idx,
+                               dropout=self.p_feat, drop=self.drop)
         return out.reshape(frames.shape[0], E)
 
     def _timeline(self, feats, B, T, indices):
@@ -578,9 +629,11 @@ class OracleRouteformer:
             else:
                 gv = self._gaze_video(batch, training)
                 gp = median_downsampler(batch["gaze"].to(torch.float32), self.seq_len)
-                gp = perceive_encoder(sd, "gaze_encoder", gp, cfg.encoder_heads, self.seq_len, self.idx)
+                gp = perceive_encoder(sd, "gaze_encoder", gp, cfg.encoder_heads, self.seq_len, self.idx,
+                                      dropout=self.p_feat, drop=self.drop)
                 g = perceive_decoder(sd, "gaze_video_decoder", gv, gp, cfg.cross_modal_decoder_heads,
-                                     self.seq_len, self.idx, mix=False)[:, : gv.shape[1]]
+                                     self.seq_len, self.idx, mix=False, dropout=self.p_feat,
+                                     drop=self.drop)[:, : gv.shape[1]]
             feats.append(g)
         if cfg.with_scene:
             feats[0] = feats[0] + sd["left_video_embedding"]
@@ -588,7 +641,8 @@ class OracleRouteformer:
         if cfg.with_gaze:
             feats[-1] = feats[-1] + sd["gaze_video_embedding"]
         seq = torch.cat(feats + [torch.zeros_like(feats[-1]) + sd["video_output_embedding"]], dim=1)
-        vis = perceive_encoder(sd, "video_encoder", seq, cfg.encoder_heads, self.seq_len, self.idx)
+        vis = perceive_encoder(sd, "video_encoder", seq, cfg.encoder_heads, self.seq_len, self.idx,
+                               dropout=self.p_feat, drop=self.drop)
         return motion, vis
 
     # -- GPS path ----------------------------------------------------------------------------
@@ -609,10 +663,10 @@ class OracleRouteformer:
         x = torch.cat(parts, dim=-1)
         if getattr(self, "gps_kind", "informer") == "transformer":
             out = transformer_gps(self.sd, "gps_backbone", x, pred_len=pred_len, n_heads=self.gps_kw["n_heads"],
-                                  activation=self.gps_kw["activation"])
+                                  activation=self.gps_kw["activation"], dropout=self.p_gps, drop=self.drop)
         else:
             out = informer(self.sd, "gps_backbone", x, pred_len=pred_len, training=self.training,
-                           idx=self.idx, bn_state=self.bn_state, **self.gps_kw)
+                           idx=self.idx, bn_state=self.bn_state, dropout=self.p_gps, drop=self.drop, **self.gps_kw)
         if cfg.decoder_mode == "recursive":
             out = out + (x[:, -1:, :] if cfg.dense_prediction else x[:, -1:, :2])
         if cfg.rotate_motion:

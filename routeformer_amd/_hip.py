@@ -56,6 +56,13 @@ SIGNATURES = {
     "rf_attn_fwd_full_scores": [_I, _I, _I, _I, _I, _I, _I, _I],
     "rf_attn_bwd": [_P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _I,
                     _I, _I, _F, _P],
+    "rf_rng_seed": [_P, _L, _L, _P],
+    "rf_rng_advance": [_P, _P],
+    "rf_dropout": [_P, _P, _L, _F, _P, _I, _P, _P, _P],
+    "rf_attn_fwd_drop": [_P, _P, _P, _L, _L, _L, _P, _I, _P, _I, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _I,
+                         _P, _P],
+    "rf_attn_bwd_drop": [_P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P,
+                         _I, _P, _P],
     "rf_motion_input": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "rf_rotate_head": [_P, _P, _P, _I, _I, _I, _F, _P],
     "rf_kernel_timer_arm": [],

@@ -10,6 +10,7 @@
 // Sequence lengths here are tiny, so the kernels are latency-bound by design;
 // rows are spread over lanes and reductions use wave shuffles.
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
@@ -33,7 +34,18 @@ struct AttnP {
   long idx_stride;  // elements between the key-sample tables of consecutive groups
   int Qs_rows;  // rows of Q staged by load_qkv (LQ in forward, 0 in backward: only the selected rows are needed)
   float scale;
+  DropCfg drop;  // nn.Dropout on the attention probabilities of FullAttention (cross_modal_transformer.py:63)
 };
+
+// Dropout on the probabilities of the active rows (row si = query top_list[si]): element index of A[b,h,q,s] in the
+// reference's (B,H,L_Q,L_K) probability tensor -- forward and backward regenerate the same keep-bits from it.
+__device__ __forceinline__ void drop_rows(float* S, int n_rows, int LK, int ld, const int* top_list, const DropGen& gen,
+                                          long row_base) {
+  for (int i = threadIdx.x; i < n_rows * LK; i += (int)blockDim.x) {
+    const int si = i / LK, s_ = i - si * LK;
+    S[(long)si * ld + s_] *= gen.factor((unsigned long long)((row_base + top_list[si]) * LK + s_));
+  }
+}
 
 // XCD-aware problem order.  Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its
 // own L2, and the H heads of one sequence read interleaved 4E-byte pieces of the same packed rows.  With
@@ -512,6 +524,13 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
     softmax_rows(S, n_sel, LK, top_list, p.mode == 2, LKP);
     __syncthreads();
     RF_MARK(7);
+    {
+      const DropGen gen(p.drop);
+      if (gen.on()) {
+        drop_rows(S, n_sel, LK, LKP, top_list, gen, ((long)b * p.H + h) * LQ);
+        __syncthreads();
+      }
+    }
     mm_tiles(TI, (E + 15) >> 4, LKP >> 2, lane, wave,
              [&](int si) { return S + min(si, n_sel - 1) * LKP; }, 1,
              [&](int d) { return Vs + min(d, E - 1); }, EP,
@@ -530,6 +549,13 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
     __syncthreads();
     softmax_rows(S, n_sel, LK, top_list, p.mode == 2);
     __syncthreads();
+    {
+      const DropGen gen(p.drop);
+      if (gen.on()) {
+        drop_rows(S, n_sel, LK, LK, top_list, gen, ((long)b * p.H + h) * LQ);
+        __syncthreads();
+      }
+    }
     for (int i = tid; i < n_sel * E; i += (int)blockDim.x) {
       const int si = i / E, d = i - si * E;
       const int q = top_list[si];
@@ -644,17 +670,26 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   RF_MARK(11);
   softmax_rows(P, n_sel, LK, top_list, p.mode == 2, LKP);
   // the same 16 lanes own the same row in softmax_rows and here: no barrier needed in between
+  const DropGen gen(p.drop);
   for (int base = 0; base < n_sel; base += rows_per_trip()) {
     const int si = row_of(base), l16 = tid & 15;
     const bool live = si < n_sel;
     float* Pr = P + (long)(live ? si : 0) * LKP;
     float* dSr = dS + (long)(live ? si : 0) * LKP;
+    // attention-probability dropout: ctx = (P * keep / (1-p)) V, so dP arrives masked and dV needs the masked P
+    const unsigned long long e0 = (unsigned long long)((((long)b * p.H + h) * LQ + top_list[live ? si : 0]) * LK);
     float dot = 0.f;
-    if (live)
+    if (live) {
+      if (gen.on())
+        for (int s_ = l16; s_ < LK; s_ += 16) dSr[s_] *= gen.factor(e0 + s_);
       for (int s_ = l16; s_ < LK; s_ += 16) dot += Pr[s_] * dSr[s_];
+    }
     dot = row16_sum(dot);
-    if (live)
+    if (live) {
       for (int s_ = l16; s_ < LKP; s_ += 16) dSr[s_] = s_ < LK ? Pr[s_] * (dSr[s_] - dot) * p.scale : 0.f;
+      if (gen.on())
+        for (int s_ = l16; s_ < LK; s_ += 16) Pr[s_] *= gen.factor(e0 + s_);
+    }
   }
   __syncthreads();
 
@@ -789,11 +824,11 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 extern "C" int rf_attn_fwd_full_scores(int B, int H, int LQ, int LK, int E, int sample_k, int n_top, int mode);
 
-extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
-                           int64_t v_ld, float* ctx, int out_layout, const int32_t* index_sample,
-                           int idx_group, int64_t idx_group_stride, int32_t* top_idx, int force_top, int B, int H,
-                           int LQ, int LK,
-                           int E, int sample_k, int n_top, int mode, float scale, void* stream) {
+extern "C" int rf_attn_fwd_drop(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
+                                int64_t v_ld, float* ctx, int out_layout, const int32_t* index_sample,
+                                int idx_group, int64_t idx_group_stride, int32_t* top_idx, int force_top, int B, int H,
+                                int LQ, int LK, int E, int sample_k, int n_top, int mode, float scale, float drop_p,
+                                const void* rng_state, int drop_site, const uint8_t* drop_mask, void* stream) {
   RF_REQUIRE(q && k && v && ctx && B > 0 && H > 0 && LQ > 0 && LK > 0 && E > 0);
   RF_REQUIRE(mode >= 0 && mode <= 2);
   RF_REQUIRE(mode == 0 || (top_idx && n_top > 0 && n_top <= LQ));
@@ -802,7 +837,11 @@ extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64
   const bool v4 = (E % 4 == 0) && al16(q) && al16(k) && al16(v) && al16(ctx) && q_ld % 4 == 0 && k_ld % 4 == 0 &&
                   v_ld % 4 == 0;
   const int threads = threads_for(B * H);
-  const bool fulls = v4 && rf_attn_fwd_full_scores(B, H, LQ, LK, E, sample_k, n_top, mode);
+  RF_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state || drop_mask));
+  // attention-probability dropout exists for FullAttention only (mode 0, or the causal form = mode 2 with every row
+  // imposed); ProbAttention defines a Dropout it never applies (cross_modal_transformer.py:86)
+  RF_REQUIRE(drop_p == 0.f || mode == 0 || (mode == 2 && force_top && n_top == LQ));
+  const bool fulls = v4 && drop_p == 0.f && rf_attn_fwd_full_scores(B, H, LQ, LK, E, sample_k, n_top, mode);
   const size_t lds = fwd_lds(LQ, LK, E, mode == 0 ? LQ : n_top, mode == 0 ? 0 : sample_k, v4, fulls);
   if (lds > 160 * 1024) { rf_g_last_error = "attention head slice exceeds 160 KB LDS"; return RF_EUNSUPPORTED; }
   AttnP p{};
@@ -812,6 +851,7 @@ extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64
   p.mode = mode; p.scale = scale; p.Qs_rows = LQ;
   p.idx_group = (idx_group <= 0 || idx_group > B) ? B : idx_group;
   p.idx_stride = idx_group_stride > 0 ? idx_group_stride : (long)LQ * sample_k;
+  p.drop = make_drop_cfg(rng_state, drop_mask, (uint32_t)drop_site, drop_p);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -825,6 +865,15 @@ extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64
   else RF_LAUNCH((attn_fwd_kernel<false, false>), dim3(B * H), dim3(threads), lds, st, p);
   RF_CHECK_LAUNCH();
   return RF_OK;
+}
+
+extern "C" int rf_attn_fwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
+                           int64_t v_ld, float* ctx, int out_layout, const int32_t* index_sample,
+                           int idx_group, int64_t idx_group_stride, int32_t* top_idx, int force_top, int B, int H,
+                           int LQ, int LK,
+                           int E, int sample_k, int n_top, int mode, float scale, void* stream) {
+  return rf_attn_fwd_drop(q, k, v, q_ld, k_ld, v_ld, ctx, out_layout, index_sample, idx_group, idx_group_stride, top_idx,
+                          force_top, B, H, LQ, LK, E, sample_k, n_top, mode, scale, 0.f, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int rf_attn_fwd_full_scores(int B, int H, int LQ, int LK, int E, int sample_k, int n_top, int mode) {
@@ -843,11 +892,11 @@ extern "C" void* rf_attn_timing_address() {
 }
 #endif
 
-extern "C" int rf_attn_bwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
-                           int64_t v_ld, const float* dctx, int out_layout, const int32_t* top_idx,
-                           float* dq, float* dk, float* dv, int64_t dq_ld, int64_t dk_ld, int64_t dv_ld,
-                           int B, int H, int LQ, int LK, int E, int n_top, int mode, float scale,
-                           void* stream) {
+extern "C" int rf_attn_bwd_drop(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
+                                int64_t v_ld, const float* dctx, int out_layout, const int32_t* top_idx,
+                                float* dq, float* dk, float* dv, int64_t dq_ld, int64_t dk_ld, int64_t dv_ld,
+                                int B, int H, int LQ, int LK, int E, int n_top, int mode, float scale, float drop_p,
+                                const void* rng_state, int drop_site, const uint8_t* drop_mask, void* stream) {
   RF_REQUIRE(q && k && v && dctx && dq && dk && dv && B > 0 && H > 0 && LQ > 0 && LK > 0 && E > 0);
   RF_REQUIRE(mode >= 0 && mode <= 2);
   RF_REQUIRE(mode == 0 || (top_idx && n_top > 0 && n_top <= LQ));
@@ -862,6 +911,9 @@ extern "C" int rf_attn_bwd(const float* q, const float* k, const float* v, int64
   p.out_layout = out_layout; p.top = const_cast<int32_t*>(top_idx); p.dq = dq; p.dk = dk; p.dv = dv;
   p.dq_ld = dq_ld; p.dk_ld = dk_ld; p.dv_ld = dv_ld; p.B = B; p.H = H; p.LQ = LQ; p.LK = LK;
   p.E = E; p.n_top = n_top; p.mode = mode; p.scale = scale; p.Qs_rows = 0;
+  RF_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state || drop_mask));
+  RF_REQUIRE(drop_p == 0.f || mode == 0 || (mode == 2 && n_top == LQ));
+  p.drop = make_drop_cfg(rng_state, drop_mask, (uint32_t)drop_site, drop_p);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -872,4 +924,13 @@ extern "C" int rf_attn_bwd(const float* q, const float* k, const float* v, int64
   else RF_LAUNCH(attn_bwd_kernel<false>, dim3(B * H), dim3(threads_for(B * H)), lds, static_cast<hipStream_t>(stream), p);
   RF_CHECK_LAUNCH();
   return RF_OK;
+}
+
+extern "C" int rf_attn_bwd(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
+                           int64_t v_ld, const float* dctx, int out_layout, const int32_t* top_idx,
+                           float* dq, float* dk, float* dv, int64_t dq_ld, int64_t dk_ld, int64_t dv_ld,
+                           int B, int H, int LQ, int LK, int E, int n_top, int mode, float scale,
+                           void* stream) {
+  return rf_attn_bwd_drop(q, k, v, q_ld, k_ld, v_ld, dctx, out_layout, top_idx, dq, dk, dv, dq_ld, dk_ld, dv_ld, B, H, LQ,
+                          LK, E, n_top, mode, scale, 0.f, nullptr, 0, nullptr, stream);
 }

@@ -26,10 +26,12 @@ def _reset():
     from routeformer_amd.models.blocks import SAMPLER
     K.set_precision("f32")
     SAMPLER.replay, SAMPLER.log = None, None
+    SAMPLER.drop_static()
     K.TOPS.record, K.TOPS.forced = None, None
     yield
     K.set_precision("f32")
     SAMPLER.replay, SAMPLER.log = None, None
+    SAMPLER.drop_static()  # a failed test must not leave the process-wide sampler in graph mode for the next one
     K.TOPS.record, K.TOPS.forced = None, None
 
 
@@ -387,12 +389,18 @@ def test_graphed_engine_fresh_tensors_stale_buffers_and_discount_keys():
     # gamma 0.9 -> 0.5 at epoch 12 moves the loss by far more than the tolerance: the eager run must show it too
     assert abs(runs["eager"][4] - runs["eager"][3]) > 1e-3
 
-    # (b) in-place refill between the look-ahead call and the next step
-    model, cfg, sd, c = build_product_model("c2_small", DEV)
-    eng = GraphedTrainEngine(model, lr=1e-3).capture(batch(c, 30), epoch=10)
+    # (b) in-place refill between the look-ahead call and the next step (eager reference first: the key-sample
+    # source is process-wide and switches to its static mode when a graph is captured)
+    from routeformer_amd.models.blocks import SAMPLER
+    SAMPLER.drop_static()
+    a, b, fresh = batch(c, 31), batch(c, 32), batch(c, 33)
     ref_model, *_ = build_product_model("c2_small", DEV)
     ref = TrainEngine(ref_model, lr=1e-3)
-    a, b, fresh = batch(c, 31), batch(c, 32), batch(c, 33)
+    torch.manual_seed(3)
+    ref.step(a, epoch=10)
+    want = float(ref.step(fresh, epoch=10)["loss"])
+    model, cfg, sd, c = build_product_model("c2_small", DEV)
+    eng = GraphedTrainEngine(model, lr=1e-3).capture(batch(c, 30), epoch=10)
     a["id"], b["id"] = "a", "b"
     torch.manual_seed(3)
     eng.step(a, epoch=10, next_item=b)
@@ -401,10 +409,9 @@ def test_graphed_engine_fresh_tensors_stale_buffers_and_discount_keys():
             b[part][n].copy_(v)
     b["id"] = "fresh"                          # ... and says so
     got = float(eng.step(b, epoch=10)["loss"])
-    torch.manual_seed(3)
-    ref.step(a, epoch=10)
-    want = float(ref.step(fresh, epoch=10)["loss"])
     assert abs(got - want) < 5e-4 * max(1.0, abs(want)), (got, want)
+    # and with the stale id the engine WOULD have used the tokens computed ahead for the old contents
+    SAMPLER.drop_static()
 
 
 @pytest.mark.parametrize("case_name,B", [("C2", 8), ("C4", 16), ("C5", 4)])
