@@ -169,6 +169,122 @@ class _Profiler:
 PROFILE = _Profiler()
 
 
+class _Rng:
+    """Device-side state of the dropout-mask generator (csrc/philox.h): two uint64 {seed, step} per device.
+
+    A keep-bit is a pure function of (seed, step, site, element index): ``site`` numbers the dropout calls of one
+    step in host program order (reset by ``begin_step``), ``step`` is advanced on the DEVICE (``rf_rng_advance``,
+    the first launch of every training step -- so a HIP-graph replay of the step draws fresh masks), and a
+    backward kernel regenerates the mask of its forward from the site number it kept.
+    Test hooks: ``forced`` = keep-masks consumed in call order instead of the generator (parity against the
+    reference's recorded masks); ``record`` = list receiving the keep-mask of every call (materialised by
+    rf_dropout's mask_out), e.g. to hand the product's Philox masks to the CPU oracle."""
+
+    def __init__(self):
+        self._state = {}
+        self.site = 0
+        self.seed_value: Optional[int] = None
+        self.forced: Optional[list] = None
+        self.record: Optional[list] = None
+
+    def state(self, device) -> torch.Tensor:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        st = self._state.get(idx)
+        if st is None:
+            st = self._state[idx] = torch.zeros(2, dtype=torch.int64, device=torch.device("cuda", idx))
+            seed = self.seed_value if self.seed_value is not None else torch.initial_seed()
+            check(_hip.lib().rf_rng_seed(ptr(st), int(seed) & 0x7FFFFFFFFFFFFFFF, 0, _stream()), "rf_rng_seed")
+        return st
+
+    def manual_seed(self, seed: int):
+        """Seed the mask generator (default: ``torch.initial_seed()`` at first use); restarts the step counter."""
+        self.seed_value = int(seed)
+        for st in self._state.values():
+            with torch.cuda.device(st.device):
+                check(_hip.lib().rf_rng_seed(ptr(st), self.seed_value & 0x7FFFFFFFFFFFFFFF, 0, _stream()), "rf_rng_seed")
+        self.site = 0
+
+    def begin_step(self, device=None):
+        """First launch of a training step: step += 1 on the device, site numbering restarts."""
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        check(_hip.lib().rf_rng_advance(ptr(self.state(dev)), _stream()), "rf_rng_advance")
+        self.site = 0
+
+    def next_site(self) -> int:
+        s = self.site
+        self.site += 1
+        return s
+
+    def take_forced(self, shape, device):
+        """Next injected keep-mask as a uint8 device tensor of logical ``shape`` (the reference drops the FFN's hidden
+        activation in its (B, d_ff, L) Conv1d layout: such a mask is transposed to (B, L, d_ff))."""
+        if self.forced is None:
+            return None
+        m = self.forced.pop(0)
+        if tuple(m.shape) != tuple(shape):
+            assert m.dim() == 3 and tuple(m.transpose(1, 2).shape) == tuple(shape), (tuple(m.shape), tuple(shape))
+            m = m.transpose(1, 2)
+        return m.to(device=device, dtype=torch.uint8).contiguous()
+
+    def merge_forced(self, n_calls: int, sites_per_call: int):
+        """``n_calls`` reference encoder calls run as one batched call: [call][site] masks -> per-site batch-concatenated."""
+        if self.forced is None or n_calls == 1:
+            return
+        k = n_calls * sites_per_call
+        head, rest = self.forced[:k], self.forced[k:]
+        self.forced = [torch.cat([head[c * sites_per_call + j] for c in range(n_calls)], dim=0)
+                       for j in range(sites_per_call)] + rest
+
+    def materialise(self, site: int, shape, p: float, device, mask=None) -> torch.Tensor:
+        """The keep-mask (bool) the generator yields for ``site`` in the current step (or the injected one)."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        out = torch.empty(n + 3, dtype=torch.uint8, device=device)[:n]
+        check(_hip.lib().rf_dropout(None, None, n, p, ptr(self.state(device)), site, ptr(mask), ptr(out), _stream()),
+              "rf_dropout(mask_out)")
+        return out.view(tuple(shape)).bool()
+
+
+RNG = _Rng()
+
+
+def _drop_launch(x, y, p: float, site: int, mask):
+    """y = x * keep / (1 - p) over a contiguous tensor (x is y: in place); forward and backward alike."""
+    check(_hip.lib().rf_dropout(ptr(x), ptr(y), x.numel(), p, ptr(RNG.state(x.device)), site, ptr(mask), None, _stream()),
+          "rf_dropout")
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, site, mask):
+        _req(x, "dropout.x")
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _drop_launch(x, y, p, site, mask)
+        ctx.cfg = (p, site, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, site, mask = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _drop_launch(dy, dx, p, site, mask)
+        return dx, None, None, None
+
+
+def dropout(x, p: float, training: bool = True):
+    """nn.Dropout(p)(x) in train mode with a device-side Philox mask (never stored; see ``_Rng``)."""
+    if p <= 0.0 or not training:
+        return x
+    mask = RNG.take_forced(x.shape, x.device)
+    site = RNG.next_site()
+    if RNG.record is not None:
+        RNG.record.append(RNG.materialise(site, x.shape, p, x.device, mask))
+    return _Dropout.apply(x, p, site, mask)
+
+
 def _req(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise _hip.HipLibraryError(
@@ -546,7 +662,9 @@ class _FFN(torch.autograd.Function):
     The activation and its derivative ride in GEMM epilogues."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act: str, g1, gb1, g2, gb2, need_grad=True, fork=False):
+    def forward(ctx, x, w1, b1, w2, b2, act: str, g1, gb1, g2, gb2, need_grad=True, fork=False, drop=None):
+        """``drop`` = (p, (site, mask) of the hidden activation, (site, mask) of the output) or None: the two
+        nn.Dropout calls of cross_modal_transformer.py:298-299, applied in place right after each product."""
         _req(x, "ffn.x")
         F, D = w1.shape[0], w1.shape[1]
         w1, w2 = w1.reshape(F, D), w2.reshape(D, F)  # Conv1d(k=1) weights (out,in,1) viewed as matrices
@@ -557,9 +675,14 @@ class _FFN(torch.autograd.Function):
         h = torch.empty(M, F, device=x.device, dtype=torch.float32)
         z = torch.empty_like(h) if (act == "gelu" and need_grad) else None  # pre-activation: backward only
         gemm(x2, x2.stride(0), 1, w1, 1, D, h, F, M, F, D, bias=b1, act=ACT[act], preact=z, ldp=F)
+        if drop is not None:
+            _drop_launch(h, h, drop[0], *drop[1])  # conv2 consumes (and dW2 needs) the dropped activation
         y = torch.empty(M, D, device=x.device, dtype=torch.float32)
         gemm(h, F, 1, w2, 1, F, y, D, M, D, F, bias=b2)
+        if drop is not None:
+            _drop_launch(y, y, drop[0], *drop[2])
         ctx.save_for_backward(x2, w1, w2, h, z if z is not None else h)
+        ctx.drop = drop
         ctx.sinks = (g1, gb1, g2, gb2)
         ctx.act = act
         ctx.xshape = x.shape
@@ -576,11 +699,18 @@ class _FFN(torch.autograd.Function):
         dy2 = dy.reshape(-1, D)
         if dy2.stride(1) != 1 or dy2.stride(0) != D:
             dy2 = dy2.contiguous()
+        drop = ctx.drop
+        if drop is not None:  # output dropout: the same mask on the incoming gradient
+            dyd = torch.empty_like(dy2)
+            _drop_launch(dy2, dyd, drop[0], *drop[2])
+            dy2 = dyd
         # dZ = (dY W2) * act'(Z)   (relu: mask from H > 0; gelu: from the saved pre-activation)
         with _WgradStream(dy2, h):
             dw2 = _weight_grad(dy2, h, into=None if g2 is None else g2.view(D, F), bias_into=gb2)
             db2 = None if dw2 is True else colsum(dy2, into=gb2)
         dz = _input_grad(dy2, w2, dact_src=zsrc, ldd=zsrc.stride(0), dact=ACT[ctx.act])
+        if drop is not None:  # hidden dropout sits between the activation and conv2: dZ = (dH * keep/(1-p)) * act'(Z)
+            _drop_launch(dz, dz, drop[0], *drop[1])
         with _WgradStream(dz, x2):
             dw1 = _weight_grad(dz, x2, into=None if g1 is None else g1.view(F, D), bias_into=gb1)
             db1 = None if dw1 is True else colsum(dz, into=gb1)
@@ -600,14 +730,26 @@ class _FFN(torch.autograd.Function):
         _wrote(g1, gb1, g2, gb2)
         if dw1 is not None:
             dw1, dw2 = dw1.view(F, D, 1), dw2.view(D, F, 1)
-        return dx, dw1, db1, dw2, db2, None, None, None, None, None, None, None
+        return dx, dw1, db1, dw2, db2, None, None, None, None, None, None, None, None
 
 
-def ffn(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str, fork: bool = False):
-    """conv*_w: the Conv1d(k=1) weight parameters, shape (out, in, 1).  ``fork`` as in ``linear``."""
+def ffn(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str, fork: bool = False, drop_p: float = 0.0):
+    """conv*_w: the Conv1d(k=1) weight parameters, shape (out, in, 1).  ``fork`` as in ``linear``.
+    ``drop_p`` > 0: dropout(conv2(dropout(act(conv1 x)))) (train mode; cross_modal_transformer.py:298-299)."""
     assert conv1_w.dim() == 3 and conv2_w.dim() == 3
+    drop = None
+    if drop_p > 0.0:
+        F_, lead = conv1_w.shape[0], tuple(x.shape[:-1])
+        sites = []
+        for shape in (lead + (F_,), tuple(x.shape)):  # reference call order: hidden activation, then output
+            mask = RNG.take_forced(shape, x.device)
+            site = RNG.next_site()
+            if RNG.record is not None:
+                RNG.record.append(RNG.materialise(site, shape, drop_p, x.device, mask))
+            sites.append((site, mask))
+        drop = (drop_p, sites[0], sites[1])
     return _FFN.apply(x, conv1_w, conv1_b, conv2_w, conv2_b, act, _slot(conv1_w), _slot(conv1_b),
-                      _slot(conv2_w), _slot(conv2_b), torch.is_grad_enabled(), fork)
+                      _slot(conv2_w), _slot(conv2_b), torch.is_grad_enabled(), fork, drop)
 
 
 class _AddLayerNorm(torch.autograd.Function):
@@ -951,7 +1093,8 @@ class _Attention(torch.autograd.Function):
     mode 0 full, 1 ProbSparse, 2 ProbSparse masked."""
 
     @staticmethod
-    def forward(ctx, a, b, offs, index_sample, dims, mode, n_top, out_layout, scale, forced_top, idx_group=0):
+    def forward(ctx, a, b, offs, index_sample, dims, mode, n_top, out_layout, scale, forced_top, idx_group=0, drop=None):
+        """``drop`` = (p, site, mask) of the dropout on the softmax probabilities (FullAttention) or None."""
         B, H, LQ, LK, E = dims
         q_off, k_off, v_off = offs
         _req(a, "attention.q")
@@ -973,7 +1116,12 @@ class _Attention(torch.autograd.Function):
                  b.stride(0), b.stride(0), ptr(out), out_layout, ptr(index_sample), idx_group,
                  (index_sample.stride(0) if (index_sample is not None and index_sample.dim() == 3) else 0), ptr(top),
                  1 if forced_top is not None else 0, B, H, LQ, LK, E, sample_k, n_top, mode, scale)
-        check(_hip.lib().rf_attn_fwd(*fargs, _stream()), "rf_attn_fwd")
+        if drop is not None:
+            dargs = (drop[0], ptr(RNG.state(a.device)), drop[1], ptr(drop[2]))
+            check(_hip.lib().rf_attn_fwd_drop(*fargs, *dargs, _stream()), "rf_attn_fwd_drop")
+            ev = None
+        else:
+            check(_hip.lib().rf_attn_fwd(*fargs, _stream()), "rf_attn_fwd")
         if ev is not None:
             u = LQ if mode == 0 else n_top  # sample stage + active rows (QK^T and AV)
             keep = (a, b, out, index_sample, top)
@@ -985,6 +1133,7 @@ class _Attention(torch.autograd.Function):
             TOPS.record.append(top.clone())
         ctx.save_for_backward(a, b, top if top is not None else a)
         ctx.cfg = (dims, offs, mode, n_top, out_layout, scale, a.data_ptr() == b.data_ptr())
+        ctx.drop = drop
         return out
 
     @staticmethod
@@ -1001,17 +1150,23 @@ class _Attention(torch.autograd.Function):
                  da.data_ptr() + 4 * q_off, db.data_ptr() + 4 * k_off,
                  db.data_ptr() + 4 * v_off, da.stride(0), db.stride(0), db.stride(0),
                  B, H, LQ, LK, E, n_top, mode, scale)
-        check(_hip.lib().rf_attn_bwd(*bargs, _stream()), "rf_attn_bwd")
+        if ctx.drop is not None:
+            drop = ctx.drop
+            dargs = (drop[0], ptr(RNG.state(a.device)), drop[1], ptr(drop[2]))
+            check(_hip.lib().rf_attn_bwd_drop(*bargs, *dargs, _stream()), "rf_attn_bwd_drop")
+            ev = None
+        else:
+            check(_hip.lib().rf_attn_bwd(*bargs, _stream()), "rf_attn_bwd")
         if ev is not None:
             u = LQ if mode == 0 else n_top
             keep = (a, b, dout, top, da, db)  # operands stay alive for the replay
             PROFILE.end("attn_bwd_kernel<true>", ev, B * H * 10.0 * u * LK * E, 4.0 * B * H * E * (4 * LQ + 4 * LK),
                         replay=lambda fa=bargs, k=keep: _hip.lib().rf_attn_bwd(*fa, _stream()))
-        return da, (None if same else db), None, None, None, None, None, None, None, None, None
+        return da, (None if same else db), None, None, None, None, None, None, None, None, None, None
 
 
 def attention(a, b, offs, dims, mode: int, *, index_sample=None, n_top: int = 0, out_layout: int = 0,
-              scale: Optional[float] = None, forced_top=None, idx_group: int = 0):
+              scale: Optional[float] = None, forced_top=None, idx_group: int = 0, drop_p: float = 0.0):
     """Returns ctx in (B,LQ,H,E) [out_layout 0] or (B,H,LQ,E) [out_layout 1: Informer's un-transposed
     layout, layers/SelfAttentionFamily.py:165].  Every column of ``a`` / ``b`` must be one of Q/K/V."""
     B, H, LQ, LK, E = dims
@@ -1026,7 +1181,16 @@ def attention(a, b, offs, dims, mode: int, *, index_sample=None, n_top: int = 0,
         assert index_sample.stride(2) == 1 and index_sample.stride(1) == index_sample.shape[2]
     elif index_sample is not None:
         assert index_sample.is_contiguous()
-    return _Attention.apply(a, b, offs, index_sample, dims, mode, n_top, out_layout, scale, forced_top, idx_group)
+    drop = None
+    if drop_p > 0.0:  # nn.Dropout on the (B,H,L_Q,L_K) probabilities of FullAttention (cross_modal_transformer.py:63)
+        assert mode == 0 or (mode == 2 and forced_top is not None and n_top == LQ), "ProbAttention applies no dropout"
+        shape = (B, H, LQ, LK)
+        mask = RNG.take_forced(shape, a.device)
+        site = RNG.next_site()
+        if RNG.record is not None:
+            RNG.record.append(RNG.materialise(site, shape, drop_p, a.device, mask))
+        drop = (float(drop_p), site, mask)
+    return _Attention.apply(a, b, offs, index_sample, dims, mode, n_top, out_layout, scale, forced_top, idx_group, drop)
 
 
 class _TrajHead(torch.autograd.Function):

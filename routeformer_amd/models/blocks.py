@@ -106,7 +106,8 @@ SAMPLER = IndexSampler()
 
 
 def _dropout(x, p: float, training: bool):
-    return F.dropout(x, p, True) if (p > 0.0 and training) else x
+    """nn.Dropout(p): device-side Philox mask, regenerated (not stored) in backward (kernels.dropout)."""
+    return K.dropout(x, p, training)
 
 
 class PositionalEmbedding(nn.Module):
@@ -227,18 +228,15 @@ class AttentionLayer(nn.Module):
             offs = (0, 0, HE)
         dims = (B, H, L, S, E)
         layout = 1 if self.gps_variant else 0
+        # nn.Dropout on the softmax probabilities (FullAttention only, cross_modal_transformer.py:63): in-kernel
+        drop_p = self.attn_dropout if self.training else 0.0
         if self.kind == "full":
-            if self.attn_dropout > 0.0 and self.training:
-                raise NotImplementedError("attention-probability dropout (FullAttention) is not implemented "
-                                          "in the HIP kernel; run with feature_dropout=0")
-            ctx = K.attention(a, bm, offs, dims, 0, out_layout=layout)
+            ctx = K.attention(a, bm, offs, dims, 0, out_layout=layout, drop_p=drop_p)
         elif self.kind == "full_masked":
             # causal softmax attention = the masked ProbSparse kernel with EVERY query row active (imposed
             # selection 0..L-1: the sampling stage is skipped, no lazy rows remain)
-            if self.attn_dropout > 0.0 and self.training:
-                raise NotImplementedError("attention-probability dropout is not implemented; run with dropout=0")
             every = torch.arange(L, device=x.device, dtype=torch.int32).expand(B, H, L).contiguous()
-            ctx = K.attention(a, bm, offs, dims, 2, n_top=L, out_layout=layout, forced_top=every)
+            ctx = K.attention(a, bm, offs, dims, 2, n_top=L, out_layout=layout, forced_top=every, drop_p=drop_p)
         else:
             sample_k, n_top = K.prob_sizes(L, S, self.factor)
             if idx is None:
@@ -267,14 +265,12 @@ class EncoderLayer(nn.Module):
         self.p = dropout
         self.act = "relu" if activation == "relu" else "gelu"
 
-    def _ffn(self, x):
-        if self.p > 0.0 and self.training:
-            raise NotImplementedError("dropout inside the fused FFN is not implemented; use dropout=0")
-        return K.ffn(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.act)
-
     def _ffn_norm(self, x, norm):
-        if self.p > 0.0 and self.training:
-            raise NotImplementedError("dropout inside the fused FFN is not implemented; use dropout=0")
+        """LayerNorm(x + dropout(conv2(dropout(act(conv1 x))))) -- cross_modal_transformer.py:297-301."""
+        if self.p > 0.0 and self.training:  # dropout sites between the products: the unfused FFN + fused add-norm
+            y, skip = K.ffn(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.act,
+                            fork=True, drop_p=self.p)
+            return K.add_layer_norm(skip, y, norm.weight, norm.bias, norm.eps)
         return K.ffn_add_layer_norm(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.act,
                                     norm.weight, norm.bias, norm.eps)
 
@@ -302,7 +298,6 @@ class DecoderLayer(nn.Module):
         self.p = dropout
         self.act = "relu" if activation == "relu" else "gelu"
 
-    _ffn = EncoderLayer._ffn
     _ffn_norm = EncoderLayer._ffn_norm
 
     def forward(self, x, memory):

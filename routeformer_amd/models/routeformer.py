@@ -394,6 +394,7 @@ class Routeformer(nn.Module):
             n_per = tokens.shape[0] // len(members)
             idx_list = [self._group_tables([m[3][layer] for m in members]) for layer in range(len(members[0][3]))]
             K.TOPS.merge_forced(len(members), len(idx_list))  # test hooks only (no-ops in production)
+            K.RNG.merge_forced(len(members), 3 * len(idx_list))  # 3 dropout sites per encoder layer
             emb = self.frame_encoder(tokens.to(dtype), idx_list, n_per).view(len(members), B, -1, E)
             K.TOPS.split_record(len(members), len(idx_list))
             idx_dev = self._device_index(idx, dev)

@@ -72,3 +72,16 @@ def fro_err(a, b):
     """Relative Frobenius error: robust to a handful of ReLU-mask / top-u flips in bf16 mode."""
     a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
     return float((a - b).norm() / max(1e-12, float(b.norm())))
+
+
+def masks(gold, prefix):
+    """Recorded nn.Dropout keep-masks `<prefix>maskbits` / `<prefix>maskshapes` as a list of bool tensors (call order)."""
+    shapes = gold[prefix + "maskshapes"]
+    bits = np.unpackbits(gold[prefix + "maskbits"])
+    out, off = [], 0
+    for row in shapes:
+        shape = tuple(int(d) for d in row if d > 0)
+        n = int(np.prod(shape))
+        out.append(torch.from_numpy(bits[off:off + n].astype(bool).reshape(shape)))
+        off += n
+    return out

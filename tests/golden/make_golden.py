@@ -479,7 +479,156 @@ def gen_widen():
     save("widen", **out)
 
 
-GENERATORS = {"widen": gen_widen, "attention": gen_attention, "blocks": gen_blocks, "informer": gen_informer,
+@contextlib.contextmanager
+def record_dropout(log, seed=99):
+    """Record the keep-mask of every active ``F.dropout`` call (nn.Dropout.forward) of the reference, in call order.
+
+    The reference's own ``F.dropout`` still does the arithmetic.  On the CPU it would draw its mask from the GLOBAL
+    generator -- the one the ProbSparse key samples and the view / gaze dropout decisions come from -- whereas on a GPU
+    (where the reference trains) it draws from the device generator and leaves the host stream alone.  So each call
+    runs under a seed taken from a private generator, the mask is recovered by re-drawing under the same seed, and
+    the global CPU generator is restored afterwards: host draws are exactly those of a GPU run."""
+    import torch.nn.functional as F_
+    real = F_.dropout
+    gen = torch.Generator().manual_seed(seed)
+
+    def wrapped(input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return real(input, p, training, inplace)
+        state = torch.get_rng_state()
+        s = int(torch.empty((), dtype=torch.int64).random_(0, 2 ** 31 - 1, generator=gen))  # (not torch.randint: that is recorded)
+        torch.manual_seed(s)
+        y = real(input, p, training, False)
+        torch.manual_seed(s)
+        keep = torch.empty_like(input).bernoulli_(1 - p).bool()
+        torch.set_rng_state(state)
+        if not torch.allclose(y, input * keep / (1 - p), rtol=1e-6, atol=0):  # other draw order inside F.dropout
+            keep = torch.where(input != 0, y != 0, torch.ones_like(keep))
+            assert torch.allclose(y, input * keep / (1 - p), rtol=1e-6, atol=0)
+        log.append(keep.detach().clone())
+        return y
+
+    F_.dropout = wrapped
+    try:
+        yield
+    finally:
+        F_.dropout = real
+
+
+def pack_masks(log, prefix):
+    """Keep-masks as one bit string + their shapes (padded to 4 dims with 0)."""
+    bits = np.concatenate([m.numpy().reshape(-1) for m in log]) if log else np.zeros(0, dtype=bool)
+    shapes = np.array([list(m.shape) + [0] * (4 - m.dim()) for m in log], dtype=np.int32).reshape(-1, 4)
+    return {prefix + "maskbits": np.packbits(bits), prefix + "maskshapes": shapes}
+
+
+def gen_dropout():
+    """nn.Dropout on the trainable path (cross_modal_transformer.py:49,63,220-231,285-299; layers/Embedding.py:122-126):
+    reference blocks and one whole train step per host-draw variant in TRAIN mode with dropout > 0 -- outputs, input
+    and parameter gradients, the recorded key samples AND the recorded keep-masks of every dropout call."""
+    out = {}
+    g = torch.Generator().manual_seed(8)
+    P = 0.1
+    # (a) PerceiveEncoder (frame-encoder-like) -- sites per layer: attention output, FFN hidden, FFN output
+    enc = REF.cmt.PerceiveEncoder(in_channels=240, out_channels=64, out_len=1, n_heads=8, layers=2, d_ff=256, dropout=P)
+    load_synth(enc)
+    enc.train()
+    x = torch.randn(3, 65, 240, generator=g, requires_grad=True)
+    log, masks = [], []
+    torch.manual_seed(RSEED)
+    with record_randint(log), record_dropout(masks):
+        y = enc(x)
+    y.square().sum().backward()
+    out.update({"enc.x": x, "enc.y": y, "enc.dx": x.grad, **{"enc." + k: v for k, v in pack_draws(log).items()},
+                **pack_masks(masks, "enc."),
+                **{"enc." + k: v for k, v in grad_summary(enc, full=(
+                    "projection.bias", "encoder.norm.weight", "encoder.attn_layers.0.conv1.bias",
+                    "encoder.attn_layers.1.attention.out_projection.bias")).items()}})
+    # (b) PerceiveDecoder: + dropout on the FullAttention probabilities of the cross attention
+    dec = REF.cmt.PerceiveDecoder(query_channels=64, value_channels=64, out_channels=64, out_len=40, dropout=P, d_ff=256,
+                                  n_heads=8, layers=2, mix=False)
+    load_synth(dec)
+    dec.train()
+    mem = torch.randn(2, 40, 64, generator=g, requires_grad=True)
+    qry = torch.randn(2, 40, 64, generator=g, requires_grad=True)
+    log, masks = [], []
+    torch.manual_seed(RSEED)
+    with record_randint(log), record_dropout(masks):
+        yd = dec(mem, qry)
+    yd.square().sum().backward()
+    out.update({"dec.mem": mem, "dec.qry": qry, "dec.y": yd, "dec.dmem": mem.grad, "dec.dqry": qry.grad,
+                **{"dec." + k: v for k, v in pack_draws(log).items()}, **pack_masks(masks, "dec."),
+                **{"dec." + k: v for k, v in grad_summary(dec, full=(
+                    "projection.bias", "decoder.layers.0.norm2.weight", "decoder.layers.1.conv2.bias")).items()}})
+    # (c) Informer / Transformer GPS backbones (DataEmbedding dropout, GPS-variant layers, causal FullAttention)
+    for tag, cls in (("inf", REF.gps.Informer), ("tf", REF.gps.Transformer)):
+        gcfg = REF.gps.GPSBackboneConfig(seq_len=20, label_len=20, pred_len=10, **dict(presets.GPS_TINY, dropout=P))
+        gcfg.output_attention = False
+        gcfg.smart_decoder = True
+        gcfg._enc_in, gcfg._c_out = 69, 66
+        torch.manual_seed(0)
+        net = cls(gcfg)
+        load_synth(net)
+        net.train()
+        xg = torch.randn(3, 20, 69, generator=torch.Generator().manual_seed(17), requires_grad=True)
+        log, masks = [], []
+        torch.manual_seed(RSEED)
+        with record_randint(log), record_dropout(masks):
+            yg = net(xg)
+        yg.square().mean().backward()
+        out.update({f"{tag}.x": xg, f"{tag}.y": yg, f"{tag}.dx": xg.grad,
+                    **{f"{tag}." + k: v for k, v in pack_draws(log).items()}, **pack_masks(masks, f"{tag}."),
+                    **{f"{tag}." + k: v for k, v in grad_summary(net, full=(
+                        "decoder.projection.bias", "encoder.norm.weight",
+                        "enc_embedding.temporal_embedding.embed.weight")).items()}})
+    # (d) whole model, the paper run's dropouts in kind (full_comparison.py:272-275: view 0.6, gaze 0.2, feature 0.05;
+    # feature 0.1 here so a small model sees enough dropped elements): one train step per host seed, seeds chosen so
+    # that the host draws (torch.rand(1), routeformer.py:301,406-407) cover: nothing dropped / a view dropped / gaze dropped
+    c = presets.case("c2_small")
+    c["rf"] = dict(c["rf"], feature_dropout=P, view_dropout=0.6, gaze_dropout=0.2)
+    c["gps"] = dict(c["gps"], dropout=P)
+    model, cfg = build_ref_model(c)
+    sd = load_synth(model)
+    item = synthetic.synth_item(c["B"], c["T"], c["P"], DSEED, c["H"], c["W"], streams=c["streams"], gaze=c["gaze"])
+    want = {"none": None, "view": None, "gaze": None}
+    for seed in range(200):
+        torch.manual_seed(seed)
+        drop_one = bool(torch.rand(1) < 0.6)
+        if drop_one:
+            torch.rand(1)
+        # the right and left stream draws sit between the view and the gaze decision: replay their count
+        n_frame = (1 if drop_one else 2) * cfg.encoder_layers
+        for _ in range(n_frame):
+            torch.randint(65, (65, 25))
+        drop_gaze = bool(torch.rand(1) < 0.2)
+        kind = "gaze" if (drop_gaze and not drop_one) else ("view" if (drop_one and not drop_gaze) else
+                                                           ("none" if not (drop_one or drop_gaze) else None))
+        if kind and want[kind] is None:
+            want[kind] = seed
+        if all(v is not None for v in want.values()):
+            break
+    out["model.seeds"] = np.array([want["none"], want["view"], want["gaze"]])
+    for kind, seed in want.items():
+        model.train()
+        model.load_state_dict(sd)
+        model.zero_grad()
+        log, masks = [], []
+        torch.manual_seed(seed)
+        with record_randint(log), record_dropout(masks):
+            res = ref_train_step(model, item, 10)
+        res["loss"].backward()
+        key = f"model.{kind}."
+        for k in ("loss", "traj_loss", "dense_loss", "ade", "fde", "future_gps", "target_vis"):
+            out[key + k] = res[k]
+        out[key + "n_draws"] = np.array(len(log))
+        out[key + "rng_after"] = torch.rand(1)  # the host generator must end where the reference left it
+        out.update({key + k: v for k, v in pack_draws(log).items()})
+        out.update(pack_masks(masks, key))
+        out.update({key + k: v for k, v in grad_summary(model, full=FULL_GRADS).items()})
+    save("dropout", **out)
+
+
+GENERATORS = {"dropout": gen_dropout, "widen": gen_widen, "attention": gen_attention, "blocks": gen_blocks, "informer": gen_informer,
               "hrnet": gen_hrnet, "helpers": gen_helpers}
 
 if __name__ == "__main__":

@@ -838,3 +838,80 @@ def test_cpu_tensor_is_refused():
     from routeformer_amd import _hip, kernels as Kn
     with pytest.raises(_hip.HipLibraryError):
         Kn.linear(torch.randn(4, 8), torch.randn(8, 8).to(DEV), None)
+
+
+# ------------------------------------------------------------------------------------------------
+# nn.Dropout: device-side Philox masks (csrc/philox.h), regenerated in backward
+# ------------------------------------------------------------------------------------------------
+def test_dropout_kernel_statistics_and_consistency():
+    """Keep-rate 1 - p and 1/(1-p) scaling; the backward launch regenerates the forward's mask; masks are a pure
+    function of (seed, step, site): reproducible, and different for another site, step or seed; odd lengths."""
+    from routeformer_amd import kernels as Kn
+    Kn.RNG.manual_seed(123)
+    Kn.RNG.begin_step(torch.device(DEV))
+    for n, p in ((1 << 20, 0.05), (65 * 128 * 3 + 3, 0.3), (7, 0.5)):
+        x = (torch.rand(n, device=DEV) + 0.5).requires_grad_()
+        Kn.RNG.site = 5
+        y = Kn.dropout(x, p)
+        keep = y != 0
+        if n > 1000:
+            rate = float(keep.float().mean())
+            assert abs(rate - (1 - p)) < 4 * math.sqrt(p * (1 - p) / n) + 1e-4, (n, p, rate)
+        assert torch.allclose(y[keep], x.detach()[keep] / (1 - p), rtol=1e-6)
+        w = torch.rand(n, device=DEV) + 0.5
+        (y * w).sum().backward()
+        assert torch.equal(x.grad != 0, keep) and torch.allclose(x.grad[keep], w[keep] / (1 - p), rtol=1e-6)
+        Kn.RNG.site = 5
+        assert torch.equal(Kn.dropout(x.detach(), p) != 0, keep), "same (seed, step, site) must reproduce the mask"
+        assert torch.equal(Kn.RNG.materialise(5, (n,), p, torch.device(DEV)), keep)
+        Kn.RNG.site = 6
+        other = Kn.dropout(x.detach(), p) != 0
+        if n > 1000:
+            assert not torch.equal(other, keep)
+            # independence of two sites: P(both kept) = (1-p)^2
+            assert abs(float((other & keep).float().mean()) - (1 - p) ** 2) < 0.01
+    x = torch.ones(1 << 16, device=DEV)
+    Kn.RNG.site = 0
+    a = Kn.dropout(x, 0.2) != 0
+    Kn.RNG.begin_step(torch.device(DEV))  # step += 1 on the device
+    b = Kn.dropout(x, 0.2) != 0
+    Kn.RNG.manual_seed(124)
+    Kn.RNG.begin_step(torch.device(DEV))
+    c = Kn.dropout(x, 0.2) != 0
+    assert not torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(b, c)
+    assert Kn.dropout(x, 0.0) is x and Kn.dropout(x, 0.5, training=False) is x
+
+
+@pytest.mark.parametrize("LQ,LK,H,E,causal", [(40, 40, 8, 8, False), (30, 30, 4, 16, True), (21, 9, 2, 104, False)])
+def test_attention_probability_dropout_vs_oracle(LQ, LK, H, E, causal):
+    """FullAttention's dropout on the softmax probabilities, generated INSIDE the attention kernels (forward and
+    backward regenerate the same Philox mask): the mask the product used is materialised and handed to the CPU oracle."""
+    from routeformer_amd import kernels as Kn
+    B, p = 3, 0.25
+    g = _g(LQ + LK + E)
+    q, k, v = (torch.randn(B, L, H, E, generator=g).requires_grad_() for L in (LQ, LK, LK))
+    Kn.RNG.manual_seed(7)
+    Kn.RNG.begin_step(torch.device(DEV))
+    Kn.RNG.record = []
+    qd = q.detach().reshape(B * LQ, H * E).to(DEV).requires_grad_()
+    kv = torch.cat([k.detach().reshape(B * LK, H * E), v.detach().reshape(B * LK, H * E)], dim=1).to(DEV).requires_grad_()
+    try:
+        if causal:
+            every = torch.arange(LQ, device=DEV, dtype=torch.int32).expand(B, H, LQ).contiguous()
+            ctx = Kn.attention(qd, kv, (0, 0, H * E), (B, H, LQ, LK, E), 2, n_top=LQ, forced_top=every, drop_p=p)
+        else:
+            ctx = Kn.attention(qd, kv, (0, 0, H * E), (B, H, LQ, LK, E), 0, drop_p=p)
+        used = Kn.RNG.record
+    finally:
+        Kn.RNG.record = None
+    assert len(used) == 1 and tuple(used[0].shape) == (B, H, LQ, LK)
+    assert abs(float(used[0].float().mean()) - (1 - p)) < 0.02
+    ref = O.full_attention(q, k, v, masked=causal, dropout=p, drop=O.DropoutSource([used[0].cpu()]))
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    (ctx * w.to(DEV)).sum().backward()
+    assert rel_err(ctx, ref) < 3e-5
+    HE = H * E
+    assert rel_err(qd.grad.view(B, LQ, H, E), q.grad) < 5e-5
+    assert rel_err(kv.grad[:, :HE].reshape(B, LK, H, E), k.grad) < 5e-5
+    assert rel_err(kv.grad[:, HE:].reshape(B, LK, H, E), v.grad) < 5e-5

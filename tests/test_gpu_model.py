@@ -508,3 +508,138 @@ def test_uint8_clips_equal_fp16_clips():
         with torch.no_grad():
             outs.append(model(batch))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+# ------------------------------------------------------------------------------------------------
+# nn.Dropout on the trainable path (the paper configuration must be able to train)
+# ------------------------------------------------------------------------------------------------
+def _grads_vs_summary(G, key, named, tol):
+    names = [str(s) for s in G[key + "grad_names"]]
+    stats = G[key + "grad_stats"]
+    floor = 1e-3 * float(stats[:, 0].max())
+    bad = []
+    for n, (nrm, _) in zip(names, stats):
+        g = named[n].grad
+        got = 0.0 if g is None else float(g.double().norm())
+        if abs(got - nrm) > tol * max(floor, nrm):
+            bad.append((n, got, nrm))
+    assert not bad, bad[:8]
+    for f in G.files:
+        if f.startswith(key + "grad::"):
+            assert rel_err(named[f[len(key + "grad::"):]].grad, G[f]) < tol, f
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-4), ("bf16", 3e-2)])
+def test_dropout_blocks_vs_reference(prec, tol):
+    """The product's encoder / decoder / GPS blocks in TRAIN mode with dropout 0.1 against the reference's outputs and
+    gradients (tests/golden/dropout.npz), with the reference's recorded keep-masks injected (``K.RNG.forced``) and its
+    key samples replayed: every dropout site -- attention output, FFN hidden (dropped by the reference in its
+    (B, d_ff, L) layout) and output, the FullAttention probabilities (in-kernel), the data embedding."""
+    from conftest import masks
+    from routeformer_amd import kernels as K, presets
+    from routeformer_amd.models.blocks import SAMPLER, PerceiveDecoder, PerceiveEncoder
+    from routeformer_amd.models.gps_backbone import GPSBackboneConfig, Informer, Transformer
+    G = golden("dropout")
+    K.set_precision(prec)
+    P = 0.1
+
+    def run(module, inputs, key, loss):
+        module.train()
+        SAMPLER.replay = draws(G, key)
+        K.RNG.forced = [m.clone() for m in masks(G, key)]
+        try:
+            y = module(*inputs)
+            assert not K.RNG.forced and not SAMPLER.replay, key
+        finally:
+            K.RNG.forced, SAMPLER.replay = None, None
+        loss(y).backward()
+        return y
+
+    enc = _load(PerceiveEncoder(in_channels=240, out_channels=64, out_len=1, n_heads=8, layers=2, d_ff=256, dropout=P))
+    x = t(G["enc.x"]).to(DEV).requires_grad_()
+    y = run(enc, (x,), "enc.", lambda y: y.square().sum())
+    assert rel_err(y, G["enc.y"]) < tol and rel_err(x.grad, G["enc.dx"]) < 5 * tol
+    _grads_vs_summary(G, "enc.", dict(enc.named_parameters()), 5 * tol)
+
+    dec = _load(PerceiveDecoder(query_channels=64, value_channels=64, out_channels=64, out_len=40, dropout=P, d_ff=256,
+                                n_heads=8, layers=2, mix=False))
+    mem, qry = t(G["dec.mem"]).to(DEV).requires_grad_(), t(G["dec.qry"]).to(DEV).requires_grad_()
+    yd = run(dec, (mem, qry), "dec.", lambda y: y.square().sum())
+    assert rel_err(yd, G["dec.y"]) < tol
+    assert rel_err(mem.grad, G["dec.dmem"]) < 5 * tol and rel_err(qry.grad, G["dec.dqry"]) < 5 * tol
+    _grads_vs_summary(G, "dec.", dict(dec.named_parameters()), 5 * tol)
+
+    for tag, cls in (("inf", Informer), ("tf", Transformer)):
+        gcfg = GPSBackboneConfig(seq_len=20, label_len=20, pred_len=10, **dict(presets.GPS_TINY, dropout=P))
+        gcfg.output_attention, gcfg.smart_decoder, gcfg._enc_in, gcfg._c_out = False, True, 69, 66
+        net = _load(cls(gcfg))
+        xg = t(G[tag + ".x"]).to(DEV).requires_grad_()
+        yg = run(net, (xg,), tag + ".", lambda y: y.square().mean())
+        assert rel_err(yg, G[tag + ".y"]) < tol, tag
+        assert rel_err(xg.grad, G[tag + ".dx"]) < 5 * tol, tag
+        _grads_vs_summary(G, tag + ".", dict(net.named_parameters()), 5 * tol)
+
+
+def _dropout_case():
+    from routeformer_amd import presets
+    from routeformer_amd.models import RouteformerConfig
+    from routeformer_amd.models.gps_backbone import GPSBackboneConfig
+    from routeformer_amd.models.video_backbone import VideoBackboneConfig
+    c = presets.case("c2_small")
+    c["rf"] = dict(c["rf"], feature_dropout=0.1, view_dropout=0.6, gaze_dropout=0.2)
+    c["gps"] = dict(c["gps"], dropout=0.1)
+    _, cfg = presets.build_configs(c, GPSBackboneConfig, RouteformerConfig, VideoBackboneConfig)
+    return c, cfg
+
+
+def _dropout_model(cfg):
+    from routeformer_amd import synthetic
+    from routeformer_amd.models import Routeformer
+    from routeformer_amd.models.gps_backbone import Informer
+    from routeformer_amd.models.video_backbone import HRNet16Backbone
+    model = Routeformer(cfg, gps_backbone=Informer, video_backbone=HRNet16Backbone)
+    sd = synthetic.synth_state_dict(model.state_dict(), 7)
+    model.load_state_dict(sd)
+    return model.to(DEV), sd
+
+
+@pytest.mark.parametrize("kind", ["none", "view", "gaze"])
+def test_dropout_train_step_vs_reference(kind):
+    """A whole train step with view 0.6 / gaze 0.2 / feature 0.1 / GPS 0.1 dropout against the reference run: the same
+    host seed gives the same view / gaze decisions and key samples (the masks never touch the host generator, as on a
+    GPU run of the reference), the recorded masks are injected, the oracle's top-u selections imposed."""
+    from conftest import masks
+    from routeformer_amd import kernels as K
+    from routeformer_amd.engine import train_step_losses
+    from routeformer_amd.models.blocks import SAMPLER
+    G = golden("dropout")
+    c, cfg = _dropout_case()
+    model, sd = _dropout_model(cfg)
+    item = case_item(c)
+    item_d = {"train": _to_dev(item["train"]), "target": _to_dev(item["target"])}
+    seed = int(G["model.seeds"][["none", "view", "gaze"].index(kind)])
+    key = f"model.{kind}."
+    torch.manual_seed(seed)
+    orc = O.OracleRouteformer(cfg, sd, training=True, drop=O.DropoutSource(masks(G, key)))
+    with torch.no_grad():
+        orc.train_step(item, 10)
+    model.train()
+    K.TOPS.forced = [t_.clone() for t_ in orc.idx.tops]
+    K.RNG.forced = [m.clone() for m in masks(G, key)]
+    SAMPLER.log = []
+    torch.manual_seed(seed)
+    try:
+        res = train_step_losses(model, item_d, 10)
+        assert not K.TOPS.forced and not K.RNG.forced
+    finally:
+        K.TOPS.forced, K.RNG.forced = None, None
+    assert len(SAMPLER.log) == int(G[key + "n_draws"])
+    assert all(torch.equal(a, b) for a, b in zip(SAMPLER.log, draws(G, key)))
+    assert torch.equal(torch.rand(1), t(G[key + "rng_after"])), "host generator diverged from the reference"
+    assert rel_err(res["future_gps"], G[key + "future_gps"]) < TOL_F32
+    assert rel_err(res["target_vis"], G[key + "target_vis"]) < TOL_F32
+    for k in ("loss", "traj_loss", "dense_loss", "ade", "fde"):
+        ref = float(G[key + k])
+        assert abs(float(res[k]) - ref) < 1e-3 * max(1.0, abs(ref)), (k, float(res[k]), ref)
+    res["loss"].backward()
+    _grads_vs_summary(G, key, dict(model.named_parameters()), 5e-3)

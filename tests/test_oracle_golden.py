@@ -197,3 +197,111 @@ def test_model_train_step(name):
             g = sdg[n].grad
             got = 0.0 if g is None else float(g.double().norm())
             assert abs(got - nrm) <= 5e-4 * max(1e-3, nrm), (name, key, n, got, nrm)
+
+
+# ------------------------------------------------------------------------------------------------
+# nn.Dropout on the trainable path: the oracle with the reference's RECORDED masks (tests/golden/dropout.npz)
+# ------------------------------------------------------------------------------------------------
+def _check_grad_summary(G, key, sd, prefix, tol=1e-4):
+    names = [str(n) for n in G[key + "grad_names"]]
+    for n, (nrm, _) in zip(names, G[key + "grad_stats"]):
+        g = sd[prefix + n].grad
+        got = 0.0 if g is None else float(g.double().norm())
+        assert abs(got - nrm) <= tol * max(1.0, nrm), (n, got, nrm)
+    for f in G.files:
+        if f.startswith(key + "grad::"):
+            assert rel_err(sd[prefix + f[len(key + "grad::"):]].grad, G[f]) < tol, f
+
+
+def test_dropout_blocks_vs_reference_masks():
+    """Every dropout site of the encoder / decoder / GPS blocks, in the reference's call order and layouts: with the
+    recorded keep-masks and key samples the oracle reproduces the reference's train-mode outputs and gradients."""
+    from conftest import masks
+    from routeformer_amd import presets, synthetic
+    from routeformer_amd.models.blocks import PerceiveDecoder, PerceiveEncoder
+    from routeformer_amd.models.gps_backbone import GPSBackboneConfig, Informer, Transformer
+    G = golden("dropout")
+    P = 0.1
+    sd = _block_sd(lambda: PerceiveEncoder(in_channels=240, out_channels=64, out_len=1, n_heads=8, layers=2, d_ff=256,
+                                           dropout=P))
+    sd = {"m." + k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    x = t(G["enc.x"]).requires_grad_()
+    src = O.DropoutSource(masks(G, "enc."))
+    assert len(src.replay) == 2 * 3  # per layer: attention output, FFN hidden (B, d_ff, L), FFN output
+    y = O.perceive_encoder(sd, "m", x, 8, 1, O.IndexSource(draws(G, "enc.")), dropout=P, drop=src)
+    assert not src.replay
+    assert rel_err(y, G["enc.y"]) < TOL
+    y.square().sum().backward()
+    assert rel_err(x.grad, G["enc.dx"]) < 1e-4
+    _check_grad_summary(G, "enc.", sd, "m.")
+
+    sd = _block_sd(lambda: PerceiveDecoder(query_channels=64, value_channels=64, out_channels=64, out_len=40, dropout=P,
+                                           d_ff=256, n_heads=8, layers=2, mix=False))
+    sd = {"m." + k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    mem, qry = t(G["dec.mem"]).requires_grad_(), t(G["dec.qry"]).requires_grad_()
+    src = O.DropoutSource(masks(G, "dec."))
+    assert len(src.replay) == 2 * 5  # per layer: self out, cross probabilities (B,H,L,S), cross out, FFN hidden, FFN out
+    yd = O.perceive_decoder(sd, "m", mem, qry, 8, 40, O.IndexSource(draws(G, "dec.")), dropout=P, drop=src)
+    assert not src.replay
+    assert rel_err(yd, G["dec.y"]) < TOL
+    yd.square().sum().backward()
+    assert rel_err(mem.grad, G["dec.dmem"]) < 1e-4 and rel_err(qry.grad, G["dec.dqry"]) < 1e-4
+    _check_grad_summary(G, "dec.", sd, "m.")
+
+    for tag, cls in (("inf", Informer), ("tf", Transformer)):
+        gcfg = GPSBackboneConfig(seq_len=20, label_len=20, pred_len=10, **dict(presets.GPS_TINY, dropout=P))
+        gcfg.output_attention, gcfg.smart_decoder, gcfg._enc_in, gcfg._c_out = False, True, 69, 66
+        sd0 = synthetic.synth_state_dict(cls(gcfg).state_dict(), 7)
+        sd = {"g." + k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and not k.endswith(".pe"))
+              for k, v in sd0.items()}
+        xg = t(G[tag + ".x"]).requires_grad_()
+        src = O.DropoutSource(masks(G, tag + "."))
+        if tag == "inf":
+            yg = O.informer(sd, "g", xg, pred_len=10, n_heads=gcfg.n_heads, factor=gcfg.factor, activation=gcfg.activation,
+                            smart_decoder=True, training=True, idx=O.IndexSource(draws(G, "inf.")), dropout=P, drop=src)
+        else:
+            yg = O.transformer_gps(sd, "g", xg, pred_len=10, n_heads=gcfg.n_heads, activation=gcfg.activation, dropout=P,
+                                   drop=src)
+        assert not src.replay, tag
+        assert rel_err(yg, G[tag + ".y"]) < TOL, tag
+        yg.square().mean().backward()
+        assert rel_err(xg.grad, G[tag + ".dx"]) < 1e-4, tag
+        _check_grad_summary(G, tag + ".", sd, "g.")
+
+
+@pytest.mark.parametrize("kind", ["none", "view", "gaze"])
+def test_dropout_train_step_vs_reference(kind):
+    """One whole train step with view / gaze / feature dropout (the paper run's kinds, full_comparison.py:272-275):
+    same host seed -> same view / gaze decisions and key samples as the reference (dropout masks do not consume the
+    host generator), recorded masks -> same losses, trajectories and gradients; and the host generator ends where
+    the reference left it."""
+    from conftest import masks
+    from routeformer_amd import presets
+    from routeformer_amd.models import RouteformerConfig
+    from routeformer_amd.models.gps_backbone import GPSBackboneConfig
+    from routeformer_amd.models.video_backbone import VideoBackboneConfig
+    G = golden("dropout")
+    c = presets.case("c2_small")
+    c["rf"] = dict(c["rf"], feature_dropout=0.1, view_dropout=0.6, gaze_dropout=0.2)
+    c["gps"] = dict(c["gps"], dropout=0.1)
+    _, cfg = presets.build_configs(c, GPSBackboneConfig, RouteformerConfig, VideoBackboneConfig)
+    model, _, sd0, _ = build_product_model("c2_small")
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "video_backbone" not in k and "running" not in k
+                                      and not k.endswith(".pe")) for k, v in sd0.items()}
+    item = case_item(c)
+    seed = int(G["model.seeds"][["none", "view", "gaze"].index(kind)])
+    key = f"model.{kind}."
+    src = O.DropoutSource(masks(G, key))
+    torch.manual_seed(seed)
+    orc = O.OracleRouteformer(cfg, sd, training=True, drop=src)
+    res = orc.train_step(item, 10)
+    assert not src.replay
+    assert len(orc.idx.log) == int(G[key + "n_draws"])
+    assert all(torch.equal(a, b) for a, b in zip(orc.idx.log, draws(G, key)))
+    assert torch.equal(torch.rand(1), t(G[key + "rng_after"]))
+    assert rel_err(res["future_gps"], G[key + "future_gps"]) < 1e-4
+    assert rel_err(res["target_vis"], G[key + "target_vis"]) < 1e-4
+    for k in ("loss", "traj_loss", "dense_loss", "ade", "fde"):
+        assert abs(float(res[k]) - float(G[key + k])) < 1e-4 * max(1.0, abs(float(G[key + k]))), k
+    res["loss"].backward()
+    _check_grad_summary(G, key, sd, "", tol=2e-4)
