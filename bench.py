@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense peaks, same guide
 
 
-def build(case_name, device, precision):
+def build(case_name, device, precision, dropout="none"):
     from routeformer_amd import kernels as K, presets, synthetic
     from routeformer_amd.models import Routeformer, RouteformerConfig
     from routeformer_amd.models.gps_backbone import GPSBackboneConfig, Informer
@@ -40,6 +40,8 @@ def build(case_name, device, precision):
 
     K.set_precision(precision)
     c = presets.case(case_name)
+    if dropout == "paper":
+        c["rf"] = dict(c["rf"], feature_dropout=0.05, view_dropout=0.6, gaze_dropout=0.2)
     _, cfg = presets.build_configs(c, GPSBackboneConfig, RouteformerConfig, VideoBackboneConfig)
     torch.manual_seed(0)
     model = Routeformer(cfg, gps_backbone=Informer, video_backbone=HRNet16Backbone if cfg.with_video else None)
@@ -183,6 +185,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (N=1)")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-ade", action="store_true", help="skip the ADE-vs-CPU-reference leg (N=1, rank 0)")
+    ap.add_argument("--dropout", default="none", choices=["none", "paper"],
+                    help="paper: the reference run's dropouts (full_comparison.py:272-275: feature 0.05, view 0.6, "
+                         "gaze 0.2) instead of the parity configuration's zeros -- a second bench line, not the headline")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -225,7 +230,7 @@ def main():
     def note(msg):
         print(f"[bench r{rank}] {msg}", file=sys.stderr, flush=True)
 
-    model, cfg, sd, c = build(args.case, device, args.precision)
+    model, cfg, sd, c = build(args.case, device, args.precision, args.dropout)
     # two different synthetic batches, used alternately: the engine's look-ahead (conv trunk of the NEXT
     # batch under the current step) then always works on data it has not seen in this step
     items = [make_item(c, rank, device), make_item(c, rank + 500, device)]
@@ -379,6 +384,9 @@ def main():
                                    f"{c['H']}x{c['W']}, T={c['T']}->P={c['P']}, paper hyper-params, "
                                    f"batch {c['B']}/GPU, random-init weights, frozen HRNet-16 encoder",
                        "global_batch": c["B"] * world, "parallelism": f"dp{world}",
+                       "dropout": ({"feature": cfg.feature_dropout, "view": cfg.view_dropout, "gaze": cfg.gaze_dropout,
+                                    "gps_backbone": cfg.gps_backbone_config.dropout}
+                                   if args.dropout != "none" else "0 (parity configuration, SURVEY 8(d))"),
                        "step": "fwd + target-feature fwd + losses + bwd + grad all-reduce + clip + AdamW",
                        "launch": ("hipGraph replay of fwd+bwd" + (" (+ the previous step's clip/AdamW at its head)" if defer else ""))
                        if use_graph else "eager launches"},

@@ -131,6 +131,19 @@ def eval_step(model, item, trajectory_loss: Optional[FutureDiscountedLoss] = Non
     return torch.stack(losses), torch.stack(ades), torch.stack(fdes), future_gps
 
 
+def agree_unused(flag: bool, group) -> bool:
+    """Data-parallel agreement on "this step did not use the gaze branch": true only if EVERY rank dropped it.
+    DDP semantics of the reference (find_unused_parameters=True, full_comparison.py:794): a parameter one rank used
+    gets the averaged gradient on all ranks and is updated everywhere; one that NO rank used keeps ``grad=None`` and
+    its AdamW update is skipped everywhere.  ``group``: a host-side (gloo) process group -- the flag is known on the
+    host before the step is launched, so the exchange costs no device synchronisation; None = single process."""
+    if group is None:
+        return flag
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t))
+
+
 def trainable_parameters(model) -> List[torch.nn.Parameter]:
     """Everything but the frozen video backbone (full_comparison.py:689-691), registration order."""
     return [p for n, p in model.named_parameters() if "video_backbone" not in n and p.requires_grad]
@@ -346,15 +359,23 @@ class FusedAdamW:
                                                 self.v.data_ptr() + o, hi - lo, self.sumsq.data_ptr(), self.parts,
                                                 hyper_dev.data_ptr(), K._stream()), "rf_adamw_clip_dev")
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, skip=()):
+        """``skip``: sorted, disjoint [lo, hi) ranges of the flat buffers that took no part in this step (their
+        ``.grad`` would be None in the reference, whose AdamW then leaves the parameter AND its moments untouched --
+        no weight decay either; they contribute nothing to the clip norm: their gradient slots are zero)."""
         from routeformer_amd import _hip, kernels as K
         self.t += 1
         n = self.p.numel()
         _hip.check(_hip.lib().rf_sumsq(self.g.data_ptr(), n, self.sumsq.data_ptr(), K._stream()), "rf_sumsq")
-        _hip.check(_hip.lib().rf_adamw_clip(self.p.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                            n, self.sumsq.data_ptr(), self.parts, self.max_norm, self.lr, self.betas[0],
-                                            self.betas[1], self.eps, self.wd, self.t, grad_scale, K._stream()),
-                   "rf_adamw_clip")
+        lo = 0
+        for a, b in list(skip) + [(n, n)]:
+            if a > lo:
+                o = 4 * lo
+                _hip.check(_hip.lib().rf_adamw_clip(self.p.data_ptr() + o, self.g.data_ptr() + o, self.m.data_ptr() + o,
+                                                    self.v.data_ptr() + o, a - lo, self.sumsq.data_ptr(), self.parts,
+                                                    self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
+                                                    self.wd, self.t, grad_scale, K._stream()), "rf_adamw_clip")
+            lo = max(lo, b)
 
 
 class TrainEngine:
@@ -389,10 +410,49 @@ class TrainEngine:
                               max_grad_norm=max_grad_norm)
         self.tl = FutureDiscountedLoss(cfg.discount_factor, cfg.epsilon, loss_function="smooth_l1")
         self.dl = FutureDiscountedLoss(cfg.discount_factor, cfg.visual_epsilon, loss_function="smooth_l1")
+        # nn.Dropout anywhere on the trainable path: the device-side mask generator advances once per step
+        self._device_dropout = (getattr(cfg, "feature_dropout", 0.0) > 0
+                                or getattr(cfg.gps_backbone_config, "dropout", 0.0) > 0)
+        self._names = {id(p): n for n, p in model.named_parameters()}
+        # ranks make their own view / gaze dropout draws (the reference seeds nothing per rank): which optimizer slots
+        # a step may skip is agreed over a host-side group (agree_unused)
+        self._flag_group = None
+        if self.reducer.exchange and self.reducer.world > 1 and getattr(cfg, "gaze_dropout", 0.0) > 0:
+            self._flag_group = dist.new_group(backend="gloo")
+        self._skip_cache = {}
 
     def _begin_step_kernels(self):
         """First launches of a step: zero the flat gradient buffer (GraphedTrainEngine may add the deferred update)."""
+        self._advance_rng()
         self.reducer.zero()
+
+    def _advance_rng(self):
+        if self._device_dropout and self.reducer.flat_param.is_cuda:
+            from routeformer_amd import kernels as K
+            K.RNG.begin_step(self.reducer.flat_param.device)  # step += 1 on the device (captured: once per replay)
+
+    def _skip_ranges(self, prefixes):
+        """[lo, hi) slices of the flat buffers holding the parameters whose names start with one of ``prefixes``
+        (merged, sorted): the slots a step did not touch (gaze branch dropped, routeformer.py:299-310)."""
+        if not prefixes or not agree_unused(True, self._flag_group):
+            if not prefixes and self._flag_group is not None:
+                agree_unused(False, self._flag_group)  # every rank takes part in the exchange every step
+            return ()
+        hit = self._skip_cache.get(tuple(prefixes))
+        if hit is not None:
+            return hit
+        r = self.reducer
+        spans = sorted((r.offset[id(p)], r.offset[id(p)] + p.numel()) for p in r.params
+                       if self._names[id(p)].startswith(tuple(prefixes)))
+        merged = []
+        for a, b in spans:
+            a_al = a  # slots are padded to 64 floats: padding between two skipped neighbours is skipped too
+            if merged and a_al - merged[-1][1] < 64:
+                merged[-1][1] = b
+            else:
+                merged.append([a_al, b])
+        self._skip_cache[tuple(prefixes)] = tuple((a, b) for a, b in merged)
+        return self._skip_cache[tuple(prefixes)]
 
     def _fwd_bwd(self, item, epoch, tokens_ready: bool = False):
         from routeformer_amd import kernels as K
@@ -463,7 +523,7 @@ class TrainEngine:
         self.model.train()
         res = self._fwd_bwd(item, epoch)
         scale = self.reducer.finish()
-        self.opt.step(scale)
+        self.opt.step(scale, skip=self._skip_ranges(self.model.__dict__.get("_unused_prefixes", ())))
         return res
 
 
@@ -512,8 +572,10 @@ class GraphedTrainEngine(TrainEngine):
         self.split = self.reducer.exchange if env is None else env == "1"
         self._names = {id(p): n for n, p in model.named_parameters()}
         c = model.configs
-        if c.view_dropout > 0 or c.gaze_dropout > 0 or c.motion_noise > 0 or c.feature_dropout > 0:
-            raise ValueError("GraphedTrainEngine needs a draw-independent step (all dropouts / noise 0)")
+        if c.motion_noise > 0:
+            raise ValueError("GraphedTrainEngine: motion_noise > 0 (torch.randn_like on the inputs) is not supported")
+        if defer_update and c.gaze_dropout > 0:
+            raise ValueError("defer_update cannot skip the optimizer slots of a dropped gaze branch; use defer_update=False")
 
     def _eager_fwd_bwd(self, item, epoch):
         return self._fwd_bwd(item, epoch)
@@ -538,6 +600,7 @@ class GraphedTrainEngine(TrainEngine):
         AdamW (scalars from ``self._hyper``, a no-op while nothing is pending), the backbone's share on a side stream
         that the backbone forward joins (``model._before_gps_backbone``), each slice zeroed once it has been used."""
         from routeformer_amd import kernels as K
+        self._advance_rng()
         if not self.defer_update:
             self.reducer.zero()
             return
@@ -654,20 +717,37 @@ class GraphedTrainEngine(TrainEngine):
         self._static_item = {part: {n: (v if (v.dim() == 5 and self._pipelined) else v.clone()) for n, v in item[part].items()}
                              for part in ("train", "target")}
         self._trunk_g = None
-        # plan: which draws does one step make?
-        plan = None
+        # plan: which host draws does one step make?  One plan per variant of the host dropout decisions (view /
+        # gaze dropout, routeformer.py:301,405-410): depth-first over the outcomes, each variant run once eagerly
+        # with its decisions imposed (decisions beyond the imposed prefix default to "keep")
+        plans, unused, stack = [], [], [[]]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for i in range(max(1, warmup)):
-                SAMPLER.plan = [] if i == 0 else None
-                self._eager_fwd_bwd(self._static_item, epoch)
-                if i == 0:
+            while stack:
+                forced = stack.pop()
+                SAMPLER.plan, SAMPLER.forcing = [], list(forced)
+                try:
+                    self._eager_fwd_bwd(self._static_item, epoch)
                     plan = SAMPLER.plan
+                finally:
+                    SAMPLER.plan, SAMPLER.forcing = None, None
+                plans.append(plan)
+                unused.append(tuple(self.model.__dict__.get("_unused_prefixes", ())))
+                outcomes = [op[2] for op in plan if op[0] == "bern"]
+                for i in range(len(forced), len(outcomes)):
+                    stack.append(outcomes[:i] + [True])
+            for _ in range(max(0, warmup - len(plans))):
+                SAMPLER.forcing = []
+                try:
+                    self._eager_fwd_bwd(self._static_item, epoch)
+                finally:
+                    SAMPLER.forcing = None
         torch.cuda.current_stream().wait_stream(side)
-        SAMPLER.plan = None
-        SAMPLER.make_static(plan, dev)
+        SAMPLER.make_static(plans, dev)
+        self._variant_unused = unused
         SAMPLER.refill_static()
+        SAMPLER.select_static(0)
         torch.cuda.synchronize()
         if self._pipelined:
             clips, keys = self.model.video_clips([self._static_item["train"], self._static_item["target"]])
@@ -684,21 +764,22 @@ class GraphedTrainEngine(TrainEngine):
         self._epoch = epoch
         self._recipe = self._recipe_for(epoch)
         self._graphs = {}
-        self.graph, self._out = self._main_graph(False)
+        self.graph, self._out = self._main_graph(False, 0)
         self._ready_id = None
         return self
 
-    def _main_graph(self, lookahead: bool):
+    def _main_graph(self, lookahead: bool, variant: int = 0):
         """Graph of forward + backward on the static inputs.  With ``lookahead`` the conv-trunk pass over the
         staged frames of the NEXT batch is a parallel branch of the SAME graph (forked stream, writes
         ``_tok_next``): two separate graphs launched on two streams do not overlap on ROCm 7.2 (measured:
         14.2 + 5.4 = 19.5 ms), branches of one graph do."""
-        key = True if (lookahead and self._pipelined) else None
+        la = bool(lookahead and self._pipelined)
+        key = (la, variant)
         hit = self._graphs.get(key)
         if hit is not None:
             return hit[0], hit[1]
         clips = None
-        if key is not None:
+        if la:
             clips = self._staged()
             self.model.video_backbone.encode_clips(clips)  # warm caches outside capture (scratch output)
         if self._pipelined:
@@ -706,17 +787,18 @@ class GraphedTrainEngine(TrainEngine):
             self.model.set_video_tokens(self._tok_cur, c0, k0)
         torch.cuda.synchronize()
         from routeformer_amd.models.blocks import SAMPLER
-        SAMPLER.rewind_static()
+        now = SAMPLER._variant
+        SAMPLER.select_static(variant)  # the captured pass takes this variant's decisions and key-sample slots
         g = torch.cuda.CUDAGraph()
         if not self.split:
             with torch.cuda.graph(g, **_capture_kw()):
                 cur = torch.cuda.current_stream()
-                if key is not None:
+                if la:
                     self._tstream.wait_stream(cur)
                     with torch.cuda.stream(self._tstream):
                         self.model.video_backbone.encode_clips(clips, out=self._tok_next)
                 out = self._fwd_bwd(self._static_item, self._epoch, tokens_ready=self._pipelined)
-                if key is not None:
+                if la:
                     cur.wait_stream(self._tstream)
         else:
             # two graphs over one memory pool, replayed back to back: the host can start the all-reduce of the GPS
@@ -726,12 +808,12 @@ class GraphedTrainEngine(TrainEngine):
             try:
                 with torch.cuda.graph(g, **_capture_kw()):
                     cur = torch.cuda.current_stream()
-                    if key is not None:
+                    if la:
                         self._tstream.wait_stream(cur)
                         with torch.cuda.stream(self._tstream):
                             self.model.video_backbone.encode_clips(clips, out=self._tok_next)
                     out, carry = self._stage1(self._static_item, self._epoch, tokens_ready=self._pipelined)
-                    if key is not None:
+                    if la:
                         cur.wait_stream(self._tstream)
                 with torch.cuda.graph(g2, pool=g.pool(), **_capture_kw()):
                     self._stage2(carry)
@@ -740,6 +822,7 @@ class GraphedTrainEngine(TrainEngine):
             del carry
             g = (g, g2)
         self.model.clear_video_tokens()
+        SAMPLER.select_static(now)
         self._graphs[key] = (g, out)
         return g, out
 
@@ -760,8 +843,12 @@ class GraphedTrainEngine(TrainEngine):
             torch.cuda.synchronize()
             self._graphs.clear()
             self._epoch, self._recipe = epoch, recipe
-            self.graph, self._out = self._main_graph(False)
-        g, out = self._main_graph(next_item is not None)
+            self.graph, self._out = self._main_graph(False, 0)
+        # host side of the step first: the reference's draws in its order (key samples, view / gaze dropout decisions)
+        # into the static buffer; the decisions pick the graph variant to replay (captured on first use)
+        variant = SAMPLER.refill_static()
+        g, out = self._main_graph(next_item is not None, variant)
+        SAMPLER.select_static(variant)
         if self._pipelined:
             iid = item.get("id")
             if not (self._ready_id is not None and iid is not None and iid == self._ready_id):
@@ -778,7 +865,6 @@ class GraphedTrainEngine(TrainEngine):
                     continue  # the main graph reads trunk tokens, not clips
                 if v.data_ptr() != dst.data_ptr():
                     dst.copy_(v, non_blocking=True)
-        SAMPLER.refill_static()
         self.reducer.begin_step()  # the replay does not run the Python bookkeeping of zero()
         if self.defer_update:
             self._set_hyper()  # scalars of the update this replay starts with (or "nothing pending")
@@ -796,5 +882,5 @@ class GraphedTrainEngine(TrainEngine):
             self.opt.t += 1
             self._pending = self.opt.hyper(scale)  # applied at the start of the next replay (or by flush())
         else:
-            self.opt.step(scale)
+            self.opt.step(scale, skip=self._skip_ranges(self._variant_unused[variant]))
         return out

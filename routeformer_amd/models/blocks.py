@@ -30,22 +30,29 @@ from routeformer_amd import kernels as K
 # global generator in call order, exactly like the reference, then shipped to the device.
 # ---------------------------------------------------------------------------------------------
 class IndexSampler:
-    """Process-wide source of ``index_sample`` tensors.
+    """Process-wide source of the HOST random draws of the hot path: the ``index_sample`` tensors of ProbSparse
+    attention and the view / gaze dropout decisions.
 
     ``draw_host`` performs the reference's own call ``torch.randint(L_K, (L_Q, sample_k))`` on the host, so
-    a ``torch.manual_seed`` reproduces the reference's samples.  ``replay`` injects recorded samples
-    (tests); ``log`` keeps what was drawn (draw-order tests).
+    a ``torch.manual_seed`` reproduces the reference's samples; ``bernoulli(p)`` is its ``torch.rand(1) < p``
+    (routeformer.py:301,406-407), drawn from the same generator at the same point of the sequence.  ``replay``
+    injects recorded samples (tests); ``log`` keeps what was drawn (draw-order tests).
 
-    Static mode (HIP-graph replay, ``engine.GraphedTrainEngine``): the sequence of draws of one step is
-    fixed by the shapes, so all of them are made on the host BEFORE the replay -- same calls, same order --
-    into one pinned buffer, shipped with a single async copy, and ``draw`` hands out views of the static
-    device buffer in call order (no host work and no copies inside the captured region)."""
+    Static mode (HIP-graph replay, ``engine.GraphedTrainEngine``): the sequence of draws of one step is fixed by
+    the shapes and by the dropout decisions made so far, so the engine records one PLAN (list of draw operations)
+    per decision variant up front.  Before every replay ``refill_static`` walks the plans on the host -- same
+    calls, same order as the reference; a decision narrows the candidate variants -- into one pinned buffer,
+    ships it with a single async copy and returns the variant, whose graph the engine then replays; inside a
+    capture ``draw`` / ``bernoulli`` hand out views of the static device buffer / the variant's decisions in
+    call order (no host work and no copies inside the captured region)."""
 
     def __init__(self):
         self.replay: Optional[list] = None
         self.log: Optional[list] = None
-        self.plan: Optional[list] = None      # recording: [(L_K, L_Q, sample_k)] of one step
-        self._static = None                   # (device buffer, pinned buffer, [(offset, L_K, L_Q, k)])
+        self.plan: Optional[list] = None      # recording: [("int", L_K, L_Q, k) | ("bern", p, outcome)] of one step
+        self.forcing: Optional[list] = None   # plan recording: decisions to impose (exhausted -> False), no host draw
+        self._static = None                   # (device buffer, pinned buffer, [plan per variant])
+        self._variant = 0
         self._cursor = 0
 
     def draw_host(self, L_K: int, L_Q: int, sample_k: int) -> torch.Tensor:
@@ -62,44 +69,95 @@ class IndexSampler:
     def draw(self, L_K: int, L_Q: int, sample_k: int, device) -> torch.Tensor:
         """(L_Q, sample_k) int32 on ``device``."""
         if self._static is not None:
-            dev_buf, _, slots = self._static
-            off, lk, lq, k = slots[self._cursor]
-            assert (lk, lq, k) == (L_K, L_Q, sample_k), "draw sequence changed since the graph was planned"
+            dev_buf, _, plans = self._static
+            op = plans[self._variant][self._cursor]
+            assert op[:4] == ("int", L_K, L_Q, sample_k), "draw sequence changed since the graph was planned"
             self._cursor += 1
-            return dev_buf[off:off + lq * k].view(lq, k)
+            return dev_buf[op[4]:op[4] + L_Q * sample_k].view(L_Q, sample_k)
         if self.plan is not None:
-            self.plan.append((L_K, L_Q, sample_k))
+            self.plan.append(("int", L_K, L_Q, sample_k))
         return self.draw_host(L_K, L_Q, sample_k).to(torch.int32).to(device, non_blocking=True)
 
-    # -- static mode ------------------------------------------------------------------------------
-    def make_static(self, plan, device):
-        slots, off = [], 0
-        for lk, lq, k in plan:
-            slots.append((off, lk, lq, k))
-            off += lq * k
-        self._static = (torch.zeros(off, dtype=torch.int32, device=device),
-                        torch.zeros(off, dtype=torch.int32).pin_memory(), slots)
-        self._cursor = 0
+    def bernoulli(self, p: float) -> bool:
+        """The reference's host decision ``bool(torch.rand(1) < p)`` (view / gaze dropout)."""
+        if self._static is not None:
+            op = self._static[2][self._variant][self._cursor]
+            assert op[0] == "bern" and op[1] == p, "draw sequence changed since the graph was planned"
+            self._cursor += 1
+            return op[2]
+        if self.forcing is not None:
+            out = self.forcing.pop(0) if self.forcing else False
+        else:
+            out = bool(torch.rand(1) < p)
+        if self.plan is not None:
+            self.plan.append(("bern", p, out))
+        return out
 
-    def refill_static(self):
-        """Host side of one step: the reference's draws in order, then ONE async H2D copy."""
-        dev_buf, pinned, slots = self._static
+    # -- static mode ------------------------------------------------------------------------------
+    def make_static(self, plans, device):
+        """``plans``: one op list per decision variant (a single list of ("int", ...) ops = no decisions)."""
+        if plans and not isinstance(plans[0], list):
+            plans = [plans]
+        plans = [[("int",) + tuple(op) if op[0] not in ("int", "bern") else tuple(op) for op in plan] for plan in plans]
+        laid, size = [], 0
+        for plan in plans:
+            off, ops = 0, []
+            for op in plan:
+                if op[0] == "int":
+                    ops.append(op[:4] + (off,))
+                    off += op[2] * op[3]
+                else:
+                    ops.append(op)
+            laid.append(ops)
+            size = max(size, off)
+        host = torch.zeros(max(size, 1), dtype=torch.int32)
+        self._static = (torch.zeros(max(size, 1), dtype=torch.int32, device=device),
+                        host.pin_memory() if torch.cuda.is_available() else host, laid)
+        self._variant, self._cursor = 0, 0
+
+    @property
+    def n_variants(self) -> int:
+        return len(self._static[2]) if self._static is not None else 0
+
+    def decisions(self, variant: int):
+        return tuple(op[2] for op in self._static[2][variant] if op[0] == "bern")
+
+    def refill_static(self) -> int:
+        """Host side of one step: the reference's draws in order (a decision narrows the candidate variants), then
+        ONE async H2D copy.  Returns the variant the decisions selected."""
+        dev_buf, pinned, plans = self._static
         ev = self.__dict__.get("_copied")
         if ev is not None:
             ev.synchronize()  # the previous step's copy must have left the pinned buffer before it is rewritten
-        for off, lk, lq, k in slots:
-            pinned[off:off + lq * k].copy_(self.draw_host(lk, lq, k).view(-1))
+        cand, pos = list(range(len(plans))), 0
+        while pos < len(plans[cand[0]]):
+            op = plans[cand[0]][pos]
+            if op[0] == "bern":
+                out = bool(torch.rand(1) < op[1])
+                cand = [v for v in cand if plans[v][pos][0] == "bern" and plans[v][pos][2] == out]
+                if not cand:
+                    raise RuntimeError("host dropout decisions selected a step variant that was not planned")
+            else:
+                _, lk, lq, k, off = op
+                pinned[off:off + lq * k].copy_(self.draw_host(lk, lq, k).view(-1))
+            pos += 1
+        assert len(cand) == 1, "two planned variants with the same decisions"
         dev_buf.copy_(pinned, non_blocking=True)
         if dev_buf.is_cuda:
             self._copied = torch.cuda.Event()
             self._copied.record()
-        self._cursor = 0
+        self._variant, self._cursor = cand[0], 0
+        return cand[0]
+
+    def select_static(self, variant: int):
+        """Capture / eager pass of one variant on the static buffers."""
+        self._variant, self._cursor = variant, 0
 
     def rewind_static(self):
         self._cursor = 0
 
     def drop_static(self):
-        self._static, self._cursor = None, 0
+        self._static, self._cursor, self._variant = None, 0, 0
 
 
 SAMPLER = IndexSampler()

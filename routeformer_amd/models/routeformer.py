@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from routeformer_amd import kernels as K
-from routeformer_amd.models.blocks import PerceiveDecoder, PerceiveEncoder
+from routeformer_amd.models.blocks import SAMPLER, PerceiveDecoder, PerceiveEncoder
 from routeformer_amd.models.config import RouteformerConfig
 from routeformer_amd.models.gps_backbone import Informer
 from routeformer_amd.models.video_backbone import VideoBackboneModule
@@ -191,9 +191,9 @@ class Routeformer(nn.Module):
                 left = batch["left_video"]
                 right = batch.get("right_video", left)
                 drop_left, drop_right = False, "right_video" not in batch
-                if self.view_dropout > 0.0 and training:
-                    drop_one = bool(torch.rand(1) < self.view_dropout)
-                    drop_left = drop_one and bool(torch.rand(1) < 0.5)
+                if self.view_dropout > 0.0 and training:  # host draws (routeformer.py:405-410), reference order
+                    drop_one = SAMPLER.bernoulli(self.view_dropout)
+                    drop_left = drop_one and SAMPLER.bernoulli(0.5)
                     drop_right = (drop_one and not drop_left) or "right_video" not in batch
                 idx = self._frame_indices(left.shape[1], c.video_fps, "Video")
                 visual.extend([None, None])
@@ -206,7 +206,11 @@ class Routeformer(nn.Module):
             drop_gaze = False
             if self.with_gaze:
                 if self.gaze_dropout > 0.0 and training:
-                    drop_gaze = bool(torch.rand(1) < self.gaze_dropout)
+                    drop_gaze = SAMPLER.bernoulli(self.gaze_dropout)
+                if training:  # (the target-side pass of a train step never drops: it must not overwrite the note)
+                    # parameters that take no part in this step (their gradient stays None in the reference, so its
+                    # AdamW skips them -- weight decay included): the engine's fused update skips the same slots
+                    self.__dict__["_unused_prefixes"] = ("gaze_encoder.", "gaze_video_decoder.") if drop_gaze else ()
                 visual.append(None)
                 if drop_gaze:
                     fv = batch["front_video"]

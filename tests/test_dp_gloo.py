@@ -139,3 +139,29 @@ def test_single_process_reducer_is_a_noop():
     assert red.finish() == 1.0
     assert float(red.flat_grad.abs().sum()) > 0
     assert net.a.weight.data_ptr() >= red.flat_param.data_ptr()
+
+
+def _agree_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from routeformer_amd.engine import agree_unused
+    grp = dist.new_group(backend="gloo")
+    # step 1: only rank 0 dropped the gaze branch -> nobody may skip; step 2: both dropped it -> both skip
+    q.put((rank, agree_unused(rank == 0, grp), agree_unused(True, grp), agree_unused(False, grp)))
+    dist.destroy_process_group()
+
+
+def test_unused_parameter_agreement_two_ranks():
+    """Optimizer slots of the gaze branch are skipped only when EVERY rank dropped the branch this step (the
+    reference's DDP(find_unused_parameters=True) + AdamW(grad None -> skip) behaviour)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, 29731, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert got == [(0, False, True, False), (1, False, True, False)]

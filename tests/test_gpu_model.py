@@ -543,28 +543,38 @@ def test_dropout_blocks_vs_reference(prec, tol):
     K.set_precision(prec)
     P = 0.1
 
-    def run(module, inputs, key, loss):
+    def run(module, inputs, key, loss, oracle):
+        """``oracle(sd, idx, drop)``: the CPU oracle on the same weights / samples / masks -- only to learn its top-u
+        selections, which are imposed on the kernels (the selection is discontinuous: a bf16 rounding can flip it)."""
         module.train()
+        sd = {"m." + k: v.detach().cpu() for k, v in module.state_dict().items()}
+        src = O.IndexSource(draws(G, key))
+        with torch.no_grad():
+            oracle(sd, src, O.DropoutSource(masks(G, key)))
         SAMPLER.replay = draws(G, key)
         K.RNG.forced = [m.clone() for m in masks(G, key)]
+        K.TOPS.forced = [t_.clone() for t_ in src.tops]
         try:
             y = module(*inputs)
-            assert not K.RNG.forced and not SAMPLER.replay, key
+            assert not K.RNG.forced and not SAMPLER.replay and not K.TOPS.forced, key
         finally:
-            K.RNG.forced, SAMPLER.replay = None, None
+            K.RNG.forced, SAMPLER.replay, K.TOPS.forced = None, None, None
         loss(y).backward()
         return y
 
     enc = _load(PerceiveEncoder(in_channels=240, out_channels=64, out_len=1, n_heads=8, layers=2, d_ff=256, dropout=P))
     x = t(G["enc.x"]).to(DEV).requires_grad_()
-    y = run(enc, (x,), "enc.", lambda y: y.square().sum())
+    y = run(enc, (x,), "enc.", lambda y: y.square().sum(),
+            lambda sd, idx, drop: O.perceive_encoder(sd, "m", t(G["enc.x"]), 8, 1, idx, dropout=P, drop=drop))
     assert rel_err(y, G["enc.y"]) < tol and rel_err(x.grad, G["enc.dx"]) < 5 * tol
     _grads_vs_summary(G, "enc.", dict(enc.named_parameters()), 5 * tol)
 
     dec = _load(PerceiveDecoder(query_channels=64, value_channels=64, out_channels=64, out_len=40, dropout=P, d_ff=256,
                                 n_heads=8, layers=2, mix=False))
     mem, qry = t(G["dec.mem"]).to(DEV).requires_grad_(), t(G["dec.qry"]).to(DEV).requires_grad_()
-    yd = run(dec, (mem, qry), "dec.", lambda y: y.square().sum())
+    yd = run(dec, (mem, qry), "dec.", lambda y: y.square().sum(),
+             lambda sd, idx, drop: O.perceive_decoder(sd, "m", t(G["dec.mem"]), t(G["dec.qry"]), 8, 40, idx, dropout=P,
+                                                      drop=drop))
     assert rel_err(yd, G["dec.y"]) < tol
     assert rel_err(mem.grad, G["dec.dmem"]) < 5 * tol and rel_err(qry.grad, G["dec.dqry"]) < 5 * tol
     _grads_vs_summary(G, "dec.", dict(dec.named_parameters()), 5 * tol)
@@ -574,7 +584,14 @@ def test_dropout_blocks_vs_reference(prec, tol):
         gcfg.output_attention, gcfg.smart_decoder, gcfg._enc_in, gcfg._c_out = False, True, 69, 66
         net = _load(cls(gcfg))
         xg = t(G[tag + ".x"]).to(DEV).requires_grad_()
-        yg = run(net, (xg,), tag + ".", lambda y: y.square().mean())
+        if tag == "inf":
+            orc = lambda sd, idx, drop: O.informer(sd, "m", t(G["inf.x"]), pred_len=10, n_heads=gcfg.n_heads,  # noqa: E731
+                                                   factor=gcfg.factor, activation=gcfg.activation, smart_decoder=True,
+                                                   training=True, idx=idx, dropout=P, drop=drop)
+        else:
+            orc = lambda sd, idx, drop: O.transformer_gps(sd, "m", t(G["tf.x"]), pred_len=10, n_heads=gcfg.n_heads,  # noqa: E731
+                                                          activation=gcfg.activation, dropout=P, drop=drop)
+        yg = run(net, (xg,), tag + ".", lambda y: y.square().mean(), orc)
         assert rel_err(yg, G[tag + ".y"]) < tol, tag
         assert rel_err(xg.grad, G[tag + ".dx"]) < 5 * tol, tag
         _grads_vs_summary(G, tag + ".", dict(net.named_parameters()), 5 * tol)
@@ -643,3 +660,48 @@ def test_dropout_train_step_vs_reference(kind):
         assert abs(float(res[k]) - ref) < 1e-3 * max(1.0, abs(ref)), (k, float(res[k]), ref)
     res["loss"].backward()
     _grads_vs_summary(G, key, dict(model.named_parameters()), 5e-3)
+
+
+def test_graphed_engine_with_dropouts_matches_eager():
+    """The paper run's dropouts (full_comparison.py:272-275) under HIP-graph replay: the host decisions (view / gaze
+    dropout) are drawn before every replay in the reference's order and select one of the captured step variants;
+    the device-side masks advance with a device-resident step counter.  Same host seed + same mask seed -> the
+    graphed engine takes the same decisions and computes the same steps as the eager engine, and the optimizer skips
+    the gaze branch's slots on the steps that dropped it (grad None -> AdamW skip in the reference)."""
+    from routeformer_amd import kernels as K, synthetic
+    from routeformer_amd.engine import GraphedTrainEngine, TrainEngine
+    from routeformer_amd.models.blocks import SAMPLER
+    c, cfg = _dropout_case()
+    items = []
+    for seed in (11, 12):
+        it = synthetic.synth_item(c["B"], c["T"], c["P"], seed, c["H"], c["W"], streams=c["streams"], gaze=c["gaze"])
+        items.append({"train": _to_dev(it["train"]), "target": _to_dev(it["target"]), "id": seed})
+    runs = {}
+    for mode in ("eager", "graph"):
+        model, sd = _dropout_model(cfg)
+        eng = TrainEngine(model, lr=1e-4) if mode == "eager" else GraphedTrainEngine(model, lr=1e-4).capture(items[0], epoch=10)
+        if mode == "graph":
+            assert SAMPLER.n_variants == 6  # view: keep | drop left | drop right, x gaze: keep | drop
+        K.RNG.manual_seed(11)   # restarts the device step counter: both engines draw the same masks from here on
+        torch.manual_seed(5)
+        gaze_w = dict(model.named_parameters())["gaze_encoder.projection.weight"]
+        losses, decisions, gaze_moved = [], [], []
+        for i in range(14):
+            before = gaze_w.detach().clone()
+            res = eng.step(items[i % 2], epoch=10, next_item=items[(i + 1) % 2] if mode == "graph" else None)
+            losses.append(float(res["loss"].detach()))
+            decisions.append(tuple(model.__dict__.get("_unused_prefixes", ())) if mode == "eager"
+                             else tuple(eng._variant_unused[SAMPLER._variant]))
+            gaze_moved.append(bool((gaze_w.detach() != before).any()))
+        torch.cuda.synchronize()
+        runs[mode] = (losses, decisions, gaze_moved, eng.reducer.flat_param.clone(), torch.get_rng_state())
+        if mode == "graph":
+            assert len({k[1] for k in eng._graphs}) >= 3, "expected several decision variants in 14 steps"
+        SAMPLER.drop_static()
+    (le, de, me, pe, re_), (lg, dg, mg, pg, rg) = runs["eager"], runs["graph"]
+    assert de == dg and torch.equal(re_, rg), "host decisions / generator diverged between eager and graph mode"
+    assert any(de) and not all(de), "the schedule should contain steps with and without the gaze branch"
+    # dropped gaze branch: its parameters do not move that step (no weight decay, no moment decay) -- in both engines
+    assert me == [not d for d in de] and mg == me
+    assert all(abs(a - b) < 2e-3 * max(1.0, abs(a)) for a, b in zip(le, lg)), (le, lg)
+    assert rel_err(pg, pe) < 14 * 3e-4
