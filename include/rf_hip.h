@@ -270,6 +270,48 @@ int rf_attn_bwd(const float* q, const float* k, const float* v, int64_t q_ld, in
                 float* dk, float* dv, int64_t dq_ld, int64_t dk_ld, int64_t dv_ld, int B, int H,
                 int LQ, int LK, int E, int n_top, int mode, float scale, void* stream);
 
+/* ---- fused per-sequence encoder stack (bf16-input MFMA only) ---------------------------------------
+ * One workgroup owns one sequence (L <= 80 tokens, d_model 128, 8 heads of 16) and walks EVERY EncoderLayer of a
+ * PerceiveEncoder in one launch: QKV projection -> ProbSparse attention -> out-projection + residual + LayerNorm ->
+ * conv1 -> act -> conv2 + residual + LayerNorm (cross_modal_transformer.py:288-301, the loop of :322-324, called from
+ * routeformer.py:488 for every frame of every camera stream).  The residual stream stays in registers, the GEMM
+ * operands are bf16 LDS images, weight fragments come from a fragment-ordered bf16 copy (rf_seqlayer_pack).
+ * RfSeqStack describes the stack with a handful of base pointers (every per-layer quantity sits at a fixed stride):
+ *   wpack  : per layer one blob of rf_seqlayer_pack_bytes(d_ff) bytes (wpack_stride apart): the four weights in bf16
+ *            fragment order [Wq;Wk;Wv] (384x128) | Wo (128x128) | conv1 (d_ff x 128) | conv2 (128 x d_ff), then fp32
+ *            vectors bqkv[384] bo[128] b1[d_ff] b2[128] norm1.weight norm1.bias norm2.weight norm2.bias [128 each]
+ *            -- written by rf_seqlayer_pack (entries with K == 0 copy an fp32 vector of N floats);
+ *   idx[i] : key samples of layer i, int32 [G, L, sample_k]; sequence b uses table b / idx_group, tables idx_stride
+ *            elements apart (<= 0: packed);
+ *   top    : int32 [layers, B, 8, n_top] selected rows (written; read when force_top);
+ *   y      : [layers, B*L, 128] layer outputs (layer i + 1 continues from registers; y[layers-1] is the result);
+ *            with save == 0 only the LAST layer's output is written, to y[0] (a [B*L, 128] buffer suffices);
+ *   with save != 0 what the layer-by-layer backward kernels consume, each [layers, B*L, width]: qkv (384: q | k | v
+ *   packed as the projection GEMM emits them), ctx (128), xhat1 / xhat2 (128) and rstd1 / rstd2 (1) of the two
+ *   norms, x1 (128: norm1 output = conv1 input), z (optional) / h (d_ff: conv1 pre-activation / activation).
+ * rf_seqlayer_pack: bf16 fragment order of a weight for the 16x16x32 MFMA B operand -- out[((n/16 * K/32 + k/32) * 64
+ * + lane) * 8 + j] = W[n = 16 (n/16) + lane % 16][k = 32 (k/32) + 8 (lane / 16) + j], W[n][k] = w[n * ldw + k]
+ * (transpose: w[k * ldw + n], the dX orientation); N % 16 == 0, K % 32 == 0; up to RF_SEQLAYER_MAX_PACK per launch. */
+#define RF_SEQLAYER_MAX_LAYERS 8
+#define RF_SEQLAYER_MAX_PACK 64
+typedef struct RfSeqStack {
+  const void* wpack; int64_t wpack_stride;
+  const int32_t* idx[RF_SEQLAYER_MAX_LAYERS]; int64_t idx_stride;
+  int32_t* top;
+  float* y;
+  float *qkv, *ctx, *xhat1, *rstd1, *x1, *z, *h, *xhat2, *rstd2;
+  int n_layers, pad;
+} RfSeqStack;
+typedef struct RfSeqPackEntry {
+  const float* w; void* out; int64_t ldw; int N, K, transpose, pad;
+} RfSeqPackEntry;
+int rf_seqlayer_pack(const RfSeqPackEntry* entries, int count, void* stream);
+int64_t rf_seqlayer_pack_bytes(int d_ff);
+int rf_seqlayer_supported(int L, int d_model, int n_heads, int d_ff, int sample_k, int n_top);
+int rf_seqlayer_fwd(const RfSeqStack* stack, const float* x, int B, int L, int d_model, int n_heads, int d_ff, int act,
+                    int sample_k, int n_top, int idx_group, int force_top, int save, float scale, float eps,
+                    void* stream);
+
 /* ---- dropout on the trainable path -------------------------------------------------------------
  * nn.Dropout of cross_modal_transformer.py:49,63,220-231,285-299, gps_backbone/layers/Embedding.py:122-126,
  * layers/TransformerEncoderDecoder.py:41-50,102-113.  Masks are never stored: the keep-bit of element e of dropout

@@ -56,6 +56,10 @@ SIGNATURES = {
     "rf_attn_fwd_full_scores": [_I, _I, _I, _I, _I, _I, _I, _I],
     "rf_attn_bwd": [_P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _I,
                     _I, _I, _F, _P],
+    "rf_seqlayer_pack": [_P, _I, _P],
+    "rf_seqlayer_supported": [_I, _I, _I, _I, _I, _I],
+    "rf_seqlayer_pack_bytes": [_I],
+    "rf_seqlayer_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "rf_rng_seed": [_P, _L, _L, _P],
     "rf_rng_advance": [_P, _P],
     "rf_dropout": [_P, _P, _L, _F, _P, _I, _P, _P, _P],
@@ -93,6 +97,23 @@ class ConvEntry(ctypes.Structure):
                 ("N", c_int), ("H", c_int), ("W", c_int), ("cin", c_int), ("cout", c_int), ("relu", c_int)]
 
 
+SEQLAYER_MAX_LAYERS, SEQLAYER_MAX_PACK = 8, 64  # RF_SEQLAYER_MAX_LAYERS / RF_SEQLAYER_MAX_PACK
+
+
+class SeqStack(ctypes.Structure):
+    """RfSeqStack of include/rf_hip.h."""
+    _fields_ = ([("wpack", c_void_p), ("wpack_stride", c_int64), ("idx", c_void_p * SEQLAYER_MAX_LAYERS),
+                 ("idx_stride", c_int64), ("top", c_void_p), ("y", c_void_p)]
+                + [(n, c_void_p) for n in ("qkv", "ctx", "xhat1", "rstd1", "x1", "z", "h", "xhat2", "rstd2")]
+                + [("n_layers", c_int), ("pad", c_int)])
+
+
+class SeqPackEntry(ctypes.Structure):
+    """RfSeqPackEntry of include/rf_hip.h."""
+    _fields_ = [("w", c_void_p), ("out", c_void_p), ("ldw", c_int64), ("N", c_int), ("K", c_int), ("transpose", c_int),
+                ("pad", c_int)]
+
+
 class HipLibraryError(RuntimeError):
     pass
 
@@ -113,6 +134,7 @@ def lib():
             fn.restype = c_int
         handle.rf_conv3x3_packed_elems.restype = c_int64
         handle.rf_pointwise_packed_elems.restype = c_int64
+        handle.rf_seqlayer_pack_bytes.restype = c_int64
         handle.rf_last_error.restype = ctypes.c_char_p
         handle.rf_last_error.argtypes = []
         _lib = handle

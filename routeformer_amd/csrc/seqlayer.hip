@@ -1,0 +1,621 @@
+// Fused per-sequence encoder stack (SURVEY section 7 step 5, 8(b) `encoder_layer_fused`): ONE workgroup owns ONE
+// sequence (L <= 80 tokens x d_model 128) and walks every EncoderLayer of a PerceiveEncoder
+// (cross_modal_transformer.py:288-301 x layers, called from routeformer.py:488 for 8 B sequences per camera stream):
+//
+//     QKV projection -> ProbSparse attention (8 heads) -> out-projection + residual + LayerNorm
+//     -> conv1 -> GELU -> conv2 + residual + LayerNorm,            for every layer, in one launch.
+//
+// Layout of the work inside the workgroup (8 waves, two per SIMD):
+//   * the fp32 residual stream never leaves REGISTERS: wave w holds columns 16w..16w+15 of every row in the MFMA
+//     accumulator layout (the out-projection, conv2 and both LayerNorms produce exactly that slice);
+//   * every GEMM operand A (x, ctx, x1, h) is a bf16 image in LDS, every weight B-fragment is read straight from a
+//     fragment-ordered bf16 copy of the weights in global memory (rf_seqlayer_pack: the 64 lanes of a fragment read
+//     one contiguous 1-KB block; the 262 KB of a layer stay L2-resident across the 192-336 workgroups);
+//     all contractions are v_mfma_f32_16x16x32_bf16 with fp32 accumulation;
+//   * attention: wave h owns head h from the projection to the context -- q, k (row-major) and v (transposed) of
+//     the head stay in LDS as bf16; Q K^T of 16 queries at a time goes through a wave-private score tile from
+//     which the sampled scores of the sparsity measure are gathered; the top-u ranking, the softmax of the
+//     selected rows and P V need no workgroup barrier at all.
+// Training mode writes what the (layer-by-layer) backward kernels consume -- packed q|k|v, ctx, x-hat / 1/sigma of
+// both norms, x1, z, h, the selected rows -- with the same meaning as the unfused forward's saved tensors.
+// bf16 matrix-core mode only (like rowblock.hip); the exact-fp32 mode keeps the layer-by-layer path.
+#include "common.h"
+#include "philox.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SL_D = 128, SL_H = 8, SL_E = 16, SL_NW = 8, SL_NT = 64 * SL_NW;
+constexpr int SL_XP = SL_D + 8;  // bf16 pitch of the 128-column A images (272 B rows: conflict-light b128 reads)
+
+// Everything a layer needs sits at a fixed offset from one per-layer base (weights: one packed blob per layer, saves:
+// [layer][B*L][width] slabs), so the kernel carries a handful of base pointers instead of 25 pointers per layer.
+struct SeqStackP {
+  const float* x;               // (B, L, 128) input of the first layer
+  const unsigned char* wpack;   // per layer: fragment-ordered bf16 weights + fp32 vectors (layout: pack_offsets)
+  long wpack_stride;            // bytes between layers
+  const int32_t* idx[RF_SEQLAYER_MAX_LAYERS];  // (G, L, sample_k) key samples per layer
+  long idx_stride;              // elements between consecutive group tables
+  int32_t* top;                 // (layers, B, 8, n_top): written (read when force_top); may be null without save
+  float* y;                     // (layers, B*L, 128): layer outputs
+  float *qkv, *ctx, *xhat1, *rstd1, *x1, *z, *h, *xhat2, *rstd2;  // training saves (layers, B*L, width)
+  int B, L, F, n_layers, act, sample_k, n_top, idx_group, force_top, save;
+  float scale, eps;
+};
+
+// byte offsets inside a layer's packed blob
+struct PackOff { long wqkv, wo, w1, w2, vec, total; };
+__host__ __device__ inline PackOff pack_offsets(int F) {
+  PackOff o;
+  o.wqkv = 0;
+  o.wo = o.wqkv + 24L * 4 * 1024;          // 24 column tiles x 4 k-steps x 1 KB
+  o.w1 = o.wo + 8L * 4 * 1024;
+  o.w2 = o.w1 + (long)(F / 16) * 4 * 1024;
+  o.vec = o.w2 + 8L * (F / 32) * 1024;     // fp32: bqkv[384] bo[128] b1[F] b2[128] g1 be1 g2 be2 [128 each]
+  o.total = (o.vec + (1152L + F) * 4 + 255) & ~255L;
+  return o;
+}
+
+__device__ __forceinline__ float sl_gelu(float x) {  // erf-GELU, Abramowitz-Stegun 7.1.26 (|erf err| <= 1.5e-7)
+  const float u = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float erf_abs = 1.0f - poly * t * __expf(-u * u);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+__device__ __forceinline__ bf16x8 ld_frag(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 zero_frag() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f;
+  return z;
+}
+// B fragment number `f` of a fragment-ordered weight: 64 lanes x 16 B contiguous
+__device__ __forceinline__ bf16x8 ld_wfrag(const __bf16* base, int f, int lane) {
+  return *reinterpret_cast<const bf16x8*>(base + ((long)f * 64 + lane) * 8);
+}
+
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// One 16 x 16 fp32 tile in the MFMA accumulator layout (acc[r] = row 4 (lane >> 4) + r, column lane & 15) -> global rows
+// g[row * ld + 0..15]: transposed through a wave-private LDS patch so that every lane issues ONE 16-B store (16 rows x
+// 64 B per wave-instruction instead of four 4-B stores per lane).  tb: wave-private, 16 x 20 floats.
+__device__ __forceinline__ void tile_store(const f32x4& acc, float* __restrict__ tb, float* __restrict__ g, int ld,
+                                           int rows_valid, int lane) {
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tb[(fq * 4 + r) * 20 + fr] = acc[r];
+  wave_sync_lds();
+  const int rr = lane >> 2, c4 = (lane & 3) * 4;
+  const float4 o = *reinterpret_cast<const float4*>(tb + rr * 20 + c4);
+  if (rr < rows_valid) *reinterpret_cast<float4*>(g + rr * ld + c4) = o;
+  wave_sync_lds();
+}
+
+// LayerNorm over the 128 columns of every row, the columns of a row being spread over the 8 waves (16 each, MFMA
+// accumulator layout: v[rt][r] = row 16 rt + 4 (lane >> 4) + r, column 16 wave + (lane & 15)).  Per-wave partial
+// (sum, sum of squares) meet in part[row][wave]; one thread per row folds them into stat[row] = (mean, 1/sigma)
+// (biased variance: nn.LayerNorm); two workgroup barriers.  v becomes x-hat.
+template <int RT>
+__device__ __forceinline__ void stack_layer_norm(f32x4 (&v)[RT], float* __restrict__ rstd_g, int L, float2* __restrict__ part,
+                                                 float2* __restrict__ stat, int wave, int lane, float eps) {
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s1 = row16_sum(v[rt][r]), s2 = row16_sum(v[rt][r] * v[rt][r]);
+      if (fr == 0) part[(rt * 16 + fq * 4 + r) * SL_NW + wave] = make_float2(s1, s2);
+    }
+  __syncthreads();
+  {
+    const int row = wave * 64 + lane;
+    if (row < 16 * RT) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < SL_NW; w += 2) {
+        const float4 a = *reinterpret_cast<const float4*>(part + row * SL_NW + w);
+        s1 += a.x + a.z;
+        s2 += a.y + a.w;
+      }
+      const float mean = s1 * (1.f / 128.f);
+      const float rs = __builtin_amdgcn_rsqf(fmaxf(s2 * (1.f / 128.f) - mean * mean, 0.f) + eps);
+      stat[row] = make_float2(mean, rs);
+      if (rstd_g && row < L) rstd_g[row] = rs;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float2 st = stat[rt * 16 + fq * 4 + r];
+      v[rt][r] = (v[rt][r] - st.x) * st.y;
+    }
+}
+
+// RT = row tiles of 16 (L <= 16 RT).  LDS (bytes), RT = 5:
+//   xb   bf16 [16 RT][136]            21 760   x / ctx / x1 as MFMA A operand (one image, reused phase by phase)
+//   qs   bf16 [8][16 RT][16]          20 480 \
+//   ks   bf16 [8][16 RT][16]          20 480  } conv-pair phase: hb bf16 [16 RT][F + 8] (<= 42 240) aliases these
+//   vt   bf16 [8][16][KS32 + 8]       26 624 /
+//   scr  per wave 7 168               57 344   score tile fp32 [16][16 RT + 4] / P bf16 [32][KS32 + 8]; Ms, top, flags
+//   part float2 [16 RT][8] + stat float2 [16 RT]   5 760   LayerNorm partial sums / per-row (mean, 1/sigma)
+//   idx  uint8 [L][sample_k]           2 048   key samples of the layer (shared by the 8 heads)
+template <int RT>
+__global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p) {
+  constexpr int LP = 16 * RT, KS32 = ((LP + 31) / 32) * 32, KSTEPS = KS32 / 32, VP = KS32 + 8, SP = LP + 4;
+  constexpr int SCR_BYTES = 7168;
+  static_assert(16 * SP * 4 <= 6656 && 32 * VP * 2 <= 6656, "wave scratch layout");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* xb = reinterpret_cast<__bf16*>(smem);
+  __bf16* qs = xb + LP * SL_XP;
+  __bf16* ks = qs + SL_H * LP * SL_E;
+  __bf16* vt = ks + SL_H * LP * SL_E;
+  unsigned char* scr_base = reinterpret_cast<unsigned char*>(vt + SL_H * SL_E * VP);
+  float2* part = reinterpret_cast<float2*>(scr_base + SL_NW * SCR_BYTES);
+  float2* stat = part + LP * SL_NW;
+  unsigned char* idx8 = reinterpret_cast<unsigned char*>(stat + LP);
+  __bf16* hb = qs;  // conv-pair phase alias
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.x, L = p.L, F = p.F, HP = F + 8;
+  unsigned char* scr = scr_base + wave * SCR_BYTES;
+  float* sc_f = reinterpret_cast<float*>(scr);           // score tile fp32 [16][SP]
+  __bf16* sc_p = reinterpret_cast<__bf16*>(scr);         // probabilities bf16 [32][VP]
+  float* Ms = reinterpret_cast<float*>(scr + 6656);      // [LP] sparsity measure (320 B)
+  int* top_l = reinterpret_cast<int*>(scr + 6656 + 320);  // [32] selected rows, ascending (128 B)
+
+  // ---- residual stream slice of this wave + bf16 image of x ----
+  f32x4 xres[RT];
+  {
+    const float* xg = p.x + (long)b * L * SL_D;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + fq * 4 + r;
+        const float v = row < L ? xg[(long)row * SL_D + wave * 16 + fr] : 0.f;
+        xres[rt][r] = v;
+        xb[row * SL_XP + wave * 16 + fr] = (__bf16)v;
+      }
+  }
+
+#pragma unroll 1
+  for (int li = 0; li < p.n_layers; ++li) {
+    const PackOff po = pack_offsets(F);
+    const unsigned char* wl = p.wpack + (long)li * p.wpack_stride;
+    const __bf16* w_qkv = reinterpret_cast<const __bf16*>(wl + po.wqkv);
+    const __bf16* w_o = reinterpret_cast<const __bf16*>(wl + po.wo);
+    const __bf16* w_1 = reinterpret_cast<const __bf16*>(wl + po.w1);
+    const __bf16* w_2 = reinterpret_cast<const __bf16*>(wl + po.w2);
+    const float* vec = reinterpret_cast<const float*>(wl + po.vec);
+    const long lrow = ((long)li * p.B + b) * L;  // first row of this sequence in a [layers][B*L][...] slab
+    // key samples of this layer -> LDS (uint8: L <= 80)
+    {
+      const int32_t* ig = p.idx[li] + (long)(b / p.idx_group) * p.idx_stride;
+      for (int i = tid; i < L * p.sample_k; i += SL_NT) idx8[i] = (unsigned char)ig[i];
+    }
+    // zero the key padding of V^T (columns LP..KS32-1 are never written; the conv-pair phase overwrote the region)
+    if constexpr (KS32 > LP) {
+      for (int i = lane; i < SL_E * (KS32 - LP); i += 64)
+        vt[(wave * SL_E + i / (KS32 - LP)) * VP + LP + i % (KS32 - LP)] = (__bf16)0.f;
+    }
+    __syncthreads();  // xb complete (written by all waves), idx8 visible
+
+    // ================= phase 1: q | k | v of head `wave` =================
+    {
+      bf16x8 wf[3][4];
+      float bias[3];
+#pragma unroll
+      for (int pt = 0; pt < 3; ++pt) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wf[pt][kk] = ld_wfrag(w_qkv, (pt * 8 + wave) * 4 + kk, lane);
+        bias[pt] = vec[pt * SL_D + wave * 16 + fr];
+      }
+      float* qkv_g = p.save ? p.qkv + lrow * (3 * SL_D) : nullptr;
+#pragma unroll 1
+      for (int rt = 0; rt < RT; ++rt) {
+        bf16x8 a[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a[kk] = ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8);
+        f32x4 acc[3];
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt) {
+          acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk], wf[pt][kk], acc[pt], 0, 0, 0);
+        }
+        const int row0 = rt * 16 + fq * 4;
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[pt][r] = row0 + r < L ? acc[pt][r] + bias[pt] : 0.f;  // padded rows: exact zeros (masked keys, unused queries)
+          if (qkv_g) tile_store(acc[pt], sc_f, qkv_g + rt * 16 * (3 * SL_D) + pt * SL_D + wave * 16, 3 * SL_D, L - rt * 16, lane);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          qs[(wave * LP + row0 + r) * SL_E + fr] = (__bf16)acc[0][r];
+          ks[(wave * LP + row0 + r) * SL_E + fr] = (__bf16)acc[1][r];
+        }
+        const bf16x4 v4 = {(__bf16)acc[2][0], (__bf16)acc[2][1], (__bf16)acc[2][2], (__bf16)acc[2][3]};
+        *reinterpret_cast<bf16x4*>(vt + (wave * SL_E + fr) * VP + row0) = v4;  // V^T: 4 consecutive keys of channel fr
+      }
+    }
+    __syncthreads();  // every wave is done with xb: it becomes the ctx image
+
+    // ================= phase 2: ProbSparse attention of head `wave` (no workgroup barrier inside) =================
+    {
+      const __bf16* Q = qs + wave * LP * SL_E;
+      const __bf16* Kh = ks + wave * LP * SL_E;
+      const __bf16* Vt = vt + wave * SL_E * VP;
+      int32_t* top_g = p.top ? p.top + (((long)li * p.B + b) * SL_H + wave) * p.n_top : nullptr;
+      const int u = p.n_top;
+      bf16x8 kb[RT];
+#pragma unroll
+      for (int ct = 0; ct < RT; ++ct) kb[ct] = fq < 2 ? ld_frag(Kh + (ct * 16 + fr) * SL_E + fq * 8) : zero_frag();
+
+      unsigned long long sel_lo = 0, sel_hi = 0;  // bit q = query q is among the top-u (rows 0..63 / 64..LP-1)
+      if (!p.force_top) {
+        // (a) sparsity measure M[q] = max_j s(q, idx[q,j]) - sum_j s(q, idx[q,j]) / L from 16-query score tiles
+#pragma unroll 1
+        for (int rt = 0; rt < RT; ++rt) {
+          const bf16x8 qa = fq < 2 ? ld_frag(Q + (rt * 16 + fr) * SL_E + fq * 8) : zero_frag();
+#pragma unroll
+          for (int ct = 0; ct < RT; ++ct) {
+            const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kb[ct], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc_f[(fq * 4 + r) * SP + ct * 16 + fr] = s[r];
+          }
+          wave_sync_lds();
+          {
+            const int q = rt * 16 + (lane >> 2), sub = lane & 3, qq = min(q, L - 1);
+            float mx = -INFINITY, sm = 0.f;
+            for (int j = sub; j < p.sample_k; j += 4) {
+              const float d = sc_f[(lane >> 2) * SP + idx8[qq * p.sample_k + j]];
+              mx = fmaxf(mx, d);
+              sm += d;
+            }
+            mx = fmaxf(mx, dpp_move<0xB1>(mx));
+            mx = fmaxf(mx, dpp_move<0x4E>(mx));
+            sm += dpp_move<0xB1>(sm);
+            sm += dpp_move<0x4E>(sm);
+            if (sub == 0) Ms[q] = q < L ? mx - sm / (float)L : -INFINITY;
+          }
+          wave_sync_lds();
+        }
+        // (b) rank: selected <=> fewer than u rows have a larger measure (ties: lower index first)
+        {
+          const int q1 = lane, q2 = lane + 64;
+          const float m1 = Ms[min(q1, LP - 1)], m2 = Ms[min(q2, LP - 1)];
+          int r1 = 0, r2 = 0;
+          for (int o = 0; o < L; ++o) {
+            const float mo = Ms[o];
+            r1 += (mo > m1) || (mo == m1 && o < q1);
+            r2 += (mo > m2) || (mo == m2 && o < q2);
+          }
+          sel_lo = __ballot(q1 < L && r1 < u);
+          sel_hi = __ballot(q2 < L && r2 < u);
+          const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+          if ((sel_lo >> lane) & 1ull) top_l[__popcll(sel_lo & below)] = q1;
+          if ((sel_hi >> lane) & 1ull) top_l[__popcll(sel_lo) + __popcll(sel_hi & below)] = q2;
+        }
+        wave_sync_lds();
+        if (top_g && lane < u) top_g[lane] = top_l[lane];
+      } else {
+        const int t = top_g[min(lane, u - 1)];
+        if (lane < u) top_l[lane] = t;
+        // every lane learns the whole selection: u <= 32 uniform steps
+        for (int i = 0; i < u; ++i) {
+          const int ti = __builtin_amdgcn_readlane(t, i);
+          if (ti < 64) sel_lo |= 1ull << ti; else sel_hi |= 1ull << (ti - 64);
+        }
+        wave_sync_lds();
+      }
+
+      // (c) lazy rows: ctx[q] = mean_s V[s]  (cross_modal_transformer.py:113-116)
+      {
+        float a = 0.f;
+        for (int s = fq; s < L; s += 4) a += (float)Vt[fr * VP + s];
+        a += __shfl_xor(a, 16);
+        a += __shfl_xor(a, 32);
+        const float vm = a / (float)L;
+        const __bf16 vmb = (__bf16)vm;
+        for (int q = fq; q < L; q += 4) {
+          const bool selq = q < 64 ? ((sel_lo >> q) & 1ull) : ((sel_hi >> (q - 64)) & 1ull);
+          if (!selq) xb[q * SL_XP + wave * 16 + fr] = vmb;
+        }
+      }
+
+      // (d) active rows: P = softmax(scale * Q_sel K^T), ctx[top] = P V
+      // zero the key padding of the probability image once (columns LP..KS32-1 of the 32 rows)
+      if constexpr (KS32 > LP) {
+        for (int i = lane; i < 32 * (KS32 - LP); i += 64) sc_p[(i / (KS32 - LP)) * VP + LP + i % (KS32 - LP)] = (__bf16)0.f;
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        if (t2 * 16 < u) {
+          const int qrow = top_l[min(t2 * 16 + fr, u - 1)];
+          const bf16x8 qa = fq < 2 ? ld_frag(Q + qrow * SL_E + fq * 8) : zero_frag();
+          f32x4 s[RT];
+          float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+          for (int ct = 0; ct < RT; ++ct) {
+            s[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kb[ct], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const bool live = ct * 16 + fr < L;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              s[ct][r] = live ? s[ct][r] * p.scale : -INFINITY;
+              mx[r] = fmaxf(mx[r], s[ct][r]);
+            }
+          }
+          float sum[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            mx[r] = row16_max(mx[r]);
+            sum[r] = 0.f;
+          }
+#pragma unroll
+          for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              s[ct][r] = __expf(s[ct][r] - mx[r]);
+              sum[r] += s[ct][r];
+            }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sum[r] = __builtin_amdgcn_rcpf(row16_sum(sum[r]));
+#pragma unroll
+          for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc_p[(t2 * 16 + fq * 4 + r) * VP + ct * 16 + fr] = (__bf16)(s[ct][r] * sum[r]);
+        }
+      }
+      wave_sync_lds();
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        if (t2 * 16 < u) {
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < KSTEPS; ++kk) {
+            const bf16x8 pa = ld_frag(sc_p + (t2 * 16 + fr) * VP + kk * 32 + fq * 8);
+            const bf16x8 vb = ld_frag(Vt + fr * VP + kk * 32 + fq * 8);
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = t2 * 16 + fq * 4 + r;
+            if (i < u) {
+              const int q = top_l[i];
+              xb[q * SL_XP + wave * 16 + fr] = (__bf16)o[r];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // ctx image complete
+    if (p.save) {  // the context as the out-projection (and its weight gradient) consumes it: the bf16 image, widened
+      float* ctx_g = p.ctx + lrow * SL_D;
+      for (int i = tid; i < L * (SL_D / 4); i += SL_NT) {
+        const int row = i >> 5, c4 = (i & 31) * 4;
+        const bf16x4 c = *reinterpret_cast<const bf16x4*>(xb + row * SL_XP + c4);
+        *reinterpret_cast<float4*>(ctx_g + row * SL_D + c4) = make_float4((float)c[0], (float)c[1], (float)c[2], (float)c[3]);
+      }
+    }
+
+    // ================= phase 3: out-projection + residual + LayerNorm 1 (wave = 16 output columns) =================
+    {
+      bf16x8 wf[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) wf[kk] = ld_wfrag(w_o, wave * 4 + kk, lane);
+      const int col = wave * 16 + fr;
+      const float bo = vec[384 + col], g1 = vec[640 + F + col], be1 = vec[768 + F + col];
+      f32x4 v[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8), wf[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[rt][r] = acc[r] + bo + xres[rt][r];
+      }
+      stack_layer_norm<RT>(v, p.save ? p.rstd1 + lrow : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the ctx reads)
+      float* xh_g = p.save ? p.xhat1 + lrow * SL_D + wave * 16 : nullptr;
+      float* x1_g = p.save ? p.x1 + lrow * SL_D + wave * 16 : nullptr;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        if (p.save) tile_store(v[rt], sc_f, xh_g + rt * 16 * SL_D, SL_D, L - rt * 16, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y1 = v[rt][r] * g1 + be1;
+          xres[rt][r] = y1;
+          xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)y1;
+        }
+        if (p.save) tile_store(xres[rt], sc_f, x1_g + rt * 16 * SL_D, SL_D, L - rt * 16, lane);
+      }
+    }
+    __syncthreads();  // x1 image complete; q / k / v^T are dead: their LDS becomes the hidden activation image
+
+    // ================= phase 4: conv1 + activation (wave = column tiles wave, wave + 8, ...) =================
+    {
+      float* z_g = (p.save && p.z) ? p.z + lrow * F : nullptr;
+      float* h_g = p.save ? p.h + lrow * F : nullptr;
+#pragma unroll 1
+      for (int ct = wave; ct < F / 16; ct += SL_NW) {
+        bf16x8 wf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wf[kk] = ld_wfrag(w_1, ct * 4 + kk, lane);
+        const int col = ct * 16 + fr;
+        const float b1 = vec[512 + col];
+#pragma unroll 1
+        for (int rt = 0; rt < RT; ++rt) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8), wf[kk], acc, 0, 0, 0);
+          f32x4 hh;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[r] += b1;
+            hh[r] = p.act == RF_ACT_GELU ? sl_gelu(acc[r]) : (p.act == RF_ACT_RELU ? fmaxf(acc[r], 0.f) : apply_act(acc[r], p.act));
+            hb[(rt * 16 + fq * 4 + r) * HP + col] = (__bf16)hh[r];
+          }
+          if (z_g) tile_store(acc, sc_f, z_g + rt * 16 * F + ct * 16, F, L - rt * 16, lane);
+          if (h_g) tile_store(hh, sc_f, h_g + rt * 16 * F + ct * 16, F, L - rt * 16, lane);
+        }
+      }
+    }
+    __syncthreads();  // hidden activation image complete
+
+    // ================= phase 5: conv2 + residual + LayerNorm 2 =================
+    {
+      const int col = wave * 16 + fr;
+      const float b2 = vec[512 + F + col], g2 = vec[896 + F + col], be2 = vec[1024 + F + col];
+      f32x4 v[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) v[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+      for (int kk = 0; kk < F / 32; ++kk) {
+        const bf16x8 wf = ld_wfrag(w_2, wave * (F / 32) + kk, lane);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          v[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(hb + (rt * 16 + fr) * HP + kk * 32 + fq * 8), wf, v[rt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[rt][r] += b2 + xres[rt][r];
+      stack_layer_norm<RT>(v, p.save ? p.rstd2 + lrow : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the hb / xb reads)
+      // without saves only the last layer's output is needed: it goes to slab 0
+      const bool store_y = p.save || li == p.n_layers - 1;
+      float* y_g = p.y + (p.save ? lrow : (long)b * L) * SL_D + wave * 16;
+      float* xh_g = p.save ? p.xhat2 + lrow * SL_D + wave * 16 : nullptr;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        if (p.save) tile_store(v[rt], sc_f, xh_g + rt * 16 * SL_D, SL_D, L - rt * 16, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y2 = v[rt][r] * g2 + be2;
+          xres[rt][r] = y2;
+          xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)y2;  // next layer's A operand
+        }
+        if (store_y) tile_store(xres[rt], sc_f, y_g + rt * 16 * SL_D, SL_D, L - rt * 16, lane);
+      }
+    }
+    // (the barrier at the head of the next layer publishes xb)
+  }
+}
+
+template <int RT>
+constexpr size_t stack_lds_bytes() {
+  constexpr int LP = 16 * RT, KS32 = ((LP + 31) / 32) * 32, VP = KS32 + 8;
+  return (size_t)LP * SL_XP * 2 + 2 * (size_t)SL_H * LP * SL_E * 2 + (size_t)SL_H * SL_E * VP * 2 + SL_NW * 7168 +
+         (size_t)LP * SL_NW * 8 + (size_t)LP * 8 + 2048;
+}
+
+// ---- weight fragments -------------------------------------------------------------------------------------------
+struct PackTable {
+  int count, pad;
+  RfSeqPackEntry e[RF_SEQLAYER_MAX_PACK];
+  int first_block[RF_SEQLAYER_MAX_PACK + 1];
+};
+
+// one workgroup of 256 threads per 4 fragments (4 KB of output)
+__global__ __launch_bounds__(256) void seq_pack_kernel(const PackTable t) {
+  int e = 0;
+  while (e + 1 < t.count && (int)blockIdx.x >= t.first_block[e + 1]) ++e;
+  const RfSeqPackEntry& ent = t.e[e];
+  if (ent.K == 0) {  // fp32 vector copy (biases, norm parameters), N floats
+    const int i = ((int)blockIdx.x - t.first_block[e]) * 256 + threadIdx.x;
+    if (i < ent.N) static_cast<float*>(ent.out)[i] = ent.w[i];
+    return;
+  }
+  const int KS = ent.K / 32, nfrag = (ent.N / 16) * KS;
+  const int f = ((int)blockIdx.x - t.first_block[e]) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (f >= nfrag) return;
+  const int ct = f / KS, kk = f % KS, n = ct * 16 + (lane & 15), k0 = kk * 32 + (lane >> 4) * 8;
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    o[j] = (__bf16)(ent.transpose ? ent.w[(long)(k0 + j) * ent.ldw + n] : ent.w[(long)n * ent.ldw + k0 + j]);
+  *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(ent.out) + ((long)f * 64 + lane) * 8) = o;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int rf_seqlayer_pack(const RfSeqPackEntry* entries, int count, void* stream) {
+  RF_REQUIRE(entries && count > 0 && count <= RF_SEQLAYER_MAX_PACK);
+  PackTable t{};
+  t.count = count;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const RfSeqPackEntry& e = entries[i];
+    RF_REQUIRE(e.w && e.out && e.N > 0 && e.K >= 0);
+    RF_REQUIRE(e.K == 0 || (e.N % 16 == 0 && e.K % 32 == 0 && al16(e.out)));
+    t.e[i] = e;
+    t.first_block[i] = blocks;
+    blocks += e.K == 0 ? (e.N + 255) / 256 : ((e.N / 16) * (e.K / 32) + 3) / 4;
+  }
+  t.first_block[count] = blocks;
+  RF_LAUNCH(seq_pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), t);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_seqlayer_supported(int L, int d_model, int n_heads, int d_ff, int sample_k, int n_top) {
+  return L >= 2 && L <= 80 && d_model == SL_D && n_heads == SL_H && d_ff >= 32 && d_ff <= 256 && d_ff % 32 == 0 &&
+         sample_k >= 1 && sample_k <= L && n_top >= 1 && n_top <= 32 && n_top <= L && L * sample_k <= 2048;
+}
+
+extern "C" int64_t rf_seqlayer_pack_bytes(int d_ff) { return pack_offsets(d_ff).total; }
+
+extern "C" int rf_seqlayer_fwd(const RfSeqStack* st_, const float* x, int B, int L, int d_model, int n_heads, int d_ff,
+                               int act, int sample_k, int n_top, int idx_group, int force_top, int save, float scale,
+                               float eps, void* stream) {
+  RF_REQUIRE(st_ && x && B > 0 && st_->n_layers > 0 && st_->n_layers <= RF_SEQLAYER_MAX_LAYERS);
+  if (!rf_seqlayer_supported(L, d_model, n_heads, d_ff, sample_k, n_top)) {
+    rf_g_last_error = "rf_seqlayer_fwd: shape outside the fused kernel's range";
+    return RF_EUNSUPPORTED;
+  }
+  const RfSeqStack& s = *st_;
+  RF_REQUIRE(s.wpack && al16(s.wpack) && s.wpack_stride >= rf_seqlayer_pack_bytes(d_ff) && s.wpack_stride % 16 == 0 && s.y);
+  RF_REQUIRE(!force_top || s.top);
+  RF_REQUIRE(!save || (s.qkv && s.ctx && s.xhat1 && s.rstd1 && s.x1 && s.h && s.xhat2 && s.rstd2 && s.top));
+  SeqStackP p{};
+  p.x = x; p.wpack = static_cast<const unsigned char*>(s.wpack); p.wpack_stride = s.wpack_stride;
+  for (int i = 0; i < s.n_layers; ++i) {
+    RF_REQUIRE(force_top || s.idx[i]);
+    p.idx[i] = s.idx[i];
+  }
+  p.idx_stride = s.idx_stride > 0 ? s.idx_stride : (long)L * sample_k;
+  p.top = s.top; p.y = s.y;
+  p.qkv = s.qkv; p.ctx = s.ctx; p.xhat1 = s.xhat1; p.rstd1 = s.rstd1; p.x1 = s.x1; p.z = s.z; p.h = s.h;
+  p.xhat2 = s.xhat2; p.rstd2 = s.rstd2;
+  p.B = B; p.L = L; p.F = d_ff; p.n_layers = s.n_layers; p.act = act; p.sample_k = sample_k; p.n_top = n_top;
+  p.idx_group = (idx_group <= 0 || idx_group > B) ? B : idx_group;
+  p.force_top = force_top; p.save = save; p.scale = scale; p.eps = eps;
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_fwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_fwd_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  if (L <= 48) RF_LAUNCH(seq_stack_fwd_kernel<3>, dim3(B), dim3(SL_NT), stack_lds_bytes<3>(), st, p);
+  else RF_LAUNCH(seq_stack_fwd_kernel<5>, dim3(B), dim3(SL_NT), stack_lds_bytes<5>(), st, p);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}

@@ -358,6 +358,7 @@ class FusedAdamW:
         _hip.check(_hip.lib().rf_adamw_clip_dev(self.p.data_ptr() + o, self.g.data_ptr() + o, self.m.data_ptr() + o,
                                                 self.v.data_ptr() + o, hi - lo, self.sumsq.data_ptr(), self.parts,
                                                 hyper_dev.data_ptr(), K._stream()), "rf_adamw_clip_dev")
+        K.WEIGHTS_EPOCH += 1
 
     def step(self, grad_scale: float = 1.0, skip=()):
         """``skip``: sorted, disjoint [lo, hi) ranges of the flat buffers that took no part in this step (their
@@ -376,6 +377,7 @@ class FusedAdamW:
                                                     self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
                                                     self.wd, self.t, grad_scale, K._stream()), "rf_adamw_clip")
             lo = max(lo, b)
+        K.WEIGHTS_EPOCH += 1  # parameters were rewritten in place: cached bf16 copies are stale
 
 
 class TrainEngine:
@@ -424,7 +426,23 @@ class TrainEngine:
     def _begin_step_kernels(self):
         """First launches of a step: zero the flat gradient buffer (GraphedTrainEngine may add the deferred update)."""
         self._advance_rng()
+        self._repack_fused()
         self.reducer.zero()
+
+    def _repack_fused(self):
+        """bf16 fragment copies of the fused encoder stacks' weights (blocks.FusedStack): re-packed from the fp32
+        masters at the head of every step -- one launch per stack, part of the captured graph, before the
+        target-side pass forks off."""
+        if not self.reducer.flat_param.is_cuda:
+            return
+        from routeformer_amd import kernels as K
+        stacks = self.__dict__.get("_fused_stacks")
+        if stacks is None:
+            stacks = self._fused_stacks = [st for m in self.model.modules() if hasattr(m, "fused_stack")
+                                           for st in [m.fused_stack()] if st is not None]
+        if K.SEQSTACK and K.get_precision() == "bf16":
+            for st in stacks:
+                st.refresh(force=True)
 
     def _advance_rng(self):
         if self._device_dropout and self.reducer.flat_param.is_cuda:
@@ -602,6 +620,7 @@ class GraphedTrainEngine(TrainEngine):
         from routeformer_amd import kernels as K
         self._advance_rng()
         if not self.defer_update:
+            self._repack_fused()
             self.reducer.zero()
             return
         r, opt = self.reducer, self.opt
@@ -626,6 +645,7 @@ class GraphedTrainEngine(TrainEngine):
             r.flat_grad.zero_()
         r.begin_step()
         K.WGRAD.begin_step()
+        self._repack_fused()  # after the (deferred) update of the encoders' slots, on this stream
 
     def _set_hyper(self):
         """Ship the pending update's scalars (or "nothing pending") ahead of the replay."""

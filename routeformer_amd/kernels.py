@@ -1343,3 +1343,204 @@ def assemble_streams(streams, embeddings):
         # sizes outside the kernel's range: same arithmetic from device-side torch ops
         return torch.cat([(torch.zeros_like(first) if t is None else t) + e for t, e in zip(streams, embeddings)], dim=1)
     return _AssembleStreams.apply(n, *streams, *embeddings, *[_slot(e) for e in embeddings])
+
+
+# ---------------------------------------------------------------------------------------------------
+# Fused per-sequence encoder stack (csrc/seqlayer.hip): every EncoderLayer of a PerceiveEncoder in ONE launch,
+# one workgroup per sequence.  bf16 matrix-core mode, L <= 80, d_model 128, 8 heads; the backward pass runs the
+# layer-by-layer kernels on the tensors the fused forward saved.
+# ---------------------------------------------------------------------------------------------------
+SEQSTACK = os.environ.get("RF_SEQSTACK", "1") != "0"
+WEIGHTS_EPOCH = 0  # bumped by the training engine after every optimizer update (kernels write parameters in place)
+
+
+def seqstack_supported(L: int, d_model: int, n_heads: int, d_ff: int, sample_k: int, n_top: int) -> bool:
+    return bool(SEQSTACK and _PRECISION == 1 and _hip.lib().rf_seqlayer_supported(L, d_model, n_heads, d_ff, sample_k, n_top))
+
+
+def seqstack_pack(layers, out: torch.Tensor, stride: int):
+    """layers: per layer a dict of fp32 device tensors -- wq/wk/wv (128,128) or wqkv (384,128), wo (128,128), w1
+    (F,128), w2 (128,F), bqkv (384) or bq/bk/bv, bo, b1, b2, g1, be1, g2, be2 -> ``out`` (uint8, n_layers * stride)."""
+    import ctypes
+    ents = []
+    base = out.data_ptr()
+
+    def mat(w, off, N, K):
+        assert w.dtype == torch.float32 and w.stride(-1) == 1
+        ents.append((w, off, w.stride(0), N, K))
+
+    def vecs(v, off, n):
+        assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == n
+        ents.append((v, off, 0, n, 0))
+
+    for li, d in enumerate(layers):
+        F_ = d["w1"].shape[0]
+        o = base + li * stride
+        o_wo, o_w1 = 24 * 4096, 24 * 4096 + 8 * 4096
+        o_w2 = o_w1 + (F_ // 16) * 4096
+        o_vec = o_w2 + 8 * (F_ // 32) * 1024
+        if "wqkv" in d:
+            mat(d["wqkv"], o, 384, 128)
+            vecs(d["bqkv"], o + o_vec, 384)
+        else:
+            for i, n in enumerate(("q", "k", "v")):
+                mat(d["w" + n], o + i * 32 * 1024, 128, 128)
+                vecs(d["b" + n], o + o_vec + i * 512, 128)
+        mat(d["wo"], o + o_wo, 128, 128)
+        mat(d["w1"], o + o_w1, F_, 128)
+        mat(d["w2"], o + o_w2, 128, F_)
+        for n, pos, cnt in (("bo", 384, 128), ("b1", 512, F_), ("b2", 512 + F_, 128), ("g1", 640 + F_, 128),
+                            ("be1", 768 + F_, 128), ("g2", 896 + F_, 128), ("be2", 1024 + F_, 128)):
+            vecs(d[n], o + o_vec + 4 * pos, cnt)
+    for s0 in range(0, len(ents), _hip.SEQLAYER_MAX_PACK):
+        chunk = ents[s0:s0 + _hip.SEQLAYER_MAX_PACK]
+        arr = (_hip.SeqPackEntry * len(chunk))()
+        for e, (w, off, ldw, N, K_) in zip(arr, chunk):
+            e.w, e.out, e.ldw, e.N, e.K, e.transpose, e.pad = w.data_ptr(), off, ldw, N, K_, 0, 0
+        check(_hip.lib().rf_seqlayer_pack(arr, len(chunk), _stream()), "rf_seqlayer_pack")
+
+
+def seqstack_pack_bytes(d_ff: int) -> int:
+    return int(_hip.lib().rf_seqlayer_pack_bytes(d_ff))
+
+
+def _seqstack_launch(x2, wpack, stride, idx_list, idx_group, B, L, F_, act, sample_k, n_top, save, forced_tops, eps):
+    """Run the fused forward.  -> dict of output / saved tensors ([layers, B*L, width] slabs)."""
+    import ctypes
+    n = len(idx_list)
+    dev, M = x2.device, B * L
+    f32 = dict(device=dev, dtype=torch.float32)
+    sv = {"y": torch.empty(n if save else 1, M, 128, **f32)}
+    force = forced_tops is not None
+    if save or force:
+        sv["top"] = (torch.stack([t.to(device=dev, dtype=torch.int32) for t in forced_tops]).contiguous() if force
+                     else torch.empty(n, B, 8, n_top, device=dev, dtype=torch.int32))
+    if save:
+        for name, width in (("qkv", 384), ("ctx", 128), ("xhat1", 128), ("x1", 128), ("xhat2", 128), ("h", F_)):
+            sv[name] = torch.empty(n, M, width, **f32)
+        if act == "gelu":
+            sv["z"] = torch.empty(n, M, F_, **f32)
+        sv["rstd1"] = torch.empty(n, M, **f32)
+        sv["rstd2"] = torch.empty(n, M, **f32)
+    st = _hip.SeqStack()
+    st.wpack, st.wpack_stride, st.n_layers = wpack.data_ptr(), stride, n
+    idx_stride = 0
+    for i, t in enumerate(idx_list):
+        assert t.dim() == 3 and t.dtype == torch.int32 and t.stride(2) == 1 and t.stride(1) == t.shape[2], "key-sample table"
+        st.idx[i] = t.data_ptr()
+        s_ = t.stride(0) if t.shape[0] > 1 else L * sample_k
+        assert i == 0 or s_ == idx_stride, "the layers' key-sample tables must share one group stride"
+        idx_stride = s_
+    st.idx_stride = idx_stride
+    for name in ("top", "y", "qkv", "ctx", "xhat1", "rstd1", "x1", "z", "h", "xhat2", "rstd2"):
+        setattr(st, name, ptr(sv.get(name)))
+    ev = PROFILE.begin() if PROFILE.on else None
+    args = (ctypes.byref(st), ptr(x2), B, L, 128, 8, F_, ACT[act], sample_k, n_top, idx_group, 1 if force else 0,
+            1 if save else 0, 1.0 / math.sqrt(16.0), eps)
+    check(_hip.lib().rf_seqlayer_fwd(*args, _stream()), "rf_seqlayer_fwd")
+    if ev is not None:
+        flops = n * B * (2.0 * L * 128 * (384 + 128 + 2 * F_) + 8 * (2.0 * L * L * 16 + 4.0 * n_top * L * 16))
+        nbytes = 4.0 * M * 128 * 2 + n * (2.0 * (4 * 128 * 128 + 2 * 128 * F_)
+                                          + (4.0 * M * (384 + 128 * 5 + 2 * F_ + 2) if save else 0.0))
+        keep = (x2, wpack, idx_list, sv, st)
+        PROFILE.end(f"seq_stack_fwd_kernel<{3 if L <= 48 else 5}>", ev, flops, nbytes,
+                    replay=lambda a=args, k=keep: _hip.lib().rf_seqlayer_fwd(*a, _stream()))
+    return sv
+
+
+class _SeqStack(torch.autograd.Function):
+    """y = EncoderLayer_n(... EncoderLayer_1(x)) for a stack of ProbSparse encoder layers (dropout 0): ONE fused
+    forward launch; backward = per layer the row-block / attention backward kernels on the saved tensors, parameter
+    gradients through the engine's sinks (the fused path is only taken with sinks active or without grad)."""
+
+    @staticmethod
+    def forward(ctx, x, stack, idx_list, idx_group, save):
+        B, L, D = x.shape
+        x2 = x.reshape(B * L, D).contiguous()
+        lay0 = stack.layers[0]
+        F_ = lay0.conv1.weight.shape[0]
+        sample_k, n_top = prob_sizes(L, L, lay0.attention.factor)
+        forced = None
+        if TOPS.forced is not None:
+            forced = [TOPS.forced.pop(0) for _ in stack.layers]
+        sv = _seqstack_launch(x2, stack.wpack, stack.stride, idx_list, idx_group, B, L, F_, lay0.act, sample_k, n_top,
+                              save, forced, lay0.norm1.eps)
+        if TOPS.record is not None and "top" in sv:
+            for t in sv["top"]:
+                TOPS.record.append(t.clone())
+        if save:
+            ctx.sv, ctx.stack, ctx.x2, ctx.dims = sv, stack, x2, (B, L, F_, n_top)
+        return sv["y"][-1].view(B, L, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        sv, stack, x2, (B, L, F_, n_top) = ctx.sv, ctx.stack, ctx.x2, ctx.dims
+        M, D, H, E = B * L, 128, 8, 16
+        dy2 = dy.reshape(M, D).contiguous()
+        for li in reversed(range(len(stack.layers))):
+            lay = stack.layers[li]
+            x_in = x2 if li == 0 else sv["y"][li - 1]
+            w1, w2 = lay.conv1.weight.reshape(F_, D), lay.conv2.weight.reshape(D, F_)
+            zsrc = sv["z"][li] if "z" in sv else sv["h"][li]
+            # ---- norm2 + conv pair (as _FFNAddLN.backward) ----
+            gg, gbeta = _slot(lay.norm2.weight), _slot(lay.norm2.bias)
+            xhat2, rstd2, h, x1 = sv["xhat2"][li], sv["rstd2"][li], sv["h"][li], sv["x1"][li]
+            if _rowblock_nn_ok(w2, ln=True) and _rowblock_nn_ok(w1) and not DETERMINISTIC:
+                dpre = torch.empty_like(xhat2)
+                dz = _rowblock_nn(w2, M, ln=(dy2, xhat2, rstd2, lay.norm2.weight), dpre=dpre, dgam=gg, dbet=gbeta,
+                                  dsrc=zsrc, dact=ACT[lay.act])
+                _wrote(gg, gbeta)
+            else:
+                dpre, _, _ = _ln_backward(dy2, xhat2, rstd2, lay.norm2.weight, gg, gbeta)
+                dz = _input_grad(dpre, w2, dact_src=zsrc, ldd=zsrc.stride(0), dact=ACT[lay.act])
+            g2, gb2, g1, gb1 = (_slot(lay.conv2.weight), _slot(lay.conv2.bias), _slot(lay.conv1.weight),
+                                _slot(lay.conv1.bias))
+            if _weight_grad(dpre, h, into=g2.view(D, F_), bias_into=gb2) is not True:
+                colsum(dpre, into=gb2)
+            if _weight_grad(dz, x1, into=g1.view(F_, D), bias_into=gb1) is not True:
+                colsum(dz, into=gb1)
+            if _rowblock_nn_ok(w1):
+                dx1 = _rowblock_nn(w1, M, a=dz, res=dpre)
+            else:
+                dx1 = _input_grad(dz, w1, residual=dpre, ldr=D, res_rows=M)
+            _wrote(g1, gb1, g2, gb2)
+            # ---- norm1 + out-projection (as _LinearAddLN.backward) ----
+            att = lay.attention
+            wo = att.out_projection.weight
+            gg, gbeta = _slot(lay.norm1.weight), _slot(lay.norm1.bias)
+            xhat1, rstd1, ctx2 = sv["xhat1"][li], sv["rstd1"][li], sv["ctx"][li]
+            if _rowblock_nn_ok(wo, ln=True) and not DETERMINISTIC:
+                dpre1 = torch.empty_like(xhat1)
+                dctx = _rowblock_nn(wo, M, ln=(dx1, xhat1, rstd1, lay.norm1.weight), dpre=dpre1, dgam=gg, dbet=gbeta)
+                _wrote(gg, gbeta)
+            else:
+                dpre1, _, _ = _ln_backward(dx1, xhat1, rstd1, lay.norm1.weight, gg, gbeta)
+                dctx = _input_grad(dpre1, wo)
+            gwo, gbo = _slot(wo), _slot(att.out_projection.bias)
+            if _weight_grad(dpre1, ctx2, into=gwo, bias_into=gbo) is not True:
+                colsum(dpre1, into=gbo)
+            _wrote(gwo, gbo)
+            # ---- attention core ----
+            qkv = sv["qkv"][li]
+            dqkv = torch.empty_like(qkv)
+            HE = H * E
+            ev = PROFILE.begin() if PROFILE.on else None
+            bargs = (qkv.data_ptr(), qkv.data_ptr() + 4 * HE, qkv.data_ptr() + 8 * HE, 3 * HE, 3 * HE, 3 * HE, ptr(dctx), 0,
+                     ptr(sv["top"][li]), dqkv.data_ptr(), dqkv.data_ptr() + 4 * HE, dqkv.data_ptr() + 8 * HE, 3 * HE,
+                     3 * HE, 3 * HE, B, H, L, L, E, n_top, 1, 1.0 / math.sqrt(E))
+            check(_hip.lib().rf_attn_bwd(*bargs, _stream()), "rf_attn_bwd")
+            if ev is not None:
+                keep = (qkv, dctx, dqkv, sv)
+                PROFILE.end("attn_bwd_kernel<true>", ev, B * H * 10.0 * n_top * L * E, 4.0 * B * H * E * 8 * L,
+                            replay=lambda fa=bargs, k=keep: _hip.lib().rf_attn_bwd(*fa, _stream()))
+            # ---- packed q | k | v projection (as _Linear.backward with the skip gradient folded in) ----
+            pk = att._packed
+            if _weight_grad(dqkv, x_in, into=pk["gw"], bias_into=pk["gb"]) is not True:
+                colsum(dqkv, into=pk["gb"])
+            if _rowblock_nn_ok(pk["w"]):
+                dy2 = _rowblock_nn(pk["w"], M, a=dqkv, res=dpre1)
+            else:
+                dy2 = _input_grad(dqkv, pk["w"], residual=dpre1, ldr=D, res_rows=M)
+            _wrote(pk["gw"], pk["gb"])
+        ctx.sv = None
+        return dy2.view(B, L, D), None, None, None, None

