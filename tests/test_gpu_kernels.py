@@ -1008,10 +1008,12 @@ def test_fused_encoder_stack_forward(B, L, F_, n_layers, groups, act):
     for li in range(n_layers):
         for name in ("qkv", "ctx", "x1", "xhat1", "h", "xhat2", "y") + (("z",) if act == "gelu" else ()):
             got, want = forced[name][li].cpu(), saves[li][name].reshape(M, -1)
-            assert rel_err(got, want) < 2e-3 * (li + 1), (li, name, rel_err(got, want))
-        r1 = 1.0 / torch.sqrt((saves[li]["x1"] * 0 + 1).sum(-1))  # placeholder keeps shapes explicit
-        assert forced["rstd1"][li].shape == (M,) and r1.shape == (B, L)
-    assert rel_err(forced["y"][-1].cpu(), y_ref.reshape(M, D)) < 2e-3 * n_layers
+            # ctx is saved as the bf16 image the out-projection consumes: one bf16 ulp (2^-8) when a rounding flips
+            tol = 1e-2 if name == "ctx" else 4e-3 * (li + 1)
+            assert rel_err(got, want) < tol, (li, name, rel_err(got, want))
+        assert forced["rstd1"][li].shape == (M,) and bool(torch.isfinite(forced["rstd1"][li]).all())
+        assert bool((forced["rstd2"][li] > 0).all())
+    assert rel_err(forced["y"][-1].cpu(), y_ref.reshape(M, D)) < 4e-3 * n_layers
     assert torch.equal(nosave["y"][0], forced["y"][-1]), "the no-save variant must compute the same output"
     if all(same):
         assert torch.equal(free["y"][-1], forced["y"][-1])
