@@ -144,6 +144,16 @@ __device__ __forceinline__ void stack_layer_norm(f32x4 (&v)[RT], float* __restri
     }
 }
 
+// Phase timing aid (tools/seqlayer_probe.py builds a private copy with -DRF_SL_TIMING): lane 0 of every wave stamps
+// the shader clock at the phase boundaries of the FIRST layer into rf_sl_timing[workgroup][wave][16].
+#ifdef RF_SL_TIMING
+__device__ unsigned long long rf_sl_timing[512 * 8 * 16];
+#define SL_MARK(k) do { if (li == 0 && (threadIdx.x & 63) == 0 && blockIdx.x < 512) \
+  rf_sl_timing[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SL_MARK(k) do {} while (0)
+#endif
+
 // RT = row tiles of 16 (L <= 16 RT).  LDS (bytes), RT = 5:
 //   xb   bf16 [16 RT][136]            21 760   x / ctx / x1 as MFMA A operand (one image, reused phase by phase)
 //   qs   bf16 [8][16 RT][16]          20 480 \
@@ -151,12 +161,12 @@ __device__ __forceinline__ void stack_layer_norm(f32x4 (&v)[RT], float* __restri
 //   vt   bf16 [8][16][KS32 + 8]       26 624 /
 //   scr  per wave 7 168               57 344   score tile fp32 [16][16 RT + 4] / P bf16 [32][KS32 + 8]; Ms, top, flags
 //   part float2 [16 RT][8] + stat float2 [16 RT]   5 760   LayerNorm partial sums / per-row (mean, 1/sigma)
-//   idx  uint8 [L][sample_k]           2 048   key samples of the layer (shared by the 8 heads)
+//   cnt  uint8 [16 RT][16 RT]         6 400   cnt[key][query] = how often `key` is among the query's samples (all heads)
 template <int RT>
 __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p) {
   constexpr int LP = 16 * RT, KS32 = ((LP + 31) / 32) * 32, KSTEPS = KS32 / 32, VP = KS32 + 8, SP = LP + 4;
-  constexpr int SCR_BYTES = 7168;
-  static_assert(16 * SP * 4 <= 6656 && 32 * VP * 2 <= 6656, "wave scratch layout");
+  constexpr int SCR_BYTES = 7168, TB = 320;  // TB: floats of one staged 16 x 16 tile (pitch 20)
+  static_assert(32 * VP * 2 <= 6656 && 5 * TB * 4 <= 6656 && SP > 0, "wave scratch layout");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* xb = reinterpret_cast<__bf16*>(smem);
   __bf16* qs = xb + LP * SL_XP;
@@ -165,35 +175,38 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
   unsigned char* scr_base = reinterpret_cast<unsigned char*>(vt + SL_H * SL_E * VP);
   float2* part = reinterpret_cast<float2*>(scr_base + SL_NW * SCR_BYTES);
   float2* stat = part + LP * SL_NW;
-  unsigned char* idx8 = reinterpret_cast<unsigned char*>(stat + LP);
+  unsigned int* cnt32 = reinterpret_cast<unsigned int*>(stat + LP);  // [key][query / 4]: four queries per word
   __bf16* hb = qs;  // conv-pair phase alias
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
   const int b = blockIdx.x, L = p.L, F = p.F, HP = F + 8;
   unsigned char* scr = scr_base + wave * SCR_BYTES;
-  float* sc_f = reinterpret_cast<float*>(scr);           // score tile fp32 [16][SP]
+  float* sc_f = reinterpret_cast<float*>(scr);           // score tile fp32 [16][SP] / staged output tiles [5][16][20]
   __bf16* sc_p = reinterpret_cast<__bf16*>(scr);         // probabilities bf16 [32][VP]
   float* Ms = reinterpret_cast<float*>(scr + 6656);      // [LP] sparsity measure (320 B)
   int* top_l = reinterpret_cast<int*>(scr + 6656 + 320);  // [32] selected rows, ascending (128 B)
+  const int srow = lane >> 2, sc4 = (lane & 3) * 4;      // staged-tile read-back: row, first column of this lane
 
   // ---- residual stream slice of this wave + bf16 image of x ----
   f32x4 xres[RT];
   {
-    const float* xg = p.x + (long)b * L * SL_D;
+    const float* xg = p.x + (long)b * L * SL_D + wave * 16 + fr;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rt * 16 + fq * 4 + r;
-        const float v = row < L ? xg[(long)row * SL_D + wave * 16 + fr] : 0.f;
-        xres[rt][r] = v;
-        xb[row * SL_XP + wave * 16 + fr] = (__bf16)v;
+        xres[rt][r] = xg[min(row, L - 1) * SL_D];  // clamped, unconditional (padded rows are never stored)
       }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xb[(rt * 16 + fq * 4 + r) * SL_XP + wave * 16 + fr] = (__bf16)xres[rt][r];
   }
+  const PackOff po = pack_offsets(F);
 
 #pragma unroll 1
   for (int li = 0; li < p.n_layers; ++li) {
-    const PackOff po = pack_offsets(F);
     const unsigned char* wl = p.wpack + (long)li * p.wpack_stride;
     const __bf16* w_qkv = reinterpret_cast<const __bf16*>(wl + po.wqkv);
     const __bf16* w_o = reinterpret_cast<const __bf16*>(wl + po.wo);
@@ -201,30 +214,49 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
     const __bf16* w_2 = reinterpret_cast<const __bf16*>(wl + po.w2);
     const float* vec = reinterpret_cast<const float*>(wl + po.vec);
     const long lrow = ((long)li * p.B + b) * L;  // first row of this sequence in a [layers][B*L][...] slab
-    // key samples of this layer -> LDS (uint8: L <= 80)
-    {
+
+    // weight fragments of the projection are requested first: their L2 latency hides behind the staging below
+    bf16x8 wf[3][4];
+    float bias[3];
+#pragma unroll
+    for (int pt = 0; pt < 3; ++pt) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) wf[pt][kk] = ld_wfrag(w_qkv, (pt * 8 + wave) * 4 + kk, lane);
+      bias[pt] = vec[pt * SL_D + wave * 16 + fr];
+    }
+    // key samples of this layer -> count image cnt[key][query] (uint8, four queries per word): the sparsity measure
+    // needs sum_j s(q, idx[q,j]) and max_j s(q, idx[q,j]) -- with the multiplicities in the layout of the MFMA
+    // accumulator both come straight from the score registers (no score tile in LDS, no gathers)
+    if (!p.force_top) {
       const int32_t* ig = p.idx[li] + (long)(b / p.idx_group) * p.idx_stride;
-      for (int i = tid; i < L * p.sample_k; i += SL_NT) idx8[i] = (unsigned char)ig[i];
+      const int n = L * p.sample_k;
+      int v4[4];
+#pragma unroll
+      for (int u4 = 0; u4 < 4; ++u4) v4[u4] = ig[min(tid + u4 * SL_NT, n - 1)];
+      for (int i = tid; i < LP * LP / 4; i += SL_NT) cnt32[i] = 0u;
+      __syncthreads();
+#pragma unroll
+      for (int u4 = 0; u4 < 4; ++u4) {
+        const int i = tid + u4 * SL_NT;
+        if (i < n) {
+          const int q = i / p.sample_k;
+          atomicAdd(&cnt32[(v4[u4] * LP + q) >> 2], 1u << (8 * (q & 3)));
+        }
+      }
     }
     // zero the key padding of V^T (columns LP..KS32-1 are never written; the conv-pair phase overwrote the region)
     if constexpr (KS32 > LP) {
       for (int i = lane; i < SL_E * (KS32 - LP); i += 64)
         vt[(wave * SL_E + i / (KS32 - LP)) * VP + LP + i % (KS32 - LP)] = (__bf16)0.f;
     }
+    SL_MARK(0);
     __syncthreads();  // xb complete (written by all waves), idx8 visible
+    SL_MARK(1);
 
     // ================= phase 1: q | k | v of head `wave` =================
     {
-      bf16x8 wf[3][4];
-      float bias[3];
+      float* qkv_g = p.save ? p.qkv + lrow * (3 * SL_D) + wave * 16 : nullptr;
 #pragma unroll
-      for (int pt = 0; pt < 3; ++pt) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) wf[pt][kk] = ld_wfrag(w_qkv, (pt * 8 + wave) * 4 + kk, lane);
-        bias[pt] = vec[pt * SL_D + wave * 16 + fr];
-      }
-      float* qkv_g = p.save ? p.qkv + lrow * (3 * SL_D) : nullptr;
-#pragma unroll 1
       for (int rt = 0; rt < RT; ++rt) {
         bf16x8 a[4];
 #pragma unroll
@@ -238,12 +270,10 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
         }
         const int row0 = rt * 16 + fq * 4;
 #pragma unroll
-        for (int pt = 0; pt < 3; ++pt) {
+        for (int pt = 0; pt < 3; ++pt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             acc[pt][r] = row0 + r < L ? acc[pt][r] + bias[pt] : 0.f;  // padded rows: exact zeros (masked keys, unused queries)
-          if (qkv_g) tile_store(acc[pt], sc_f, qkv_g + rt * 16 * (3 * SL_D) + pt * SL_D + wave * 16, 3 * SL_D, L - rt * 16, lane);
-        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           qs[(wave * LP + row0 + r) * SL_E + fr] = (__bf16)acc[0][r];
@@ -251,9 +281,29 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
         }
         const bf16x4 v4 = {(__bf16)acc[2][0], (__bf16)acc[2][1], (__bf16)acc[2][2], (__bf16)acc[2][3]};
         *reinterpret_cast<bf16x4*>(vt + (wave * SL_E + fr) * VP + row0) = v4;  // V^T: 4 consecutive keys of channel fr
+        if (qkv_g) {  // q | k | v of these 16 rows: three staged tiles, one 16-B store per lane and tile
+#pragma unroll
+          for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc_f[pt * TB + (fq * 4 + r) * 20 + fr] = acc[pt][r];
+          wave_sync_lds();
+          if (rt * 16 + srow < L) {
+#pragma unroll
+            for (int pt = 0; pt < 3; ++pt)
+              *reinterpret_cast<float4*>(qkv_g + (rt * 16 + srow) * (3 * SL_D) + pt * SL_D + sc4) =
+                  *reinterpret_cast<const float4*>(sc_f + pt * TB + srow * 20 + sc4);
+          }
+          wave_sync_lds();
+        }
       }
     }
+    // out-projection fragments travel during the attention phase
+    bf16x8 wfo[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wfo[kk] = ld_wfrag(w_o, wave * 4 + kk, lane);
+    SL_MARK(2);
     __syncthreads();  // every wave is done with xb: it becomes the ctx image
+    SL_MARK(3);
 
     // ================= phase 2: ProbSparse attention of head `wave` (no workgroup barrier inside) =================
     {
@@ -266,81 +316,109 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
 #pragma unroll
       for (int ct = 0; ct < RT; ++ct) kb[ct] = fq < 2 ? ld_frag(Kh + (ct * 16 + fr) * SL_E + fq * 8) : zero_frag();
 
-      unsigned long long sel_lo = 0, sel_hi = 0;  // bit q = query q is among the top-u (rows 0..63 / 64..LP-1)
       if (!p.force_top) {
-        // (a) sparsity measure M[q] = max_j s(q, idx[q,j]) - sum_j s(q, idx[q,j]) / L from 16-query score tiles
-#pragma unroll 1
+        // (a) sparsity measure M[q] = max_j s(q, idx[q,j]) - sum_j s(q, idx[q,j]) / L, 16 queries per MFMA pass: each lane
+        //     weighs its 4 x RT score registers with the sample multiplicities (one word = the 4 rows of a column)
+#pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const bf16x8 qa = fq < 2 ? ld_frag(Q + (rt * 16 + fr) * SL_E + fq * 8) : zero_frag();
+          float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ct = 0; ct < RT; ++ct) {
-            const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kb[ct], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const unsigned int c4 = cnt32[((ct * 16 + fr) * LP + rt * 16 + fq * 4) >> 2];
+            const f32x4 sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kb[ct], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sc_f[(fq * 4 + r) * SP + ct * 16 + fr] = s[r];
-          }
-          wave_sync_lds();
-          {
-            const int q = rt * 16 + (lane >> 2), sub = lane & 3, qq = min(q, L - 1);
-            float mx = -INFINITY, sm = 0.f;
-            for (int j = sub; j < p.sample_k; j += 4) {
-              const float d = sc_f[(lane >> 2) * SP + idx8[qq * p.sample_k + j]];
-              mx = fmaxf(mx, d);
-              sm += d;
+            for (int r = 0; r < 4; ++r) {
+              const unsigned int c = (c4 >> (8 * r)) & 0xffu;
+              sm[r] = fmaf((float)c, sv[r], sm[r]);
+              mx[r] = fmaxf(mx[r], c ? sv[r] : -INFINITY);
             }
-            mx = fmaxf(mx, dpp_move<0xB1>(mx));
-            mx = fmaxf(mx, dpp_move<0x4E>(mx));
-            sm += dpp_move<0xB1>(sm);
-            sm += dpp_move<0x4E>(sm);
-            if (sub == 0) Ms[q] = q < L ? mx - sm / (float)L : -INFINITY;
           }
-          wave_sync_lds();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float m_ = row16_max(mx[r]) - row16_sum(sm[r]) / (float)L;
+            const int q = rt * 16 + fq * 4 + r;
+            if (fr == 0) Ms[q] = q < L ? m_ : -INFINITY;
+          }
         }
-        // (b) rank: selected <=> fewer than u rows have a larger measure (ties: lower index first)
+        wave_sync_lds();
+        SL_MARK(4);
+        // (b) rank: lane l ranks rows l and l + 64 against all measures (broadcast 16-B LDS reads, compare + carry-add in
+        //     the vector unit only).  selected <=> fewer than u rows have a larger measure; ties: lower index first.
+        //     Fast pass with strict comparisons; it selects exactly u rows unless a tie straddles the cut -- only then the
+        //     exact tie-breaking pass runs.
         {
           const int q1 = lane, q2 = lane + 64;
           const float m1 = Ms[min(q1, LP - 1)], m2 = Ms[min(q2, LP - 1)];
           int r1 = 0, r2 = 0;
-          for (int o = 0; o < L; ++o) {
-            const float mo = Ms[o];
-            r1 += (mo > m1) || (mo == m1 && o < q1);
-            r2 += (mo > m2) || (mo == m2 && o < q2);
+#pragma unroll
+          for (int c = 0; c < LP / 4; ++c) {
+            const float4 mo = *reinterpret_cast<const float4*>(Ms + 4 * c);  // rows >= L hold -inf: never larger
+            r1 += (int)(mo.x > m1) + (int)(mo.y > m1) + (int)(mo.z > m1) + (int)(mo.w > m1);
+            r2 += (int)(mo.x > m2) + (int)(mo.y > m2) + (int)(mo.z > m2) + (int)(mo.w > m2);
           }
-          sel_lo = __ballot(q1 < L && r1 < u);
-          sel_hi = __ballot(q2 < L && r2 < u);
+          unsigned long long sel_lo = __ballot(q1 < L && r1 < u), sel_hi = __ballot(q2 < L && r2 < u);
+          if (__popcll(sel_lo) + __popcll(sel_hi) != u) {  // (wave-uniform) a tie at the cut: exact ranks
+#ifdef RF_SL_TIMING
+            if (lane == 0 && blockIdx.x < 512) atomicAdd(&rf_sl_timing[(blockIdx.x * 8 + wave) * 16 + 15], 1ull);
+#endif
+            r1 = r2 = 0;
+            for (int o = 0; o < L; ++o) {
+              const float mo = Ms[o];
+              r1 += (int)((mo > m1) | ((mo == m1) & (o < q1)));
+              r2 += (int)((mo > m2) | ((mo == m2) & (o < q2)));
+            }
+            sel_lo = __ballot(q1 < L && r1 < u);
+            sel_hi = __ballot(q2 < L && r2 < u);
+          }
           const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
           if ((sel_lo >> lane) & 1ull) top_l[__popcll(sel_lo & below)] = q1;
           if ((sel_hi >> lane) & 1ull) top_l[__popcll(sel_lo) + __popcll(sel_hi & below)] = q2;
         }
         wave_sync_lds();
         if (top_g && lane < u) top_g[lane] = top_l[lane];
+        SL_MARK(5);
       } else {
-        const int t = top_g[min(lane, u - 1)];
-        if (lane < u) top_l[lane] = t;
-        // every lane learns the whole selection: u <= 32 uniform steps
-        for (int i = 0; i < u; ++i) {
-          const int ti = __builtin_amdgcn_readlane(t, i);
-          if (ti < 64) sel_lo |= 1ull << ti; else sel_hi |= 1ull << (ti - 64);
-        }
+        if (lane < u) top_l[lane] = top_g[lane];
         wave_sync_lds();
       }
 
-      // (c) lazy rows: ctx[q] = mean_s V[s]  (cross_modal_transformer.py:113-116)
+      // (c) lazy rows: ctx[q] = mean_s V[s]  (cross_modal_transformer.py:113-116).  Every row is filled with the mean
+      //     first (full 32-B row slices, no selection test); the selected rows are overwritten by (d) -- LDS
+      //     operations of one wave execute in order.
       {
         float a = 0.f;
-        for (int s = fq; s < L; s += 4) a += (float)Vt[fr * VP + s];
+#pragma unroll
+        for (int c = 0; c < (KS32 / 8 + 3) / 4; ++c) {  // 16-B chunks of channel fr's key row: chunk fq + 4 c
+          if (fq + 4 * c < KS32 / 8) {
+            const bf16x8 vv = ld_frag(Vt + fr * VP + (fq + 4 * c) * 8);  // (keys >= L hold exact zeros)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += (float)vv[j];
+          }
+        }
         a += __shfl_xor(a, 16);
         a += __shfl_xor(a, 32);
-        const float vm = a / (float)L;
-        const __bf16 vmb = (__bf16)vm;
-        for (int q = fq; q < L; q += 4) {
-          const bool selq = q < 64 ? ((sel_lo >> q) & 1ull) : ((sel_hi >> (q - 64)) & 1ull);
-          if (!selq) xb[q * SL_XP + wave * 16 + fr] = vmb;
+        const float vm = a / (float)L;  // lane (fr, *) holds the mean of channel fr
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 lo, hi;  // the 16 means as packed bf16 pairs, wave-uniform
+#pragma unroll
+        for (int e2 = 0; e2 < 8; ++e2) {
+          const float m0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vm), 2 * e2));
+          const float m1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vm), 2 * e2 + 1));
+          typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+          const bf16x2 pk = {(__bf16)m0, (__bf16)m1};
+          const unsigned int w = *reinterpret_cast<const unsigned int*>(&pk);
+          if (e2 < 4) lo[e2] = w; else hi[e2 - 4] = w;
+        }
+        for (int q = lane; q < L; q += 64) {
+          *reinterpret_cast<u32x4*>(xb + q * SL_XP + wave * 16) = lo;
+          *reinterpret_cast<u32x4*>(xb + q * SL_XP + wave * 16 + 8) = hi;
         }
       }
+      SL_MARK(6);
 
       // (d) active rows: P = softmax(scale * Q_sel K^T), ctx[top] = P V
-      // zero the key padding of the probability image once (columns LP..KS32-1 of the 32 rows)
-      if constexpr (KS32 > LP) {
+      if constexpr (KS32 > LP) {  // zero the key padding of the probability image (columns LP..KS32-1 of the 32 rows)
         for (int i = lane; i < 32 * (KS32 - LP); i += 64) sc_p[(i / (KS32 - LP)) * VP + LP + i % (KS32 - LP)] = (__bf16)0.f;
       }
 #pragma unroll
@@ -348,16 +426,16 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
         if (t2 * 16 < u) {
           const int qrow = top_l[min(t2 * 16 + fr, u - 1)];
           const bf16x8 qa = fq < 2 ? ld_frag(Q + qrow * SL_E + fq * 8) : zero_frag();
-          f32x4 s[RT];
+          f32x4 sv[RT];
           float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
           for (int ct = 0; ct < RT; ++ct) {
-            s[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kb[ct], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            sv[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kb[ct], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             const bool live = ct * 16 + fr < L;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              s[ct][r] = live ? s[ct][r] * p.scale : -INFINITY;
-              mx[r] = fmaxf(mx[r], s[ct][r]);
+              sv[ct][r] = live ? sv[ct][r] * p.scale : -INFINITY;
+              mx[r] = fmaxf(mx[r], sv[ct][r]);
             }
           }
           float sum[4];
@@ -370,15 +448,15 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
           for (int ct = 0; ct < RT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              s[ct][r] = __expf(s[ct][r] - mx[r]);
-              sum[r] += s[ct][r];
+              sv[ct][r] = __expf(sv[ct][r] - mx[r]);
+              sum[r] += sv[ct][r];
             }
 #pragma unroll
           for (int r = 0; r < 4; ++r) sum[r] = __builtin_amdgcn_rcpf(row16_sum(sum[r]));
 #pragma unroll
           for (int ct = 0; ct < RT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sc_p[(t2 * 16 + fq * 4 + r) * VP + ct * 16 + fr] = (__bf16)(s[ct][r] * sum[r]);
+            for (int r = 0; r < 4; ++r) sc_p[(t2 * 16 + fq * 4 + r) * VP + ct * 16 + fr] = (__bf16)(sv[ct][r] * sum[r]);
         }
       }
       wave_sync_lds();
@@ -395,29 +473,17 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = t2 * 16 + fq * 4 + r;
-            if (i < u) {
-              const int q = top_l[i];
-              xb[q * SL_XP + wave * 16 + fr] = (__bf16)o[r];
-            }
+            if (i < u) xb[top_l[i] * SL_XP + wave * 16 + fr] = (__bf16)o[r];
           }
         }
       }
     }
+    SL_MARK(7);
     __syncthreads();  // ctx image complete
-    if (p.save) {  // the context as the out-projection (and its weight gradient) consumes it: the bf16 image, widened
-      float* ctx_g = p.ctx + lrow * SL_D;
-      for (int i = tid; i < L * (SL_D / 4); i += SL_NT) {
-        const int row = i >> 5, c4 = (i & 31) * 4;
-        const bf16x4 c = *reinterpret_cast<const bf16x4*>(xb + row * SL_XP + c4);
-        *reinterpret_cast<float4*>(ctx_g + row * SL_D + c4) = make_float4((float)c[0], (float)c[1], (float)c[2], (float)c[3]);
-      }
-    }
+    SL_MARK(8);
 
     // ================= phase 3: out-projection + residual + LayerNorm 1 (wave = 16 output columns) =================
     {
-      bf16x8 wf[4];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) wf[kk] = ld_wfrag(w_o, wave * 4 + kk, lane);
       const int col = wave * 16 + fr;
       const float bo = vec[384 + col], g1 = vec[640 + F + col], be1 = vec[768 + F + col];
       f32x4 v[RT];
@@ -426,57 +492,119 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8), wf[kk], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8), wfo[kk], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[rt][r] = acc[r] + bo + xres[rt][r];
       }
+      if (p.save) {  // the context as the out-projection (and its weight gradient) consumes it: the bf16 image, widened
+        float* ctx_g = p.ctx + lrow * SL_D;
+        for (int i = tid; i < L * (SL_D / 4); i += SL_NT) {
+          const int row = i >> 5, c4 = (i & 31) * 4;
+          const bf16x4 c = *reinterpret_cast<const bf16x4*>(xb + row * SL_XP + c4);
+          *reinterpret_cast<float4*>(ctx_g + row * SL_D + c4) = make_float4((float)c[0], (float)c[1], (float)c[2], (float)c[3]);
+        }
+      }
       stack_layer_norm<RT>(v, p.save ? p.rstd1 + lrow : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the ctx reads)
-      float* xh_g = p.save ? p.xhat1 + lrow * SL_D + wave * 16 : nullptr;
-      float* x1_g = p.save ? p.x1 + lrow * SL_D + wave * 16 : nullptr;
+      if (p.save) {  // x-hat of norm1: RT staged tiles, one sync pair
+        float* xh_g = p.xhat1 + lrow * SL_D + wave * 16;
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        if (p.save) tile_store(v[rt], sc_f, xh_g + rt * 16 * SL_D, SL_D, L - rt * 16, lane);
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc_f[rt * TB + (fq * 4 + r) * 20 + fr] = v[rt][r];
+        wave_sync_lds();
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          if (rt * 16 + srow < L)
+            *reinterpret_cast<float4*>(xh_g + (rt * 16 + srow) * SL_D + sc4) = *reinterpret_cast<const float4*>(sc_f + rt * TB + srow * 20 + sc4);
+        wave_sync_lds();
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float y1 = v[rt][r] * g1 + be1;
           xres[rt][r] = y1;
           xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)y1;
         }
-        if (p.save) tile_store(xres[rt], sc_f, x1_g + rt * 16 * SL_D, SL_D, L - rt * 16, lane);
+      if (p.save) {
+        float* x1_g = p.x1 + lrow * SL_D + wave * 16;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc_f[rt * TB + (fq * 4 + r) * 20 + fr] = xres[rt][r];
+        wave_sync_lds();
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          if (rt * 16 + srow < L)
+            *reinterpret_cast<float4*>(x1_g + (rt * 16 + srow) * SL_D + sc4) = *reinterpret_cast<const float4*>(sc_f + rt * TB + srow * 20 + sc4);
+        wave_sync_lds();
       }
     }
+    SL_MARK(9);
     __syncthreads();  // x1 image complete; q / k / v^T are dead: their LDS becomes the hidden activation image
+    SL_MARK(10);
 
-    // ================= phase 4: conv1 + activation (wave = column tiles wave, wave + 8, ...) =================
+    // ================= phase 4: conv1 + activation (wave = column tiles wave, wave + 8) =================
     {
       float* z_g = (p.save && p.z) ? p.z + lrow * F : nullptr;
       float* h_g = p.save ? p.h + lrow * F : nullptr;
 #pragma unroll 1
       for (int ct = wave; ct < F / 16; ct += SL_NW) {
-        bf16x8 wf[4];
+        bf16x8 wf1[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) wf[kk] = ld_wfrag(w_1, ct * 4 + kk, lane);
+        for (int kk = 0; kk < 4; ++kk) wf1[kk] = ld_wfrag(w_1, ct * 4 + kk, lane);
         const int col = ct * 16 + fr;
         const float b1 = vec[512 + col];
-#pragma unroll 1
+        f32x4 zz[RT], hh[RT];
+#pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          zz[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8), wf[kk], acc, 0, 0, 0);
-          f32x4 hh;
+            zz[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8), wf1[kk], zz[rt], 0, 0, 0);
+        }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            acc[r] += b1;
-            hh[r] = p.act == RF_ACT_GELU ? sl_gelu(acc[r]) : (p.act == RF_ACT_RELU ? fmaxf(acc[r], 0.f) : apply_act(acc[r], p.act));
-            hb[(rt * 16 + fq * 4 + r) * HP + col] = (__bf16)hh[r];
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zz[rt][r] += b1;
+        if (p.act == RF_ACT_GELU) {  // (one uniform branch per tile column, not one per element)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hh[rt][r] = sl_gelu(zz[rt][r]);
+        } else {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hh[rt][r] = p.act == RF_ACT_RELU ? fmaxf(zz[rt][r], 0.f) : zz[rt][r];
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hb[(rt * 16 + fq * 4 + r) * HP + col] = (__bf16)hh[rt][r];
+        if (h_g) {
+#pragma unroll
+          for (int which = 0; which < 2; ++which) {
+            float* dst = which == 0 ? z_g : h_g;
+            if (dst) {
+#pragma unroll
+              for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc_f[rt * TB + (fq * 4 + r) * 20 + fr] = which == 0 ? zz[rt][r] : hh[rt][r];
+              wave_sync_lds();
+#pragma unroll
+              for (int rt = 0; rt < RT; ++rt)
+                if (rt * 16 + srow < L)
+                  *reinterpret_cast<float4*>(dst + (rt * 16 + srow) * F + ct * 16 + sc4) = *reinterpret_cast<const float4*>(sc_f + rt * TB + srow * 20 + sc4);
+              wave_sync_lds();
+            }
           }
-          if (z_g) tile_store(acc, sc_f, z_g + rt * 16 * F + ct * 16, F, L - rt * 16, lane);
-          if (h_g) tile_store(hh, sc_f, h_g + rt * 16 * F + ct * 16, F, L - rt * 16, lane);
         }
       }
     }
+    SL_MARK(11);
     __syncthreads();  // hidden activation image complete
+    SL_MARK(12);
 
     // ================= phase 5: conv2 + residual + LayerNorm 2 =================
     {
@@ -485,12 +613,17 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
       f32x4 v[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) v[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-      for (int kk = 0; kk < F / 32; ++kk) {
-        const bf16x8 wf = ld_wfrag(w_2, wave * (F / 32) + kk, lane);
+      const int nk = F / 32;  // <= 8
+      bf16x8 wf2[8];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-          v[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(hb + (rt * 16 + fr) * HP + kk * 32 + fq * 8), wf, v[rt], 0, 0, 0);
+      for (int kk = 0; kk < 8; ++kk) wf2[kk] = ld_wfrag(w_2, wave * nk + min(kk, nk - 1), lane);  // one round trip, not nk
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        if (kk < nk) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            v[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(hb + (rt * 16 + fr) * HP + kk * 32 + fq * 8), wf2[kk], v[rt], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -500,19 +633,41 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
       // without saves only the last layer's output is needed: it goes to slab 0
       const bool store_y = p.save || li == p.n_layers - 1;
       float* y_g = p.y + (p.save ? lrow : (long)b * L) * SL_D + wave * 16;
-      float* xh_g = p.save ? p.xhat2 + lrow * SL_D + wave * 16 : nullptr;
+      if (p.save) {
+        float* xh_g = p.xhat2 + lrow * SL_D + wave * 16;
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        if (p.save) tile_store(v[rt], sc_f, xh_g + rt * 16 * SL_D, SL_D, L - rt * 16, lane);
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc_f[rt * TB + (fq * 4 + r) * 20 + fr] = v[rt][r];
+        wave_sync_lds();
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          if (rt * 16 + srow < L)
+            *reinterpret_cast<float4*>(xh_g + (rt * 16 + srow) * SL_D + sc4) = *reinterpret_cast<const float4*>(sc_f + rt * TB + srow * 20 + sc4);
+        wave_sync_lds();
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float y2 = v[rt][r] * g2 + be2;
           xres[rt][r] = y2;
           xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)y2;  // next layer's A operand
         }
-        if (store_y) tile_store(xres[rt], sc_f, y_g + rt * 16 * SL_D, SL_D, L - rt * 16, lane);
+      if (store_y) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc_f[rt * TB + (fq * 4 + r) * 20 + fr] = xres[rt][r];
+        wave_sync_lds();
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          if (rt * 16 + srow < L)
+            *reinterpret_cast<float4*>(y_g + (rt * 16 + srow) * SL_D + sc4) = *reinterpret_cast<const float4*>(sc_f + rt * TB + srow * 20 + sc4);
+        wave_sync_lds();
       }
     }
+    SL_MARK(13);
     // (the barrier at the head of the next layer publishes xb)
   }
 }
@@ -521,7 +676,7 @@ template <int RT>
 constexpr size_t stack_lds_bytes() {
   constexpr int LP = 16 * RT, KS32 = ((LP + 31) / 32) * 32, VP = KS32 + 8;
   return (size_t)LP * SL_XP * 2 + 2 * (size_t)SL_H * LP * SL_E * 2 + (size_t)SL_H * SL_E * VP * 2 + SL_NW * 7168 +
-         (size_t)LP * SL_NW * 8 + (size_t)LP * 8 + 2048;
+         (size_t)LP * SL_NW * 8 + (size_t)LP * 8 + (size_t)LP * LP;
 }
 
 // ---- weight fragments -------------------------------------------------------------------------------------------
@@ -555,6 +710,14 @@ __global__ __launch_bounds__(256) void seq_pack_kernel(const PackTable t) {
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+#ifdef RF_SL_TIMING
+extern "C" void* rf_sl_timing_address() {
+  void* a = nullptr;
+  (void)hipGetSymbolAddress(&a, HIP_SYMBOL(rf_sl_timing));
+  return a;
+}
+#endif
 
 extern "C" int rf_seqlayer_pack(const RfSeqPackEntry* entries, int count, void* stream) {
   RF_REQUIRE(entries && count > 0 && count <= RF_SEQLAYER_MAX_PACK);

@@ -1,0 +1,81 @@
+"""Per-phase shader-clock breakdown of the fused encoder-stack kernel (private -DRF_SL_TIMING build).  GPU box only:
+    python tools/seqlayer_probe.py [B] [L] [F] [layers] [save]"""
+import ctypes, math, os, subprocess, sys
+import numpy as np
+import torch
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+src = os.path.join(root, "routeformer_amd", "csrc")
+out = os.path.join(root, "gpurun_out", "librf_sltiming.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-DRF_SL_TIMING",
+                       f"-I{root}/include", f"-I{src}", os.path.join(src, "seqlayer.hip"), os.path.join(src, "vision.hip"), "-o", out])
+from routeformer_amd import _hip
+_hip.LIB_PATH = out  # the whole binding layer on the private build (vision.hip carries the library's globals)
+_hip._lib = None
+handle = ctypes.CDLL(out)
+B, L, F_, n, save = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 192), (2, 65), (3, 256), (4, 8), (5, 1)))
+dev = "cuda"
+P = ctypes.c_void_p
+g = torch.Generator().manual_seed(0)
+D = 128
+stride = int(handle.rf_seqlayer_pack_bytes(F_)) if hasattr(handle, "rf_seqlayer_pack_bytes") else 0
+handle.rf_seqlayer_pack_bytes.restype = ctypes.c_int64
+stride = handle.rf_seqlayer_pack_bytes(F_)
+wpack = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
+ents = []
+keep = []
+for li in range(n):
+    o = wpack.data_ptr() + li * stride
+    o_wo, o_w1 = 24 * 4096, 24 * 4096 + 8 * 4096
+    o_w2 = o_w1 + (F_ // 16) * 4096
+    o_vec = o_w2 + 8 * (F_ // 32) * 1024
+    for (N, K_, off) in ((384, 128, 0), (128, 128, o_wo), (F_, 128, o_w1), (128, F_, o_w2)):
+        w = (torch.randn(N, K_, generator=g) / math.sqrt(K_)).to(dev); keep.append(w)
+        ents.append((w, o + off, K_, N, K_))
+    v = (0.1 * torch.randn(1152 + F_, generator=g)).to(dev); v[640 + F_:768 + F_] += 1; v[896 + F_:1024 + F_] += 1; keep.append(v)
+    ents.append((v, o + o_vec, 0, 1152 + F_, 0))
+arr = (_hip.SeqPackEntry * len(ents))()
+for e, (w, off, ldw, N, K_) in zip(arr, ents):
+    e.w, e.out, e.ldw, e.N, e.K, e.transpose, e.pad = w.data_ptr(), off, ldw, N, K_, 0, 0
+st0 = torch.cuda.current_stream().cuda_stream
+assert handle.rf_seqlayer_pack(arr, len(ents), P(st0)) == 0
+sample_k = min(5 * math.ceil(math.log(L)), L); n_top = sample_k
+M = B * L
+x = torch.randn(M, D, device=dev)
+idx = [torch.randint(L, (1, L, sample_k), generator=g).to(torch.int32).to(dev) for _ in range(n)]
+f32 = dict(device=dev, dtype=torch.float32)
+sv = {"y": torch.empty(n if save else 1, M, 128, **f32), "top": torch.empty(n, B, 8, n_top, device=dev, dtype=torch.int32)}
+if save:
+    for name, width in (("qkv", 384), ("ctx", 128), ("xhat1", 128), ("x1", 128), ("xhat2", 128), ("h", F_), ("z", F_)):
+        sv[name] = torch.empty(n, M, width, **f32)
+    sv["rstd1"] = torch.empty(n, M, **f32); sv["rstd2"] = torch.empty(n, M, **f32)
+st = _hip.SeqStack()
+st.wpack, st.wpack_stride, st.n_layers, st.idx_stride = wpack.data_ptr(), stride, n, L * sample_k
+for i, t in enumerate(idx): st.idx[i] = t.data_ptr()
+for name in ("top", "y", "qkv", "ctx", "xhat1", "rstd1", "x1", "z", "h", "xhat2", "rstd2"):
+    setattr(st, name, sv[name].data_ptr() if name in sv else None)
+def call():
+    return handle.rf_seqlayer_fwd(ctypes.byref(st), P(x.data_ptr()), B, L, 128, 8, F_, 2, sample_k, n_top, B, 0, save,
+                                  ctypes.c_float(0.25), ctypes.c_float(1e-5), P(st0))
+for _ in range(3): assert call() == 0, handle.rf_last_error()
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record(); [call() for _ in range(10)]; e.record(); torch.cuda.synchronize()
+us = s.elapsed_time(e) / 10 * 1e3
+flops = n * B * (2.0 * L * 128 * (384 + 128 + 2 * F_) + 8 * (2.0 * L * L * 16 + 4.0 * n_top * L * 16))
+print(f"launch: {us:.1f} us for B={B} L={L} F={F_} layers={n} save={save}  ({us / n:.1f} us per layer, {flops / us / 1e6:.2f} TFLOP/s)")
+handle.rf_sl_timing_address.restype = ctypes.c_void_p
+hip = ctypes.CDLL("libamdhip64.so")
+nb = min(B, 512)
+buf = torch.zeros(512 * 8 * 16, device=dev, dtype=torch.int64)
+hip.hipMemcpy(P(buf.data_ptr()), P(handle.rf_sl_timing_address()), ctypes.c_size_t(8 * 512 * 8 * 16), 3)
+t = buf.cpu().numpy().reshape(512, 8, 16)[:nb].astype(np.float64)
+names = ["wait barrier (x image)", "QKV projection (+ saves)", "wait barrier", "attention: score tiles + measure", "attention: rank + select",
+         "attention: lazy rows", "attention: softmax + PV", "wait barrier (ctx)", "ctx save + out-proj + LN1 (+ saves)", "wait barrier",
+         "conv1 + act (+ saves)", "wait barrier", "conv2 + LN2 (+ saves)"]
+d = np.diff(t[:, :, :14], axis=2)
+for i, nm in enumerate(names):
+    print(f"{nm:42s} mean {d[:, :, i].mean():9.0f}   max-wave {d[:, :, i].max(axis=1).mean():9.0f} cycles")
+print(f"{'layer 0 total':42s} {(t[:, :, 13] - t[:, :, 0]).mean():9.0f} cycles")
+print(f"exact tie-breaking passes taken (all layers, all launches so far): {int(t[:, :, 15].sum())} of {nb * 8 * n * 13} head-layers")
