@@ -162,7 +162,7 @@ __device__ unsigned long long rf_sl_timing[512 * 8 * 16];
 //   scr  per wave 7 168               57 344   score tile fp32 [16][16 RT + 4] / P bf16 [32][KS32 + 8]; Ms, top, flags
 //   part float2 [16 RT][8] + stat float2 [16 RT]   5 760   LayerNorm partial sums / per-row (mean, 1/sigma)
 //   cnt  uint8 [16 RT][16 RT]         6 400   cnt[key][query] = how often `key` is among the query's samples (all heads)
-template <int RT>
+template <int RT, bool SAVE>
 __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p) {
   constexpr int LP = 16 * RT, KS32 = ((LP + 31) / 32) * 32, KSTEPS = KS32 / 32, VP = KS32 + 8, SP = LP + 4;
   constexpr int SCR_BYTES = 7168, TB = 320;  // TB: floats of one staged 16 x 16 tile (pitch 20)
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
 
     // ================= phase 1: q | k | v of head `wave` =================
     {
-      float* qkv_g = p.save ? p.qkv + lrow * (3 * SL_D) + wave * 16 : nullptr;
+      float* qkv_g = SAVE ? p.qkv + lrow * (3 * SL_D) + wave * 16 : nullptr;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         bf16x8 a[4];
@@ -316,6 +316,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
 #pragma unroll
       for (int ct = 0; ct < RT; ++ct) kb[ct] = fq < 2 ? ld_frag(Kh + (ct * 16 + fr) * SL_E + fq * 8) : zero_frag();
 
+      const float inv_L = 1.0f / (float)L;
       if (!p.force_top) {
         // (a) sparsity measure M[q] = max_j s(q, idx[q,j]) - sum_j s(q, idx[q,j]) / L, 16 queries per MFMA pass: each lane
         //     weighs its 4 x RT score registers with the sample multiplicities (one word = the 4 rows of a column)
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float m_ = row16_max(mx[r]) - row16_sum(sm[r]) / (float)L;
+            const float m_ = row16_max(mx[r]) - row16_sum(sm[r]) * inv_L;
             const int q = rt * 16 + fq * 4 + r;
             if (fr == 0) Ms[q] = q < L ? m_ : -INFINITY;
           }
@@ -372,8 +373,9 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
             sel_hi = __ballot(q2 < L && r2 < u);
           }
           const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-          if ((sel_lo >> lane) & 1ull) top_l[__popcll(sel_lo & below)] = q1;
-          if ((sel_hi >> lane) & 1ull) top_l[__popcll(sel_lo) + __popcll(sel_hi & below)] = q2;
+          const int p1 = __popcll(sel_lo & below), p2 = __popcll(sel_lo) + __popcll(sel_hi & below);
+          if (((sel_lo >> lane) & 1ull) && p1 < 32) top_l[p1] = q1;  // (p < 32 always holds for finite measures)
+          if (((sel_hi >> lane) & 1ull) && p2 < 32) top_l[p2] = q2;
         }
         wave_sync_lds();
         if (top_g && lane < u) top_g[lane] = top_l[lane];
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
         }
         a += __shfl_xor(a, 16);
         a += __shfl_xor(a, 32);
-        const float vm = a / (float)L;  // lane (fr, *) holds the mean of channel fr
+        const float vm = a * inv_L;  // lane (fr, *) holds the mean of channel fr
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         u32x4 lo, hi;  // the 16 means as packed bf16 pairs, wave-uniform
 #pragma unroll
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[rt][r] = acc[r] + bo + xres[rt][r];
       }
-      if (p.save) {  // the context as the out-projection (and its weight gradient) consumes it: the bf16 image, widened
+      if (SAVE) {  // the context as the out-projection (and its weight gradient) consumes it: the bf16 image, widened
         float* ctx_g = p.ctx + lrow * SL_D;
         for (int i = tid; i < L * (SL_D / 4); i += SL_NT) {
           const int row = i >> 5, c4 = (i & 31) * 4;
@@ -504,8 +506,8 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
           *reinterpret_cast<float4*>(ctx_g + row * SL_D + c4) = make_float4((float)c[0], (float)c[1], (float)c[2], (float)c[3]);
         }
       }
-      stack_layer_norm<RT>(v, p.save ? p.rstd1 + lrow : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the ctx reads)
-      if (p.save) {  // x-hat of norm1: RT staged tiles, one sync pair
+      stack_layer_norm<RT>(v, SAVE ? p.rstd1 + lrow : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the ctx reads)
+      if (SAVE) {  // x-hat of norm1: RT staged tiles, one sync pair
         float* xh_g = p.xhat1 + lrow * SL_D + wave * 16;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
           xres[rt][r] = y1;
           xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)y1;
         }
-      if (p.save) {
+      if (SAVE) {
         float* x1_g = p.x1 + lrow * SL_D + wave * 16;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -546,8 +548,8 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
 
     // ================= phase 4: conv1 + activation (wave = column tiles wave, wave + 8) =================
     {
-      float* z_g = (p.save && p.z) ? p.z + lrow * F : nullptr;
-      float* h_g = p.save ? p.h + lrow * F : nullptr;
+      float* z_g = (SAVE && p.z) ? p.z + lrow * F : nullptr;
+      float* h_g = SAVE ? p.h + lrow * F : nullptr;
 #pragma unroll 1
       for (int ct = wave; ct < F / 16; ct += SL_NW) {
         bf16x8 wf1[4];
@@ -629,11 +631,11 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[rt][r] += b2 + xres[rt][r];
-      stack_layer_norm<RT>(v, p.save ? p.rstd2 + lrow : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the hb / xb reads)
+      stack_layer_norm<RT>(v, SAVE ? p.rstd2 + lrow : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the hb / xb reads)
       // without saves only the last layer's output is needed: it goes to slab 0
-      const bool store_y = p.save || li == p.n_layers - 1;
-      float* y_g = p.y + (p.save ? lrow : (long)b * L) * SL_D + wave * 16;
-      if (p.save) {
+      const bool store_y = SAVE || li == p.n_layers - 1;
+      float* y_g = p.y + (SAVE ? lrow : (long)b * L) * SL_D + wave * 16;
+      if (SAVE) {
         float* xh_g = p.xhat2 + lrow * SL_D + wave * 16;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -773,12 +775,19 @@ extern "C" int rf_seqlayer_fwd(const RfSeqStack* st_, const float* x, int B, int
   const hipStream_t st = static_cast<hipStream_t>(stream);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_fwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_fwd_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_fwd_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_fwd_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_fwd_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_fwd_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  if (L <= 48) RF_LAUNCH(seq_stack_fwd_kernel<3>, dim3(B), dim3(SL_NT), stack_lds_bytes<3>(), st, p);
-  else RF_LAUNCH(seq_stack_fwd_kernel<5>, dim3(B), dim3(SL_NT), stack_lds_bytes<5>(), st, p);
+  if (L <= 48) {
+    if (save) RF_LAUNCH((seq_stack_fwd_kernel<3, true>), dim3(B), dim3(SL_NT), stack_lds_bytes<3>(), st, p);
+    else RF_LAUNCH((seq_stack_fwd_kernel<3, false>), dim3(B), dim3(SL_NT), stack_lds_bytes<3>(), st, p);
+  } else {
+    if (save) RF_LAUNCH((seq_stack_fwd_kernel<5, true>), dim3(B), dim3(SL_NT), stack_lds_bytes<5>(), st, p);
+    else RF_LAUNCH((seq_stack_fwd_kernel<5, false>), dim3(B), dim3(SL_NT), stack_lds_bytes<5>(), st, p);
+  }
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

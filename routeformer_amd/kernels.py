@@ -1443,7 +1443,7 @@ def _seqstack_launch(x2, wpack, stride, idx_list, idx_group, B, L, F_, act, samp
         nbytes = 4.0 * M * 128 * 2 + n * (2.0 * (4 * 128 * 128 + 2 * 128 * F_)
                                           + (4.0 * M * (384 + 128 * 5 + 2 * F_ + 2) if save else 0.0))
         keep = (x2, wpack, idx_list, sv, st)
-        PROFILE.end(f"seq_stack_fwd_kernel<{3 if L <= 48 else 5}>", ev, flops, nbytes,
+        PROFILE.end(f"seq_stack_fwd_kernel<{3 if L <= 48 else 5}, {'true' if save else 'false'}>", ev, flops, nbytes,
                     replay=lambda a=args, k=keep: _hip.lib().rf_seqlayer_fwd(*a, _stream()))
     return sv
 
