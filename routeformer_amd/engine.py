@@ -156,9 +156,27 @@ class GradReducer:
     Parameters are laid out in REVERSE registration order so buckets fill in roughly the order
     backward produces gradients (GPS backbone first, frame encoder last)."""
 
-    def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 32.0, group=None, groups=()):
+    def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 32.0, group=None, groups=(), mode=None,
+                 lead=None, coalesce=None):
         """``groups``: lists of parameters that must sit back to back, in the given order (e.g. the Q, K, V
-        projection weights of one attention layer, so they can be used as ONE packed matrix)."""
+        projection weights of one attention layer, so they can be used as ONE packed matrix).
+
+        ``mode`` (default: env RF_DP_MODE or "allreduce") -- how the gradient exchange is done:
+          "allreduce"   bucketed ``all_reduce`` (RCCL ring / tree), every rank then updates every parameter;
+          "direct"      direct reduce-scatter: one ``all_to_all`` per region sends chunk j of the gradients straight to
+                        rank j over its own xGMI link (all 7 links busy at once instead of a ring hop per link), rank j
+                        sums the W chunks in rank order (fp32), updates ITS chunk of the parameters (sharded AdamW) and an
+                        in-place ``all_gather`` returns the updated chunks to everyone (SURVEY section 5 / 8(e));
+          "direct_bf16" the same with bf16 on the wire (half the reduce-scatter bytes), accumulation in fp32.
+        Every element is reduced by exactly one rank in a fixed order and the parameters are gathered, so replicas
+        are bit-identical in all modes.  ``lead``: ids of the parameters forming the leading region (the GPS backbone,
+        whose gradients are final first): regions are exchanged independently, each padded to W chunks.
+        ``coalesce`` (default: env RF_DP_COALESCE != "0"): neighbouring all-reduce buckets that are ready together leave
+        as one collective; off = one collective per bucket."""
+        import os as _os
+        self.mode = mode or _os.environ.get("RF_DP_MODE", "allreduce")
+        assert self.mode in ("allreduce", "direct", "direct_bf16"), self.mode
+        self.coalesce = (_os.environ.get("RF_DP_COALESCE", "1") != "0") if coalesce is None else bool(coalesce)
         order = list(reversed(params))
         member = {id(p): g for g in groups for p in g}
         seen, laid = set(), []
@@ -177,28 +195,45 @@ class GradReducer:
         self.exchange = self.world > 1 or (os.environ.get("RF_REHEARSE_COLLECTIVES") == "1" and dist.is_initialized())
         dev = self.params[0].device
         ALIGN = 64  # floats: every parameter starts on a 256-B boundary (16-B vector loads in the GEMMs)
-        total = sum(-(-p.numel() // ALIGN) * ALIGN for p in self.params)
-        self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.flat_param = torch.zeros(total, device=dev, dtype=torch.float32)
+        # layout pass: offsets, buckets, regions (direct modes: every region is padded to W equal chunks)
+        sharded = self.mode != "allreduce" and self.exchange
+        W = max(1, self.world)
+        quantum = ALIGN * W if sharded else ALIGN
+        lead = set(lead or ())
         cap = max(1, int(bucket_mb * (1 << 20) / 4))
         self.buckets: List[tuple] = []  # (start, end)
         self._bucket_of: Dict[int, int] = {}
         self.offset: Dict[int, int] = {}
-        off, b_start = 0, 0
-        for p in self.params:
-            n = p.numel()
-            self.flat_param[off:off + n].copy_(p.detach().reshape(-1))
-            p.data = self.flat_param[off:off + n].view_as(p)
-            p.grad = self.flat_grad[off:off + n].view_as(p)
-            p._rf_grad = p.grad  # gradient sink picked up by routeformer_amd.kernels
+        self.regions: List[tuple] = []
+        off, b_start, r_start = 0, 0, 0
+        for i, p in enumerate(self.params):
+            if sharded and i > 0 and (id(p) in lead) != (id(self.params[i - 1]) in lead) and off > r_start:
+                off = -(-off // quantum) * quantum  # region boundary: close bucket and region
+                if off > b_start:
+                    self.buckets.append((b_start, off))
+                    b_start = off
+                self.regions.append((r_start, off))
+                r_start = off
             self.offset[id(p)] = off
             self._bucket_of[id(p)] = len(self.buckets)
-            off += -(-n // ALIGN) * ALIGN
+            off += -(-p.numel() // ALIGN) * ALIGN
             if off - b_start >= cap:
                 self.buckets.append((b_start, off))
                 b_start = off
-        if off > b_start:
-            self.buckets.append((b_start, off))
+        total = -(-off // quantum) * quantum
+        if total > b_start:
+            self.buckets.append((b_start, total))
+        self.regions.append((r_start, total))
+        self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat_param = torch.zeros(total, device=dev, dtype=torch.float32)
+        for p in self.params:
+            o, n = self.offset[id(p)], p.numel()
+            self.flat_param[o:o + n].copy_(p.detach().reshape(-1))
+            p.data = self.flat_param[o:o + n].view_as(p)
+            p.grad = self.flat_grad[o:o + n].view_as(p)
+            p._rf_grad = p.grad  # gradient sink picked up by routeformer_amd.kernels
+        self._region_done = [False] * len(self.regions)
+        self._region_work: Dict[int, tuple] = {}
         self._members = [0] * len(self.buckets)
         for p in self.params:
             self._members[self._bucket_of[id(p)]] += 1
@@ -207,7 +242,7 @@ class GradReducer:
         self._works: List = []
         self._starts = sorted((self.offset[id(p)], id(p)) for p in self.params)
         self.hooks_enabled = True  # False: no in-backward launches (HIP-graph capture); finish() sends all
-        if self.exchange:
+        if self.exchange and not self.sharded:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -215,7 +250,7 @@ class GradReducer:
         """A kernel accumulated straight into ``view`` (a slice of flat_grad): same bookkeeping as the
         autograd hook, for every parameter slot the view covers (packed Q/K/V views cover three)."""
         import bisect
-        if not self.hooks_enabled:
+        if not self.hooks_enabled or self.sharded:
             return
         lo = (view.data_ptr() - self.flat_grad.data_ptr()) // 4
         hi = lo + view.numel()
@@ -250,6 +285,75 @@ class GradReducer:
         self._pending = list(self._members)
         self._launched = [False] * len(self.buckets)
         self._works = []
+        self._region_done = [False] * len(self.regions)
+        self._region_work = {}
+
+    # -- direct reduce-scatter / all-gather (modes "direct", "direct_bf16") ------------------------------------------
+    @property
+    def sharded(self) -> bool:
+        return self.mode != "allreduce" and self.exchange
+
+    def _rank(self) -> int:
+        return dist.get_rank(self.group)
+
+    def local_chunks(self):
+        """[lo, hi) slices of the flat buffers this rank owns, one per region (the whole buffer when not sharded)."""
+        if not self.sharded:
+            return [(0, self.flat_param.numel())]
+        r = self._rank()
+        return [(lo + r * ((hi - lo) // self.world), lo + (r + 1) * ((hi - lo) // self.world)) for lo, hi in self.regions]
+
+    def _host_staged(self, t):
+        """gloo moves host memory: device tensors are staged through the host for it (tests / rehearsal only)."""
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def _exchange_region(self, ri: int):
+        """Start the direct reduce-scatter of region ``ri``: chunk j of this rank's gradients goes to rank j."""
+        lo, hi = self.regions[ri]
+        g = self.flat_grad[lo:hi]
+        wire = g.to(torch.bfloat16) if self.mode == "direct_bf16" else g
+        if self._host_staged(wire):
+            send = wire.cpu()
+            recv = torch.empty_like(send)
+            work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+        else:
+            recv = torch.empty_like(wire)
+            work = dist.all_to_all_single(recv, wire, group=self.group, async_op=True)
+        self._region_work[ri] = (work, recv, wire)
+        self._region_done[ri] = True
+
+    def _finish_region(self, ri: int):
+        """Sum the W received chunks in rank order (fp32) into this rank's chunk of the flat gradient buffer."""
+        work, recv, _ = self._region_work.pop(ri)
+        work.wait()
+        lo, hi = self.regions[ri]
+        c = (hi - lo) // self.world
+        total = recv.view(self.world, c).to(torch.float32).sum(dim=0)
+        a, b = self.local_chunks()[ri]
+        self.flat_grad[a:b].copy_(total, non_blocking=True)
+
+    def gather_params(self):
+        """After the sharded update: every rank's chunk of the parameters goes to all ranks (in place)."""
+        if not self.sharded:
+            return
+        for (lo, hi), (a, b) in zip(self.regions, self.local_chunks()):
+            full, mine = self.flat_param[lo:hi], self.flat_param[a:b]
+            if self._host_staged(full):
+                out = torch.empty(hi - lo, dtype=full.dtype)
+                dist.all_gather_into_tensor(out, mine.cpu(), group=self.group)
+                full.copy_(out)
+            else:
+                dist.all_gather_into_tensor(full, mine, group=self.group)
+
+    def all_gather_floats(self, local: torch.Tensor) -> torch.Tensor:
+        """Concatenation over ranks of a small fp32 vector (the per-chunk partial sums of the gradient norm)."""
+        if self._host_staged(local):
+            out = torch.empty(self.world * local.numel(), dtype=local.dtype)
+            dist.all_gather_into_tensor(out, local.cpu(), group=self.group)
+            return out.to(local.device)
+        out = torch.empty(self.world * local.numel(), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=self.group)
+        return out
 
     def _launch(self, b: int):
         s, e = self.buckets[b]
@@ -271,6 +375,14 @@ class GradReducer:
         gradients are final).  Returns how many were launched."""
         if not self.exchange:
             return 0
+        if self.sharded:  # regions are the unit of exchange: those made up only of ``prefix`` parameters go now
+            n = 0
+            for ri, (lo, hi) in enumerate(self.regions):
+                inside = [p for p in self.params if lo <= self.offset[id(p)] < hi]
+                if not self._region_done[ri] and inside and all(names_of[id(p)].startswith(prefix) for p in inside):
+                    self._exchange_region(ri)
+                    n += 1
+            return n
         return self._launch_runs([b for b in range(len(self.buckets))
                                   if not self._launched[b] and self._bucket_prefix_ok(b, names_of, prefix)])
 
@@ -281,7 +393,7 @@ class GradReducer:
         i, n = 0, 0
         while i < len(ready):
             j = i
-            while j + 1 < len(ready) and ready[j + 1] == ready[j] + 1:
+            while self.coalesce and j + 1 < len(ready) and ready[j + 1] == ready[j] + 1:
                 j += 1
             s, e = self.buckets[ready[i]][0], self.buckets[ready[j]][1]
             self._works.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
@@ -304,7 +416,13 @@ class GradReducer:
         """Flush buckets whose parameters got no gradient this step (e.g. gaze branch dropped), then
         make the compute stream wait for all reductions.  Gradients hold the SUM over ranks; the
         1/world factor is folded into the optimizer kernel (``grad_scale``)."""
-        if self.exchange:
+        if self.sharded:
+            for ri in range(len(self.regions)):
+                if not self._region_done[ri]:
+                    self._exchange_region(ri)
+            for ri in sorted(self._region_work):
+                self._finish_region(ri)
+        elif self.exchange:
             self._launch_runs([b for b in range(len(self.buckets)) if not self._launched[b]])
             for w in self._works:
                 w.wait()
@@ -360,6 +478,34 @@ class FusedAdamW:
                                                 hyper_dev.data_ptr(), K._stream()), "rf_adamw_clip_dev")
         K.WEIGHTS_EPOCH += 1
 
+    def step_sharded(self, reducer: "GradReducer", grad_scale: float, skip=()):
+        """Modes "direct" / "direct_bf16": this rank holds the rank-summed gradients of ITS chunk of every region; it
+        clips with the GLOBAL norm (per-chunk partial sums of squares, all-gathered: every rank adds the same W x P
+        partials in the same order, so the coefficient is bit-identical everywhere), updates its chunks, and the
+        in-place all-gather of the parameters follows (``reducer.gather_params``)."""
+        from routeformer_amd import _hip, kernels as K
+        self.t += 1
+        chunks = reducer.local_chunks()
+        parts = [int(_hip.lib().rf_sumsq_parts(b - a)) for a, b in chunks]
+        local = torch.zeros(sum(parts), device=self.p.device, dtype=torch.float32)
+        o = 0
+        for (a, b), n_p in zip(chunks, parts):
+            _hip.check(_hip.lib().rf_sumsq(self.g.data_ptr() + 4 * a, b - a, local.data_ptr() + 4 * o, K._stream()), "rf_sumsq")
+            o += n_p
+        everyone = reducer.all_gather_floats(local)
+        for a, b in chunks:
+            lo = a
+            for sa, sb in [(max(x, a), min(y, b)) for x, y in skip if max(x, a) < min(y, b)] + [(b, b)]:
+                if sa > lo:
+                    q = 4 * lo
+                    _hip.check(_hip.lib().rf_adamw_clip(self.p.data_ptr() + q, self.g.data_ptr() + q, self.m.data_ptr() + q,
+                                                        self.v.data_ptr() + q, sa - lo, everyone.data_ptr(), everyone.numel(),
+                                                        self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
+                                                        self.wd, self.t, grad_scale, K._stream()), "rf_adamw_clip")
+                lo = max(lo, sb)
+        reducer.gather_params()
+        K.WEIGHTS_EPOCH += 1
+
     def step(self, grad_scale: float = 1.0, skip=()):
         """``skip``: sorted, disjoint [lo, hi) ranges of the flat buffers that took no part in this step (their
         ``.grad`` would be None in the reference, whose AdamW then leaves the parameter AND its moments untouched --
@@ -393,7 +539,8 @@ class TrainEngine:
         cfg = model.configs
         layers = [m for m in model.modules() if hasattr(m, "packing_groups")]
         groups = [g for m in layers for g in m.packing_groups()]
-        self.reducer = GradReducer(trainable_parameters(model), bucket_mb, groups=groups)
+        lead = {id(p) for n, p in model.named_parameters() if n.startswith("gps_backbone.")}
+        self.reducer = GradReducer(trainable_parameters(model), bucket_mb, groups=groups, lead=lead)
         # Kernels write parameter gradients through sinks and through deferred grouped launches, and autograd's
         # post-accumulate hooks also fire for parameters whose Function returned None -- "this slot is final" is
         # only known at the end of backward (or at the stage boundary of the two-graph step), so buckets are
@@ -541,8 +688,15 @@ class TrainEngine:
         self.model.train()
         res = self._fwd_bwd(item, epoch)
         scale = self.reducer.finish()
-        self.opt.step(scale, skip=self._skip_ranges(self.model.__dict__.get("_unused_prefixes", ())))
+        self._update(scale, self._skip_ranges(self.model.__dict__.get("_unused_prefixes", ())))
         return res
+
+    def _update(self, scale: float, skip=()):
+        """Clip + AdamW: every rank on the whole buffer, or (direct modes) on its own chunks + parameter all-gather."""
+        if self.reducer.sharded:
+            self.opt.step_sharded(self.reducer, scale, skip)
+        else:
+            self.opt.step(scale, skip=skip)
 
 
 class GraphedTrainEngine(TrainEngine):
@@ -594,6 +748,8 @@ class GraphedTrainEngine(TrainEngine):
             raise ValueError("GraphedTrainEngine: motion_noise > 0 (torch.randn_like on the inputs) is not supported")
         if defer_update and c.gaze_dropout > 0:
             raise ValueError("defer_update cannot skip the optimizer slots of a dropped gaze branch; use defer_update=False")
+        if defer_update and self.reducer.sharded:
+            raise ValueError("defer_update replays the whole-buffer update; use RF_DP_MODE=allreduce with it")
 
     def _eager_fwd_bwd(self, item, epoch):
         return self._fwd_bwd(item, epoch)
@@ -902,5 +1058,5 @@ class GraphedTrainEngine(TrainEngine):
             self.opt.t += 1
             self._pending = self.opt.hyper(scale)  # applied at the start of the next replay (or by flush())
         else:
-            self.opt.step(scale, skip=self._skip_ranges(self._variant_unused[variant]))
+            self._update(scale, self._skip_ranges(self._variant_unused[variant]))
         return out

@@ -21,8 +21,10 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     K.set_precision("f32")
-    mode = sys.argv[1]  # "graph" | "graph_split" | "eager"
-    os.environ["RF_SPLIT_BWD"] = "1" if mode == "graph_split" else "0"
+    mode = sys.argv[1]  # "graph" | "graph_split" | "eager" | "eager_nooverlap" | "graph_split_direct" | "graph_direct_bf16"
+    os.environ["RF_SPLIT_BWD"] = "1" if mode.startswith("graph_split") else "0"
+    if "direct" in mode:  # direct reduce-scatter + sharded AdamW + parameter all-gather (engine.GradReducer modes)
+        os.environ["RF_DP_MODE"] = "direct_bf16" if mode.endswith("bf16") else "direct"
     model, cfg, sd, c = build_product_model("c2_small", "cuda:0")
     model.train()
 
@@ -46,7 +48,8 @@ def main():
     dist.all_gather(gathered, flat)
     same = all(torch.equal(gathered[0], g) for g in gathered)
     if rank == 0:
-        torch.save({"same": same, "flat": flat}, sys.argv[2])
+        params = torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()])
+        torch.save({"same": same, "flat": flat, "params": params}, sys.argv[2])
     dist.barrier()
     dist.destroy_process_group()
 

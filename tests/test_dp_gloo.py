@@ -165,3 +165,98 @@ def test_unused_parameter_agreement_two_ranks():
     for p in procs:
         p.join(60)
     assert got == [(0, False, True, False), (1, False, True, False)]
+
+
+def _worker_modes(rank, world, port, mode, out):
+    """Direct reduce-scatter modes: after finish() this rank's chunk of every region holds the rank-summed gradient;
+    a (reference, pure-torch) sharded AdamW on the chunks + gather_params leaves identical parameters everywhere."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from routeformer_amd.engine import GradReducer
+    torch.manual_seed(0)
+    net = _Net()
+    lead = {id(p) for n, p in net.named_parameters() if n.startswith("c.")}
+    red = GradReducer(list(net.parameters()), bucket_mb=0.0001, mode=mode, lead=lead)
+    red.hooks_enabled = False
+    red.broadcast_parameters(0)
+    names = {id(p): n for n, p in net.named_parameters()}
+    assert red.sharded and len(red.regions) == 2 and all((hi - lo) % (64 * world) == 0 for lo, hi in red.regions)
+    m = torch.zeros_like(red.flat_param)
+    v = torch.zeros_like(red.flat_param)
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(5, 8, generator=g)
+    chunks_seen = []
+    for step in range(2):
+        red.zero()
+        net(x).square().sum().backward()
+        full = red.flat_grad.clone()                       # this rank's own gradients, before the exchange
+        early = red.launch_complete_prefix(names, "c.")   # the leading region goes first (stage boundary)
+        scale = red.finish()
+        mine = red.local_chunks()
+        chunks_seen.append([red.flat_grad[a:b].clone() * scale for a, b in mine])
+        for a, b in mine:                                  # reference sharded AdamW (lr 1e-2, no clip / decay)
+            gr = red.flat_grad[a:b] * scale
+            m[a:b].mul_(0.9).add_(gr, alpha=0.1)
+            v[a:b].mul_(0.999).addcmul_(gr, gr, value=0.001)
+            mh, vh = m[a:b] / (1 - 0.9 ** (step + 1)), v[a:b] / (1 - 0.999 ** (step + 1))
+            red.flat_param[a:b].add_(-1e-2 * mh / (vh.sqrt() + 1e-8))
+        red.gather_params()
+    out[rank] = (red.flat_param.clone(), chunks_seen, mine, full, early, list(red.regions),
+                 torch.cat([p.detach().reshape(-1) for p in net.parameters()]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["direct", "direct_bf16"])
+def test_direct_reduce_scatter_modes(mode):
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_modes, args=(world, port, mode, out), nprocs=world, join=True)
+        r0, r1 = out[0], out[1]
+    assert torch.equal(r0[0], r1[0]), "replicas must be bit-identical after the parameter all-gather"
+    assert torch.equal(r0[6], r1[6]), "module parameters (views of the flat buffer) must agree too"
+    assert r0[4] == 1 and r0[5] == r1[5], "one leading region launched early; same region table on every rank"
+    # last step: rank r's chunk of the mean gradient == mean over ranks of the full local gradients on that slice
+    tol = 1e-6 if mode == "direct" else 1e-2
+    for me, other in ((r0, r1), (r1, r0)):
+        for (a, b), got in zip(me[2], me[1][-1]):
+            want = (me[3][a:b] + other[3][a:b]) / 2
+            assert torch.allclose(got, want, atol=tol * max(1.0, float(want.abs().max())), rtol=0), mode
+    # the chunks tile every region exactly once
+    cover = sorted([c for c in r0[2]] + [c for c in r1[2]])
+    assert cover[0][0] == 0 and all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
+
+
+def _worker_coalesce(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from routeformer_amd.engine import GradReducer
+    torch.manual_seed(0)
+    net = _Net()
+    res = {}
+    for coalesce in (True, False):
+        red = GradReducer(list(net.parameters()), bucket_mb=0.0001, coalesce=coalesce)
+        red.hooks_enabled = False
+        calls = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda t, *a, **k: (calls.append(t.numel()), real(t, *a, **k))[1]
+        try:
+            red.zero()
+            net(torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + rank))).square().sum().backward()
+            scale = red.finish()
+        finally:
+            dist.all_reduce = real
+        res[coalesce] = (len(calls), len(red.buckets), red.flat_grad.clone() * scale)
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_per_bucket_launches_equal_coalesced_runs():
+    """RF_DP_COALESCE=0: one collective per bucket instead of one per run of neighbouring buckets -- same result."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_coalesce, args=(world, port, out), nprocs=world, join=True)
+        r0 = out[0]
+    assert r0[True][0] == 1 and r0[False][0] == r0[False][1] >= 3
+    assert torch.equal(r0[True][2], r0[False][2])

@@ -23,17 +23,25 @@ def _run(mode, out, port):
 
 def test_two_rank_engines_agree(tmp_path):
     res = {m: _run(m, str(tmp_path / f"{m}.pt"), 29600 + i)
-           for i, m in enumerate(("eager_nooverlap", "eager", "graph", "graph_split"))}
+           for i, m in enumerate(("eager_nooverlap", "eager", "graph", "graph_split", "graph_split_direct",
+                                  "graph_direct_bf16"))}
     print({m: r["same"] for m, r in res.items()})
     for m, r in res.items():
         assert r["same"], f"{m}: replicas diverged"
     # engines agree up to the order of fp32 atomic accumulation in the gradient slots; Adam turns rounding noise in
     # tiny gradients into O(lr) differences (lr = 1e-3, 3 steps) -- replicas of ONE run are bit-identical
     ref = res["eager"]["flat"]
-    for m in ("eager_nooverlap", "graph", "graph_split"):
-        d = (res[m]["flat"] - ref).abs()
-        assert float(d.max() / ref.abs().max()) < 5e-3, (m, float(d.max()))   # <= a few Adam steps of lr
-        assert float(d.mean() / ref.abs().mean()) < 1e-4, (m, float(d.mean()))  # ... on a handful of parameters
+    for m in ("eager_nooverlap", "graph", "graph_split", "graph_split_direct", "graph_direct_bf16"):
+        flat = res[m]["flat"]
+        if flat.numel() != ref.numel():  # the direct modes pad every region to W chunks: compare parameter by parameter
+            assert "direct" in m
+            flat, refp = res[m]["params"], res["eager"]["params"]
+        else:
+            refp = ref
+        d = (flat - refp).abs()
+        # (bf16 on the wire: gradients carry 2^-9 relative rounding, Adam's normalisation keeps the steps at <= lr)
+        assert float(d.max() / refp.abs().max()) < 5e-3, (m, float(d.max()))   # <= a few Adam steps of lr
+        assert float(d.mean() / refp.abs().mean()) < (1e-3 if m.endswith("bf16") else 1e-4), (m, float(d.mean()))
 
 
 def test_bench_launches_its_own_ranks():
