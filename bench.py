@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (N=1)")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-ade", action="store_true", help="skip the ADE-vs-CPU-reference leg (N=1, rank 0)")
+    ap.add_argument("--trunk-cache", action="store_true",
+                    help="attach the HBM-resident backbone-feature cache (the reference's @torchcache steady state: the "
+                         "frozen trunk is skipped for frames it has seen) -- a second bench line, not the headline")
     ap.add_argument("--dropout", default="none", choices=["none", "paper"],
                     help="paper: the reference run's dropouts (full_comparison.py:272-275: feature 0.05, view 0.6, "
                          "gaze 0.2) instead of the parity configuration's zeros -- a second bench line, not the headline")
@@ -235,6 +238,9 @@ def main():
         print(f"[bench r{rank}] {msg}", file=sys.stderr, flush=True)
 
     model, cfg, sd, c = build(args.case, device, args.precision, args.dropout)
+    if args.trunk_cache and cfg.with_video:
+        from routeformer_amd.models.video_backbone import TokenCache
+        model.video_backbone.token_cache = TokenCache(4096, device)
     # two different synthetic batches, used alternately: the engine's look-ahead (conv trunk of the NEXT
     # batch under the current step) then always works on data it has not seen in this step
     items = [make_item(c, rank, device), make_item(c, rank + 500, device)]
@@ -388,6 +394,9 @@ def main():
                                    f"{c['H']}x{c['W']}, T={c['T']}->P={c['P']}, paper hyper-params, "
                                    f"batch {c['B']}/GPU, random-init weights, frozen HRNet-16 encoder",
                        "global_batch": c["B"] * world, "parallelism": f"dp{world}",
+                       "trunk": ("HBM token cache: every frame of the two alternating batches is resident after the warm-up, "
+                                 "the frozen conv trunk is skipped (the reference's torchcache steady state)"
+                                 if args.trunk_cache else "runs every step (uncached: the headline configuration)"),
                        "dropout": ({"feature": cfg.feature_dropout, "view": cfg.view_dropout, "gaze": cfg.gaze_dropout,
                                     "gps_backbone": cfg.gps_backbone_config.dropout}
                                    if args.dropout != "none" else "0 (parity configuration, SURVEY 8(d))"),

@@ -312,6 +312,25 @@ int rf_seqlayer_fwd(const RfSeqStack* stack, const float* x, int B, int L, int d
                     int sample_k, int n_top, int idx_group, int force_top, int save, float scale, float eps,
                     void* stream);
 
+/* ---- video ingest ---------------------------------------------------------------
+ * rf_resize_area: cv2.resize(..., interpolation=cv2.INTER_AREA) of io/dataset.py:1476-1497 (down-scaling, factor < 1)
+ *   on uint8 planes [n_planes][H][W] -> [n_planes][h][w]: coverage-weighted mean of the source pixels under each
+ *   output pixel, rounded half-to-even and saturated (integer factors: plain s x s block means).
+ * rf_frame_hash: keys[f] = 64-bit content hash (never 0) of frame frame_ids[f] (NULL: f) of `frames` (frames of
+ *   bytes_per_frame bytes, back to back): the key of the backbone-feature cache that stands in for @torchcache(persistent=True)
+ *   (models/video_backbone/__init__.py:14-32).
+ * rf_cache_lookup: slots[i] = token slot of keys[i] in the open-addressing table (table_keys[capacity] uint64, 0 =
+ *   empty; table_slots[capacity] int32; capacity a power of two) or -1; *misses += number of -1 (caller zeroes it).
+ * rf_cache_insert: for every i with slots[i] < 0 claim a table entry and the next free token slot (*next_slot,
+ *   atomically; at most n_slots); duplicates inside one call and a full cache stay -1 (look up again afterwards). */
+int rf_resize_area(const uint8_t* src, uint8_t* dst, int64_t n_planes, int H, int W, int h, int w, void* stream);
+int rf_frame_hash(const void* frames, const int64_t* frame_ids, int64_t n_frames, int64_t bytes_per_frame, uint64_t* keys,
+                  int64_t seed, void* stream);
+int rf_cache_lookup(const uint64_t* keys, int n, const uint64_t* table_keys, const int32_t* table_slots, int capacity,
+                    int32_t* slots, int32_t* misses, void* stream);
+int rf_cache_insert(const uint64_t* keys, int n, uint64_t* table_keys, int32_t* table_slots, int capacity,
+                    int32_t* next_slot, int n_slots, int32_t* slots, void* stream);
+
 /* ---- dropout on the trainable path -------------------------------------------------------------
  * nn.Dropout of cross_modal_transformer.py:49,63,220-231,285-299, gps_backbone/layers/Embedding.py:122-126,
  * layers/TransformerEncoderDecoder.py:41-50,102-113.  Masks are never stored: the keep-bit of element e of dropout

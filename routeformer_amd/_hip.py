@@ -56,6 +56,10 @@ SIGNATURES = {
     "rf_attn_fwd_full_scores": [_I, _I, _I, _I, _I, _I, _I, _I],
     "rf_attn_bwd": [_P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _I,
                     _I, _I, _F, _P],
+    "rf_resize_area": [_P, _P, _L, _I, _I, _I, _I, _P],
+    "rf_frame_hash": [_P, _P, _L, _L, _P, _L, _P],
+    "rf_cache_lookup": [_P, _I, _P, _P, _I, _P, _P, _P],
+    "rf_cache_insert": [_P, _I, _P, _P, _I, _P, _I, _P, _P],
     "rf_seqlayer_pack": [_P, _I, _P],
     "rf_seqlayer_supported": [_I, _I, _I, _I, _I, _I],
     "rf_seqlayer_pack_bytes": [_I],

@@ -735,6 +735,7 @@ class GraphedTrainEngine(TrainEngine):
         self._out = None
         self._trunk_g = None
         self._ready_id = None
+        self._cached_ids = {}
         self._clip_stage = self._clip_idx = None
         self._recipe = None
         self._tstream = None
@@ -855,14 +856,44 @@ class GraphedTrainEngine(TrainEngine):
     def _staged(self):
         return [(t, None) for t in self._clip_stage]  # frame index None = every staged frame
 
+    def _encode(self, clips, out=None):
+        """The trunk itself (never the token cache: the engine consults that per batch id, outside its graphs)."""
+        vb = self.model.video_backbone
+        return getattr(vb, "_encode_clips_uncached", vb.encode_clips)(clips, out=out)
+
+    # -- backbone-feature cache (token_cache.TokenCache on the video backbone) --------------------------------------------
+    def _cache(self):
+        return getattr(self.model.video_backbone, "token_cache", None) if self._pipelined else None
+
+    def _cached_tokens_into_next(self, item) -> bool:
+        """Tokens of a batch the cache already holds (known by its explicit id) -> ``_tok_next``; no trunk pass, no
+        host synchronisation."""
+        cache, iid = self._cache(), item.get("id")
+        slots = self._cached_ids.get(iid) if (cache is not None and iid is not None) else None
+        if slots is None:
+            return False
+        cache.gather(slots, self._tok_next)
+        return True
+
+    def _remember_tokens(self, item, keys):
+        """After a trunk pass over the staged frames of ``item``: store its tokens (content-keyed), and remember the
+        slots under the batch id (one device synchronisation, the first time a batch is seen)."""
+        cache, iid = self._cache(), item.get("id")
+        if cache is None or keys is None:
+            return
+        slots, _ = cache.lookup(keys, count_misses=False)
+        final = cache.insert(keys, slots, self._tok_next)
+        if iid is not None and bool((final >= 0).all()):
+            self._cached_ids[iid] = final
+
     def _trunk_graph(self):
         """Graph of one trunk pass over the staged frames into ``self._tok_next`` (cold start / no look-ahead)."""
         if self._trunk_g is None:
-            self.model.video_backbone.encode_clips(self._staged(), out=self._tok_next)  # warm (weight folding, caches)
+            self._encode(self._staged(), out=self._tok_next)  # warm (weight folding, caches)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, **_capture_kw()):
-                self.model.video_backbone.encode_clips(self._staged(), out=self._tok_next)
+                self._encode(self._staged(), out=self._tok_next)
             self._trunk_g = g
         return self._trunk_g
 
@@ -957,7 +988,7 @@ class GraphedTrainEngine(TrainEngine):
         clips = None
         if la:
             clips = self._staged()
-            self.model.video_backbone.encode_clips(clips)  # warm caches outside capture (scratch output)
+            self._encode(clips)  # warm caches outside capture (scratch output)
         if self._pipelined:
             c0, k0 = self.model.video_clips([self._static_item["train"], self._static_item["target"]])
             self.model.set_video_tokens(self._tok_cur, c0, k0)
@@ -972,7 +1003,7 @@ class GraphedTrainEngine(TrainEngine):
                 if la:
                     self._tstream.wait_stream(cur)
                     with torch.cuda.stream(self._tstream):
-                        self.model.video_backbone.encode_clips(clips, out=self._tok_next)
+                        self._encode(clips, out=self._tok_next)
                 out = self._fwd_bwd(self._static_item, self._epoch, tokens_ready=self._pipelined)
                 if la:
                     cur.wait_stream(self._tstream)
@@ -987,7 +1018,7 @@ class GraphedTrainEngine(TrainEngine):
                     if la:
                         self._tstream.wait_stream(cur)
                         with torch.cuda.stream(self._tstream):
-                            self.model.video_backbone.encode_clips(clips, out=self._tok_next)
+                            self._encode(clips, out=self._tok_next)
                     out, carry = self._stage1(self._static_item, self._epoch, tokens_ready=self._pipelined)
                     if la:
                         cur.wait_stream(self._tstream)
@@ -1023,17 +1054,29 @@ class GraphedTrainEngine(TrainEngine):
         # host side of the step first: the reference's draws in its order (key samples, view / gaze dropout decisions)
         # into the static buffer; the decisions pick the graph variant to replay (captured on first use)
         variant = SAMPLER.refill_static()
-        g, out = self._main_graph(next_item is not None, variant)
-        SAMPLER.select_static(variant)
-        if self._pipelined:
+        pending = None  # (item, keys) whose freshly computed tokens go into the cache after the replay
+        if not self._pipelined:
+            g, out = self._main_graph(False, variant)
+        else:
             iid = item.get("id")
+            cache = self._cache()
             if not (self._ready_id is not None and iid is not None and iid == self._ready_id):
-                self._stage_clips(item)                   # cold start / no look-ahead: run this batch's trunk now
-                self._trunk_graph().replay()
+                if not self._cached_tokens_into_next(item):  # cold start / no look-ahead: run this batch's trunk now
+                    self._stage_clips(item)
+                    self._trunk_graph().replay()
+                    if cache is not None:
+                        self._remember_tokens(item, cache.keys_of(self._staged()))
             self._tok_cur.copy_(self._tok_next)
             self._ready_id = None
-            if next_item is not None:
+            lookahead = next_item is not None
+            if lookahead and self._cached_tokens_into_next(next_item):
+                lookahead = False  # tokens of the next batch are already in _tok_next: no trunk branch this step
+            elif lookahead:
                 self._stage_clips(next_item)
+                if cache is not None:
+                    pending = (next_item, cache.keys_of(self._staged()))
+            g, out = self._main_graph(lookahead, variant)
+        SAMPLER.select_static(variant)
         for part in ("train", "target"):
             for n, v in item[part].items():
                 dst = self._static_item[part][n]
@@ -1053,6 +1096,8 @@ class GraphedTrainEngine(TrainEngine):
             g.replay()
         if self._pipelined and next_item is not None:
             self._ready_id = next_item.get("id")
+            if pending is not None:
+                self._remember_tokens(*pending)
         scale = self.reducer.finish()
         if self.defer_update:
             self.opt.t += 1

@@ -3,8 +3,9 @@
 out of scope (SURVEY.md 2 #6); any ``VideoBackboneModule`` subclass plugs into ``Routeformer``."""
 from .config import InverseFormBackboneConfig, VideoBackboneConfig, VideoBackboneModule
 from .hrnet16 import HRNet16Backbone
+from .token_cache import TokenCache
 
 InverseForm = HRNet16Backbone  # name used by the reference's experiment driver
 
 __all__ = ["VideoBackboneConfig", "VideoBackboneModule", "InverseFormBackboneConfig", "HRNet16Backbone",
-           "InverseForm"]
+           "InverseForm", "TokenCache"]

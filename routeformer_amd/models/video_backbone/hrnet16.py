@@ -122,6 +122,7 @@ class HRNet16Backbone(VideoBackboneModule):
         self._folded: Optional[Dict[str, tuple]] = None
         self._folded_key = None
         self._fidx_cache: Dict[tuple, torch.Tensor] = {}
+        self.token_cache = None  # optional token_cache.TokenCache (persistent backbone-feature cache)
 
     # ---- plugin contract ---------------------------------------------------------------------
     @property
@@ -342,6 +343,17 @@ class HRNet16Backbone(VideoBackboneModule):
         return self.encode_clips([(v, frame_idx) for v in videos])
 
     def encode_clips(self, clips, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``_encode_clips_uncached`` behind the optional ``token_cache`` (token_cache.TokenCache, the counterpart of
+        the reference's ``@torchcache(persistent=True)``, video_backbone/__init__.py:14-32): frames whose content has
+        been seen are served from HBM, a pass with unknown frames runs the trunk once and stores its tokens.  Inside a
+        stream capture (the engine's trunk graphs) the trunk always runs: the engine consults the cache itself."""
+        cache = getattr(self, "token_cache", None)
+        if cache is None or torch.cuda.is_current_stream_capturing():
+            return self._encode_clips_uncached(clips, out)
+        clips = [((v if v.dtype in (torch.float16, torch.float32, torch.uint8) else v.float()).contiguous(), fi) for v, fi in clips]
+        return cache.tokens_for(clips, self._encode_clips_uncached, out)
+
+    def _encode_clips_uncached(self, clips, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """clips: [(video (B,T,3,H,W), frame_idx (F,) or None)] -- clips may differ in B, T and frame
         indices (e.g. the history and the target window of one training item) but share H x W.
         One trunk pass over ALL selected frames -> tokens (sum_i B_i*F_i, 65, 240), clip-major."""

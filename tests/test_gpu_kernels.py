@@ -1017,3 +1017,66 @@ def test_fused_encoder_stack_forward(B, L, F_, n_layers, groups, act):
     assert torch.equal(nosave["y"][0], forced["y"][-1]), "the no-save variant must compute the same output"
     if all(same):
         assert torch.equal(free["y"][-1], forced["y"][-1])
+
+
+# ------------------------------------------------------------------------------------------------
+# video ingest: area resize, content hash, HBM token cache
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,factor", [((2, 3, 3, 64, 96), 0.5), ((1, 2, 3, 90, 120), 1 / 3), ((3, 1, 60, 80), 0.6),
+                                           ((2, 3, 37, 53), 0.75), ((1, 1, 8, 8), 1.0)])
+def test_resize_area_vs_restatement(shape, factor):
+    """rf_resize_area against the CPU restatement of cv2.INTER_AREA down-scaling (oracle/ingest_oracle.py; parity
+    with OpenCV itself is unpinned: cv2 is absent) and, for integer factors, against exact block means."""
+    from oracle import ingest_oracle as IO
+    from routeformer_amd.utils.video import resize_area
+    g = _g(int(shape[-1] * 10 * factor))
+    x = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+    got = resize_area(x.to(DEV), factor).cpu().numpy()
+    want = IO.resize_area(x.numpy(), factor)
+    assert got.shape == want.shape
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())  # fp32 vs fp64 at exact .5 ties
+    inv = 1.0 / factor
+    if abs(inv - round(inv)) < 1e-9 and shape[-2] % round(inv) == 0 and shape[-1] % round(inv) == 0:
+        s = int(round(inv))
+        blocks = x.numpy().astype(np.float64).reshape(shape[:-2] + (shape[-2] // s, s, shape[-1] // s, s)).mean(axis=(-3, -1))
+        assert np.array_equal(got, np.rint(blocks).astype(np.uint8))
+
+
+def test_token_cache_semantics():
+    """Content-keyed HBM cache of trunk tokens: keys depend on the bytes only (not on the address, the clip layout or
+    the frame sub-sampling), equal frames share a slot, lookups after an insert hit, a full cache degrades to "uncached",
+    and a saved cache answers in a new process-equivalent instance (persistent=True of torchcache)."""
+    from oracle import ingest_oracle as IO
+    from routeformer_amd.models.video_backbone import TokenCache
+    g = _g(3)
+    B, T, H, W = 2, 6, 16, 24
+    vid = torch.randint(0, 256, (B, T, 3, H, W), generator=g, dtype=torch.uint8)
+    vid[1, 4] = vid[0, 1]                       # an identical frame inside the batch
+    v = vid.to(DEV)
+    idx = torch.tensor([1, 3, 4])
+    cache = TokenCache(5, DEV)                  # room for 5 frames, the batch selects 6 (5 distinct)
+    keys = cache.keys_of([(v, idx)])
+    assert keys.shape == (B * 3,) and int(keys[0]) == int(keys[5]) and len(set(keys.tolist())) == 5
+    sub = v[:, idx].contiguous()                # the same frames at other addresses, as a compact clip
+    assert torch.equal(cache.keys_of([(sub, None)]), keys)
+    assert not torch.equal(cache.keys_of([(sub.flip(-1).contiguous(), None)]), keys)
+    slots, miss = cache.lookup(keys)
+    assert miss == 6 and bool((slots < 0).all())
+    tokens = torch.randn(6, 65, 240, device=DEV)
+    tokens[5] = tokens[0]
+    final = cache.insert(keys, slots, tokens)
+    model = IO.TokenCacheModel(5)
+    want = model.insert(keys.tolist())
+    assert sorted(set(final.tolist())) == sorted(set(want)) and int(final[0]) == int(final[5])
+    slots2, miss2 = cache.lookup(keys)
+    assert miss2 == 0 and torch.equal(slots2, final) and torch.equal(cache.gather(slots2), tokens)
+    other = torch.randint(0, 256, (1, 2, 3, H, W), generator=g, dtype=torch.uint8).to(DEV)
+    k2 = cache.keys_of([(other, None)])
+    s2, m2 = cache.lookup(k2)
+    f2 = cache.insert(k2, s2, torch.randn(2, 65, 240, device=DEV))
+    assert m2 == 2 and int((f2 >= 0).sum()) == 0 and int(cache.next_slot) >= 5, "5 slots were taken: the cache is full"
+    again = TokenCache(5, DEV)
+    again.load_state_dict(cache.state_dict())
+    s3, m3 = again.lookup(keys)
+    assert m3 == 0 and torch.equal(again.gather(s3), tokens)

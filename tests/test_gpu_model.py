@@ -758,3 +758,55 @@ def test_fused_stack_matches_layerwise_train_step():
     assert abs(l0 - l1) < 2e-2 * max(1.0, abs(l0)), (l0, l1)
     assert rel_err(f1, f0) < TOL_BF16
     assert fro_err(g1, g0) < 0.1, fro_err(g1, g0)
+
+
+def test_token_cache_in_model_and_engine():
+    """The backbone-feature cache (the reference's torchcache steady state) changes nothing but the work: eval outputs
+    with the cache cold, warm and absent are bit-identical; the graphed engine with the cache skips the trunk for batch
+    ids it has seen and still computes the eager engine's steps."""
+    from routeformer_amd import synthetic
+    from routeformer_amd.engine import GraphedTrainEngine, TrainEngine
+    from routeformer_amd.models.blocks import SAMPLER
+    from routeformer_amd.models.video_backbone import TokenCache
+    model, cfg, sd, c = build_product_model("c2_small", DEV)
+    model.eval()
+    item = case_item(c)
+    batch = _to_dev(item["train"])
+
+    def run():
+        torch.manual_seed(5)
+        with torch.no_grad():
+            return model(batch)
+
+    ref = run()
+    model.video_backbone.token_cache = TokenCache(64, DEV)
+    cold, warm = run(), run()
+    assert model.video_backbone.token_cache.hits > 0
+    for a in (cold, warm):
+        assert torch.equal(a[0], ref[0]) and torch.equal(a[1], ref[1])
+    model.video_backbone.token_cache = None
+
+    items = []
+    for seed in (11, 12):
+        it = synthetic.synth_item(c["B"], c["T"], c["P"], seed, c["H"], c["W"], streams=c["streams"], gaze=c["gaze"])
+        items.append({"train": _to_dev(it["train"]), "target": _to_dev(it["target"]), "id": seed})
+    losses = {}
+    for mode in ("eager", "graph_cached"):
+        m2, *_ = build_product_model("c2_small", DEV)
+        if mode == "eager":
+            eng = TrainEngine(m2, lr=1e-3)
+        else:
+            m2.video_backbone.token_cache = TokenCache(64, DEV)
+            eng = GraphedTrainEngine(m2, lr=1e-3).capture(items[0], epoch=10)
+        torch.manual_seed(9)
+        losses[mode] = [float(eng.step(items[i % 2], epoch=10, next_item=items[(i + 1) % 2])["loss"].detach()) for i in range(5)]
+        if mode != "eager":
+            assert set(eng._cached_ids) == {11, 12} and eng._trunk_g is not None
+            replays = []
+            real = eng._trunk_g.replay
+            eng._trunk_g.replay = lambda: (replays.append(1), real())[1]
+            n_graphs = len(eng._graphs)
+            eng.step(items[1], epoch=10, next_item=items[0])
+            assert not replays and len(eng._graphs) == n_graphs, "a cached batch must not run the trunk"
+        SAMPLER.drop_static()
+    assert all(abs(a - b) < 5e-4 * max(1.0, abs(a)) for a, b in zip(losses["eager"], losses["graph_cached"])), losses
