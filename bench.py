@@ -385,6 +385,18 @@ def main():
                     "algorithmic_bytes_per_launch": nbytes / launches, "launches_per_step": launches, "avg_us": avg_s * 1e6,
                     "flop_per_byte": flops / max(nbytes, 1), "alt_tflops": tfl, "alt_gbs": gbs,
                     "eager_event_ms_by_kernel": {k: round(v["total_ms"], 3) for k, v in ranked[:12]}}
+        # the fused per-sequence encoder stack (csrc/seqlayer.hip) against the bf16 matrix-core
+        # peak, per launch shape: the one kernel family of the step whose operands stay on chip
+        fused = []
+        for tag in [k for k in prof if k.startswith("seq_stack_fwd_kernel")]:
+            fine = K.PROFILE.refine(tag)
+            if fine is None:
+                continue
+            n_l, us, fl, by = fine
+            fused.append({"kernel": tag, "bound": "mfma", "launches_per_step": n_l, "avg_us": us / n_l,
+                          "achieved": fl / (us * 1e-6) / 1e12, "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                          "frac": fl / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS["bf16"],
+                          "algorithmic_gbs": by / (us * 1e-6) / 1e9, "flop_per_byte": fl / max(by, 1)})
         out = {
             "metric": "samples/sec (train step) on synthetic GEM batch",
             "value": total_samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -404,7 +416,7 @@ def main():
                        "launch": ("hipGraph replay of fwd+bwd" + (" (+ the previous step's clip/AdamW at its head)" if defer else ""))
                        if use_graph else "eager launches"},
             "loss": float(res["loss"].detach()), "rccl_ranks": rccl_ranks, "batch_independence_rel": indep,
-            "roofline": roof,
+            "roofline": roof, "roofline_fused_encoder_stack": fused or None,
         }
         if rehearse:
             out["config"]["rehearsal"] = "one-rank RCCL group, N>1 code path (RF_REHEARSE_COLLECTIVES=1)"

@@ -529,7 +529,7 @@ def _grads_vs_summary(G, key, named, tol):
             assert rel_err(named[f[len(key + "grad::"):]].grad, G[f]) < tol, f
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-4), ("bf16", 5e-2)])
 def test_dropout_blocks_vs_reference(prec, tol):
     """The product's encoder / decoder / GPS blocks in TRAIN mode with dropout 0.1 against the reference's outputs and
     gradients (tests/golden/dropout.npz), with the reference's recorded keep-masks injected (``K.RNG.forced``) and its
@@ -796,7 +796,7 @@ def test_token_cache_in_model_and_engine():
         if mode == "eager":
             eng = TrainEngine(m2, lr=1e-3)
         else:
-            m2.video_backbone.token_cache = TokenCache(64, DEV)
+            m2.video_backbone.token_cache = TokenCache(256, DEV)
             eng = GraphedTrainEngine(m2, lr=1e-3).capture(items[0], epoch=10)
         torch.manual_seed(9)
         losses[mode] = [float(eng.step(items[i % 2], epoch=10, next_item=items[(i + 1) % 2])["loss"].detach()) for i in range(5)]
