@@ -308,9 +308,13 @@ typedef struct RfSeqPackEntry {
 int rf_seqlayer_pack(const RfSeqPackEntry* entries, int count, void* stream);
 int64_t rf_seqlayer_pack_bytes(int d_ff);
 int rf_seqlayer_supported(int L, int d_model, int n_heads, int d_ff, int sample_k, int n_top);
+ /* drop_p > 0: nn.Dropout(p) of the layers in train mode (cross_modal_transformer.py:295,298,299), masks from the
+ * counter-based generator below -- layer i draws sites drop_site0 + 3 i + {0: attention output [B*L,128], 1: hidden
+ * activation [B*L,d_ff] (saved h = the dropped activation), 2: conv2 output [B*L,128]}, element index row * cols + col:
+ * exactly the masks rf_dropout generates for the same (site, element), which the layer-by-layer backward re-applies. */
 int rf_seqlayer_fwd(const RfSeqStack* stack, const float* x, int B, int L, int d_model, int n_heads, int d_ff, int act,
                     int sample_k, int n_top, int idx_group, int force_top, int save, float scale, float eps,
-                    void* stream);
+                    float drop_p, const void* rng_state, int drop_site0, void* stream);
 
 /* ---- video ingest ---------------------------------------------------------------
  * rf_resize_area: cv2.resize(..., interpolation=cv2.INTER_AREA) of io/dataset.py:1476-1497 (down-scaling, factor < 1)

@@ -44,6 +44,8 @@ struct SeqStackP {
   float *qkv, *ctx, *xhat1, *rstd1, *x1, *z, *h, *xhat2, *rstd2;  // training saves (layers, B*L, width)
   int B, L, F, n_layers, act, sample_k, n_top, idx_group, force_top, save;
   float scale, eps;
+  DropCfg drop;   // nn.Dropout of the layers (cross_modal_transformer.py:295,298,299); state == null: off
+  int drop_site0; // layer i uses sites drop_site0 + 3 i + {0: attention output, 1: hidden activation, 2: conv2 output}
 };
 
 // byte offsets inside a layer's packed blob
@@ -100,6 +102,30 @@ __device__ __forceinline__ void tile_store(const f32x4& acc, float* __restrict__
   const float4 o = *reinterpret_cast<const float4*>(tb + rr * 20 + c4);
   if (rr < rows_valid) *reinterpret_cast<float4*>(g + rr * ld + c4) = o;
   wave_sync_lds();
+}
+
+// Dropout factors (0 or 1 / (1 - p)) of the four accumulator elements of this lane -- rows row0 + 4 (lane >> 4) + r,
+// column `col` of a [rows, ncols] dropout site (element index row * ncols + col, the numbering rf_dropout uses, so the
+// layer-by-layer backward regenerates the same mask).  One Philox call per lane and tile: the four lanes of a quad
+// hold four neighbouring columns, i.e. the same Philox quad of every row; lane j of the quad evaluates row j and the
+// keep-bits travel by DPP quad broadcasts.
+__device__ __forceinline__ f32x4 drop_factors(const DropCfg& d, uint2 key, uint32_t step, uint32_t site, long row0, int ncols,
+                                              int col, int lane) {
+  const int fq = lane >> 4, j = lane & 3;
+  const unsigned long long e = (unsigned long long)((row0 + fq * 4 + j) * ncols + (col & ~3));
+  DropCfg c = d;
+  c.site = site;
+  const int bits = (int)drop_keep4(c, key, step, e >> 2);
+  const int b0 = __builtin_amdgcn_update_dpp(0, bits, 0x00, 0xF, 0xF, true);
+  const int b1 = __builtin_amdgcn_update_dpp(0, bits, 0x55, 0xF, 0xF, true);
+  const int b2 = __builtin_amdgcn_update_dpp(0, bits, 0xAA, 0xF, 0xF, true);
+  const int b3 = __builtin_amdgcn_update_dpp(0, bits, 0xFF, 0xF, 0xF, true);
+  f32x4 f;
+  f[0] = ((b0 >> j) & 1) ? d.scale : 0.f;
+  f[1] = ((b1 >> j) & 1) ? d.scale : 0.f;
+  f[2] = ((b2 >> j) & 1) ? d.scale : 0.f;
+  f[3] = ((b3 >> j) & 1) ? d.scale : 0.f;
+  return f;
 }
 
 // LayerNorm over the 128 columns of every row, the columns of a row being spread over the 8 waves (16 each, MFMA
@@ -162,7 +188,7 @@ __device__ unsigned long long rf_sl_timing[512 * 8 * 16];
 //   scr  per wave 7 168               57 344   score tile fp32 [16][16 RT + 4] / P bf16 [32][KS32 + 8]; Ms, top, flags
 //   part float2 [16 RT][8] + stat float2 [16 RT]   5 760   LayerNorm partial sums / per-row (mean, 1/sigma)
 //   cnt  uint8 [16 RT][16 RT]         6 400   cnt[key][query] = how often `key` is among the query's samples (all heads)
-template <int RT, bool SAVE>
+template <int RT, bool SAVE, bool DROP>
 __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p) {
   constexpr int LP = 16 * RT, KS32 = ((LP + 31) / 32) * 32, KSTEPS = KS32 / 32, VP = KS32 + 8, SP = LP + 4;
   constexpr int SCR_BYTES = 7168, TB = 320;  // TB: floats of one staged 16 x 16 tile (pitch 20)
@@ -204,6 +230,13 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
       for (int r = 0; r < 4; ++r) xb[(rt * 16 + fq * 4 + r) * SL_XP + wave * 16 + fr] = (__bf16)xres[rt][r];
   }
   const PackOff po = pack_offsets(F);
+  uint2 dkey = make_uint2(0, 0);
+  uint32_t dstep = 0;
+  if constexpr (DROP) {
+    const unsigned long long sd = p.drop.state->seed;
+    dkey = make_uint2((uint32_t)sd, (uint32_t)(sd >> 32));
+    dstep = (uint32_t)p.drop.state->step;
+  }
 
 #pragma unroll 1
   for (int li = 0; li < p.n_layers; ++li) {
@@ -495,8 +528,14 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8), wfo[kk], acc, 0, 0, 0);
+        if constexpr (DROP) {
+          const f32x4 f = drop_factors(p.drop, dkey, dstep, (uint32_t)(p.drop_site0 + 3 * li), (long)b * L + rt * 16, SL_D, col, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[rt][r] = acc[r] + bo + xres[rt][r];
+          for (int r = 0; r < 4; ++r) v[rt][r] = (acc[r] + bo) * f[r] + xres[rt][r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[rt][r] = acc[r] + bo + xres[rt][r];
+        }
       }
       if (SAVE) {  // the context as the out-projection (and its weight gradient) consumes it: the bf16 image, widened
         float* ctx_g = p.ctx + lrow * SL_D;
@@ -580,6 +619,14 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) hh[rt][r] = p.act == RF_ACT_RELU ? fmaxf(zz[rt][r], 0.f) : zz[rt][r];
         }
+        if constexpr (DROP) {  // conv2 consumes (and the backward needs) the dropped activation
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const f32x4 f = drop_factors(p.drop, dkey, dstep, (uint32_t)(p.drop_site0 + 3 * li + 1), (long)b * L + rt * 16, F, col, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hh[rt][r] *= f[r];
+          }
+        }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -627,10 +674,19 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
             v[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(hb + (rt * 16 + fr) * HP + kk * 32 + fq * 8), wf2[kk], v[rt], 0, 0, 0);
         }
       }
+      if constexpr (DROP) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < RT; ++rt) {
+          const f32x4 f = drop_factors(p.drop, dkey, dstep, (uint32_t)(p.drop_site0 + 3 * li + 2), (long)b * L + rt * 16, SL_D, col, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[rt][r] += b2 + xres[rt][r];
+          for (int r = 0; r < 4; ++r) v[rt][r] = (v[rt][r] + b2) * f[r] + xres[rt][r];
+        }
+      } else {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[rt][r] += b2 + xres[rt][r];
+      }
       stack_layer_norm<RT>(v, SAVE ? p.rstd2 + lrow : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the hb / xb reads)
       // without saves only the last layer's output is needed: it goes to slab 0
       const bool store_y = SAVE || li == p.n_layers - 1;
@@ -749,7 +805,7 @@ extern "C" int64_t rf_seqlayer_pack_bytes(int d_ff) { return pack_offsets(d_ff).
 
 extern "C" int rf_seqlayer_fwd(const RfSeqStack* st_, const float* x, int B, int L, int d_model, int n_heads, int d_ff,
                                int act, int sample_k, int n_top, int idx_group, int force_top, int save, float scale,
-                               float eps, void* stream) {
+                               float eps, float drop_p, const void* rng_state, int drop_site0, void* stream) {
   RF_REQUIRE(st_ && x && B > 0 && st_->n_layers > 0 && st_->n_layers <= RF_SEQLAYER_MAX_LAYERS);
   if (!rf_seqlayer_supported(L, d_model, n_heads, d_ff, sample_k, n_top)) {
     rf_g_last_error = "rf_seqlayer_fwd: shape outside the fused kernel's range";
@@ -772,22 +828,33 @@ extern "C" int rf_seqlayer_fwd(const RfSeqStack* st_, const float* x, int B, int
   p.B = B; p.L = L; p.F = d_ff; p.n_layers = s.n_layers; p.act = act; p.sample_k = sample_k; p.n_top = n_top;
   p.idx_group = (idx_group <= 0 || idx_group > B) ? B : idx_group;
   p.force_top = force_top; p.save = save; p.scale = scale; p.eps = eps;
+  RF_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state));
+  p.drop = make_drop_cfg(rng_state, nullptr, 0, drop_p);
+  p.drop_site0 = drop_site0;
   const hipStream_t st = static_cast<hipStream_t>(stream);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_fwd_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_fwd_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_fwd_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_fwd_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  const bool drop = p.drop.state != nullptr;
+#define RF_SL_GO(RT_, SAVE_, DROP_)                                                                                  \
+  do {                                                                                                               \
+    static bool attr = false;                                                                                        \
+    if (!attr) {                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_fwd_kernel<RT_, SAVE_, DROP_>),              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
+      attr = true;                                                                                                   \
+    }                                                                                                                \
+    RF_LAUNCH((seq_stack_fwd_kernel<RT_, SAVE_, DROP_>), dim3(B), dim3(SL_NT), stack_lds_bytes<RT_>(), st, p);       \
+  } while (0)
   if (L <= 48) {
-    if (save) RF_LAUNCH((seq_stack_fwd_kernel<3, true>), dim3(B), dim3(SL_NT), stack_lds_bytes<3>(), st, p);
-    else RF_LAUNCH((seq_stack_fwd_kernel<3, false>), dim3(B), dim3(SL_NT), stack_lds_bytes<3>(), st, p);
+    if (drop && save) RF_SL_GO(3, true, true);
+    else if (drop) RF_SL_GO(3, false, true);   // train-mode forward without grad (the target-side pass of a train step)
+    else if (save) RF_SL_GO(3, true, false);
+    else RF_SL_GO(3, false, false);
   } else {
-    if (save) RF_LAUNCH((seq_stack_fwd_kernel<5, true>), dim3(B), dim3(SL_NT), stack_lds_bytes<5>(), st, p);
-    else RF_LAUNCH((seq_stack_fwd_kernel<5, false>), dim3(B), dim3(SL_NT), stack_lds_bytes<5>(), st, p);
+    if (drop && save) RF_SL_GO(5, true, true);
+    else if (drop) RF_SL_GO(5, false, true);
+    else if (save) RF_SL_GO(5, true, false);
+    else RF_SL_GO(5, false, false);
   }
+#undef RF_SL_GO
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

@@ -1404,7 +1404,8 @@ def seqstack_pack_bytes(d_ff: int) -> int:
     return int(_hip.lib().rf_seqlayer_pack_bytes(d_ff))
 
 
-def _seqstack_launch(x2, wpack, stride, idx_list, idx_group, B, L, F_, act, sample_k, n_top, save, forced_tops, eps):
+def _seqstack_launch(x2, wpack, stride, idx_list, idx_group, B, L, F_, act, sample_k, n_top, save, forced_tops, eps,
+                     drop_p: float = 0.0, drop_site0: int = 0):
     """Run the fused forward.  -> dict of output / saved tensors ([layers, B*L, width] slabs)."""
     import ctypes
     n = len(idx_list)
@@ -1436,14 +1437,16 @@ def _seqstack_launch(x2, wpack, stride, idx_list, idx_group, B, L, F_, act, samp
         setattr(st, name, ptr(sv.get(name)))
     ev = PROFILE.begin() if PROFILE.on else None
     args = (ctypes.byref(st), ptr(x2), B, L, 128, 8, F_, ACT[act], sample_k, n_top, idx_group, 1 if force else 0,
-            1 if save else 0, 1.0 / math.sqrt(16.0), eps)
+            1 if save else 0, 1.0 / math.sqrt(16.0), eps, float(drop_p), ptr(RNG.state(dev)) if drop_p > 0 else None,
+            drop_site0)
     check(_hip.lib().rf_seqlayer_fwd(*args, _stream()), "rf_seqlayer_fwd")
     if ev is not None:
         flops = n * B * (2.0 * L * 128 * (384 + 128 + 2 * F_) + 8 * (2.0 * L * L * 16 + 4.0 * n_top * L * 16))
         nbytes = 4.0 * M * 128 * 2 + n * (2.0 * (4 * 128 * 128 + 2 * 128 * F_)
                                           + (4.0 * M * (384 + 128 * 5 + 2 * F_ + 2) if save else 0.0))
         keep = (x2, wpack, idx_list, sv, st)
-        PROFILE.end(f"seq_stack_fwd_kernel<{3 if L <= 48 else 5}, {'true' if save else 'false'}>", ev, flops, nbytes,
+        PROFILE.end(f"seq_stack_fwd_kernel<{3 if L <= 48 else 5}, {'true' if save else 'false'}, {'true' if drop_p > 0 else 'false'}>",
+                    ev, flops, nbytes,
                     replay=lambda a=args, k=keep: _hip.lib().rf_seqlayer_fwd(*a, _stream()))
     return sv
 
@@ -1454,7 +1457,7 @@ class _SeqStack(torch.autograd.Function):
     gradients through the engine's sinks (the fused path is only taken with sinks active or without grad)."""
 
     @staticmethod
-    def forward(ctx, x, stack, idx_list, idx_group, save):
+    def forward(ctx, x, stack, idx_list, idx_group, save, drop_p=0.0):
         B, L, D = x.shape
         x2 = x.reshape(B * L, D).contiguous()
         lay0 = stack.layers[0]
@@ -1463,20 +1466,36 @@ class _SeqStack(torch.autograd.Function):
         forced = None
         if TOPS.forced is not None:
             forced = [TOPS.forced.pop(0) for _ in stack.layers]
+        site0 = 0
+        if drop_p > 0.0:  # three dropout sites per layer, numbered in the reference's call order
+            assert RNG.forced is None
+            site0 = RNG.site
+            RNG.site += 3 * len(stack.layers)
+            if RNG.record is not None:
+                for li in range(len(stack.layers)):
+                    for k, cols in enumerate((D, F_, D)):
+                        RNG.record.append(RNG.materialise(site0 + 3 * li + k, (B, L, cols), drop_p, x.device))
         sv = _seqstack_launch(x2, stack.wpack, stack.stride, idx_list, idx_group, B, L, F_, lay0.act, sample_k, n_top,
-                              save, forced, lay0.norm1.eps)
+                              save, forced, lay0.norm1.eps, drop_p, site0)
         if TOPS.record is not None and "top" in sv:
             for t in sv["top"]:
                 TOPS.record.append(t.clone())
         if save:
-            ctx.sv, ctx.stack, ctx.x2, ctx.dims = sv, stack, x2, (B, L, F_, n_top)
+            ctx.sv, ctx.stack, ctx.x2, ctx.dims, ctx.drop = sv, stack, x2, (B, L, F_, n_top), (float(drop_p), site0)
         return sv["y"][-1].view(B, L, D)
 
     @staticmethod
     def backward(ctx, dy):
         sv, stack, x2, (B, L, F_, n_top) = ctx.sv, ctx.stack, ctx.x2, ctx.dims
+        drop_p, site0 = ctx.drop
         M, D, H, E = B * L, 128, 8, 16
         dy2 = dy.reshape(M, D).contiguous()
+
+        def masked(t, site):  # t * keep / (1 - p) with the mask the fused forward drew for `site` (new tensor)
+            out = torch.empty_like(t)
+            _drop_launch(t, out, drop_p, site, None)
+            return out
+
         for li in reversed(range(len(stack.layers))):
             lay = stack.layers[li]
             x_in = x2 if li == 0 else sv["y"][li - 1]
@@ -1485,7 +1504,13 @@ class _SeqStack(torch.autograd.Function):
             # ---- norm2 + conv pair (as _FFNAddLN.backward) ----
             gg, gbeta = _slot(lay.norm2.weight), _slot(lay.norm2.bias)
             xhat2, rstd2, h, x1 = sv["xhat2"][li], sv["rstd2"][li], sv["h"][li], sv["x1"][li]
-            if _rowblock_nn_ok(w2, ln=True) and _rowblock_nn_ok(w1) and not DETERMINISTIC:
+            dpm = None  # gradient of the conv2 output: d(pre-norm) with the output-dropout mask (== dpre without dropout)
+            if drop_p > 0.0:  # dropout sites sit between the products: unfused chain with the masks regenerated
+                dpre, _, _ = _ln_backward(dy2, xhat2, rstd2, lay.norm2.weight, gg, gbeta)
+                dpm = masked(dpre, site0 + 3 * li + 2)
+                dz = _input_grad(dpm, w2, dact_src=zsrc, ldd=zsrc.stride(0), dact=ACT[lay.act])
+                _drop_launch(dz, dz, drop_p, site0 + 3 * li + 1, None)
+            elif _rowblock_nn_ok(w2, ln=True) and _rowblock_nn_ok(w1) and not DETERMINISTIC:
                 dpre = torch.empty_like(xhat2)
                 dz = _rowblock_nn(w2, M, ln=(dy2, xhat2, rstd2, lay.norm2.weight), dpre=dpre, dgam=gg, dbet=gbeta,
                                   dsrc=zsrc, dact=ACT[lay.act])
@@ -1495,8 +1520,9 @@ class _SeqStack(torch.autograd.Function):
                 dz = _input_grad(dpre, w2, dact_src=zsrc, ldd=zsrc.stride(0), dact=ACT[lay.act])
             g2, gb2, g1, gb1 = (_slot(lay.conv2.weight), _slot(lay.conv2.bias), _slot(lay.conv1.weight),
                                 _slot(lay.conv1.bias))
-            if _weight_grad(dpre, h, into=g2.view(D, F_), bias_into=gb2) is not True:
-                colsum(dpre, into=gb2)
+            dpw = dpm if dpm is not None else dpre
+            if _weight_grad(dpw, h, into=g2.view(D, F_), bias_into=gb2) is not True:
+                colsum(dpw, into=gb2)
             if _weight_grad(dz, x1, into=g1.view(F_, D), bias_into=gb1) is not True:
                 colsum(dz, into=gb1)
             if _rowblock_nn_ok(w1):
@@ -1509,7 +1535,12 @@ class _SeqStack(torch.autograd.Function):
             wo = att.out_projection.weight
             gg, gbeta = _slot(lay.norm1.weight), _slot(lay.norm1.bias)
             xhat1, rstd1, ctx2 = sv["xhat1"][li], sv["rstd1"][li], sv["ctx"][li]
-            if _rowblock_nn_ok(wo, ln=True) and not DETERMINISTIC:
+            dpo = None  # gradient of the out-projection output (masked by the attention-output dropout)
+            if drop_p > 0.0:
+                dpre1, _, _ = _ln_backward(dx1, xhat1, rstd1, lay.norm1.weight, gg, gbeta)
+                dpo = masked(dpre1, site0 + 3 * li)
+                dctx = _input_grad(dpo, wo)
+            elif _rowblock_nn_ok(wo, ln=True) and not DETERMINISTIC:
                 dpre1 = torch.empty_like(xhat1)
                 dctx = _rowblock_nn(wo, M, ln=(dx1, xhat1, rstd1, lay.norm1.weight), dpre=dpre1, dgam=gg, dbet=gbeta)
                 _wrote(gg, gbeta)
@@ -1517,8 +1548,9 @@ class _SeqStack(torch.autograd.Function):
                 dpre1, _, _ = _ln_backward(dx1, xhat1, rstd1, lay.norm1.weight, gg, gbeta)
                 dctx = _input_grad(dpre1, wo)
             gwo, gbo = _slot(wo), _slot(att.out_projection.bias)
-            if _weight_grad(dpre1, ctx2, into=gwo, bias_into=gbo) is not True:
-                colsum(dpre1, into=gbo)
+            dow = dpo if dpo is not None else dpre1
+            if _weight_grad(dow, ctx2, into=gwo, bias_into=gbo) is not True:
+                colsum(dow, into=gbo)
             _wrote(gwo, gbo)
             # ---- attention core ----
             qkv = sv["qkv"][li]
@@ -1543,4 +1575,4 @@ class _SeqStack(torch.autograd.Function):
                 dy2 = _input_grad(dqkv, pk["w"], residual=dpre1, ldr=D, res_rows=M)
             _wrote(pk["gw"], pk["gb"])
         ctx.sv = None
-        return dy2.view(B, L, D), None, None, None, None
+        return dy2.view(B, L, D), None, None, None, None, None

@@ -458,8 +458,9 @@ class Encoder(nn.Module):
             return None
         lay0 = self.attn_layers[0]
         B, L, D = x.shape
-        if any(lay.p > 0.0 for lay in self.attn_layers) and self.training:
-            return None  # dropout sites between the fused phases: layer-by-layer path
+        drop_p = lay0.p if self.training else 0.0
+        if drop_p > 0.0 and (K.RNG.forced is not None or any(lay.p != lay0.p for lay in self.attn_layers)):
+            return None  # injected masks (parity tests) go through the layer-by-layer path
         sample_k, n_top = K.prob_sizes(L, L, lay0.attention.factor)
         if not K.seqstack_supported(L, D, 8, lay0.conv1.weight.shape[0], sample_k, n_top):
             return None
@@ -478,7 +479,7 @@ class Encoder(nn.Module):
             st.refresh()  # (the training engine re-packs at the head of every step instead)
         elif st.wpack is None:
             st.refresh(force=True)
-        return K._SeqStack.apply(x, st, idx_list, idx_group or B, need_grad)
+        return K._SeqStack.apply(x, st, idx_list, idx_group or B, need_grad, drop_p)
 
     def forward(self, x, idx_list=None, idx_group: int = 0):
         if self.conv_layers is not None:

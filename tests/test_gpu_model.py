@@ -810,3 +810,65 @@ def test_token_cache_in_model_and_engine():
             assert not replays and len(eng._graphs) == n_graphs, "a cached batch must not run the trunk"
         SAMPLER.drop_static()
     assert all(abs(a - b) < 5e-4 * max(1.0, abs(a)) for a, b in zip(losses["eager"], losses["graph_cached"])), losses
+
+
+def test_fused_stack_dropout_vs_oracle_and_layerwise():
+    """Dropout INSIDE the fused encoder stack (train mode, p = 0.2): the Philox masks the kernel drew are materialised
+    (``K.RNG.record``) and handed to the CPU oracle -- outputs must agree (bf16 tolerance, the oracle's selections
+    imposed); and the backward (layer-by-layer kernels regenerating the same masks from (seed, step, site)) must agree
+    with the layer-by-layer forward + backward run on the same masks and selections."""
+    from conftest import fro_err
+    from routeformer_amd import kernels as K, synthetic
+    from routeformer_amd.engine import TrainEngine
+    from routeformer_amd.models.blocks import SAMPLER, PerceiveEncoder
+    K.set_precision("bf16")
+    P, B, L = 0.2, 6, 65
+    g = torch.Generator().manual_seed(3)
+    x_cpu = torch.randn(B, L, 240, generator=g)
+    w_cpu = torch.randn(B, 1, 64, generator=g)
+    out = {}
+    try:
+        for fused in (True, False):
+            K.SEQSTACK = fused
+            enc = _load(PerceiveEncoder(in_channels=240, out_channels=64, out_len=1, n_heads=8, layers=3, d_ff=256, dropout=P))
+            enc.train()
+            eng = TrainEngine(enc)      # gradient sinks + packed QKV views: what the fused path needs for its backward
+            K.SINK.active = True
+            K.RNG.manual_seed(77)
+            K.RNG.begin_step(torch.device(DEV))
+            eng.reducer.zero()
+            x = x_cpu.to(DEV).requires_grad_()
+            torch.manual_seed(11)
+            if fused:
+                K.RNG.record, K.TOPS.record = [], []
+                SAMPLER.log = []
+            else:
+                K.RNG.forced = [m.clone() for m in out[True]["masks"]]
+                K.TOPS.forced = [t_.clone() for t_ in out[True]["tops"]]
+            y = enc(x)
+            (y * w_cpu.to(DEV)).sum().backward()
+            K.flush_weight_grads()
+            torch.cuda.synchronize()
+            out[fused] = dict(y=y.detach().cpu(), dx=x.grad.detach().cpu(), grad=eng.reducer.flat_grad.clone().cpu(),
+                              masks=K.RNG.record, tops=K.TOPS.record, draws=SAMPLER.log,
+                              sd={k: v.detach().cpu().clone() for k, v in enc.state_dict().items()})
+            K.RNG.record, K.RNG.forced, K.TOPS.record, K.TOPS.forced, SAMPLER.log = None, None, None, None, None
+            K.SINK.active = False
+    finally:
+        K.SEQSTACK = True
+        K.SINK.active = False
+        K.RNG.record, K.RNG.forced, K.TOPS.record, K.TOPS.forced, SAMPLER.log = None, None, None, None, None
+    f, u = out[True], out[False]
+    assert len(f["masks"]) == 9 and abs(float(torch.stack([m.float().mean() for m in f["masks"]]).mean()) - (1 - P)) < 0.01
+    # vs the CPU oracle with the same masks (the oracle drops the hidden activation in its (B, d_ff, L) layout)
+    sd = {"m." + k: v for k, v in f["sd"].items()}
+    masks = [m.cpu() if (i % 3) != 1 else m.cpu().transpose(1, 2) for i, m in enumerate(f["masks"])]
+    src = O.IndexSource([d.clone() for d in f["draws"]])
+    y_o = O.perceive_encoder(sd, "m", x_cpu, 8, 1, src, dropout=P, drop=O.DropoutSource(masks))
+    same_sel = all(torch.equal(a.cpu().long(), b) for a, b in zip(f["tops"], src.tops))
+    print(f"fused dropout: selections equal to the oracle's: {same_sel}; rel err {rel_err(f['y'], y_o):.2e}")
+    if same_sel:
+        assert rel_err(f["y"], y_o) < 3e-2
+    # vs the layer-by-layer path on the same masks and selections
+    assert rel_err(f["y"], u["y"]) < 3e-2
+    assert fro_err(f["dx"], u["dx"]) < 0.1 and fro_err(f["grad"], u["grad"]) < 0.1, (fro_err(f["dx"], u["dx"]), fro_err(f["grad"], u["grad"]))

@@ -57,7 +57,7 @@ for name in ("top", "y", "qkv", "ctx", "xhat1", "rstd1", "x1", "z", "h", "xhat2"
     setattr(st, name, sv[name].data_ptr() if name in sv else None)
 def call():
     return handle.rf_seqlayer_fwd(ctypes.byref(st), P(x.data_ptr()), B, L, 128, 8, F_, 2, sample_k, n_top, B, 0, save,
-                                  ctypes.c_float(0.25), ctypes.c_float(1e-5), P(st0))
+                                  ctypes.c_float(0.25), ctypes.c_float(1e-5), ctypes.c_float(0.0), None, 0, P(st0))
 for _ in range(3): assert call() == 0, handle.rf_last_error()
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
