@@ -819,7 +819,7 @@ def test_fused_stack_dropout_vs_oracle_and_layerwise():
     with the layer-by-layer forward + backward run on the same masks and selections."""
     from conftest import fro_err
     from routeformer_amd import kernels as K, synthetic
-    from routeformer_amd.engine import TrainEngine
+    from routeformer_amd.engine import GradReducer
     from routeformer_amd.models.blocks import SAMPLER, PerceiveEncoder
     K.set_precision("bf16")
     P, B, L = 0.2, 6, 65
@@ -832,7 +832,14 @@ def test_fused_stack_dropout_vs_oracle_and_layerwise():
             K.SEQSTACK = fused
             enc = _load(PerceiveEncoder(in_channels=240, out_channels=64, out_len=1, n_heads=8, layers=3, d_ff=256, dropout=P))
             enc.train()
-            eng = TrainEngine(enc)      # gradient sinks + packed QKV views: what the fused path needs for its backward
+            # gradient sinks + packed QKV views (what TrainEngine sets up): the fused path needs them for its backward
+            layers = [m for m in enc.modules() if hasattr(m, "packing_groups")]
+            red = GradReducer(list(enc.parameters()), groups=[g_ for m in layers for g_ in m.packing_groups()])
+            for m in layers:
+                gw, gb = m.packing_groups()
+                vw, vb = red.packed_view(gw), red.packed_view(gb)
+                m._packed = {"w": vw[0], "gw": vw[1], "b": vb[0], "gb": vb[1]}
+            eng = type("E", (), {"reducer": red})()
             K.SINK.active = True
             K.RNG.manual_seed(77)
             K.RNG.begin_step(torch.device(DEV))
