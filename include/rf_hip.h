@@ -316,6 +316,32 @@ int rf_seqlayer_fwd(const RfSeqStack* stack, const float* x, int B, int L, int d
                     int sample_k, int n_top, int idx_group, int force_top, int save, float scale, float eps,
                     float drop_p, const void* rng_state, int drop_site0, void* stream);
 
+/* Backward of the same stack, one launch (one workgroup per sequence, the gradient of the residual stream in
+ * registers from the last layer to the first): per layer LayerNorm-2 backward -> conv2^T -> act' -> conv1^T + skip ->
+ * LayerNorm-1 backward -> out-projection^T -> ProbSparse attention backward -> packed q|k|v projection^T + skip
+ * (the reverse of cross_modal_transformer.py:288-301; replaces 4 rf_rowblock_linear_nn + 1 rf_attn_bwd per layer).
+ *   wpack  : per layer one blob of rf_seqlayer_bwd_pack_bytes(d_ff) bytes -- rf_seqlayer_pack with transpose = 1 of
+ *            conv2 (N = d_ff, K = 128) | conv1 (N = 128, K = d_ff) | Wo (N = 128, K = 128) | [Wq;Wk;Wv] (N = 128,
+ *            K = 384), then fp32 norm1.weight[128] norm2.weight[128];
+ *   qkv, xhat1, rstd1, xhat2, rstd2, top : the saves of rf_seqlayer_fwd; zsrc = z (GELU) or h (ReLU);
+ *   dpre2, dz, dpre1, dqkv : [layers, B*L, 128 | d_ff | 128 | 384] -- written: the gradients of the conv2 output,
+ *            conv1 output, out-projection output and packed projection output, i.e. the `dy` operands of the four
+ *            weight-gradient GEMMs of each layer (values rounded to bf16, as those GEMMs round them anyway);
+ *   dgamma1/dbeta1/dgamma2/dbeta2[i] : [128] accumulators of layer i's LayerNorm parameters (atomicAdd).
+ * dy / dx: [B*L, 128] gradient of the stack output / input.  Dropout-free stacks only. */
+typedef struct RfSeqStackBwd {
+  const void* wpack; int64_t wpack_stride;
+  const float *qkv, *xhat1, *rstd1, *zsrc, *xhat2, *rstd2;
+  const int32_t* top;
+  float *dpre2, *dz, *dpre1, *dqkv;
+  float* dgamma1[RF_SEQLAYER_MAX_LAYERS]; float* dbeta1[RF_SEQLAYER_MAX_LAYERS];
+  float* dgamma2[RF_SEQLAYER_MAX_LAYERS]; float* dbeta2[RF_SEQLAYER_MAX_LAYERS];
+  int n_layers, pad;
+} RfSeqStackBwd;
+int64_t rf_seqlayer_bwd_pack_bytes(int d_ff);
+int rf_seqlayer_bwd(const RfSeqStackBwd* stack, const float* dy, float* dx, int B, int L, int d_model, int n_heads,
+                    int d_ff, int act, int n_top, float scale, void* stream);
+
 /* ---- video ingest ---------------------------------------------------------------
  * rf_resize_area: cv2.resize(..., interpolation=cv2.INTER_AREA) of io/dataset.py:1476-1497 (down-scaling, factor < 1)
  *   on uint8 planes [n_planes][H][W] -> [n_planes][h][w]: coverage-weighted mean of the source pixels under each

@@ -64,6 +64,8 @@ SIGNATURES = {
     "rf_seqlayer_supported": [_I, _I, _I, _I, _I, _I],
     "rf_seqlayer_pack_bytes": [_I],
     "rf_seqlayer_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _P, _I, _P],
+    "rf_seqlayer_bwd_pack_bytes": [_I],
+    "rf_seqlayer_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "rf_rng_seed": [_P, _L, _L, _P],
     "rf_rng_advance": [_P, _P],
     "rf_dropout": [_P, _P, _L, _F, _P, _I, _P, _P, _P],
@@ -112,6 +114,15 @@ class SeqStack(ctypes.Structure):
                 + [("n_layers", c_int), ("pad", c_int)])
 
 
+class SeqStackBwd(ctypes.Structure):
+    """RfSeqStackBwd of include/rf_hip.h."""
+    _fields_ = ([("wpack", c_void_p), ("wpack_stride", c_int64)]
+                + [(n, c_void_p) for n in ("qkv", "xhat1", "rstd1", "zsrc", "xhat2", "rstd2", "top", "dpre2", "dz", "dpre1",
+                                           "dqkv")]
+                + [(n, c_void_p * SEQLAYER_MAX_LAYERS) for n in ("dgamma1", "dbeta1", "dgamma2", "dbeta2")]
+                + [("n_layers", c_int), ("pad", c_int)])
+
+
 class SeqPackEntry(ctypes.Structure):
     """RfSeqPackEntry of include/rf_hip.h."""
     _fields_ = [("w", c_void_p), ("out", c_void_p), ("ldw", c_int64), ("N", c_int), ("K", c_int), ("transpose", c_int),
@@ -139,6 +150,7 @@ def lib():
         handle.rf_conv3x3_packed_elems.restype = c_int64
         handle.rf_pointwise_packed_elems.restype = c_int64
         handle.rf_seqlayer_pack_bytes.restype = c_int64
+        handle.rf_seqlayer_bwd_pack_bytes.restype = c_int64
         handle.rf_last_error.restype = ctypes.c_char_p
         handle.rf_last_error.argtypes = []
         _lib = handle

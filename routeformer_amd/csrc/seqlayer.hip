@@ -19,17 +19,10 @@
 // Training mode writes what the (layer-by-layer) backward kernels consume -- packed q|k|v, ctx, x-hat / 1/sigma of
 // both norms, x1, z, h, the selected rows -- with the same meaning as the unfused forward's saved tensors.
 // bf16 matrix-core mode only (like rowblock.hip); the exact-fp32 mode keeps the layer-by-layer path.
-#include "common.h"
-#include "philox.h"
+#include "seqlayer_common.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int SL_D = 128, SL_H = 8, SL_E = 16, SL_NW = 8, SL_NT = 64 * SL_NW;
-constexpr int SL_XP = SL_D + 8;  // bf16 pitch of the 128-column A images (272 B rows: conflict-light b128 reads)
 
 // Everything a layer needs sits at a fixed offset from one per-layer base (weights: one packed blob per layer, saves:
 // [layer][B*L][width] slabs), so the kernel carries a handful of base pointers instead of 25 pointers per layer.
@@ -59,73 +52,6 @@ __host__ __device__ inline PackOff pack_offsets(int F) {
   o.vec = o.w2 + 8L * (F / 32) * 1024;     // fp32: bqkv[384] bo[128] b1[F] b2[128] g1 be1 g2 be2 [128 each]
   o.total = (o.vec + (1152L + F) * 4 + 255) & ~255L;
   return o;
-}
-
-__device__ __forceinline__ float sl_gelu(float x) {  // erf-GELU, Abramowitz-Stegun 7.1.26 (|erf err| <= 1.5e-7)
-  const float u = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float erf_abs = 1.0f - poly * t * __expf(-u * u);
-  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
-}
-
-__device__ __forceinline__ bf16x8 ld_frag(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
-__device__ __forceinline__ bf16x8 zero_frag() {
-  bf16x8 z;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f;
-  return z;
-}
-// B fragment number `f` of a fragment-ordered weight: 64 lanes x 16 B contiguous
-__device__ __forceinline__ bf16x8 ld_wfrag(const __bf16* base, int f, int lane) {
-  return *reinterpret_cast<const bf16x8*>(base + ((long)f * 64 + lane) * 8);
-}
-
-__device__ __forceinline__ void wave_sync_lds() {
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
-// One 16 x 16 fp32 tile in the MFMA accumulator layout (acc[r] = row 4 (lane >> 4) + r, column lane & 15) -> global rows
-// g[row * ld + 0..15]: transposed through a wave-private LDS patch so that every lane issues ONE 16-B store (16 rows x
-// 64 B per wave-instruction instead of four 4-B stores per lane).  tb: wave-private, 16 x 20 floats.
-__device__ __forceinline__ void tile_store(const f32x4& acc, float* __restrict__ tb, float* __restrict__ g, int ld,
-                                           int rows_valid, int lane) {
-  const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) tb[(fq * 4 + r) * 20 + fr] = acc[r];
-  wave_sync_lds();
-  const int rr = lane >> 2, c4 = (lane & 3) * 4;
-  const float4 o = *reinterpret_cast<const float4*>(tb + rr * 20 + c4);
-  if (rr < rows_valid) *reinterpret_cast<float4*>(g + rr * ld + c4) = o;
-  wave_sync_lds();
-}
-
-// Dropout factors (0 or 1 / (1 - p)) of the four accumulator elements of this lane -- rows row0 + 4 (lane >> 4) + r,
-// column `col` of a [rows, ncols] dropout site (element index row * ncols + col, the numbering rf_dropout uses, so the
-// layer-by-layer backward regenerates the same mask).  One Philox call per lane and tile: the four lanes of a quad
-// hold four neighbouring columns, i.e. the same Philox quad of every row; lane j of the quad evaluates row j and the
-// keep-bits travel by DPP quad broadcasts.
-__device__ __forceinline__ f32x4 drop_factors(const DropCfg& d, uint2 key, uint32_t step, uint32_t site, long row0, int ncols,
-                                              int col, int lane) {
-  const int fq = lane >> 4, j = lane & 3;
-  const unsigned long long e = (unsigned long long)((row0 + fq * 4 + j) * ncols + (col & ~3));
-  DropCfg c = d;
-  c.site = site;
-  const int bits = (int)drop_keep4(c, key, step, e >> 2);
-  const int b0 = __builtin_amdgcn_update_dpp(0, bits, 0x00, 0xF, 0xF, true);
-  const int b1 = __builtin_amdgcn_update_dpp(0, bits, 0x55, 0xF, 0xF, true);
-  const int b2 = __builtin_amdgcn_update_dpp(0, bits, 0xAA, 0xF, 0xF, true);
-  const int b3 = __builtin_amdgcn_update_dpp(0, bits, 0xFF, 0xF, 0xF, true);
-  f32x4 f;
-  f[0] = ((b0 >> j) & 1) ? d.scale : 0.f;
-  f[1] = ((b1 >> j) & 1) ? d.scale : 0.f;
-  f[2] = ((b2 >> j) & 1) ? d.scale : 0.f;
-  f[3] = ((b3 >> j) & 1) ? d.scale : 0.f;
-  return f;
 }
 
 // LayerNorm over the 128 columns of every row, the columns of a row being spread over the 8 waves (16 each, MFMA

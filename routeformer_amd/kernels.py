@@ -1400,6 +1400,71 @@ def seqstack_pack(layers, out: torch.Tensor, stride: int):
         check(_hip.lib().rf_seqlayer_pack(arr, len(chunk), _stream()), "rf_seqlayer_pack")
 
 
+def seqstack_bwd_pack(layers, out: torch.Tensor, stride: int):
+    """Transposed fragment order of the weights for the fused backward (csrc/seqlayer_bwd.hip): per layer dict with wqkv
+    (384,128), wo (128,128), w1 (F,128), w2 (128,F), g1, g2 -> ``out`` (uint8, n_layers * stride)."""
+    ents, base = [], out.data_ptr()
+    for li, d in enumerate(layers):
+        F_ = d["w1"].shape[0]
+        o = base + li * stride
+        o_w1t = (F_ // 16) * 4096
+        o_wot = o_w1t + 8 * (F_ // 32) * 1024
+        o_wqkvt = o_wot + 32 * 1024
+        o_vec = o_wqkvt + 96 * 1024
+        for w, off, N, K_ in ((d["w2"], o, F_, 128), (d["w1"], o + o_w1t, 128, F_), (d["wo"], o + o_wot, 128, 128),
+                              (d["wqkv"], o + o_wqkvt, 128, 384)):
+            assert w.dtype == torch.float32 and w.stride(-1) == 1 and tuple(w.shape) == (K_, N)
+            ents.append((w.data_ptr(), off, w.stride(0), N, K_, 1))
+        for v, pos in ((d["g1"], 0), (d["g2"], 128)):
+            assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == 128
+            ents.append((v.data_ptr(), o + o_vec + 4 * pos, 0, 128, 0, 0))
+    for s0 in range(0, len(ents), _hip.SEQLAYER_MAX_PACK):
+        chunk = ents[s0:s0 + _hip.SEQLAYER_MAX_PACK]
+        arr = (_hip.SeqPackEntry * len(chunk))()
+        for e, (w, off, ldw, N, K_, tr) in zip(arr, chunk):
+            e.w, e.out, e.ldw, e.N, e.K, e.transpose, e.pad = w, off, ldw, N, K_, tr, 0
+        check(_hip.lib().rf_seqlayer_pack(arr, len(chunk), _stream()), "rf_seqlayer_pack")
+
+
+def seqstack_bwd_pack_bytes(d_ff: int) -> int:
+    return int(_hip.lib().rf_seqlayer_bwd_pack_bytes(d_ff))
+
+
+SEQSTACK_BWD = os.environ.get("RF_SEQSTACK_BWD", "1") != "0"  # fused backward of the encoder stacks (else per layer)
+
+
+def _seqstack_bwd_launch(dy2, sv, wpack, stride, ln_slots, B, L, F_, act, n_top):
+    """Run the fused backward on the saves `sv` of `_seqstack_launch`.  ln_slots: per layer (dgamma1, dbeta1, dgamma2,
+    dbeta2) fp32 accumulators.  -> (dx, {"dpre2", "dz", "dpre1", "dqkv"} slabs [layers, B*L, width])."""
+    import ctypes
+    n, M, dev = len(ln_slots), B * L, dy2.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    out = {"dpre2": torch.empty(n, M, 128, **f32), "dz": torch.empty(n, M, F_, **f32),
+           "dpre1": torch.empty(n, M, 128, **f32), "dqkv": torch.empty(n, M, 384, **f32)}
+    dx = torch.empty(M, 128, **f32)
+    st = _hip.SeqStackBwd()
+    st.wpack, st.wpack_stride, st.n_layers = wpack.data_ptr(), stride, n
+    for name in ("qkv", "xhat1", "rstd1", "xhat2", "rstd2", "top"):
+        setattr(st, name, ptr(sv[name]))
+    st.zsrc = ptr(sv["z"] if "z" in sv else sv["h"])
+    for name, t in out.items():
+        setattr(st, name, ptr(t))
+    for i, (a, b_, c, d) in enumerate(ln_slots):
+        for t in (a, b_, c, d):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == 128
+        st.dgamma1[i], st.dbeta1[i], st.dgamma2[i], st.dbeta2[i] = a.data_ptr(), b_.data_ptr(), c.data_ptr(), d.data_ptr()
+    ev = PROFILE.begin() if PROFILE.on else None
+    args = (ctypes.byref(st), ptr(dy2), ptr(dx), B, L, 128, 8, F_, ACT[act], n_top, 1.0 / math.sqrt(16.0))
+    check(_hip.lib().rf_seqlayer_bwd(*args, _stream()), "rf_seqlayer_bwd")
+    if ev is not None:
+        flops = n * B * (2.0 * L * 128 * (384 + 128 + 2 * F_) + 8 * 10.0 * n_top * L * 16)
+        nbytes = 4.0 * M * 128 * 2 + n * (2.0 * (4 * 128 * 128 + 2 * 128 * F_) + 4.0 * M * (384 * 2 + 128 * 4 + 2 * F_ + 2))
+        keep = (dy2, dx, sv, out, wpack, st, ln_slots)
+        PROFILE.end(f"seq_stack_bwd_kernel<{3 if L <= 48 else 5}>", ev, flops, nbytes,
+                    replay=lambda a=args, k=keep: _hip.lib().rf_seqlayer_bwd(*a, _stream()))
+    return dx, out
+
+
 def seqstack_pack_bytes(d_ff: int) -> int:
     return int(_hip.lib().rf_seqlayer_pack_bytes(d_ff))
 
@@ -1490,6 +1555,26 @@ class _SeqStack(torch.autograd.Function):
         drop_p, site0 = ctx.drop
         M, D, H, E = B * L, 128, 8, 16
         dy2 = dy.reshape(M, D).contiguous()
+        if drop_p == 0.0 and SEQSTACK_BWD and not DETERMINISTIC and stack.wpack_bwd is not None:
+            # ---- one launch for the data path of every layer; the weight gradients follow as grouped GEMMs ----
+            slots = [(_slot(l.norm1.weight), _slot(l.norm1.bias), _slot(l.norm2.weight), _slot(l.norm2.bias))
+                     for l in stack.layers]
+            dx, g = _seqstack_bwd_launch(dy2, sv, stack.wpack_bwd, stack.stride_bwd, slots, B, L, F_, stack.layers[0].act,
+                                         n_top)
+            for li in reversed(range(len(stack.layers))):
+                lay = stack.layers[li]
+                att, pk = lay.attention, lay.attention._packed
+                _wrote(*slots[li])
+                for gy, xin, w_into, b_into in (
+                        (g["dpre2"][li], sv["h"][li], _slot(lay.conv2.weight).view(D, F_), _slot(lay.conv2.bias)),
+                        (g["dz"][li], sv["x1"][li], _slot(lay.conv1.weight).view(F_, D), _slot(lay.conv1.bias)),
+                        (g["dpre1"][li], sv["ctx"][li], _slot(att.out_projection.weight), _slot(att.out_projection.bias)),
+                        (g["dqkv"][li], x2 if li == 0 else sv["y"][li - 1], pk["gw"], pk["gb"])):
+                    if _weight_grad(gy, xin, into=w_into, bias_into=b_into) is not True:
+                        colsum(gy, into=b_into)
+                    _wrote(w_into, b_into)
+            ctx.sv = None
+            return dx.view(B, L, D), None, None, None, None, None
 
         def masked(t, site):  # t * keep / (1 - p) with the mask the fused forward drew for `site` (new tensor)
             out = torch.empty_like(t)

@@ -394,6 +394,7 @@ class FusedStack:
     def __init__(self, layers):
         self.layers = list(layers)
         self.wpack, self.stride, self._key = None, 0, None
+        self.wpack_bwd, self.stride_bwd = None, 0  # transposed fragments for the fused backward (training only)
 
     def _params(self):
         for lay in self.layers:
@@ -426,6 +427,14 @@ class FusedStack:
                              bq=a.query_projection.bias, bk=a.key_projection.bias, bv=a.value_projection.bias)
                 descs.append({k: v.detach() for k, v in d.items()})
             K.seqstack_pack(descs, self.wpack, stride)
+            if all("wqkv" in d for d in descs) and K.SEQSTACK_BWD:  # packed projections exist: a training engine owns the model
+                sb = K.seqstack_bwd_pack_bytes(F_)
+                if self.wpack_bwd is None or self.wpack_bwd.device != dev or self.stride_bwd != sb:
+                    self.wpack_bwd = torch.empty(len(self.layers) * sb, dtype=torch.uint8, device=dev)
+                    self.stride_bwd = sb
+                K.seqstack_bwd_pack(descs, self.wpack_bwd, sb)
+            else:
+                self.wpack_bwd = None
         self._key = key
 
 

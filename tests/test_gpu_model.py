@@ -879,3 +879,67 @@ def test_fused_stack_dropout_vs_oracle_and_layerwise():
     # vs the layer-by-layer path on the same masks and selections
     assert rel_err(f["y"], u["y"]) < 3e-2
     assert fro_err(f["dx"], u["dx"]) < 0.1 and fro_err(f["grad"], u["grad"]) < 0.1, (fro_err(f["dx"], u["dx"]), fro_err(f["grad"], u["grad"]))
+
+
+@pytest.mark.parametrize("shape", [(6, 65, 8, "gelu"), (5, 40, 3, "gelu"), (3, 80, 2, "relu"), (4, 17, 2, "gelu")])
+def test_fused_stack_backward_vs_layerwise(shape):
+    """The fused backward of the encoder stack (csrc/seqlayer_bwd.hip, one launch for every layer's data path) against
+    the layer-by-layer backward kernels on the SAME saved tensors (same fused forward, same selections): dx and every
+    parameter gradient.  Both round their GEMM operands to bf16; the layer-by-layer attention backward keeps fp32
+    probabilities, hence the (small) tolerance.  Shapes: the frame encoder (L = 65, 8 layers), the gaze encoder's
+    length (L = 40, the 3-row-tile kernel), the longest supported sequence, a ragged short one; GELU and ReLU."""
+    from conftest import fro_err
+    from routeformer_amd import kernels as K
+    from routeformer_amd.engine import GradReducer
+    from routeformer_amd.models.blocks import SAMPLER, PerceiveEncoder
+    K.set_precision("bf16")
+    B, L, layers, act = shape
+    g = torch.Generator().manual_seed(3)
+    x_cpu = torch.randn(B, L, 240, generator=g)
+    w_cpu = torch.randn(B, 1, 64, generator=g)
+    out, used = {}, []
+    real = K._seqstack_bwd_launch
+    try:
+        for fused_bwd in (True, False):
+            K.SEQSTACK_BWD = True  # (the transposed fragments are packed either way; the switch below picks the path)
+            enc = _load(PerceiveEncoder(in_channels=240, out_channels=64, out_len=1, n_heads=8, layers=layers, d_ff=256,
+                                        dropout=0.0, activation=act))
+            enc.train()
+            mods = [m for m in enc.modules() if hasattr(m, "packing_groups")]
+            red = GradReducer(list(enc.parameters()), groups=[g_ for m in mods for g_ in m.packing_groups()])
+            for m in mods:
+                gw, gb = m.packing_groups()
+                vw, vb = red.packed_view(gw), red.packed_view(gb)
+                m._packed = {"w": vw[0], "gw": vw[1], "b": vb[0], "gb": vb[1]}
+            K.SINK.active = True
+            red.zero()
+            x = x_cpu.to(DEV).requires_grad_()
+            torch.manual_seed(11)
+            y = enc(x)
+            K.SEQSTACK_BWD = fused_bwd
+            K._seqstack_bwd_launch = lambda *a, **k: (used.append(fused_bwd), real(*a, **k))[1]
+            (y * w_cpu.to(DEV)).sum().backward()
+            K.flush_weight_grads()
+            torch.cuda.synchronize()
+            names = [n for n, _ in enc.named_parameters()]
+            grads = {n: p._rf_grad.detach().cpu().clone() for n, p in enc.named_parameters()}
+            out[fused_bwd] = dict(y=y.detach().cpu(), dx=x.grad.detach().cpu(), grads=grads, names=names)
+            K.SINK.active = False
+    finally:
+        K.SEQSTACK_BWD, K._seqstack_bwd_launch = True, real
+        K.SINK.active = False
+    assert used and all(used), "the fused backward did not run"
+    f, u = out[True], out[False]
+    assert torch.equal(f["y"], u["y"])
+    assert torch.isfinite(f["dx"]).all()
+    e_dx = fro_err(f["dx"], u["dx"])
+    # (key-projection biases have a mathematically zero gradient -- softmax ignores a per-query constant -- so both
+    #  paths hold rounding noise there: errors are measured against the RMS gradient magnitude of the whole model)
+    rms = float(torch.cat([v.flatten() for v in u["grads"].values()]).square().mean().sqrt())
+    def err(n):
+        a, b_ = f["grads"][n].double(), u["grads"][n].double()
+        return float((a - b_).norm() / max(float(b_.norm()), rms * b_.numel() ** 0.5 * 0.05))
+    worst = max((err(n), n) for n in f["names"])
+    print(f"fused backward {shape}: dx fro err {e_dx:.2e}; worst parameter gradient {worst[0]:.2e} ({worst[1]})")
+    assert e_dx < 2e-2, e_dx
+    assert worst[0] < 3e-2, worst
