@@ -388,7 +388,7 @@ def main():
         # the fused per-sequence encoder stack (csrc/seqlayer.hip) against the bf16 matrix-core
         # peak, per launch shape: the one kernel family of the step whose operands stay on chip
         fused = []
-        for tag in [k for k in prof if k.startswith("seq_stack_fwd_kernel")]:
+        for tag in [k for k in prof if k.startswith("seq_stack_")]:  # forward and backward
             fine = K.PROFILE.refine(tag)
             if fine is None:
                 continue

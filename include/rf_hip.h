@@ -328,7 +328,10 @@ int rf_seqlayer_fwd(const RfSeqStack* stack, const float* x, int B, int L, int d
  *            conv1 output, out-projection output and packed projection output, i.e. the `dy` operands of the four
  *            weight-gradient GEMMs of each layer (values rounded to bf16, as those GEMMs round them anyway);
  *   dgamma1/dbeta1/dgamma2/dbeta2[i] : [128] accumulators of layer i's LayerNorm parameters (atomicAdd).
- * dy / dx: [B*L, 128] gradient of the stack output / input.  Dropout-free stacks only. */
+ * dy / dx: [B*L, 128] gradient of the stack output / input.
+ * drop_p > 0: the masks rf_seqlayer_fwd drew (same rng_state step, same drop_site0) are regenerated in the kernel; dpre2
+ * and dpre1 then hold the gradients BEHIND the conv2-output / attention-output dropout (what the weight gradients of
+ * conv2 / the out-projection consume), the skip connections carry the unmasked ones. */
 typedef struct RfSeqStackBwd {
   const void* wpack; int64_t wpack_stride;
   const float *qkv, *xhat1, *rstd1, *zsrc, *xhat2, *rstd2;
@@ -340,7 +343,8 @@ typedef struct RfSeqStackBwd {
 } RfSeqStackBwd;
 int64_t rf_seqlayer_bwd_pack_bytes(int d_ff);
 int rf_seqlayer_bwd(const RfSeqStackBwd* stack, const float* dy, float* dx, int B, int L, int d_model, int n_heads,
-                    int d_ff, int act, int n_top, float scale, void* stream);
+                    int d_ff, int act, int n_top, float scale, float drop_p, const void* rng_state, int drop_site0,
+                    void* stream);
 
 /* ---- video ingest ---------------------------------------------------------------
  * rf_resize_area: cv2.resize(..., interpolation=cv2.INTER_AREA) of io/dataset.py:1476-1497 (down-scaling, factor < 1)

@@ -65,7 +65,7 @@ SIGNATURES = {
     "rf_seqlayer_pack_bytes": [_I],
     "rf_seqlayer_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _P, _I, _P],
     "rf_seqlayer_bwd_pack_bytes": [_I],
-    "rf_seqlayer_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "rf_seqlayer_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _I, _P],
     "rf_rng_seed": [_P, _L, _L, _P],
     "rf_rng_advance": [_P, _P],
     "rf_dropout": [_P, _P, _L, _F, _P, _I, _P, _P, _P],

@@ -37,6 +37,8 @@ struct SeqStackBwdP {
   float* db2[RF_SEQLAYER_MAX_LAYERS];
   int B, L, F, n_layers, act, n_top;
   float scale;
+  DropCfg drop;   // the forward's nn.Dropout masks are regenerated from (seed, step, site, element); state == null: off
+  int drop_site0; // layer i: sites drop_site0 + 3 i + {0: attention output, 1: hidden activation, 2: conv2 output}
 };
 
 struct BwdPackOff { long w2t, w1t, wot, wqkvt, vec, total; };
@@ -141,13 +143,23 @@ __device__ __forceinline__ void save_image(const __bf16* __restrict__ img, int p
   }
 }
 
+// Phase timing aid (tools/seqlayer_probe.py: private -DRF_SL_TIMING build): lane 0 of every wave stamps the shader
+// clock at the phase boundaries of the LAST layer (the first one processed) into rf_slb_timing[workgroup][wave][16].
+#ifdef RF_SL_TIMING
+__device__ unsigned long long rf_slb_timing[512 * 8 * 16];
+#define SLB_MARK(k) do { if (li == p.n_layers - 1 && (threadIdx.x & 63) == 0 && blockIdx.x < 512) \
+  rf_slb_timing[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SLB_MARK(k) do {} while (0)
+#endif
+
 // RT = row tiles of 16 (L <= 16 RT).  LDS (bytes), RT = 5, F = 256:
 //   xb   bf16 [16 RT][136]   21 760 \  d pre-norm images (A operand of conv2^T / out-projection^T)
 //   hb   bf16 [16 RT][F + 8] 42 240 /  dz image (A operand of conv1^T);  the attention phase reuses both as
 //                                      dq  bf16 [16 RT][392]  62 720   d q|k|v image (A operand of the projection^T)
 //   scr  per wave 10 240     81 920    dC^T bf16 [16][KS32 + 8] | P^T / dS^T bf16 [16 RT][40] or dS bf16 [32][KS32 + 8] | top
 //   part float2 [16 RT][8] + stat float4 [16 RT]   6 400
-template <int RT>
+template <int RT, bool DROP>
 __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP p) {
   constexpr int LP = 16 * RT, KS32 = ((LP + 31) / 32) * 32, KSTEPS = KS32 / 32, DTP = KS32 + 8, TP = 40, QP = 3 * SL_D + 8;
   constexpr int SCR_BYTES = 10240, DT_BYTES = 3328, BUF_BYTES = 6656;
@@ -190,6 +202,13 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
   }
   const BwdPackOff po = bwd_pack_offsets(F);
   const float inv_L = 1.0f / (float)L;
+  uint2 dkey = make_uint2(0, 0);
+  uint32_t dstep = 0;
+  if constexpr (DROP) {
+    const unsigned long long sd = p.drop.state->seed;
+    dkey = make_uint2((uint32_t)sd, (uint32_t)(sd >> 32));
+    dstep = (uint32_t)p.drop.state->step;
+  }
 
 #pragma unroll 1
   for (int li = p.n_layers - 1; li >= 0; --li) {
@@ -202,6 +221,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
     const long lrow = ((long)li * p.B + b) * L;
     f32x4 res[RT];  // the skip gradient: d pre-norm-2, later d pre-norm-1
 
+    SLB_MARK(0);
     // ================= norm2 backward =================
     SLB_LOCAL();
     stack_ln_bwd<RT>(dyres, p.xhat2 + lrow * SL_D + col, p.rstd2 + lrow, vec[SL_D + col], p.dg2[li] + col, p.db2[li] + col, L,
@@ -209,10 +229,18 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       res[rt] = dyres[rt];
+      f32x4 m = dyres[rt];
+      if constexpr (DROP) {  // the conv pair sees the gradient through the conv2-output dropout; the skip does not
+        const f32x4 f = drop_factors(p.drop, dkey, dstep, (uint32_t)(p.drop_site0 + 3 * li + 2), (long)b * L + rt * 16, SL_D, col, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)dyres[rt][r];
+        for (int r = 0; r < 4; ++r) m[r] *= f[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)m[r];
     }
+    SLB_MARK(1);
     __syncthreads();  // d pre-norm-2 image complete
+    SLB_MARK(2);
     save_image(xb, SL_XP, SL_D, p.dpre2 + lrow * SL_D, L, tid);
 
     // ================= conv2^T + activation' : dz (wave = column tiles wave, wave + 8, ...) =================
@@ -247,13 +275,24 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[rt][r] = zz[rt][r] > 0.f ? acc[rt][r] : 0.f;
         }
+        if constexpr (DROP) {  // hidden-activation dropout
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const f32x4 f = drop_factors(p.drop, dkey, dstep, (uint32_t)(p.drop_site0 + 3 * li + 1), (long)b * L + rt * 16, F,
+                                         ct * 16 + fr, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rt][r] *= f[r];
+          }
+        }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) hb[(rt * 16 + fq * 4 + r) * HP + ct * 16 + fr] = (__bf16)acc[rt][r];
       }
     }
+    SLB_MARK(3);
     __syncthreads();  // dz image complete
+    SLB_MARK(4);
     save_image(hb, HP, F, p.dz + lrow * F, L, tid);
 
     // ================= conv1^T + skip, norm1 backward =================
@@ -279,10 +318,18 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       res[rt] = dyres[rt];
+      f32x4 m = dyres[rt];
+      if constexpr (DROP) {  // attention-output dropout
+        const f32x4 f = drop_factors(p.drop, dkey, dstep, (uint32_t)(p.drop_site0 + 3 * li), (long)b * L + rt * 16, SL_D, col, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)dyres[rt][r];
+        for (int r = 0; r < 4; ++r) m[r] *= f[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)m[r];
     }
+    SLB_MARK(5);
     __syncthreads();  // d pre-norm-1 image complete
+    SLB_MARK(6);
     save_image(xb, SL_XP, SL_D, p.dpre1 + lrow * SL_D, L, tid);
 
     // ================= out-projection^T: dC of head `wave` =================
@@ -342,6 +389,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
     lz += __shfl_xor(lz, 32);
     lz *= inv_L;
 
+    SLB_MARK(7);
     // ---- P = softmax(scale Q_sel K^T), recomputed as in the forward ----
     SLB_LOCAL();
     f32x4 P[2][RT], dS[2][RT];
@@ -398,6 +446,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
           for (int r = 0; r < 4; ++r) P[t2][ct][r] *= sum[r];
       }
     }
+    SLB_MARK(8);
     // ---- dP = dC_sel V^T, dS ----
     SLB_LOCAL();
     {
@@ -434,8 +483,10 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
           for (int r = 0; r < 4; ++r) dS[t2][ct][r] = P[t2][ct][r] * (dS[t2][ct][r] - rs[r]) * p.scale;
       }
     }
+    SLB_MARK(9);
     // (every wave must have finished reading xb -- out-projection^T -- before any wave writes the dq image)
     __syncthreads();
+    SLB_MARK(10);
     // ---- dV = P^T dC_sel + lazy term ----
     SLB_LOCAL();
     {
@@ -463,6 +514,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
       }
       wave_sync_lds();
     }
+    SLB_MARK(11);
     // ---- dK = dS^T Q_sel ----
     SLB_LOCAL();
     {
@@ -493,6 +545,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
       }
       wave_sync_lds();
     }
+    SLB_MARK(12);
     // ---- dQ[top] = dS K ----
     SLB_LOCAL();
     {
@@ -538,7 +591,9 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
     bf16x8 wfp[12];
 #pragma unroll
     for (int kk = 0; kk < 12; ++kk) wfp[kk] = ld_wfrag(w_qkvt, wave * 12 + kk, lane);
+    SLB_MARK(13);
     __syncthreads();  // d q|k|v image complete
+    SLB_MARK(14);
     save_image(dqi, QP, 3 * SL_D, p.dqkv + lrow * (3 * SL_D), L, tid);
 
     // ================= packed q|k|v projection^T + skip =================
@@ -552,6 +607,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
 #pragma unroll
       for (int r = 0; r < 4; ++r) dyres[rt][r] = rt * 16 + fq * 4 + r < L ? acc[r] : 0.f;
     }
+    SLB_MARK(15);
     // (the next layer writes xb only behind the two barriers of its norm2 backward)
   }
 
@@ -579,10 +635,19 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
+#ifdef RF_SL_TIMING
+extern "C" void* rf_slb_timing_address() {
+  void* a = nullptr;
+  (void)hipGetSymbolAddress(&a, HIP_SYMBOL(rf_slb_timing));
+  return a;
+}
+#endif
+
 extern "C" int64_t rf_seqlayer_bwd_pack_bytes(int d_ff) { return bwd_pack_offsets(d_ff).total; }
 
 extern "C" int rf_seqlayer_bwd(const RfSeqStackBwd* st_, const float* dy, float* dx, int B, int L, int d_model, int n_heads,
-                               int d_ff, int act, int n_top, float scale, void* stream) {
+                               int d_ff, int act, int n_top, float scale, float drop_p, const void* rng_state, int drop_site0,
+                               void* stream) {
   RF_REQUIRE(st_ && dy && dx && B > 0 && st_->n_layers > 0 && st_->n_layers <= RF_SEQLAYER_MAX_LAYERS);
   if (!rf_seqlayer_supported(L, d_model, n_heads, d_ff, 1, n_top)) {
     rf_g_last_error = "rf_seqlayer_bwd: shape outside the fused kernel's range";
@@ -602,19 +667,28 @@ extern "C" int rf_seqlayer_bwd(const RfSeqStackBwd* st_, const float* dy, float*
     p.dg1[i] = s.dgamma1[i]; p.db1[i] = s.dbeta1[i]; p.dg2[i] = s.dgamma2[i]; p.db2[i] = s.dbeta2[i];
   }
   p.B = B; p.L = L; p.F = d_ff; p.n_layers = s.n_layers; p.act = act; p.n_top = n_top; p.scale = scale;
+  RF_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state));
+  p.drop = make_drop_cfg(rng_state, nullptr, 0, drop_p);
+  p.drop_site0 = drop_site0;
+  const bool drop = p.drop.state != nullptr;
   const hipStream_t st = static_cast<hipStream_t>(stream);
-#define RF_SLB_GO(RT_)                                                                                              \
+#define RF_SLB_GO(RT_, DROP_)                                                                                       \
   do {                                                                                                              \
     static bool attr = false;                                                                                       \
     if (!attr) {                                                                                                    \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_bwd_kernel<RT_>),                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_stack_bwd_kernel<RT_, DROP_>),                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                            \
       attr = true;                                                                                                  \
     }                                                                                                               \
-    RF_LAUNCH((seq_stack_bwd_kernel<RT_>), dim3(B), dim3(SL_NT), stack_bwd_lds_bytes<RT_>(d_ff), st, p);            \
+    RF_LAUNCH((seq_stack_bwd_kernel<RT_, DROP_>), dim3(B), dim3(SL_NT), stack_bwd_lds_bytes<RT_>(d_ff), st, p);     \
   } while (0)
-  if (L <= 48) RF_SLB_GO(3);
-  else RF_SLB_GO(5);
+  if (L <= 48) {
+    if (drop) RF_SLB_GO(3, true);
+    else RF_SLB_GO(3, false);
+  } else {
+    if (drop) RF_SLB_GO(5, true);
+    else RF_SLB_GO(5, false);
+  }
 #undef RF_SLB_GO
   RF_CHECK_LAUNCH();
   return RF_OK;

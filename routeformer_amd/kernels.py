@@ -1433,7 +1433,7 @@ def seqstack_bwd_pack_bytes(d_ff: int) -> int:
 SEQSTACK_BWD = os.environ.get("RF_SEQSTACK_BWD", "1") != "0"  # fused backward of the encoder stacks (else per layer)
 
 
-def _seqstack_bwd_launch(dy2, sv, wpack, stride, ln_slots, B, L, F_, act, n_top):
+def _seqstack_bwd_launch(dy2, sv, wpack, stride, ln_slots, B, L, F_, act, n_top, drop_p: float = 0.0, drop_site0: int = 0):
     """Run the fused backward on the saves `sv` of `_seqstack_launch`.  ln_slots: per layer (dgamma1, dbeta1, dgamma2,
     dbeta2) fp32 accumulators.  -> (dx, {"dpre2", "dz", "dpre1", "dqkv"} slabs [layers, B*L, width])."""
     import ctypes
@@ -1454,13 +1454,14 @@ def _seqstack_bwd_launch(dy2, sv, wpack, stride, ln_slots, B, L, F_, act, n_top)
             assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == 128
         st.dgamma1[i], st.dbeta1[i], st.dgamma2[i], st.dbeta2[i] = a.data_ptr(), b_.data_ptr(), c.data_ptr(), d.data_ptr()
     ev = PROFILE.begin() if PROFILE.on else None
-    args = (ctypes.byref(st), ptr(dy2), ptr(dx), B, L, 128, 8, F_, ACT[act], n_top, 1.0 / math.sqrt(16.0))
+    args = (ctypes.byref(st), ptr(dy2), ptr(dx), B, L, 128, 8, F_, ACT[act], n_top, 1.0 / math.sqrt(16.0), float(drop_p),
+            ptr(RNG.state(dev)) if drop_p > 0 else None, drop_site0)
     check(_hip.lib().rf_seqlayer_bwd(*args, _stream()), "rf_seqlayer_bwd")
     if ev is not None:
         flops = n * B * (2.0 * L * 128 * (384 + 128 + 2 * F_) + 8 * 10.0 * n_top * L * 16)
         nbytes = 4.0 * M * 128 * 2 + n * (2.0 * (4 * 128 * 128 + 2 * 128 * F_) + 4.0 * M * (384 * 2 + 128 * 4 + 2 * F_ + 2))
         keep = (dy2, dx, sv, out, wpack, st, ln_slots)
-        PROFILE.end(f"seq_stack_bwd_kernel<{3 if L <= 48 else 5}>", ev, flops, nbytes,
+        PROFILE.end(f"seq_stack_bwd_kernel<{3 if L <= 48 else 5}, {'true' if drop_p > 0 else 'false'}>", ev, flops, nbytes,
                     replay=lambda a=args, k=keep: _hip.lib().rf_seqlayer_bwd(*a, _stream()))
     return dx, out
 
@@ -1517,9 +1518,12 @@ def _seqstack_launch(x2, wpack, stride, idx_list, idx_group, B, L, F_, act, samp
 
 
 class _SeqStack(torch.autograd.Function):
-    """y = EncoderLayer_n(... EncoderLayer_1(x)) for a stack of ProbSparse encoder layers (dropout 0): ONE fused
-    forward launch; backward = per layer the row-block / attention backward kernels on the saved tensors, parameter
-    gradients through the engine's sinks (the fused path is only taken with sinks active or without grad)."""
+    """y = EncoderLayer_n(... EncoderLayer_1(x)) for a stack of ProbSparse encoder layers: ONE fused forward launch
+    (dropout inside, Philox masks).  Backward: ONE fused launch for the data path of every layer
+    (csrc/seqlayer_bwd.hip, masks regenerated) followed by the grouped weight-gradient GEMMs; with
+    ``RF_SEQSTACK_BWD=0`` or in deterministic mode per layer the row-block / attention backward kernels on the same
+    saved tensors.  Parameter gradients go through the engine's sinks (the fused path is only taken with sinks
+    active or without grad)."""
 
     @staticmethod
     def forward(ctx, x, stack, idx_list, idx_group, save, drop_p=0.0):
@@ -1555,12 +1559,12 @@ class _SeqStack(torch.autograd.Function):
         drop_p, site0 = ctx.drop
         M, D, H, E = B * L, 128, 8, 16
         dy2 = dy.reshape(M, D).contiguous()
-        if drop_p == 0.0 and SEQSTACK_BWD and not DETERMINISTIC and stack.wpack_bwd is not None:
+        if SEQSTACK_BWD and not DETERMINISTIC and stack.wpack_bwd is not None:
             # ---- one launch for the data path of every layer; the weight gradients follow as grouped GEMMs ----
             slots = [(_slot(l.norm1.weight), _slot(l.norm1.bias), _slot(l.norm2.weight), _slot(l.norm2.bias))
                      for l in stack.layers]
             dx, g = _seqstack_bwd_launch(dy2, sv, stack.wpack_bwd, stack.stride_bwd, slots, B, L, F_, stack.layers[0].act,
-                                         n_top)
+                                         n_top, drop_p, site0)
             for li in reversed(range(len(stack.layers))):
                 lay = stack.layers[li]
                 att, pk = lay.attention, lay.attention._packed

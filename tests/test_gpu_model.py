@@ -881,19 +881,22 @@ def test_fused_stack_dropout_vs_oracle_and_layerwise():
     assert fro_err(f["dx"], u["dx"]) < 0.1 and fro_err(f["grad"], u["grad"]) < 0.1, (fro_err(f["dx"], u["dx"]), fro_err(f["grad"], u["grad"]))
 
 
-@pytest.mark.parametrize("shape", [(6, 65, 8, "gelu"), (5, 40, 3, "gelu"), (3, 80, 2, "relu"), (4, 17, 2, "gelu")])
+@pytest.mark.parametrize("shape", [(6, 65, 8, "gelu", 0.0), (5, 40, 3, "gelu", 0.0), (3, 80, 2, "relu", 0.0),
+                                   (4, 17, 2, "gelu", 0.0), (6, 65, 3, "gelu", 0.2), (3, 40, 2, "relu", 0.1)])
 def test_fused_stack_backward_vs_layerwise(shape):
     """The fused backward of the encoder stack (csrc/seqlayer_bwd.hip, one launch for every layer's data path) against
     the layer-by-layer backward kernels on the SAME saved tensors (same fused forward, same selections): dx and every
     parameter gradient.  Both round their GEMM operands to bf16; the layer-by-layer attention backward keeps fp32
     probabilities, hence the (small) tolerance.  Shapes: the frame encoder (L = 65, 8 layers), the gaze encoder's
-    length (L = 40, the 3-row-tile kernel), the longest supported sequence, a ragged short one; GELU and ReLU."""
+    length (L = 40, the 3-row-tile kernel), the longest supported sequence, a ragged short one; GELU and ReLU; with
+    dropout the fused backward regenerates the forward's Philox masks in the kernel, the layer-by-layer path through
+    rf_dropout -- same (seed, step, site, element) -> same masks."""
     from conftest import fro_err
     from routeformer_amd import kernels as K
     from routeformer_amd.engine import GradReducer
     from routeformer_amd.models.blocks import SAMPLER, PerceiveEncoder
     K.set_precision("bf16")
-    B, L, layers, act = shape
+    B, L, layers, act, drop_p = shape
     g = torch.Generator().manual_seed(3)
     x_cpu = torch.randn(B, L, 240, generator=g)
     w_cpu = torch.randn(B, 1, 64, generator=g)
@@ -903,8 +906,10 @@ def test_fused_stack_backward_vs_layerwise(shape):
         for fused_bwd in (True, False):
             K.SEQSTACK_BWD = True  # (the transposed fragments are packed either way; the switch below picks the path)
             enc = _load(PerceiveEncoder(in_channels=240, out_channels=64, out_len=1, n_heads=8, layers=layers, d_ff=256,
-                                        dropout=0.0, activation=act))
+                                        dropout=drop_p, activation=act))
             enc.train()
+            K.RNG.manual_seed(77)
+            K.RNG.begin_step(torch.device(DEV))
             mods = [m for m in enc.modules() if hasattr(m, "packing_groups")]
             red = GradReducer(list(enc.parameters()), groups=[g_ for m in mods for g_ in m.packing_groups()])
             for m in mods:
