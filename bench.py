@@ -294,6 +294,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_graph and args.dropout != "none":
+        # the host dropout decisions select among graph variants: hold all of them before the clock starts (a training
+        # run meets every variant within its first few hundred steps; a 10-step window would time the captures)
+        note(f"{engine.precapture()} graph variants captured")
     note(f"engine ready ({'hipGraph' if use_graph else 'eager'}), warm-up")
     for i in range(args.warmup):
         engine.step(items[i % 2], epoch=10, next_item=items[(i + 1) % 2])

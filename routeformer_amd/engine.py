@@ -1033,6 +1033,18 @@ class GraphedTrainEngine(TrainEngine):
         self._graphs[key] = (g, out)
         return g, out
 
+    def precapture(self, lookahead: bool = True) -> int:
+        """Capture the main graph of EVERY variant of the host dropout decisions now (they are otherwise captured on
+        first use, i.e. in the middle of training: ~50 ms each).  -> number of graphs held."""
+        from routeformer_amd.models.blocks import SAMPLER
+        assert self.graph is not None, "capture() first"
+        for variant in range(max(1, SAMPLER.n_variants)):
+            self._main_graph(False, variant)
+            if lookahead and self._pipelined:
+                self._main_graph(True, variant)
+        torch.cuda.synchronize()
+        return len(self._graphs)
+
     def step(self, item, epoch: int = 0, next_item=None):
         """One train step on ``item``; ``next_item`` (optional) = the batch of the following step, whose
         conv-trunk pass runs underneath this step (a parallel branch of the replayed graph).
