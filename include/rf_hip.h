@@ -59,6 +59,20 @@ int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_
             int prec, int splitk, float* workspace, int atomic_accumulate, float* a_rowsum,
             uint32_t* tile_counters, void* stream);
 
+/* Skinny variant of rf_gemm for the GPS backbone's linear layers at training batch sizes (M = B x L <= 640 rows against
+ * 832..3328-wide weights; same call sites as rf_gemm): the launch streams the weight matrix once with every operand of
+ * a workgroup requested up front (one HBM round trip), 8 waves interleave the k-steps of an output tile and meet in LDS,
+ * the epilogue runs in the launch.  bf16-input MFMA, fp32 accumulation (rf_gemm's prec = 1 contract).  A must be k
+ * contiguous (lda_k == 1), B either k contiguous (ldb_k == 1: y = x W^T) or n contiguous (ldb_n == 1: dX = dY W);
+ * K % 8 == 0.  rf_gemm_skinny_split returns the number of K slices the kernel will use for a problem (0: not
+ * supported -- call rf_gemm); with more than one slice `workspace` must hold slices * M * N floats. */
+int rf_gemm_skinny_split(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k, int64_t ldb_n,
+                         int M, int N, int K);
+int rf_gemm_skinny(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k, int64_t ldb_n,
+                   float* C, int64_t ldc, int M, int N, int K, const float* bias, const float* residual,
+                   int64_t ldr, int res_rows, int res_before_act, int act, float* preact, int64_t ldp,
+                   const float* dact_src, int64_t ldd, int dact_mode, float* workspace, void* stream);
+
 /* out[n] (+)= sum_m X[m*ldx + n] (bias gradients; accumulate=1 adds into out, e.g. a slot of the flat
  * gradient buffer).  workspace: parts*N floats, parts = rf_colsum_parts(M,N). */
 int rf_colsum_parts(int M, int N);

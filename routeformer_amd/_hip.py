@@ -18,6 +18,8 @@ _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "rf_gemm": [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _I, _P, _L, _P, _L,
                 _I, _I, _I, _P, _I, _P, _P, _P],
+    "rf_gemm_skinny_split": [_P, _L, _L, _P, _L, _L, _I, _I, _I],
+    "rf_gemm_skinny": [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _I, _P, _L, _P, _L, _I, _P, _P],
     "rf_colsum_parts": [_I, _I],
     "rf_colsum": [_P, _L, _I, _I, _P, _I, _P, _P],
     "rf_conv2d_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _I, _I, _P],

@@ -329,9 +329,36 @@ def _auto_split(M: int, N: int, K: int) -> int:
     return max(1, min(16, K // 128, want))
 
 
+# Skinny GEMM (csrc/gemm_skinny.hip) for the small-M linear layers of the GPS backbone: RF_SKINNY=0 turns it off,
+# RF_SKINNY_MAX_M bounds the row count it takes (larger M re-reads the activation per 16-column tile: the tiled kernel wins)
+# (measured, tools/skinny_sweep.py under graph replay: K <= 1024 wins up to ~192 rows -- 6-10 us against 10.5-17.5 us
+#  for the tiled kernel + slab sum; K > 1024 needs slices + a slab sum itself and wins up to ~64 rows)
+SKINNY_GEMM = os.environ.get("RF_SKINNY", "1") != "0"
+SKINNY_MAX_M = int(os.environ.get("RF_SKINNY_MAX_M", "192"))
+SKINNY_MAX_M_DEEP = int(os.environ.get("RF_SKINNY_MAX_M_DEEP", "64"))
+
+
 def gemm(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, *, bias=None, residual=None, ldr=0,
          res_rows=0, res_before_act=0, act=0, preact=None, ldp=0, dact_src=None, ldd=0, dact=0,
          splitk=0, atomic=False, a_rowsum=None):
+    if (SKINNY_GEMM and _PRECISION == 1 and not atomic and splitk == 0 and a_rowsum is None
+            and M <= (SKINNY_MAX_M if K <= 1024 else SKINNY_MAX_M_DEEP)):
+        z = _hip.lib().rf_gemm_skinny_split(ptr(A), lda_m, lda_k, ptr(B), ldb_k, ldb_n, M, N, K)
+        if z > 0:
+            ws = torch.empty(z * M * N, device=C.device, dtype=torch.float32) if z > 1 else None
+            ev = PROFILE.begin() if PROFILE.on else None
+            args = (ptr(A), lda_m, lda_k, ptr(B), ldb_k, ldb_n, ptr(C), ldc, M, N, K, ptr(bias), ptr(residual), ldr, res_rows,
+                    res_before_act, act, ptr(preact), ldp, ptr(dact_src), ldd, dact, ptr(ws))
+            check(_hip.lib().rf_gemm_skinny(*args, _stream()), "rf_gemm_skinny")
+            if ev is not None:
+                rtm = 1 if M <= 16 else (2 if M <= 32 else 4)
+                tag = f"gemm_skinny_kernel<{rtm}, {2 if (M > 64 and N >= 1024) else 1}, {0 if ldb_k == 1 else 1}>"
+                if z > 1:
+                    tag += " + skinny_reduce_kernel"
+                keep = (A, B, C, bias, residual, preact, dact_src, ws)
+                PROFILE.end(tag, ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N),
+                            replay=lambda a=args, k=keep: _hip.lib().rf_gemm_skinny(*a, _stream()))
+            return
     if splitk == 0:
         splitk = _auto_split(M, N, K)
     ws = cnt = None

@@ -31,6 +31,16 @@ def _g(seed):
     return torch.Generator().manual_seed(seed)
 
 
+@pytest.fixture
+def request_restore():
+    """Tests that widen the skinny-GEMM dispatch thresholds append the old pair here; restored afterwards."""
+    from routeformer_amd import kernels as K
+    saved = []
+    yield saved
+    for a, b in saved:
+        K.SKINNY_MAX_M, K.SKINNY_MAX_M_DEEP = a, b
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(64, 64, 32), (520, 128, 128), (37, 66, 207), (12480, 64, 128),
                                    (560, 3328, 832), (5, 3, 6), (130, 17, 33)])
@@ -102,6 +112,54 @@ def test_gemm_epilogues(act):
     s = src.clone().requires_grad_()
     (F.relu(s) if act == "relu" else F.gelu(s)).sum().backward()
     assert rel_err(y2, (x @ w.t()) * s.grad) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 832, 832), (40, 3328, 832), (56, 832, 3328), (96, 2496, 832), (168, 832, 2496),
+                                   (320, 3328, 832), (560, 832, 832), (7, 48, 72), (33, 100, 1032), (64, 16, 64)])
+@pytest.mark.parametrize("bmode", [0, 1])
+def test_gemm_skinny(M, N, K, bmode, request_restore):
+    """The skinny GEMM of the GPS backbone's launch shapes (csrc/gemm_skinny.hip: all operands requested up front,
+    8 waves interleaving the k-steps, in-launch epilogue; K > 1024: slices + slab sum) against fp32 torch math on the
+    bf16-rounded operands (the kernel's arithmetic contract: bf16 inputs, fp32 accumulation) -- both weight orientations
+    (y = x W^T and dX = dY W), ragged M / N, every epilogue."""
+    from routeformer_amd import _hip, kernels as Kn
+    Kn.set_precision("bf16")
+    monkey = (Kn.SKINNY_MAX_M, Kn.SKINNY_MAX_M_DEEP)
+    Kn.SKINNY_MAX_M = Kn.SKINNY_MAX_M_DEEP = 640  # (the dispatch thresholds are a speed matter: test the kernel's whole range)
+    request_restore.append(monkey)
+    g = _g(5)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)   # logical W[n][k]
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    src = torch.randn(M, N, generator=g)
+    xd, bd, rd, sd = (a.to(DEV) for a in (x, b, res, src))
+    wd = (w if bmode == 0 else w.t().contiguous()).to(DEV)  # bmode 1: stored [k][n]
+    ldb = (1, K) if bmode == 0 else (N, 1)
+    assert _hip.lib().rf_gemm_skinny_split(xd.data_ptr(), K, 1, wd.data_ptr(), ldb[0], ldb[1], M, N, K) == -(-K // 1024)
+    xr, wr = x.bfloat16().float(), w.bfloat16().float()
+    zr = xr @ wr.t()
+    y = torch.empty(M, N, device=DEV)
+    Kn.gemm(xd, K, 1, wd, ldb[0], ldb[1], y, N, M, N, K)
+    assert rel_err(y, zr) < 1e-5
+    # bias + residual-before-activation + relu + pre-activation output
+    y1, z1 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    Kn.gemm(xd, K, 1, wd, ldb[0], ldb[1], y1, N, M, N, K, bias=bd, residual=rd, ldr=N, res_rows=M, res_before_act=1,
+            act=Kn.ACT["relu"], preact=z1, ldp=N)
+    assert rel_err(z1, zr + b + res) < 1e-5 and rel_err(y1, F.relu(zr + b + res)) < 1e-5
+    # activation' epilogue + residual after it (the dX form: dX = (dY W) * act'(src) + skip)
+    y2 = torch.empty(M, N, device=DEV)
+    Kn.gemm(xd, K, 1, wd, ldb[0], ldb[1], y2, N, M, N, K, dact_src=sd, ldd=N, dact=Kn.ACT["relu"], residual=rd, ldr=N,
+            res_rows=M)
+    assert rel_err(y2, zr * (src > 0).float() + res) < 1e-5
+    # and the tiled kernel agrees (same rounding contract)
+    Kn.SKINNY_GEMM = False
+    try:
+        y3 = torch.empty(M, N, device=DEV)
+        Kn.gemm(xd, K, 1, wd, ldb[0], ldb[1], y3, N, M, N, K)
+    finally:
+        Kn.SKINNY_GEMM = True
+    assert rel_err(y3, y) < 1e-5
 
 
 @pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 5e-2)])
