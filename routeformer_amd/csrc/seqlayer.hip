@@ -130,14 +130,18 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
   unsigned int* cnt32 = reinterpret_cast<unsigned int*>(stat + LP);  // [key][query / 4]: four queries per word
   __bf16* hb = qs;  // conv-pair phase alias
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+  const int wave = tid >> 6;
+  // (offsets are functions of the lane coordinates only: passing those through an empty asm at the phase boundaries keeps
+  //  the compiler from hoisting hundreds of invariant addresses out of the layer loop and spilling them)
+#define SL_LOCAL() asm volatile("" : "+v"(tid), "+v"(lane), "+v"(fr), "+v"(fq), "+v"(srow), "+v"(sc4))
   const int b = blockIdx.x, L = p.L, F = p.F, HP = F + 8;
   unsigned char* scr = scr_base + wave * SCR_BYTES;
   float* sc_f = reinterpret_cast<float*>(scr);           // score tile fp32 [16][SP] / staged output tiles [5][16][20]
   __bf16* sc_p = reinterpret_cast<__bf16*>(scr);         // probabilities bf16 [32][VP]
   float* Ms = reinterpret_cast<float*>(scr + 6656);      // [LP] sparsity measure (320 B)
   int* top_l = reinterpret_cast<int*>(scr + 6656 + 320);  // [32] selected rows, ascending (128 B)
-  const int srow = lane >> 2, sc4 = (lane & 3) * 4;      // staged-tile read-back: row, first column of this lane
+  int srow = lane >> 2, sc4 = (lane & 3) * 4;            // staged-tile read-back: row, first column of this lane
 
   // ---- residual stream slice of this wave + bf16 image of x ----
   f32x4 xres[RT];
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
     __syncthreads();  // xb complete (written by all waves), idx8 visible
     SL_MARK(1);
 
+    SL_LOCAL();
     // ================= phase 1: q | k | v of head `wave` =================
     {
       float* qkv_g = SAVE ? p.qkv + lrow * (3 * SL_D) + wave * 16 : nullptr;
@@ -264,6 +269,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
     __syncthreads();  // every wave is done with xb: it becomes the ctx image
     SL_MARK(3);
 
+    SL_LOCAL();
     // ================= phase 2: ProbSparse attention of head `wave` (no workgroup barrier inside) =================
     {
       const __bf16* Q = qs + wave * LP * SL_E;
@@ -443,6 +449,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
     __syncthreads();  // ctx image complete
     SL_MARK(8);
 
+    SL_LOCAL();
     // ================= phase 3: out-projection + residual + LayerNorm 1 (wave = 16 output columns) =================
     {
       const int col = wave * 16 + fr;
@@ -511,6 +518,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
     __syncthreads();  // x1 image complete; q / k / v^T are dead: their LDS becomes the hidden activation image
     SL_MARK(10);
 
+    SL_LOCAL();
     // ================= phase 4: conv1 + activation (wave = column tiles wave, wave + 8) =================
     {
       float* z_g = (SAVE && p.z) ? p.z + lrow * F : nullptr;
@@ -581,6 +589,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
     __syncthreads();  // hidden activation image complete
     SL_MARK(12);
 
+    SL_LOCAL();
     // ================= phase 5: conv2 + residual + LayerNorm 2 =================
     {
       const int col = wave * 16 + fr;
