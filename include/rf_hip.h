@@ -320,6 +320,12 @@ typedef struct RfSeqPackEntry {
   const float* w; void* out; int64_t ldw; int N, K, transpose, pad;
 } RfSeqPackEntry;
 int rf_seqlayer_pack(const RfSeqPackEntry* entries, int count, void* stream);
+/* The same packing driven by a table in DEVICE memory: `entries_dev` (count entries, validated by the caller as for
+ * rf_seqlayer_pack) and `first_block_dev` (count int32: prefix sums of rf_seqlayer_pack_blocks(N, K) per entry; blocks =
+ * their total).  Lets a training engine re-pack every fused stack of a model with ONE launch per step. */
+int rf_seqlayer_pack_blocks(int N, int K);
+int rf_seqlayer_pack_table(const RfSeqPackEntry* entries_dev, const int32_t* first_block_dev, int count, int blocks,
+                           void* stream);
 int64_t rf_seqlayer_pack_bytes(int d_ff);
 int rf_seqlayer_supported(int L, int d_model, int n_heads, int d_ff, int sample_k, int n_top);
  /* drop_p > 0: nn.Dropout(p) of the layers in train mode (cross_modal_transformer.py:295,298,299), masks from the

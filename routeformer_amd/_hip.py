@@ -63,6 +63,8 @@ SIGNATURES = {
     "rf_cache_lookup": [_P, _I, _P, _P, _I, _P, _P, _P],
     "rf_cache_insert": [_P, _I, _P, _P, _I, _P, _I, _P, _P],
     "rf_seqlayer_pack": [_P, _I, _P],
+    "rf_seqlayer_pack_blocks": [_I, _I],
+    "rf_seqlayer_pack_table": [_P, _P, _I, _I, _P],
     "rf_seqlayer_supported": [_I, _I, _I, _I, _I, _I],
     "rf_seqlayer_pack_bytes": [_I],
     "rf_seqlayer_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _P, _I, _P],

@@ -700,9 +700,45 @@ __global__ __launch_bounds__(256) void seq_pack_kernel(const PackTable t) {
   *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(ent.out) + ((long)f * 64 + lane) * 8) = o;
 }
 
+// the same work from a table in DEVICE memory (any number of entries: every stack of a model in one launch)
+__global__ __launch_bounds__(256) void seq_pack_table_kernel(const RfSeqPackEntry* __restrict__ ents,
+                                                             const int* __restrict__ first_block, int count) {
+  int lo = 0, hi = count - 1;  // last entry whose first block is <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const RfSeqPackEntry ent = ents[lo];
+  const int rel = (int)blockIdx.x - first_block[lo];
+  if (ent.K == 0) {
+    const int i = rel * 256 + threadIdx.x;
+    if (i < ent.N) static_cast<float*>(ent.out)[i] = ent.w[i];
+    return;
+  }
+  const int KS = ent.K / 32, nfrag = (ent.N / 16) * KS;
+  const int f = rel * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (f >= nfrag) return;
+  const int ct = f / KS, kk = f % KS, n = ct * 16 + (lane & 15), k0 = kk * 32 + (lane >> 4) * 8;
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    o[j] = (__bf16)(ent.transpose ? ent.w[(long)(k0 + j) * ent.ldw + n] : ent.w[(long)n * ent.ldw + k0 + j]);
+  *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(ent.out) + ((long)f * 64 + lane) * 8) = o;
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+extern "C" int rf_seqlayer_pack_blocks(int N, int K) { return K == 0 ? (N + 255) / 256 : ((N / 16) * (K / 32) + 3) / 4; }
+
+extern "C" int rf_seqlayer_pack_table(const RfSeqPackEntry* entries_dev, const int32_t* first_block_dev, int count, int blocks,
+                                      void* stream) {
+  RF_REQUIRE(entries_dev && first_block_dev && count > 0 && blocks > 0);
+  RF_LAUNCH(seq_pack_table_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), entries_dev, first_block_dev, count);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
 
 #ifdef RF_SL_TIMING
 extern "C" void* rf_sl_timing_address() {

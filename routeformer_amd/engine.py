@@ -587,9 +587,16 @@ class TrainEngine:
         if stacks is None:
             stacks = self._fused_stacks = [st for m in self.model.modules() if hasattr(m, "fused_stack")
                                            for st in [m.fused_stack()] if st is not None]
-        if K.SEQSTACK and K.get_precision() == "bf16":
+        if K.SEQSTACK and K.get_precision() == "bf16" and stacks:
+            plan = self.__dict__.get("_pack_plan")
+            if plan is None or plan[0] != K.SEQSTACK_BWD:
+                ents = []
+                for st in stacks:
+                    st.refresh(force=True, collect=ents)  # (allocates the blobs, keys them; the launch is the plan's)
+                plan = self._pack_plan = (K.SEQSTACK_BWD, K.PackPlan(ents, self.reducer.flat_param.device))
             for st in stacks:
-                st.refresh(force=True)
+                st._key = None  # the blobs are refreshed by the plan, not by FusedStack.refresh: never trust its key
+            plan[1].launch()
 
     def _advance_rng(self):
         if self._device_dropout and self.reducer.flat_param.is_cuda:

@@ -1385,7 +1385,45 @@ def seqstack_supported(L: int, d_model: int, n_heads: int, d_ff: int, sample_k: 
     return bool(SEQSTACK and _PRECISION == 1 and _hip.lib().rf_seqlayer_supported(L, d_model, n_heads, d_ff, sample_k, n_top))
 
 
-def seqstack_pack(layers, out: torch.Tensor, stride: int):
+class PackPlan:
+    """Every pack entry of every fused stack of a model as ONE table in device memory -> one rf_seqlayer_pack_table launch
+    per step (the entries name static addresses: parameters inside the engine's flat buffer, the stacks' blobs)."""
+
+    def __init__(self, ents, device):
+        import ctypes
+        import numpy as np
+        assert ents
+        arr = (_hip.SeqPackEntry * len(ents))()
+        first, blocks = [], 0
+        for e, (w, off, ldw, N, K_, tr) in zip(arr, ents):
+            assert K_ == 0 or (N % 16 == 0 and K_ % 32 == 0 and off % 16 == 0)
+            e.w, e.out, e.ldw, e.N, e.K, e.transpose, e.pad = w, off, ldw, N, K_, tr, 0
+            first.append(blocks)
+            blocks += int(_hip.lib().rf_seqlayer_pack_blocks(N, K_))
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        self.table = torch.from_numpy(raw).to(device)
+        self.first = torch.tensor(first, dtype=torch.int32, device=device)
+        self.count, self.blocks = len(ents), blocks
+
+    def launch(self):
+        check(_hip.lib().rf_seqlayer_pack_table(self.table.data_ptr(), self.first.data_ptr(), self.count, self.blocks,
+                                                _stream()), "rf_seqlayer_pack_table")
+
+
+def _pack_launch(ents, collect):
+    """ents: (w_ptr, out_ptr, ldw, N, K, transpose).  collect: a list that takes them (PackPlan) instead of launching."""
+    if collect is not None:
+        collect.extend(ents)
+        return
+    for s0 in range(0, len(ents), _hip.SEQLAYER_MAX_PACK):
+        chunk = ents[s0:s0 + _hip.SEQLAYER_MAX_PACK]
+        arr = (_hip.SeqPackEntry * len(chunk))()
+        for e, (w, off, ldw, N, K_, tr) in zip(arr, chunk):
+            e.w, e.out, e.ldw, e.N, e.K, e.transpose, e.pad = w, off, ldw, N, K_, tr, 0
+        check(_hip.lib().rf_seqlayer_pack(arr, len(chunk), _stream()), "rf_seqlayer_pack")
+
+
+def seqstack_pack(layers, out: torch.Tensor, stride: int, collect=None):
     """layers: per layer a dict of fp32 device tensors -- wq/wk/wv (128,128) or wqkv (384,128), wo (128,128), w1
     (F,128), w2 (128,F), bqkv (384) or bq/bk/bv, bo, b1, b2, g1, be1, g2, be2 -> ``out`` (uint8, n_layers * stride)."""
     import ctypes
@@ -1419,15 +1457,10 @@ def seqstack_pack(layers, out: torch.Tensor, stride: int):
         for n, pos, cnt in (("bo", 384, 128), ("b1", 512, F_), ("b2", 512 + F_, 128), ("g1", 640 + F_, 128),
                             ("be1", 768 + F_, 128), ("g2", 896 + F_, 128), ("be2", 1024 + F_, 128)):
             vecs(d[n], o + o_vec + 4 * pos, cnt)
-    for s0 in range(0, len(ents), _hip.SEQLAYER_MAX_PACK):
-        chunk = ents[s0:s0 + _hip.SEQLAYER_MAX_PACK]
-        arr = (_hip.SeqPackEntry * len(chunk))()
-        for e, (w, off, ldw, N, K_) in zip(arr, chunk):
-            e.w, e.out, e.ldw, e.N, e.K, e.transpose, e.pad = w.data_ptr(), off, ldw, N, K_, 0, 0
-        check(_hip.lib().rf_seqlayer_pack(arr, len(chunk), _stream()), "rf_seqlayer_pack")
+    _pack_launch([(w.data_ptr(), off, ldw, N, K_, 0) for (w, off, ldw, N, K_) in ents], collect)
 
 
-def seqstack_bwd_pack(layers, out: torch.Tensor, stride: int):
+def seqstack_bwd_pack(layers, out: torch.Tensor, stride: int, collect=None):
     """Transposed fragment order of the weights for the fused backward (csrc/seqlayer_bwd.hip): per layer dict with wqkv
     (384,128), wo (128,128), w1 (F,128), w2 (128,F), g1, g2 -> ``out`` (uint8, n_layers * stride)."""
     ents, base = [], out.data_ptr()
@@ -1445,12 +1478,7 @@ def seqstack_bwd_pack(layers, out: torch.Tensor, stride: int):
         for v, pos in ((d["g1"], 0), (d["g2"], 128)):
             assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == 128
             ents.append((v.data_ptr(), o + o_vec + 4 * pos, 0, 128, 0, 0))
-    for s0 in range(0, len(ents), _hip.SEQLAYER_MAX_PACK):
-        chunk = ents[s0:s0 + _hip.SEQLAYER_MAX_PACK]
-        arr = (_hip.SeqPackEntry * len(chunk))()
-        for e, (w, off, ldw, N, K_, tr) in zip(arr, chunk):
-            e.w, e.out, e.ldw, e.N, e.K, e.transpose, e.pad = w, off, ldw, N, K_, tr, 0
-        check(_hip.lib().rf_seqlayer_pack(arr, len(chunk), _stream()), "rf_seqlayer_pack")
+    _pack_launch(ents, collect)
 
 
 def seqstack_bwd_pack_bytes(d_ff: int) -> int:

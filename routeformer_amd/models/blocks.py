@@ -402,7 +402,9 @@ class FusedStack:
             yield from (a.query_projection.weight, a.key_projection.weight, a.value_projection.weight,
                         a.out_projection.weight, lay.conv1.weight, lay.conv2.weight, lay.norm1.weight, lay.norm2.weight)
 
-    def refresh(self, force: bool = False):
+    def refresh(self, force: bool = False, collect=None):
+        """``collect``: a list that takes the pack entries instead of launching them (kernels.PackPlan: the engine packs
+        every stack of the model with one launch per step)."""
         dev = self.layers[0].conv1.weight.device
         key = (K.WEIGHTS_EPOCH, str(dev), tuple(p._version for p in self._params()), tuple(p.data_ptr() for p in self._params()))
         if not force and key == self._key and self.wpack is not None:
@@ -426,13 +428,13 @@ class FusedStack:
                     d.update(wq=a.query_projection.weight, wk=a.key_projection.weight, wv=a.value_projection.weight,
                              bq=a.query_projection.bias, bk=a.key_projection.bias, bv=a.value_projection.bias)
                 descs.append({k: v.detach() for k, v in d.items()})
-            K.seqstack_pack(descs, self.wpack, stride)
+            K.seqstack_pack(descs, self.wpack, stride, collect)
             if all("wqkv" in d for d in descs) and K.SEQSTACK_BWD:  # packed projections exist: a training engine owns the model
                 sb = K.seqstack_bwd_pack_bytes(F_)
                 if self.wpack_bwd is None or self.wpack_bwd.device != dev or self.stride_bwd != sb:
                     self.wpack_bwd = torch.empty(len(self.layers) * sb, dtype=torch.uint8, device=dev)
                     self.stride_bwd = sb
-                K.seqstack_bwd_pack(descs, self.wpack_bwd, sb)
+                K.seqstack_bwd_pack(descs, self.wpack_bwd, sb, collect)
             else:
                 self.wpack_bwd = None
         self._key = key

@@ -402,8 +402,9 @@ class Routeformer(nn.Module):
             emb = self.frame_encoder(tokens.to(dtype), idx_list, n_per).view(len(members), B, -1, E)
             K.TOPS.split_record(len(members), len(idx_list))
             idx_dev = self._device_index(idx, dev)
+            # one zero-fill + one scatter for all member streams (per-stream timelines are views of it)
+            timelines = torch.zeros(len(members), B, T, E, device=dev, dtype=emb.dtype)
+            timelines[:, :, idx_dev] = emb
             for s_i, m in enumerate(members):
-                timeline = torch.zeros(B, T, E, device=dev)
-                timeline[:, idx_dev] = emb[s_i]
-                out.append((m[0], timeline))
+                out.append((m[0], timelines[s_i]))
         return out
