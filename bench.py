@@ -341,7 +341,7 @@ def main():
         ms = elapsed / args.steps * 1e3
         total_samples = c["B"] * world * args.steps
         prof = K.PROFILE.summary()
-        roof = None
+        roof, top = None, []
         if prof:
             # dominant kernel = largest per-step total among the kernel symbols, measured live with HIP events on the
             # launch stream that bracket each re-issued launch of that symbol (K.PROFILE.refine, rf_kernel_timer_arm)
@@ -351,10 +351,18 @@ def main():
             # the dispatch, and the largest refined total wins -- the raw eager event times include the Python launch
             # path between kernels
             best = None
-            for cand, st in [kv for kv in ranked if "+" not in kv[0]][:6]:
+            for cand, st in [kv for kv in ranked if "+" not in kv[0]][:8]:
                 fine = K.PROFILE.refine(cand)
                 if fine is None:  # no replayable launches recorded for this symbol: its eager figure is not comparable
                     continue
+                n_l, us, fl, by = fine
+                ai = fl / max(by, 1)
+                mf = ai > (MFMA_PEAK_TFLOPS[args.precision] * 1e12 / (HBM_PEAK_GBS * 1e9))
+                top.append({"kernel": cand, "launches_per_step": n_l, "avg_us": round(us / n_l, 2),
+                            "total_us_per_step": round(us, 1), "bound": "mfma" if mf else "hbm",
+                            "achieved_gbs": round(by / (us * 1e-6) / 1e9, 1), "achieved_tflops": round(fl / (us * 1e-6) / 1e12, 2),
+                            "frac": round((fl / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS[args.precision]) if mf
+                                          else (by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS), 4)})
                 if best is None or fine[1] > best[1][1]:
                     best = (cand, fine)
             if best is None:
@@ -420,7 +428,7 @@ def main():
                        "launch": ("hipGraph replay of fwd+bwd" + (" (+ the previous step's clip/AdamW at its head)" if defer else ""))
                        if use_graph else "eager launches"},
             "loss": float(res["loss"].detach()), "rccl_ranks": rccl_ranks, "batch_independence_rel": indep,
-            "roofline": roof, "roofline_fused_encoder_stack": fused or None,
+            "roofline": roof, "roofline_top": top or None, "roofline_fused_encoder_stack": fused or None,
         }
         if rehearse:
             out["config"]["rehearsal"] = "one-rank RCCL group, N>1 code path (RF_REHEARSE_COLLECTIVES=1)"

@@ -485,8 +485,14 @@ class _WgradQueue:
         with torch.cuda.stream(st):
             check(_hip.lib().rf_wgrad_grouped(arr, n, _PRECISION, st.cuda_stream), "rf_wgrad_grouped")
             if ev is not None:
+                keep = (arr, list(q))  # operands stay alive for the replay (bench's per-launch timing; it re-accumulates
+                #                        into the gradient slots, which nothing reads after the profile pass)
                 PROFILE.end(f"wgrad_grouped_kernel<{_PRECISION}>", ev, sum(2.0 * i[4] * i[5] * i[6] for i in q),
-                            sum(4.0 * (i[4] * i[5] + i[4] * i[6] + 2 * i[5] * i[6]) for i in q))
+                            # algorithmic bytes: both operands once, dW written once (plain exclusive stores) or read +
+                            # written (atomic accumulation into a slot another launch also writes)
+                            sum(4.0 * (i[4] * i[5] + i[4] * i[6] + (1 if e_.exclusive else 2) * i[5] * i[6])
+                                for i, e_ in zip(q, arr)),
+                            replay=lambda a=arr, n_=n, pr=_PRECISION, k=keep: _hip.lib().rf_wgrad_grouped(a, n_, pr, _stream()))
             for _, _, into, bias_into, *_ in q:
                 self.pending.discard(into.data_ptr())
                 if bias_into is not None:

@@ -7,6 +7,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 from routeformer_amd import kernels as K
 K.set_precision("bf16")
+K.SKINNY_MAX_M = K.SKINNY_MAX_M_DEEP = 640  # (the sweep measures the kernels, not the dispatch thresholds)
 dev = "cuda"
 shapes = [(M, N, K_, bm) for M in (32, 40, 56, 96, 168, 320, 560) for (N, K_) in ((832, 832), (2496, 832), (3328, 832), (832, 3328), (832, 2496))
           for bm in (0, 1)]
