@@ -13,6 +13,7 @@
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -20,6 +21,9 @@ import torch.distributed as dist
 
 from routeformer_amd.losses import FutureDiscountedLoss
 from routeformer_amd.score import ade, fde
+
+
+WGRAD_SIDE = os.environ.get("RF_WGRAD_SIDE", "0") == "1"  # weight-gradient groups that fill up mid-backward on a side stream
 
 
 def _capture_kw() -> dict:
@@ -632,6 +636,7 @@ class TrainEngine:
         K.SINK.active = True  # kernels accumulate parameter gradients straight into the flat buffer
         K.SINK.on_write = None
         K.WGRAD.active = self.group_wgrad
+        K.WGRAD.side_early = self.overlap and WGRAD_SIDE  # (single-graph / eager path only: no collective waits on these)
         try:
             self._begin_step_kernels()
             res = train_step_losses(self.model, item, epoch, self.tl, self.dl, tokens_ready=tokens_ready)
@@ -641,6 +646,7 @@ class TrainEngine:
                 K.join_side_streams()
         finally:
             K.SINK.active, K.SINK.on_write, K.OVERLAP, K.WGRAD.active = False, None, False, False
+            K.WGRAD.side_early = False
             self.model.__dict__.pop("_before_gps_backbone", None)
         return res
 

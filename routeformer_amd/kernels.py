@@ -439,6 +439,7 @@ class _WgradQueue:
 
     def __init__(self):
         self.active = False
+        self.side_early = False  # set by TrainEngine._fwd_bwd: groups that fill up mid-backward go to a side stream
         self.queues = {}     # stream handle -> (torch stream, [items])
         self.pending = set() # data_ptr of slots with a queued (not yet launched) write
         self.written = set() # data_ptr of slots already written by a grouped launch this step
@@ -456,14 +457,22 @@ class _WgradQueue:
         if bias_into is not None:
             self.pending.add(bias_into.data_ptr())
         if len(q) >= _hip.WGRAD_MAX_GROUP:
-            self._flush(st, q)
+            self._flush(st, q, side=self.side_early)
 
     # (flushing earlier, on a side stream underneath the dX chain, was measured: 560-590 vs 610 samples/s --
     #  the chip-filling launch slows the latency-bound chain more than it hides)
 
-    def _flush(self, st, q):
+    def _flush(self, st, q, side=False):
+        """``side``: launch on the "wgrad" side stream (forked from ``st`` here, joined by join_side_streams): a group
+        that fills up in the MIDDLE of the backward pass -- the GPS backbone's 48 weights, 288 MB of gradients -- then
+        runs underneath the rest of the backward instead of in front of it."""
         if not q:
             return
+        if side and OVERLAP and not on_side_stream():
+            sd = side_stream("wgrad")
+            sd.wait_stream(st)
+            _KEEPALIVE.append(list(q))
+            st = sd
         n = len(q)
         arr = (_hip.WgradEntry * n)()
         uses = {}
@@ -482,6 +491,11 @@ class _WgradQueue:
             e.exclusive = 1 if (uses[into.data_ptr()] == 1 and into.data_ptr() not in self.written) else 0
         self.written.update(uses)
         ev = PROFILE.begin() if PROFILE.on else None
+        if os.environ.get("RF_WGRAD_DEBUG"):
+            import collections, sys
+            hist = collections.Counter((i[4], i[5], i[6], e_.splits, e_.exclusive) for i, e_ in zip(q, arr))
+            print(f"[wgrad group] {n} problems: " + ", ".join(f"{c}x(M={m},N={n_},K={k},s={s_},x={x})" for (m, n_, k, s_, x), c in
+                                                               sorted(hist.items())), file=sys.stderr)
         with torch.cuda.stream(st):
             check(_hip.lib().rf_wgrad_grouped(arr, n, _PRECISION, st.cuda_stream), "rf_wgrad_grouped")
             if ev is not None:
@@ -503,9 +517,9 @@ class _WgradQueue:
                         SINK.on_write(bias_into)
         q.clear()
 
-    def flush(self):
+    def flush(self, side=False):
         for st, q in list(self.queues.values()):
-            self._flush(st, q)
+            self._flush(st, q, side=side)
         self.pending.clear()
 
 
