@@ -1,5 +1,5 @@
 """Per-problem time of the grouped weight-gradient kernel (rf_wgrad_grouped, one entry per launch, graph replay) on the
-step's shapes, and of the whole GPS-backbone group in one launch (GPU box):  python tools/wgrad_sweep.py"""
+step's shapes (GPU box):  python tools/wgrad_sweep.py"""
 import ctypes, os, sys
 import torch
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,4 +47,6 @@ for M, N, K in shapes:
     entry(arr[0], dy, x, dw, M, N, K, splits, 1 if splits == 1 else 0)
     us = timed(lambda: lib.rf_wgrad_grouped(arr, 1, 1, torch.cuda.current_stream().cuda_stream))
     by = 4.0 * (M * N + M * K + N * K)
-    print(f"{M:6d} {N:5d} {K:5d} {splits:5d} {us:8.1f}  {by / us / 1e3:8.1f}")
+    line = f"{M:6d} {N:5d} {K:5d} {splits:5d} {us:8.1f}  {by / us / 1e3:8.1f}"
+    print(line)
+
