@@ -203,6 +203,11 @@ typedef struct RfWgradEntry {
   int M, N, K, ld_dy, ld_x, splits, kchunk, exclusive;
 } RfWgradEntry;
 int rf_wgrad_grouped(const RfWgradEntry* entries, int count, int prec, void* stream);
+/* The bf16 matrix-core path of rf_wgrad_grouped (prec = 1 routes here; RF_WGRAD_TR=0 in the environment keeps the tiled
+ * kernel): operands copied row-major into LDS and read back with the hardware transpose read (ds_read_b64_tr_b16),
+ * 256 x 128 blocks of dW per workgroup, a three-deep register ring of global loads, reduction chunks of >= 1 024 rows;
+ * same entry semantics (plain stores for an exclusive entry that ends up with one chunk, fp32 atomics otherwise). */
+int rf_wgrad_tr(const RfWgradEntry* entries, int count, void* stream);
 
 /* ---- row-block kernels for the d_model = 128 stacks (bf16-input MFMA only) ----
  * A workgroup owns 64 complete rows and stages the whole weight matrix in LDS, so the residual add and the

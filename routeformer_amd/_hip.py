@@ -45,6 +45,7 @@ SIGNATURES = {
     "rf_bn_elu_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
     "rf_bn_elu_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "rf_wgrad_grouped": [_P, _I, _I, _P],
+    "rf_wgrad_tr": [_P, _I, _P],
     "rf_rowblock_linear_supported": [_I, _I, _I],
     "rf_rowblock_linear": [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _F, _P],
     "rf_rowblock_ffn_ln": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P],

@@ -12,6 +12,7 @@
 // Tile configs (BM x BN, BK = 32): 0 = 64x64 (2x2 waves, 2x2 tiles), 1 = 128x16 (4x1 waves, 2x1),
 // 2 = 128x32 (4x1 waves, 2x2) -- the narrow ones serve the 16/32-channel HRNet branches.
 #include "common.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1127,8 +1128,13 @@ extern "C" void* rf_gemm_timing_address() {
 }
 #endif
 
+extern "C" int rf_wgrad_tr(const RfWgradEntry* entries, int count, void* stream);
+
 extern "C" int rf_wgrad_grouped(const RfWgradEntry* entries, int count, int prec, void* stream) {
   RF_REQUIRE(entries && count >= 1 && count <= RF_WGRAD_MAX_GROUP && (prec == 0 || prec == 1));
+  // bf16 matrix-core mode: the transposed-read kernel (wgrad_tr.hip); RF_WGRAD_TR=0 keeps the tiled one below
+  static const bool tr_on = [] { const char* v = getenv("RF_WGRAD_TR"); return !(v && v[0] == '0'); }();
+  if (prec == 1 && tr_on) return rf_wgrad_tr(entries, count, stream);
   WgradTable t{};
   t.count = count;
   int blocks = 0;
