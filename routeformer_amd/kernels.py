@@ -501,7 +501,9 @@ class _WgradQueue:
             if ev is not None:
                 keep = (arr, list(q))  # operands stay alive for the replay (bench's per-launch timing; it re-accumulates
                 #                        into the gradient slots, which nothing reads after the profile pass)
-                PROFILE.end(f"wgrad_grouped_kernel<{_PRECISION}>", ev, sum(2.0 * i[4] * i[5] * i[6] for i in q),
+                tag = ("wgrad_tr_kernel" if (_PRECISION == 1 and os.environ.get("RF_WGRAD_TR", "1") != "0")
+                       else f"wgrad_grouped_kernel<{_PRECISION}>")  # (the symbol rf_wgrad_grouped dispatches to)
+                PROFILE.end(tag, ev, sum(2.0 * i[4] * i[5] * i[6] for i in q),
                             # algorithmic bytes: both operands once, dW written once (plain exclusive stores) or read +
                             # written (atomic accumulation into a slot another launch also writes)
                             sum(4.0 * (i[4] * i[5] + i[4] * i[6] + (1 if e_.exclusive else 2) * i[5] * i[6])
