@@ -54,6 +54,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* img, int t, int l
   return u.b;
 }
 
+// Phase timing aid (tools/wgrad_probe.py: private -DRF_WT_TIMING build): lane 0 of every wave of the first 64 workgroups
+// stamps the shader clock inside step 4 of its loop.
+#ifdef RF_WT_TIMING
+__device__ unsigned long long rf_wt_timing[64 * 8 * 8];
+#define WT_MARK(k) do { if (s == 4 && (threadIdx.x & 63) == 0 && blockIdx.x < 64) \
+  rf_wt_timing[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WT_MARK(k) do {} while (0)
+#endif
+
 struct Staged { float4 y[4], x[2]; };  // one thread's share of a 32-row step: dY 32 x 256, X 32 x 128
 
 __global__ __launch_bounds__(WT_NT) void wgrad_tr_kernel(const TrTable t) {
@@ -145,7 +155,9 @@ __global__ __launch_bounds__(WT_NT) void wgrad_tr_kernel(const TrTable t) {
     for (int r = 0; r < WT_RING; ++r) {
       const int s = s0 + r;
       if (s < nsteps) {  // (workgroup-uniform)
+        WT_MARK(0);
         gload(ring[r], s + WT_RING);  // set r's previous content (step s) went to LDS at the bottom of step s - 1
+        WT_MARK(1);
         {
           const unsigned char* base = lds + (s & 1) * 3 * WT_HALF;
           const unsigned char* yimg = base + (wn >> 1) * WT_HALF;  // this wave's 64 dY columns: tiles 4 (wn & 1) .. of half wn / 2
@@ -162,8 +174,11 @@ __global__ __launch_bounds__(WT_NT) void wgrad_tr_kernel(const TrTable t) {
             }
           }
         }
+        WT_MARK(2);
         if (s + 1 < nsteps) lstore(ring[(r + 1) % WT_RING], (s + 1) & 1);
+        WT_MARK(3);
         __syncthreads();
+        WT_MARK(4);
       }
     }
   }
@@ -230,6 +245,14 @@ __global__ __launch_bounds__(WT_NT) void wgrad_tr_kernel(const TrTable t) {
 }
 
 }  // namespace
+
+#ifdef RF_WT_TIMING
+extern "C" void* rf_wt_timing_address() {
+  void* a = nullptr;
+  (void)hipGetSymbolAddress(&a, HIP_SYMBOL(rf_wt_timing));
+  return a;
+}
+#endif
 
 // dW / db of up to RF_WGRAD_MAX_GROUP problems in one launch (bf16 matrix-core path of rf_wgrad_grouped).
 extern "C" int rf_wgrad_tr(const RfWgradEntry* entries, int count, void* stream) {
