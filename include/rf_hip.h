@@ -382,6 +382,16 @@ int rf_seqlayer_bwd(const RfSeqStackBwd* stack, const float* dy, float* dx, int 
  *   empty; table_slots[capacity] int32; capacity a power of two) or -1; *misses += number of -1 (caller zeroes it).
  * rf_cache_insert: for every i with slots[i] < 0 claim a table entry and the next free token slot (*next_slot,
  *   atomically; at most n_slots); duplicates inside one call and a full cache stay -1 (look up again afterwards). */
+/* Frame sub-sampling into staging buffers (the `video[:, frame_idx]` of routeformer.py:470-480 as one launch for all
+ * camera streams of a step): dst[b][f] = src[b][idx[f]], frames of frame_bytes bytes, src (B, T, ...) and dst (B, F, ...)
+ * contiguous, idx = F int64 frame numbers in DEVICE memory.  Up to RF_GATHER_MAX clips per launch. */
+#define RF_GATHER_MAX 8
+typedef struct RfGatherEntry {
+  const void* src; void* dst; const int64_t* idx;
+  int B, T, F, pad;
+  int64_t frame_bytes;
+} RfGatherEntry;
+int rf_gather_frames(const RfGatherEntry* entries, int count, void* stream);
 int rf_resize_area(const uint8_t* src, uint8_t* dst, int64_t n_planes, int H, int W, int h, int w, void* stream);
 int rf_frame_hash(const void* frames, const int64_t* frame_ids, int64_t n_frames, int64_t bytes_per_frame, uint64_t* keys,
                   int64_t seed, void* stream);

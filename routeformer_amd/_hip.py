@@ -59,6 +59,7 @@ SIGNATURES = {
     "rf_attn_fwd_full_scores": [_I, _I, _I, _I, _I, _I, _I, _I],
     "rf_attn_bwd": [_P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _I,
                     _I, _I, _F, _P],
+    "rf_gather_frames": [_P, _I, _P],
     "rf_resize_area": [_P, _P, _L, _I, _I, _I, _I, _P],
     "rf_frame_hash": [_P, _P, _L, _L, _P, _L, _P],
     "rf_cache_lookup": [_P, _I, _P, _P, _I, _P, _P, _P],
@@ -126,6 +127,15 @@ class SeqStackBwd(ctypes.Structure):
                                            "dqkv")]
                 + [(n, c_void_p * SEQLAYER_MAX_LAYERS) for n in ("dgamma1", "dbeta1", "dgamma2", "dbeta2")]
                 + [("n_layers", c_int), ("pad", c_int)])
+
+
+GATHER_MAX = 8  # RF_GATHER_MAX
+
+
+class GatherEntry(ctypes.Structure):
+    """RfGatherEntry of include/rf_hip.h."""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("idx", c_void_p), ("B", c_int), ("T", c_int), ("F", c_int),
+                ("pad", c_int), ("frame_bytes", c_int64)]
 
 
 class SeqPackEntry(ctypes.Structure):

@@ -131,9 +131,58 @@ __global__ void cache_insert_kernel(const unsigned long long* __restrict__ keys,
   }
 }
 
+// ---- frame sub-sampling into staging buffers: dst[b][f] = src[b][idx[f]] for up to 8 clips in one launch ---------------
+struct GatherTable {
+  int count, pad;
+  RfGatherEntry e[RF_GATHER_MAX];
+  long first_block[RF_GATHER_MAX + 1];
+};
+constexpr int GF_CHUNK = 16384;  // bytes per workgroup (256 threads x 4 x 16 B)
+
+__global__ __launch_bounds__(256) void gather_frames_kernel(const GatherTable t) {
+  int ei = 0;
+  while (ei + 1 < t.count && (long)blockIdx.x >= t.first_block[ei + 1]) ++ei;
+  const RfGatherEntry& e = t.e[ei];
+  const long local = (long)blockIdx.x - t.first_block[ei];
+  const long chunks = (e.frame_bytes + GF_CHUNK - 1) / GF_CHUNK;
+  const long frame = local / chunks, c = local - frame * chunks;
+  const int b = (int)(frame / e.F), f = (int)(frame - (long)b * e.F);
+  const long src_frame = (long)b * e.T + e.idx[f];
+  const unsigned char* src = static_cast<const unsigned char*>(e.src) + src_frame * e.frame_bytes + c * GF_CHUNK;
+  unsigned char* dst = static_cast<unsigned char*>(e.dst) + frame * e.frame_bytes + c * GF_CHUNK;
+  const long n = min((long)GF_CHUNK, e.frame_bytes - c * GF_CHUNK);
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+    const long n16 = n >> 4;
+    for (long i = threadIdx.x; i < n16; i += 256)
+      reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    for (long i = (n16 << 4) + threadIdx.x; i < n; i += 256) dst[i] = src[i];
+  } else {
+    for (long i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+  }
+}
+
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 }  // namespace
+
+extern "C" int rf_gather_frames(const RfGatherEntry* entries, int count, void* stream) {
+  RF_REQUIRE(entries && count >= 1 && count <= RF_GATHER_MAX);
+  GatherTable t{};
+  t.count = count;
+  long blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const RfGatherEntry& e = entries[i];
+    RF_REQUIRE(e.src && e.dst && e.idx && e.B > 0 && e.T > 0 && e.F > 0 && e.frame_bytes > 0);
+    t.e[i] = e;
+    t.first_block[i] = blocks;
+    blocks += (long)e.B * e.F * ((e.frame_bytes + GF_CHUNK - 1) / GF_CHUNK);
+  }
+  t.first_block[count] = blocks;
+  RF_REQUIRE(blocks < (1L << 31));
+  RF_LAUNCH(gather_frames_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), t);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
 
 extern "C" int rf_resize_area(const uint8_t* src, uint8_t* dst, int64_t n_planes, int H, int W, int h, int w, void* stream) {
   RF_REQUIRE(src && dst && n_planes > 0 && H > 0 && W > 0 && h > 0 && w > 0 && h <= H && w <= W);

@@ -860,11 +860,24 @@ class GraphedTrainEngine(TrainEngine):
         """Gather the frames of ``item`` the trunk reads into the engine's staging buffers (current stream)."""
         clips, _ = self.model.video_clips([item["train"], item["target"]])
         assert len(clips) == len(self._clip_stage), "the batch has a different set of camera streams than the captured one"
+        from routeformer_amd import _hip
+        todo = []
         for (v, _), dst, idx in zip(clips, self._clip_stage, self._clip_idx):
             if v.dtype != dst.dtype or v.shape[0] != dst.shape[0] or v.shape[2:] != dst.shape[2:]:
                 raise ValueError(f"clip {tuple(v.shape)} {v.dtype} does not match the captured step "
                                  f"({tuple(dst.shape)} {dst.dtype}): capture() again for a new batch shape")
-            torch.index_select(v, 1, idx, out=dst)
+            if v.is_cuda and v.is_contiguous() and dst.is_contiguous() and idx.dtype == torch.int64:
+                todo.append((v, dst, idx))
+            else:
+                torch.index_select(v, 1, idx, out=dst)
+        for s0 in range(0, len(todo), _hip.GATHER_MAX):  # one launch for all camera streams (was six index_select launches)
+            chunk = todo[s0:s0 + _hip.GATHER_MAX]
+            arr = (_hip.GatherEntry * len(chunk))()
+            for e, (v, dst, idx) in zip(arr, chunk):
+                e.src, e.dst, e.idx = v.data_ptr(), dst.data_ptr(), idx.data_ptr()
+                e.B, e.T, e.F, e.pad = v.shape[0], v.shape[1], dst.shape[1], 0
+                e.frame_bytes = v[0, 0].numel() * v.element_size()
+            _hip.check(_hip.lib().rf_gather_frames(arr, len(chunk), torch.cuda.current_stream().cuda_stream), "rf_gather_frames")
 
     def _staged(self):
         return [(t, None) for t in self._clip_stage]  # frame index None = every staged frame

@@ -1138,3 +1138,25 @@ def test_token_cache_semantics():
     again.load_state_dict(cache.state_dict())
     s3, m3 = again.lookup(keys)
     assert m3 == 0 and torch.equal(again.gather(s3), tokens)
+
+
+def test_gather_frames():
+    """rf_gather_frames (the engine's clip staging: dst[b][f] = src[b][idx[f]] for all camera streams in one launch)
+    against torch.index_select -- fp16, uint8 (odd frame size: byte tail) and fp32 clips in one call.  Bit-exact."""
+    from routeformer_amd import _hip
+    g = _g(41)
+    clips = [torch.randn(3, 10, 3, 20, 28, generator=g).half(), torch.randint(0, 255, (2, 7, 3, 11, 13), generator=g, dtype=torch.uint8),
+             torch.randn(2, 5, 4, 6, generator=g)]
+    idxs = [torch.tensor([9, 0, 4, 4]), torch.tensor([6, 5, 1]), torch.tensor([2])]
+    arr = (_hip.GatherEntry * len(clips))()
+    keep = []
+    for e, v, idx in zip(arr, clips, idxs):
+        vd, idd = v.to(DEV), idx.to(DEV)
+        dst = torch.zeros((v.shape[0], idx.numel()) + tuple(v.shape[2:]), device=DEV, dtype=v.dtype)
+        keep.append((vd, idd, dst))
+        e.src, e.dst, e.idx = vd.data_ptr(), dst.data_ptr(), idd.data_ptr()
+        e.B, e.T, e.F, e.pad, e.frame_bytes = v.shape[0], v.shape[1], idx.numel(), 0, v[0, 0].numel() * v.element_size()
+    rc = _hip.lib().rf_gather_frames(arr, len(clips), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _hip.lib().rf_last_error()
+    for (vd, idd, dst), v, idx in zip(keep, clips, idxs):
+        assert torch.equal(dst.cpu(), torch.index_select(v, 1, idx))
