@@ -1059,6 +1059,30 @@ class GraphedTrainEngine(TrainEngine):
         self._graphs[key] = (g, out)
         return g, out
 
+    def _multi_copy(self, pairs):
+        """dst <- src for every pair with one launch (rf_gather_frames with one "frame" per tensor) instead of one blit
+        kernel each; pairs that do not qualify (host tensors, dtype / layout changes) take ``copy_``."""
+        from routeformer_amd import _hip
+        todo = []
+        for src, dst in pairs:
+            if (src.is_cuda and dst.is_cuda and src.dtype == dst.dtype and src.shape == dst.shape and src.is_contiguous()
+                    and dst.is_contiguous() and src.numel() > 0):
+                todo.append((src, dst))
+            else:
+                dst.copy_(src, non_blocking=True)
+        if not todo:
+            return
+        zero = self.__dict__.get("_zero_idx")
+        if zero is None:
+            zero = self._zero_idx = torch.zeros(1, dtype=torch.int64, device=todo[0][1].device)
+        for s0 in range(0, len(todo), _hip.GATHER_MAX):
+            chunk = todo[s0:s0 + _hip.GATHER_MAX]
+            arr = (_hip.GatherEntry * len(chunk))()
+            for e, (src, dst) in zip(arr, chunk):
+                e.src, e.dst, e.idx, e.B, e.T, e.F, e.pad = src.data_ptr(), dst.data_ptr(), zero.data_ptr(), 1, 1, 1, 0
+                e.frame_bytes = src.numel() * src.element_size()
+            _hip.check(_hip.lib().rf_gather_frames(arr, len(chunk), torch.cuda.current_stream().cuda_stream), "rf_gather_frames")
+
     def precapture(self, lookahead: bool = True) -> int:
         """Capture the main graph of EVERY variant of the host dropout decisions now (they are otherwise captured on
         first use, i.e. in the middle of training: ~50 ms each).  -> number of graphs held."""
@@ -1092,6 +1116,16 @@ class GraphedTrainEngine(TrainEngine):
         # host side of the step first: the reference's draws in its order (key samples, view / gaze dropout decisions)
         # into the static buffer; the decisions pick the graph variant to replay (captured on first use)
         variant = SAMPLER.refill_static()
+        # device copies this step needs before the replay (the batch's non-video tensors into the static buffers, the
+        # look-ahead tokens into place): ONE launch instead of a blit kernel each
+        copies = []
+        for part in ("train", "target"):
+            for n, v in item[part].items():
+                dst = self._static_item[part][n]
+                if v.dim() == 5 and self._pipelined:
+                    continue  # the main graph reads trunk tokens, not clips
+                if v.data_ptr() != dst.data_ptr():
+                    copies.append((v, dst))
         pending = None  # (item, keys) whose freshly computed tokens go into the cache after the replay
         if not self._pipelined:
             g, out = self._main_graph(False, variant)
@@ -1104,7 +1138,9 @@ class GraphedTrainEngine(TrainEngine):
                     self._trunk_graph().replay()
                     if cache is not None:
                         self._remember_tokens(item, cache.keys_of(self._staged()))
-            self._tok_cur.copy_(self._tok_next)
+            copies.append((self._tok_next, self._tok_cur))
+            self._multi_copy(copies)  # (before anything below refills _tok_next for the NEXT batch)
+            copies = []
             self._ready_id = None
             lookahead = next_item is not None
             if lookahead and self._cached_tokens_into_next(next_item):
@@ -1115,13 +1151,7 @@ class GraphedTrainEngine(TrainEngine):
                     pending = (next_item, cache.keys_of(self._staged()))
             g, out = self._main_graph(lookahead, variant)
         SAMPLER.select_static(variant)
-        for part in ("train", "target"):
-            for n, v in item[part].items():
-                dst = self._static_item[part][n]
-                if v.dim() == 5 and self._pipelined:
-                    continue  # the main graph reads trunk tokens, not clips
-                if v.data_ptr() != dst.data_ptr():
-                    dst.copy_(v, non_blocking=True)
+        self._multi_copy(copies)
         self.reducer.begin_step()  # the replay does not run the Python bookkeeping of zero()
         if self.defer_update:
             self._set_hyper()  # scalars of the update this replay starts with (or "nothing pending")
