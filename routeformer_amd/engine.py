@@ -686,6 +686,8 @@ class TrainEngine:
             if g is not None:
                 p.grad.add_(g)
         K.flush_weight_grads()
+        if self.overlap:
+            K.join_side_streams()  # (the backbone's own side branch: stage 1 may be the end of a captured graph)
         return res, (cut, grads[0])
 
     def _stage2(self, carry):

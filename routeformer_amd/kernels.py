@@ -39,7 +39,7 @@ def _stream():
 # HIP streams lets the otherwise idle CUs overlap them.  Off by default (strict reference call order for
 # the test hooks); the training engine switches it on.  Host-RNG draw order is unaffected.
 OVERLAP = False
-OVERLAP_MASK = int(__import__("os").environ.get("RF_OVERLAP", "3"))  # bit0 target pass, bit1 gaze encoder, bit2 wgrad (no gain measured)
+OVERLAP_MASK = int(__import__("os").environ.get("RF_OVERLAP", "11"))  # bit0 target pass, bit1 gaze encoder, bit2 wgrad (no gain measured), bit3 decoder self-attention block beside the encoder
 _SIDE_STREAMS = {}
 
 

@@ -361,14 +361,20 @@ class DecoderLayer(nn.Module):
 
     _ffn_norm = EncoderLayer._ffn_norm
 
-    def forward(self, x, memory):
+    def self_block(self, x):
+        """x + self-attention -> norm1: the part of the layer that does not read the encoder memory."""
         if self.p > 0.0 and self.training:
-            x = K.add_layer_norm(x, _dropout(self.self_attention(x), self.p, self.training), self.norm1.weight,
-                                 self.norm1.bias)
+            return K.add_layer_norm(x, _dropout(self.self_attention(x), self.p, self.training), self.norm1.weight,
+                                    self.norm1.bias)
+        return self.self_attention(x, norm=self.norm1)
+
+    def forward(self, x, memory, after_self=None):
+        """``after_self``: the output of ``self_block`` if the caller ran it already (on another stream)."""
+        x = after_self if after_self is not None else self.self_block(x)
+        if self.p > 0.0 and self.training:
             x = K.add_layer_norm(x, _dropout(self.cross_attention(x, memory), self.p, self.training),
                                  self.norm2.weight, self.norm2.bias)
         else:
-            x = self.self_attention(x, norm=self.norm1)
             x = self.cross_attention(x, memory, norm=self.norm2)
         return self._ffn_norm(x, self.norm3)
 
@@ -519,9 +525,10 @@ class Decoder(nn.Module):
         self.norm = norm_layer
         self.projection = projection
 
-    def forward(self, x, memory):
-        for layer in self.layers:
-            x = layer(x, memory)
+    def forward(self, x, memory, first=None):
+        """``first``: the first layer's ``self_block`` output, computed by the caller (then ``x`` is not used)."""
+        for i, layer in enumerate(self.layers):
+            x = layer(x, memory, after_self=first if i == 0 else None)
         if self.norm is not None:
             x = K.add_layer_norm(x, None, self.norm.weight, self.norm.bias)
         if self.projection is not None:

@@ -5,6 +5,8 @@ Informer.py:18-167``): ``Informer(configs: GPSBackboneConfig)``, ``forward(x (B,
 import torch
 from torch import nn
 
+from routeformer_amd import kernels as K
+
 from routeformer_amd.models.blocks import (AttentionLayer, DataEmbedding, Decoder, DecoderLayer,
                                            DistilConv, Encoder, EncoderLayer)
 
@@ -45,6 +47,19 @@ class Informer(nn.Module):
         else:
             tail = torch.zeros(B, self.pred_len, C, device=x.device, dtype=torch.float32)
         x_dec = torch.cat([x, tail], dim=1)
+        fork = None
+        if (K.OVERLAP and (K.OVERLAP_MASK & 8) and x.is_cuda and not K.on_side_stream() and len(self.decoder.layers) > 0):
+            # the decoder's embedding and the self-attention block of its first layer do not depend on the encoder:
+            # they run on a side stream that forks HERE (before the encoder), although the host issues them after the
+            # encoder -- the reference's draw order (encoder layers, then decoder) is untouched
+            fork = K.side_stream("decoder")
+            fork.wait_stream(torch.cuda.current_stream())
         memory = self.encoder(self.enc_embedding(x))
-        out = self.decoder(self.dec_embedding(x_dec), memory)
+        if fork is not None:
+            with torch.cuda.stream(fork):
+                first = self.decoder.layers[0].self_block(self.dec_embedding(x_dec))
+            torch.cuda.current_stream().wait_stream(fork)
+            out = self.decoder(None, memory, first=first)
+        else:
+            out = self.decoder(self.dec_embedding(x_dec), memory)
         return out[:, -self.pred_len:, :]
