@@ -1,6 +1,7 @@
 """Steady-state kernel breakdown of the replayed train step from a rocprofv3 kernel trace (csv):
     python tools/step_breakdown.py <dir with *kernel_trace.csv> [n_steps]
-Steps are delimited by the AdamW kernel (one launch per step); the last n complete steps are analysed: per-kernel time,
+Steps are delimited by the gradient-norm kernel (sumsq_kernel: one launch per step in every engine mode); the last n
+complete steps are analysed: per-kernel time,
 launches per step, busy time (union of kernel intervals) and idle gaps of the device."""
 import collections, csv, glob, os, re, sys
 d = sys.argv[1]
@@ -11,9 +12,12 @@ with open(path) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-marks = [i for i, r in enumerate(rows) if "adamw" in r[2].lower()]
-assert len(marks) > n + 1, len(marks)
-lo, hi = marks[-n - 1] + 1, marks[-1] + 1
+marks = [i for i, r in enumerate(rows) if "sumsq_kernel" in r[2]]
+if len(marks) < 3:
+    marks = [i for i, r in enumerate(rows) if "adamw" in r[2].lower()]
+skip = int(sys.argv[3]) if len(sys.argv) > 3 else 3  # trailing marks to leave out: the final flush and the eager profile pass
+assert len(marks) > n + 1 + skip, len(marks)
+lo, hi = marks[-n - 1 - skip], marks[-1 - skip]  # [first launch of a step's head, first launch of the step n later)
 win = rows[lo:hi]
 t0, t1 = win[0][0], win[-1][1]
 def short(k):
