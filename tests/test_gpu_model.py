@@ -951,3 +951,34 @@ def test_fused_stack_backward_vs_layerwise(shape):
     print(f"fused backward {shape}: dx fro err {e_dx:.2e}; worst parameter gradient {worst[0]:.2e} ({worst[1]})")
     assert e_dx < 2e-2, e_dx
     assert worst[0] < 3e-2, worst
+
+
+def test_side_stream_branches_change_nothing():
+    """Every sub-graph the engine moves to a side stream (target-side pass, gaze encoder, the GPS backbone decoder's
+    encoder-independent block) computes what it computes on the main stream: one train step with all forks on
+    (``RF_OVERLAP`` bits 0, 1, 3) against one with none, same host draws -- loss, trajectory and gradients agree up to the
+    summation order of the fp32 atomics (LayerNorm / bias gradients)."""
+    from conftest import fro_err
+    from routeformer_amd import kernels as K
+    from routeformer_amd.engine import TrainEngine
+    K.set_precision("f32")
+    saved = K.OVERLAP_MASK
+    out = {}
+    try:
+        for mask in (0, 11):
+            K.OVERLAP_MASK = mask
+            model, cfg, sd, c = build_product_model("c2_small", DEV)
+            item = case_item(c)
+            item_d = {"train": _to_dev(item["train"]), "target": _to_dev(item["target"])}
+            eng = TrainEngine(model)
+            model.train()
+            torch.manual_seed(5)
+            res = eng._fwd_bwd(item_d, 10)
+            torch.cuda.synchronize()
+            out[mask] = (float(res["loss"].detach()), res["future_gps"].detach().clone(), eng.reducer.flat_grad.clone())
+    finally:
+        K.OVERLAP_MASK = saved
+    (l0, f0, g0), (l1, f1, g1) = out[0], out[11]
+    assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0)), (l0, l1)
+    assert rel_err(f1, f0) < 1e-5
+    assert fro_err(g1, g0) < 1e-4, fro_err(g1, g0)
