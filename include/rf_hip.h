@@ -322,7 +322,8 @@ typedef struct RfSeqStack {
   int n_layers, pad;
 } RfSeqStack;
 typedef struct RfSeqPackEntry {
-  const float* w; void* out; int64_t ldw; int N, K, transpose, pad;
+  const float* w; void* out; int64_t ldw; int N, K, transpose;
+  int residual; /* 1: emit bf16(w - bf16(w)), the low half of a split-bf16 operand (q / k projection of the forward) */
 } RfSeqPackEntry;
 int rf_seqlayer_pack(const RfSeqPackEntry* entries, int count, void* stream);
 /* The same packing driven by a table in DEVICE memory: `entries_dev` (count entries, validated by the caller as for

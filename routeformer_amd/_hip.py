@@ -141,7 +141,7 @@ class GatherEntry(ctypes.Structure):
 class SeqPackEntry(ctypes.Structure):
     """RfSeqPackEntry of include/rf_hip.h."""
     _fields_ = [("w", c_void_p), ("out", c_void_p), ("ldw", c_int64), ("N", c_int), ("K", c_int), ("transpose", c_int),
-                ("pad", c_int)]
+                ("residual", c_int)]
 
 
 class HipLibraryError(RuntimeError):

@@ -42,7 +42,7 @@ struct SeqStackP {
 };
 
 // byte offsets inside a layer's packed blob
-struct PackOff { long wqkv, wo, w1, w2, vec, total; };
+struct PackOff { long wqkv, wo, w1, w2, vec, lo, total; };
 __host__ __device__ inline PackOff pack_offsets(int F) {
   PackOff o;
   o.wqkv = 0;
@@ -50,9 +50,14 @@ __host__ __device__ inline PackOff pack_offsets(int F) {
   o.w1 = o.wo + 8L * 4 * 1024;
   o.w2 = o.w1 + (long)(F / 16) * 4 * 1024;
   o.vec = o.w2 + 8L * (F / 32) * 1024;     // fp32: bqkv[384] bo[128] b1[F] b2[128] g1 be1 g2 be2 [128 each]
-  o.total = (o.vec + (1152L + F) * 4 + 255) & ~255L;
+  o.lo = (o.vec + (1152L + F) * 4 + 255) & ~255L;  // bf16 residuals W - bf16(W) of Wq | Wk: 16 column tiles x 4 k-steps
+  o.total = o.lo + 16L * 4 * 1024;
   return o;
 }
+
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): two bf16 numbers carry ~16 mantissa bits of x (split-bf16).  A product
+// of two such operands is the sum of three bf16 MFMAs (hi hi + lo hi + hi lo; lo lo is below fp32 rounding).
+__device__ __forceinline__ __bf16 bf16_lo(float x, __bf16 hi) { return (__bf16)(x - (float)hi); }
 
 // LayerNorm over the 128 columns of every row, the columns of a row being spread over the 8 waves (16 each, MFMA
 // accumulator layout: v[rt][r] = row 16 rt + 4 (lane >> 4) + r, column 16 wave + (lane & 15)).  Per-wave partial
@@ -129,6 +134,10 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
   float2* stat = part + LP * SL_NW;
   unsigned int* cnt32 = reinterpret_cast<unsigned int*>(stat + LP);  // [key][query / 4]: four queries per word
   __bf16* hb = qs;  // conv-pair phase alias
+  // low half of the split-bf16 image of x ([LP][SL_XP], 16 RT x 272 B <= the V^T region): lives in the V^T region from
+  // the end of a layer (the conv-pair images are dead) until the q / k projection of the next one has read it
+  __bf16* xlo = vt;
+  static_assert((size_t)LP * SL_XP <= (size_t)SL_H * SL_E * VP, "x_lo image must fit the V^T region");
 
   int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
   const int wave = tid >> 6;
@@ -157,7 +166,11 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xb[(rt * 16 + fq * 4 + r) * SL_XP + wave * 16 + fr] = (__bf16)xres[rt][r];
+      for (int r = 0; r < 4; ++r) {
+        const __bf16 hi = (__bf16)xres[rt][r];
+        xb[(rt * 16 + fq * 4 + r) * SL_XP + wave * 16 + fr] = hi;
+        xlo[(rt * 16 + fq * 4 + r) * SL_XP + wave * 16 + fr] = bf16_lo(xres[rt][r], hi);
+      }
   }
   const PackOff po = pack_offsets(F);
   uint2 dkey = make_uint2(0, 0);
@@ -207,56 +220,103 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
         }
       }
     }
-    // zero the key padding of V^T (columns LP..KS32-1 are never written; the conv-pair phase overwrote the region)
-    if constexpr (KS32 > LP) {
-      for (int i = lane; i < SL_E * (KS32 - LP); i += 64)
-        vt[(wave * SL_E + i / (KS32 - LP)) * VP + LP + i % (KS32 - LP)] = (__bf16)0.f;
-    }
     SL_MARK(0);
-    __syncthreads();  // xb complete (written by all waves), idx8 visible
+    __syncthreads();  // xb / x_lo complete (written by all waves), count image visible
     SL_MARK(1);
 
     SL_LOCAL();
     // ================= phase 1: q | k | v of head `wave` =================
+    // q and k feed the ProbSparse sparsity measure, whose top-u ranking is DISCONTINUOUS: a bf16-level rounding of the
+    // projection or of q / k flips selections that the fp32 reference makes the other way (SURVEY section 7 "ProbSparse
+    // parity": measure from ~fp32-accurate scores).  Both are therefore computed in split-bf16 (x = hi + lo, W = hi + lo:
+    // three MFMAs per product, ~2^-16 relative) and kept as hi (qs / ks: what the softmax rows and the backward use)
+    // + lo (wave-private scratch, read by the measure only); v, P V, the out-projection and the conv pair stay bf16.
     {
+      constexpr int LO_BYTES = 2 * LP * SL_E * 2;
+      static_assert(LO_BYTES + TB * 4 <= 6656, "q / k low halves + one staged tile must fit the wave scratch");
       float* qkv_g = SAVE ? p.qkv + lrow * (3 * SL_D) + wave * 16 : nullptr;
+      __bf16* ql = reinterpret_cast<__bf16*>(scr);
+      __bf16* kl = ql + LP * SL_E;
+      float* st1 = reinterpret_cast<float*>(scr + LO_BYTES);  // one staged 16 x 16 tile (pitch 20)
+      const __bf16* w_lo = reinterpret_cast<const __bf16*>(wl + po.lo);
+      bf16x8 wlo[2][4];
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wlo[pt][kk] = ld_wfrag(w_lo, (pt * 8 + wave) * 4 + kk, lane);
+      // ---- 1a: q, k ----
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        bf16x8 a[4];
+        bf16x8 a[4], al[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) a[kk] = ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8);
-        f32x4 acc[3];
+        for (int kk = 0; kk < 4; ++kk) {
+          a[kk] = ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8);
+          al[kk] = ld_frag(xlo + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8);
+        }
+        f32x4 acc[2];
 #pragma unroll
-        for (int pt = 0; pt < 3; ++pt) {
+        for (int pt = 0; pt < 2; ++pt) {
           acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[kk], wf[pt][kk], acc[pt], 0, 0, 0);
+            acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk], wlo[pt][kk], acc[pt], 0, 0, 0);
+          }
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk], wf[pt][kk], acc[pt], 0, 0, 0);
         }
         const int row0 = rt * 16 + fq * 4;
 #pragma unroll
-        for (int pt = 0; pt < 3; ++pt)
+        for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             acc[pt][r] = row0 + r < L ? acc[pt][r] + bias[pt] : 0.f;  // padded rows: exact zeros (masked keys, unused queries)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          qs[(wave * LP + row0 + r) * SL_E + fr] = (__bf16)acc[0][r];
-          ks[(wave * LP + row0 + r) * SL_E + fr] = (__bf16)acc[1][r];
+          const __bf16 qh = (__bf16)acc[0][r], kh = (__bf16)acc[1][r];
+          qs[(wave * LP + row0 + r) * SL_E + fr] = qh;
+          ks[(wave * LP + row0 + r) * SL_E + fr] = kh;
+          ql[(row0 + r) * SL_E + fr] = bf16_lo(acc[0][r], qh);
+          kl[(row0 + r) * SL_E + fr] = bf16_lo(acc[1][r], kh);
         }
-        const bf16x4 v4 = {(__bf16)acc[2][0], (__bf16)acc[2][1], (__bf16)acc[2][2], (__bf16)acc[2][3]};
-        *reinterpret_cast<bf16x4*>(vt + (wave * SL_E + fr) * VP + row0) = v4;  // V^T: 4 consecutive keys of channel fr
-        if (qkv_g) {  // q | k | v of these 16 rows: three staged tiles, one 16-B store per lane and tile
+        if (qkv_g) {  // q | k of these 16 rows: a staged tile each, one 16-B store per lane and tile
 #pragma unroll
-          for (int pt = 0; pt < 3; ++pt)
+          for (int pt = 0; pt < 2; ++pt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sc_f[pt * TB + (fq * 4 + r) * 20 + fr] = acc[pt][r];
-          wave_sync_lds();
-          if (rt * 16 + srow < L) {
-#pragma unroll
-            for (int pt = 0; pt < 3; ++pt)
+            for (int r = 0; r < 4; ++r) st1[(fq * 4 + r) * 20 + fr] = acc[pt][r];
+            wave_sync_lds();
+            if (rt * 16 + srow < L)
               *reinterpret_cast<float4*>(qkv_g + (rt * 16 + srow) * (3 * SL_D) + pt * SL_D + sc4) =
-                  *reinterpret_cast<const float4*>(sc_f + pt * TB + srow * 20 + sc4);
+                  *reinterpret_cast<const float4*>(st1 + srow * 20 + sc4);
+            wave_sync_lds();
           }
+        }
+      }
+      __syncthreads();  // every wave has read x_lo: its LDS becomes V^T
+      // ---- 1b: v ----
+      // zero the key padding of V^T (columns LP..KS32-1 are never written; x_lo / the conv-pair phase overwrote the region)
+      if constexpr (KS32 > LP) {
+        for (int i = lane; i < SL_E * (KS32 - LP); i += 64)
+          vt[(wave * SL_E + i / (KS32 - LP)) * VP + LP + i % (KS32 - LP)] = (__bf16)0.f;
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8), wf[2][kk], acc, 0, 0, 0);
+        const int row0 = rt * 16 + fq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = row0 + r < L ? acc[r] + bias[2] : 0.f;
+        const bf16x4 v4 = {(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
+        *reinterpret_cast<bf16x4*>(vt + (wave * SL_E + fr) * VP + row0) = v4;  // V^T: 4 consecutive keys of channel fr
+        if (qkv_g) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st1[(fq * 4 + r) * 20 + fr] = acc[r];
+          wave_sync_lds();
+          if (rt * 16 + srow < L)
+            *reinterpret_cast<float4*>(qkv_g + (rt * 16 + srow) * (3 * SL_D) + 2 * SL_D + sc4) =
+                *reinterpret_cast<const float4*>(st1 + srow * 20 + sc4);
           wave_sync_lds();
         }
       }
@@ -275,6 +335,8 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
       const __bf16* Q = qs + wave * LP * SL_E;
       const __bf16* Kh = ks + wave * LP * SL_E;
       const __bf16* Vt = vt + wave * SL_E * VP;
+      const __bf16* Ql = reinterpret_cast<const __bf16*>(scr);  // low halves of q / k (phase 1a), dead after the measure
+      const __bf16* Kl = Ql + LP * SL_E;
       int32_t* top_g = p.top ? p.top + (((long)li * p.B + b) * SL_H + wave) * p.n_top : nullptr;
       const int u = p.n_top;
       bf16x8 kb[RT];
@@ -288,11 +350,15 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const bf16x8 qa = fq < 2 ? ld_frag(Q + (rt * 16 + fr) * SL_E + fq * 8) : zero_frag();
+          const bf16x8 qal = fq < 2 ? ld_frag(Ql + (rt * 16 + fr) * SL_E + fq * 8) : zero_frag();
           float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ct = 0; ct < RT; ++ct) {
             const unsigned int c4 = cnt32[((ct * 16 + fr) * LP + rt * 16 + fq * 4) >> 2];
-            const f32x4 sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kb[ct], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const bf16x8 kbl = fq < 2 ? ld_frag(Kl + (ct * 16 + fr) * SL_E + fq * 8) : zero_frag();
+            f32x4 sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qal, kb[ct], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kbl, sv, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kb[ct], sv, 0, 0, 0);  // ~fp32-accurate q . k
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const unsigned int c = (c4 >> (8 * r)) & 0xffu;
@@ -645,7 +711,9 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
         for (int r = 0; r < 4; ++r) {
           const float y2 = v[rt][r] * g2 + be2;
           xres[rt][r] = y2;
-          xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)y2;  // next layer's A operand
+          const __bf16 hi = (__bf16)y2;
+          xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = hi;  // next layer's A operand ...
+          xlo[(rt * 16 + fq * 4 + r) * SL_XP + col] = bf16_lo(y2, hi);  // ... and its low half (the conv-pair images are dead)
         }
       if (store_y) {
 #pragma unroll
@@ -695,8 +763,10 @@ __global__ __launch_bounds__(256) void seq_pack_kernel(const PackTable t) {
   const int ct = f / KS, kk = f % KS, n = ct * 16 + (lane & 15), k0 = kk * 32 + (lane >> 4) * 8;
   bf16x8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
-    o[j] = (__bf16)(ent.transpose ? ent.w[(long)(k0 + j) * ent.ldw + n] : ent.w[(long)n * ent.ldw + k0 + j]);
+  for (int j = 0; j < 8; ++j) {
+    const float w = ent.transpose ? ent.w[(long)(k0 + j) * ent.ldw + n] : ent.w[(long)n * ent.ldw + k0 + j];
+    o[j] = ent.residual ? bf16_lo(w, (__bf16)w) : (__bf16)w;
+  }
   *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(ent.out) + ((long)f * 64 + lane) * 8) = o;
 }
 
@@ -721,8 +791,10 @@ __global__ __launch_bounds__(256) void seq_pack_table_kernel(const RfSeqPackEntr
   const int ct = f / KS, kk = f % KS, n = ct * 16 + (lane & 15), k0 = kk * 32 + (lane >> 4) * 8;
   bf16x8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
-    o[j] = (__bf16)(ent.transpose ? ent.w[(long)(k0 + j) * ent.ldw + n] : ent.w[(long)n * ent.ldw + k0 + j]);
+  for (int j = 0; j < 8; ++j) {
+    const float w = ent.transpose ? ent.w[(long)(k0 + j) * ent.ldw + n] : ent.w[(long)n * ent.ldw + k0 + j];
+    o[j] = ent.residual ? bf16_lo(w, (__bf16)w) : (__bf16)w;
+  }
   *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(ent.out) + ((long)f * 64 + lane) * 8) = o;
 }
 

@@ -451,6 +451,7 @@ class FusedAdamW:
         self.betas, self.eps, self.wd, self.max_norm = betas, eps, weight_decay, max_grad_norm
         self.param_groups = [{"lr": lr}]  # what an LR scheduler drives (optimizers.LinearWarmupCosineAnnealingLR)
         self.t = 0
+        self._lag = {}  # (lo, hi) of a skippable range -> number of steps it was skipped (per-parameter step counters)
 
     @property
     def lr(self) -> float:
@@ -482,6 +483,25 @@ class FusedAdamW:
                                                 hyper_dev.data_ptr(), K._stream()), "rf_adamw_clip_dev")
         K.WEIGHTS_EPOCH += 1
 
+    def _segments(self, lo: int, hi: int, skip):
+        """[(a, b, t)] covering [lo, hi) minus the ``skip`` ranges, cut at the boundaries of every range that was skipped
+        in an EARLIER step: torch.optim.AdamW keeps ``state['step']`` per parameter and advances it only when the
+        parameter has a gradient (full_comparison.py:694-702 + routeformer.py:299-310: a dropped gaze branch leaves
+        ``.grad`` None), so the bias corrections of such a range use its own update count ``t - lag``."""
+        cuts = sorted(set([lo, hi] + [x for r in list(skip) + list(self._lag) for x in r if lo < x < hi]))
+        out = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if any(x <= a and b <= y for x, y in skip):
+                continue
+            lag = max([n for (x, y), n in self._lag.items() if x <= a and b <= y] + [0])
+            out.append((a, b, self.t - lag))
+        return out
+
+    def _note_skipped(self, skip):
+        for r in skip:
+            r = (int(r[0]), int(r[1]))
+            self._lag[r] = self._lag.get(r, 0) + 1
+
     def step_sharded(self, reducer: "GradReducer", grad_scale: float, skip=()):
         """Modes "direct" / "direct_bf16": this rank holds the rank-summed gradients of ITS chunk of every region; it
         clips with the GLOBAL norm (per-chunk partial sums of squares, all-gathered: every rank adds the same W x P
@@ -489,6 +509,7 @@ class FusedAdamW:
         in-place all-gather of the parameters follows (``reducer.gather_params``)."""
         from routeformer_amd import _hip, kernels as K
         self.t += 1
+        self._note_skipped(skip)
         chunks = reducer.local_chunks()
         parts = [int(_hip.lib().rf_sumsq_parts(b - a)) for a, b in chunks]
         local = torch.zeros(sum(parts), device=self.p.device, dtype=torch.float32)
@@ -498,35 +519,31 @@ class FusedAdamW:
             o += n_p
         everyone = reducer.all_gather_floats(local)
         for a, b in chunks:
-            lo = a
-            for sa, sb in [(max(x, a), min(y, b)) for x, y in skip if max(x, a) < min(y, b)] + [(b, b)]:
-                if sa > lo:
-                    q = 4 * lo
-                    _hip.check(_hip.lib().rf_adamw_clip(self.p.data_ptr() + q, self.g.data_ptr() + q, self.m.data_ptr() + q,
-                                                        self.v.data_ptr() + q, sa - lo, everyone.data_ptr(), everyone.numel(),
-                                                        self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
-                                                        self.wd, self.t, grad_scale, K._stream()), "rf_adamw_clip")
-                lo = max(lo, sb)
+            for sa, sb, t in self._segments(a, b, skip):
+                q = 4 * sa
+                _hip.check(_hip.lib().rf_adamw_clip(self.p.data_ptr() + q, self.g.data_ptr() + q, self.m.data_ptr() + q,
+                                                    self.v.data_ptr() + q, sb - sa, everyone.data_ptr(), everyone.numel(),
+                                                    self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
+                                                    self.wd, t, grad_scale, K._stream()), "rf_adamw_clip")
         reducer.gather_params()
         K.WEIGHTS_EPOCH += 1
 
     def step(self, grad_scale: float = 1.0, skip=()):
         """``skip``: sorted, disjoint [lo, hi) ranges of the flat buffers that took no part in this step (their
-        ``.grad`` would be None in the reference, whose AdamW then leaves the parameter AND its moments untouched --
-        no weight decay either; they contribute nothing to the clip norm: their gradient slots are zero)."""
+        ``.grad`` would be None in the reference, whose AdamW then leaves the parameter, its moments AND its step
+        counter untouched -- no weight decay either; they contribute nothing to the clip norm: their gradient slots
+        are zero)."""
         from routeformer_amd import _hip, kernels as K
         self.t += 1
+        self._note_skipped(skip)
         n = self.p.numel()
         _hip.check(_hip.lib().rf_sumsq(self.g.data_ptr(), n, self.sumsq.data_ptr(), K._stream()), "rf_sumsq")
-        lo = 0
-        for a, b in list(skip) + [(n, n)]:
-            if a > lo:
-                o = 4 * lo
-                _hip.check(_hip.lib().rf_adamw_clip(self.p.data_ptr() + o, self.g.data_ptr() + o, self.m.data_ptr() + o,
-                                                    self.v.data_ptr() + o, a - lo, self.sumsq.data_ptr(), self.parts,
-                                                    self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
-                                                    self.wd, self.t, grad_scale, K._stream()), "rf_adamw_clip")
-            lo = max(lo, b)
+        for a, b, t in self._segments(0, n, skip):
+            o = 4 * a
+            _hip.check(_hip.lib().rf_adamw_clip(self.p.data_ptr() + o, self.g.data_ptr() + o, self.m.data_ptr() + o,
+                                                self.v.data_ptr() + o, b - a, self.sumsq.data_ptr(), self.parts,
+                                                self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps,
+                                                self.wd, t, grad_scale, K._stream()), "rf_adamw_clip")
         K.WEIGHTS_EPOCH += 1  # parameters were rewritten in place: cached bf16 copies are stale
 
 
@@ -750,7 +767,9 @@ class GraphedTrainEngine(TrainEngine):
         self._out = None
         self._trunk_g = None
         self._ready_id = None
-        self._cached_ids = {}
+        self._cached_ids = {}     # batch id -> (cache slots, content keys) of its frames
+        self._uncached_ids = set()  # ids whose frames did not fit into the cache
+        self._id_bad = self._id_bad_host = self._id_checked = None
         self._clip_stage = self._clip_idx = None
         self._recipe = None
         self._tstream = None
@@ -895,24 +914,80 @@ class GraphedTrainEngine(TrainEngine):
 
     def _cached_tokens_into_next(self, item) -> bool:
         """Tokens of a batch the cache already holds (known by its explicit id) -> ``_tok_next``; no trunk pass, no
-        host synchronisation."""
+        host synchronisation.  An id is a promise that the frames are the ones seen under it before; the promise is
+        CHECKED: the incoming frames are hashed again on the device and compared with the keys remembered for the id,
+        the verdict is read back asynchronously and a reused id raises at the start of the next step (``verify_ids()``
+        forces the check)."""
         cache, iid = self._cache(), item.get("id")
-        slots = self._cached_ids.get(iid) if (cache is not None and iid is not None) else None
-        if slots is None:
+        hit = self._cached_ids.get(iid) if (cache is not None and iid is not None) else None
+        if hit is None:
             return False
-        cache.gather(slots, self._tok_next)
+        if not self._check_id_content(item):
+            return False  # cannot be hashed in place: take the trunk path
+        cache.gather(hit[0], self._tok_next)
         return True
+
+    def _check_id_content(self, item) -> bool:
+        """Device-side check that the frames of ``item`` are the ones remembered under its id (no host synchronisation;
+        ``verify_ids`` reads the verdict).  False when the id is unknown or the clips cannot be hashed in place."""
+        cache, iid = self._cache(), item.get("id")
+        hit = self._cached_ids.get(iid) if (cache is not None and iid is not None) else None
+        if hit is None:
+            return False
+        clips, _ = self.model.video_clips([item["train"], item["target"]])
+        if not all(v.is_cuda and v.is_contiguous() for v, _ in clips):
+            return False
+        keys = hit[1]
+        if self._id_bad is None:
+            self._id_bad = torch.zeros(1, dtype=torch.bool, device=keys.device)
+            self._id_bad_host = torch.zeros(1, dtype=torch.bool).pin_memory()
+        self._id_bad |= (cache.keys_of(clips) != keys).any()
+        self._id_bad_host.copy_(self._id_bad, non_blocking=True)
+        self._id_checked = (torch.cuda.Event(), iid)
+        self._id_checked[0].record()
+        return True
+
+    def verify_ids(self, block: bool = True):
+        """Raise if a batch id was reused for different frames (see ``_cached_tokens_into_next``).  ``block=False``: only
+        look at a verdict that has already arrived."""
+        pend = self.__dict__.get("_id_checked")
+        if pend is None:
+            return
+        if block:
+            pend[0].synchronize()
+        elif not pend[0].query():
+            return
+        self._id_checked = None
+        if bool(self._id_bad_host[0]):
+            self._cached_ids.clear()
+            self._id_bad.zero_()
+            raise RuntimeError(f"GraphedTrainEngine: batch id {pend[1]!r} (or an earlier one) came with frames that differ from "
+                               "the ones cached under it -- an id must identify the frame content for as long as the "
+                               "engine lives (forget_ids() after changing the loader); the affected step trained on "
+                               "the cached tokens")
+
+    def forget_ids(self):
+        """Drop the id -> cache-slot memory (call when the loader / dataset / id scheme changes)."""
+        self._cached_ids.clear()
+        self._uncached_ids.clear()
+        self._ready_id = None
 
     def _remember_tokens(self, item, keys):
         """After a trunk pass over the staged frames of ``item``: store its tokens (content-keyed), and remember the
-        slots under the batch id (one device synchronisation, the first time a batch is seen)."""
+        slots AND keys under the batch id (one device synchronisation, the first time a batch is seen; an id whose
+        frames did not fit is remembered too, so a cache smaller than the dataset costs no further synchronisations)."""
         cache, iid = self._cache(), item.get("id")
-        if cache is None or keys is None:
+        if cache is None or keys is None or iid is None or iid in self._uncached_ids:
             return
         slots, _ = cache.lookup(keys, count_misses=False)
         final = cache.insert(keys, slots, self._tok_next)
-        if iid is not None and bool((final >= 0).all()):
-            self._cached_ids[iid] = final
+        if bool((final >= 0).all()):
+            self._cached_ids[iid] = (final, keys)
+        else:
+            if not self._uncached_ids:
+                import warnings
+                warnings.warn("TokenCache is full: batches that do not fit keep running the conv trunk every step")
+            self._uncached_ids.add(iid)
 
     def _trunk_graph(self):
         """Graph of one trunk pass over the staged frames into ``self._tok_next`` (cold start / no look-ahead)."""
@@ -1105,6 +1180,7 @@ class GraphedTrainEngine(TrainEngine):
         tokens computed ahead for ``next_item`` are used by the following call only if its ``item`` carries the same
         id; without ids every step runs its own trunk pass first (correct, just not pipelined)."""
         from routeformer_amd.models.blocks import SAMPLER
+        self.verify_ids(block=False)
         if self.graph is None:
             self.capture(item, epoch)
         recipe = self._recipe_for(epoch)
@@ -1134,7 +1210,9 @@ class GraphedTrainEngine(TrainEngine):
         else:
             iid = item.get("id")
             cache = self._cache()
-            if not (self._ready_id is not None and iid is not None and iid == self._ready_id):
+            if self._ready_id is not None and iid is not None and iid == self._ready_id:
+                self._check_id_content(item)  # tokens were computed ahead under this id: same frames? (cache attached)
+            else:
                 if not self._cached_tokens_into_next(item):  # cold start / no look-ahead: run this batch's trunk now
                     self._stage_clips(item)
                     self._trunk_graph().replay()
@@ -1144,7 +1222,8 @@ class GraphedTrainEngine(TrainEngine):
             self._multi_copy(copies)  # (before anything below refills _tok_next for the NEXT batch)
             copies = []
             self._ready_id = None
-            lookahead = next_item is not None
+            # (a next_item without an id could not be recognised by the following call: its trunk pass would be wasted)
+            lookahead = next_item is not None and next_item.get("id") is not None
             if lookahead and self._cached_tokens_into_next(next_item):
                 lookahead = False  # tokens of the next batch are already in _tok_next: no trunk branch this step
             elif lookahead:

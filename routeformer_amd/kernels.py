@@ -1104,6 +1104,11 @@ class TopSelection:
     ``forced``: list of selections to impose, consumed in call order (teacher forcing)."""
     record: Optional[list] = None
     forced: Optional[list] = None
+    # ``shadow`` (with ``forced``): list receiving, call by call, the selection the kernel WOULD have made on the same
+    # (teacher-forced) inputs -- the call runs twice, free first (outputs discarded), then with the imposed selection.
+    # Flip-rate diagnostics (tools/flip_rate.py, bench.py ade_vs_cpu_ref): every call is judged on inputs that are
+    # still on the oracle's trajectory.  For a fused stack the free pass covers all its layers at once.
+    shadow: Optional[list] = None
 
     def merge_forced(self, n_calls: int, n_layers: int):
         """``n_calls`` reference encoder calls (each ``n_layers`` selections) run as one batched call:
@@ -1114,15 +1119,32 @@ class TopSelection:
         self.forced = [torch.cat([head[c * n_layers + l] for c in range(n_calls)], dim=0)
                        for l in range(n_layers)] + rest
 
+    def swap_blocks(self, n_first: int, n_second: int, *, before: bool):
+        """The host CALLS a block of ``n_second`` ProbSparse layers (the gaze-token encoder on its side stream) ahead of
+        the ``n_first`` layers that precede it in the reference's order (the camera streams' frame encoders).
+        ``before=True`` (ahead of the calls): queue the imposed selections in call order; ``before=False`` (after both
+        blocks ran): put what was recorded back into reference order.  Test hooks only."""
+        if before:
+            if self.forced is not None:
+                f = self.forced
+                self.forced = f[n_first:n_first + n_second] + f[:n_first] + f[n_first + n_second:]
+            return
+        for lst in (self.record, self.shadow):
+            if lst is not None and len(lst) >= n_first + n_second:
+                tail = lst[-(n_first + n_second):]
+                del lst[-(n_first + n_second):]
+                lst.extend(tail[n_second:] + tail[:n_second])
+
     def split_record(self, n_calls: int, n_layers: int):
         """Inverse bookkeeping for ``record``: re-emit a batched call's selections in reference order."""
-        if self.record is None or n_calls == 1:
-            return
-        tail = self.record[-n_layers:]
-        del self.record[-n_layers:]
-        for c in range(n_calls):
-            for l in range(n_layers):
-                self.record.append(tail[l].chunk(n_calls, dim=0)[c])
+        for lst in (self.record, self.shadow):
+            if lst is None or n_calls == 1 or len(lst) < n_layers:
+                continue
+            tail = lst[-n_layers:]
+            del lst[-n_layers:]
+            for c in range(n_calls):
+                for l in range(n_layers):
+                    lst.append(tail[l].chunk(n_calls, dim=0)[c])
 
 
 TOPS = TopSelection()
@@ -1157,6 +1179,14 @@ class _Attention(torch.autograd.Function):
             if forced_top is None and TOPS.forced is not None:
                 forced_top = TOPS.forced.pop(0).to(device=a.device, dtype=torch.int32).contiguous()
                 assert tuple(forced_top.shape) == (B, H, n_top), (tuple(forced_top.shape), (B, H, n_top))
+                if TOPS.shadow is not None and index_sample is not None:
+                    free = torch.empty(B, H, n_top, device=a.device, dtype=torch.int32)
+                    check(_hip.lib().rf_attn_fwd(
+                        a.data_ptr() + 4 * q_off, b.data_ptr() + 4 * k_off, b.data_ptr() + 4 * v_off, a.stride(0), b.stride(0),
+                        b.stride(0), ptr(out), out_layout, ptr(index_sample), idx_group,
+                        (index_sample.stride(0) if index_sample.dim() == 3 else 0), ptr(free), 0, B, H, LQ, LK, E,
+                        index_sample.shape[-1], n_top, mode, scale, _stream()), "rf_attn_fwd(shadow)")
+                    TOPS.shadow.append(free)
             top = forced_top if forced_top is not None else \
                 torch.empty(B, H, n_top, device=a.device, dtype=torch.int32)
             sample_k = index_sample.shape[-1] if index_sample is not None else 0
@@ -1419,7 +1449,7 @@ class PackPlan:
         first, blocks = [], 0
         for e, (w, off, ldw, N, K_, tr) in zip(arr, ents):
             assert K_ == 0 or (N % 16 == 0 and K_ % 32 == 0 and off % 16 == 0)
-            e.w, e.out, e.ldw, e.N, e.K, e.transpose, e.pad = w, off, ldw, N, K_, tr, 0
+            e.w, e.out, e.ldw, e.N, e.K, e.transpose, e.residual = w, off, ldw, N, K_, tr & 1, tr >> 1
             first.append(blocks)
             blocks += int(_hip.lib().rf_seqlayer_pack_blocks(N, K_))
         raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
@@ -1441,7 +1471,7 @@ def _pack_launch(ents, collect):
         chunk = ents[s0:s0 + _hip.SEQLAYER_MAX_PACK]
         arr = (_hip.SeqPackEntry * len(chunk))()
         for e, (w, off, ldw, N, K_, tr) in zip(arr, chunk):
-            e.w, e.out, e.ldw, e.N, e.K, e.transpose, e.pad = w, off, ldw, N, K_, tr, 0
+            e.w, e.out, e.ldw, e.N, e.K, e.transpose, e.residual = w, off, ldw, N, K_, tr & 1, tr >> 1
         check(_hip.lib().rf_seqlayer_pack(arr, len(chunk), _stream()), "rf_seqlayer_pack")
 
 
@@ -1452,13 +1482,13 @@ def seqstack_pack(layers, out: torch.Tensor, stride: int, collect=None):
     ents = []
     base = out.data_ptr()
 
-    def mat(w, off, N, K):
+    def mat(w, off, N, K, lo=0):
         assert w.dtype == torch.float32 and w.stride(-1) == 1
-        ents.append((w, off, w.stride(0), N, K))
+        ents.append((w, off, w.stride(0), N, K, 2 * lo))  # flags: bit 0 transpose, bit 1 low half of the split-bf16 weight
 
     def vecs(v, off, n):
         assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == n
-        ents.append((v, off, 0, n, 0))
+        ents.append((v, off, 0, n, 0, 0))
 
     for li, d in enumerate(layers):
         F_ = d["w1"].shape[0]
@@ -1466,20 +1496,24 @@ def seqstack_pack(layers, out: torch.Tensor, stride: int, collect=None):
         o_wo, o_w1 = 24 * 4096, 24 * 4096 + 8 * 4096
         o_w2 = o_w1 + (F_ // 16) * 4096
         o_vec = o_w2 + 8 * (F_ // 32) * 1024
+        o_lo = (o_vec + (1152 + F_) * 4 + 255) & ~255  # low halves of Wq | Wk (split-bf16 q / k projection)
         if "wqkv" in d:
             mat(d["wqkv"], o, 384, 128)
+            mat(d["wqkv"][:256], o + o_lo, 256, 128, lo=1)
             vecs(d["bqkv"], o + o_vec, 384)
         else:
             for i, n in enumerate(("q", "k", "v")):
                 mat(d["w" + n], o + i * 32 * 1024, 128, 128)
                 vecs(d["b" + n], o + o_vec + i * 512, 128)
+                if i < 2:
+                    mat(d["w" + n], o + o_lo + i * 32 * 1024, 128, 128, lo=1)
         mat(d["wo"], o + o_wo, 128, 128)
         mat(d["w1"], o + o_w1, F_, 128)
         mat(d["w2"], o + o_w2, 128, F_)
         for n, pos, cnt in (("bo", 384, 128), ("b1", 512, F_), ("b2", 512 + F_, 128), ("g1", 640 + F_, 128),
                             ("be1", 768 + F_, 128), ("g2", 896 + F_, 128), ("be2", 1024 + F_, 128)):
             vecs(d[n], o + o_vec + 4 * pos, cnt)
-    _pack_launch([(w.data_ptr(), off, ldw, N, K_, 0) for (w, off, ldw, N, K_) in ents], collect)
+    _pack_launch([(w.data_ptr(), off, ldw, N, K_, fl) for (w, off, ldw, N, K_, fl) in ents], collect)
 
 
 def seqstack_bwd_pack(layers, out: torch.Tensor, stride: int, collect=None):
@@ -1621,6 +1655,10 @@ class _SeqStack(torch.autograd.Function):
                 for li in range(len(stack.layers)):
                     for k, cols in enumerate((D, F_, D)):
                         RNG.record.append(RNG.materialise(site0 + 3 * li + k, (B, L, cols), drop_p, x.device))
+        if forced is not None and TOPS.shadow is not None:  # free pass on the same input, selections only
+            free = _seqstack_launch(x2, stack.wpack, stack.stride, idx_list, idx_group, B, L, F_, lay0.act, sample_k, n_top,
+                                    True, None, lay0.norm1.eps, 0.0, 0)
+            TOPS.shadow.extend(t for t in free["top"])
         sv = _seqstack_launch(x2, stack.wpack, stack.stride, idx_list, idx_group, B, L, F_, lay0.act, sample_k, n_top,
                               save, forced, lay0.norm1.eps, drop_p, site0)
         if TOPS.record is not None and "top" in sv:

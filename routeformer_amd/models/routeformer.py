@@ -227,11 +227,15 @@ class Routeformer(nn.Module):
                 # main stream encodes the video frames (its host draws still come after the frame draws)
                 fork = K.side_stream("gaze")
                 fork.wait_stream(torch.cuda.current_stream())
+                swap = (len(jobs) * len(self.frame_encoder.encoder.attn_layers), len(self.gaze_encoder.encoder.attn_layers))
+                K.TOPS.swap_blocks(*swap, before=True)  # test hooks: imposed selections arrive in the reference's order
                 with torch.cuda.stream(fork):
                     tokens = median_downsampler(batch["gaze"].to(torch.float32), c.gps_backbone_config.seq_len)
                     tokens = self.gaze_encoder(tokens)
             for slot, timeline in self._encode_streams(jobs):
                 visual[slot] = timeline
+            if fork is not None:
+                K.TOPS.swap_blocks(*swap, before=False)
             if use_gaze:
                 gaze_video = visual[-1]
                 if fork is None:

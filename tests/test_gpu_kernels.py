@@ -683,6 +683,39 @@ def test_adamw_clip():
         assert rel_err(pd, pc) < 1e-5, step
 
 
+def test_fused_adamw_skipped_ranges_keep_their_own_step_count():
+    """A parameter range that took no part in a step (dropped gaze branch: ``.grad`` None in the reference) is left
+    untouched by torch.optim.AdamW INCLUDING its per-parameter ``state['step']``: when it is updated again its bias
+    corrections use its own update count.  ``FusedAdamW.step(skip=...)`` against torch.optim.AdamW on three parameters,
+    the middle one skipped in steps 2, 3 and 5 (the fused update used the global step for every slot)."""
+    from routeformer_amd.engine import FusedAdamW
+    g = _g(9)
+    sizes = [640, 1280, 320]
+    offs = [0, 640, 1920]
+    n = sum(sizes)
+    p0 = torch.randn(n, generator=g)
+    ps = [p0[o:o + k].clone().requires_grad_() for o, k in zip(offs, sizes)]
+    ref = torch.optim.AdamW(ps, lr=1e-2, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    flat_p, flat_g = p0.clone().to(DEV), torch.zeros(n, device=DEV)
+    opt = FusedAdamW(flat_p, flat_g, lr=1e-2, weight_decay=1e-2, max_grad_norm=2.5)
+    for step in range(1, 8):
+        skipped = step in (2, 3, 5)
+        grads = [torch.randn(k, generator=g) * 0.7 for k in sizes]
+        flat_g.zero_()
+        for i, (o, k) in enumerate(zip(offs, sizes)):
+            if i == 1 and skipped:
+                ps[i].grad = None
+            else:
+                ps[i].grad = grads[i].clone()
+                flat_g[o:o + k] = grads[i].to(DEV)
+        torch.nn.utils.clip_grad_norm_([q for q in ps if q.grad is not None], 2.5)
+        ref.step()
+        opt.step(1.0, skip=((offs[1], offs[1] + sizes[1]),) if skipped else ())
+        got = flat_p.cpu()
+        for i, (o, k) in enumerate(zip(offs, sizes)):
+            assert rel_err(got[o:o + k], ps[i]) < 2e-6, (step, i)
+
+
 def _bf(x):
     return x.to(torch.bfloat16).to(torch.float32)
 

@@ -18,6 +18,7 @@ from oracle import routeformer_oracle as O  # noqa: E402
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL_F32, TOL_BF16 = 1e-3, 1e-2
+BF16_GRAD_COS, BF16_GRAD_NORM = 0.99, 5e-2  # per-parameter gradient agreement with the oracle in bf16 mode
 
 
 @pytest.fixture(autouse=True)
@@ -45,21 +46,63 @@ def _load(module, seed=7):
     return module.to(DEV)
 
 
-def _check_grads(G, key, named_params, tol):
+def _check_grads(G, key, named_params, tol, oracle_grads=None, tol_full=None, loose=(), tol_loose=0.0):
+    """Parameter gradients against the reference's record (tests/golden/make_golden.py: L2 norm AND sum of every
+    parameter gradient, a handful of full tensors) and -- ``oracle_grads`` -- against the CPU oracle's autograd
+    gradients ELEMENT BY ELEMENT for every parameter (the oracle's gradients themselves match the reference's norms and
+    sums to <= 6e-4, tests/test_oracle_golden.py::test_model_train_step): a permutation or a sign
+    error inside a large parameter cannot hide behind its norm.  Errors are relative to the parameter's own largest
+    gradient element (floored at 1e-3 of the largest gradient norm: e.g. key-projection biases have an exactly-zero true
+    gradient)."""
     names = [str(s) for s in G[key + "grad_names"]]
     stats = G[key + "grad_stats"]
     bad = []
-    floor = 1e-3 * float(stats[:, 0].max())  # e.g. key-projection biases have an exactly-zero true gradient
-    for n, (nrm, _) in zip(names, stats):
+    floor = 1e-3 * float(stats[:, 0].max())
+    for n, (nrm, total) in zip(names, stats):
         g = named_params[n].grad
         got = 0.0 if g is None else float(g.double().norm())
+        got_sum = 0.0 if g is None else float(g.double().sum())
         if abs(got - nrm) > tol * max(floor, nrm):
-            bad.append((n, got, nrm))
+            bad.append((n, "norm", got, nrm))
+        # |sum| <= sqrt(numel) * norm: compared on the norm's scale
+        if abs(got_sum - total) > tol * max(floor, nrm) * max(1.0, float(np.sqrt(named_params[n].numel())) / 8):
+            bad.append((n, "sum", got_sum, total))
     assert not bad, bad[:8]
     for f in G.files:
         if f.startswith(key + "grad::"):
             n = f[len(key + "grad::"):]
             assert rel_err(named_params[n].grad, G[f]) < tol, n
+    if oracle_grads is not None:
+        tol_full = tol if tol_full is None else tol_full
+        gmax = max(float(g.abs().max()) for g in oracle_grads.values())
+        rows = []
+        for n, go in oracle_grads.items():
+            g = named_params[n].grad
+            assert g is not None and g.shape == go.shape, n
+            scale = max(float(go.abs().max()), 1e-3 * gmax)
+            rows.append((float((g.detach().cpu().double() - go.double()).abs().max()) / scale, n))
+        rows.sort(reverse=True)
+        print(f"[{key}] full-tensor gradient error vs oracle autograd, worst five of {len(rows)}: "
+              + ", ".join(f"{n} {e:.2e}" for e, n in rows[:5]))
+        bad = [(e, n) for e, n in rows if e >= (tol_loose if n in loose else tol_full)]
+        assert not bad, bad[:5]
+
+
+def _oracle_train_step_grads(cfg, sd, item, epoch, seed=RSEED, drop=None):
+    """The CPU oracle's train step WITH autograd: -> (results, {parameter name: gradient}, top-u selections)."""
+    sdg = {}
+    for k, v in sd.items():
+        v = v.clone()
+        if (v.is_floating_point() and not k.startswith("video_backbone.") and "running_" not in k
+                and not k.endswith(".pe")):
+            v.requires_grad_(True)
+        sdg[k] = v
+    torch.manual_seed(seed)
+    orc = O.OracleRouteformer(cfg, sdg, training=True, **({"drop": drop} if drop is not None else {}))
+    res = orc.train_step(item, epoch)
+    res["loss"].backward()
+    grads = {k: v.grad.detach() for k, v in sdg.items() if v.requires_grad and v.grad is not None}
+    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in res.items()}, grads, orc.idx.tops
 
 
 def test_perceive_blocks_golden():
@@ -230,14 +273,11 @@ def test_model_train_step_golden(name):
             continue
         if name == "c2_paper" and epoch == 0:
             continue  # keep the suite short: the dense-loss epoch covers a superset of the graph
-        torch.manual_seed(RSEED)
-        orc = O.OracleRouteformer(cfg, sd, training=True)
-        with torch.no_grad():
-            orc.train_step(item, epoch)
+        _, ograds, otops = _oracle_train_step_grads(cfg, sd, item, epoch)
         model.load_state_dict(sd)
         model.train()
         model.zero_grad(set_to_none=True)
-        K.TOPS.forced = [t_.clone() for t_ in orc.idx.tops]
+        K.TOPS.forced = [t_.clone() for t_ in otops]
         torch.manual_seed(RSEED)
         res = train_step_losses(model, item_d, epoch)
         assert not K.TOPS.forced
@@ -255,7 +295,78 @@ def test_model_train_step_golden(name):
         # cancels 3-4 leading digits, so ANY fp32 implementation (the reference's included) carries ~1e-3 relative
         # noise in dQ / dK that moves with the summation order (measured 1.6e-3 .. 6.2e-3 for two thread counts of
         # the same kernel, bit-identical on well-conditioned random inputs; table: tools/dbg_grads.py) -> 1.5e-2 there
-        _check_grads(G, key, dict(model.named_parameters()), 1.5e-2 if name == "c2_paper" else 5e-3)
+        # full tensors vs oracle autograd: observed <= 5e-5 (small cases) / <= 3e-4 (c2_paper) for every parameter except
+        # the two ill-conditioned ones above, where the reference's own fp32 CPU gradient and the oracle's differ by
+        # 1.5e-2 already (tests/test_oracle_golden.py holds c2_paper's norms to that) -- they get 3e-2, the rest 1e-3
+        ill = ("gps_backbone.encoder.attn_layers.0.attention.query_projection.weight",
+               "gps_backbone.encoder.attn_layers.0.attention.key_projection.weight") if name == "c2_paper" else ()
+        _check_grads(G, key, dict(model.named_parameters()), 1.5e-2 if name == "c2_paper" else 5e-3, oracle_grads=ograds,
+                     tol_full=1e-3 if name == "c2_paper" else 2e-4, loose=ill, tol_loose=3e-2)
+
+
+def _grad_agreement(named_params, oracle_grads):
+    """Per parameter: (cosine with the oracle gradient, relative norm error), for parameters whose reference gradient
+    is not negligible (>= 1e-3 of the largest gradient norm: a key-projection bias has an exactly-zero true gradient)."""
+    gmax = max(float(g.double().norm()) for g in oracle_grads.values())
+    rows = []
+    for n, go in oracle_grads.items():
+        go = go.double().reshape(-1)
+        g = named_params[n].grad.detach().cpu().double().reshape(-1)
+        no, ng = float(go.norm()), float(g.norm())
+        if no < 1e-3 * gmax:
+            continue
+        rows.append((float(g @ go) / max(ng * no, 1e-300), abs(ng - no) / no, n))
+    return rows
+
+
+@pytest.mark.parametrize("name", ["c2_small", "c4_small", "c2_paper"])
+def test_model_train_step_bf16(name):
+    """The arithmetic mode bench.py times -- bf16 matrix-core operands, fused encoder stacks forward AND backward,
+    gradient sinks, grouped weight gradients (``TrainEngine._fwd_bwd``) -- against the reference's train step
+    (epoch 10: both losses on) with the oracle's top-u selections imposed: trajectories <= 1e-2 (north_star's bf16
+    tolerance), loss / ADE / FDE <= 1e-2 relative, and EVERY parameter gradient compared with the CPU oracle's autograd
+    gradient (cosine and norm); the worst five of each are printed."""
+    from routeformer_amd import kernels as K
+    from routeformer_amd.engine import TrainEngine
+    model, cfg, sd, c = build_product_model(name, DEV)
+    G = golden(name)
+    item = case_item(c)
+    item_d = {"train": _to_dev(item["train"]), "target": _to_dev(item["target"])}
+    epoch, key = 10, "train10."
+    ores, ograds, otops = _oracle_train_step_grads(cfg, sd, item, epoch)
+    K.set_precision("bf16")
+    calls, real = [], K._seqstack_bwd_launch
+    eng = TrainEngine(model)
+    model.train()
+    K.TOPS.forced = [t_.clone() for t_ in otops]
+    K._seqstack_bwd_launch = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    torch.manual_seed(RSEED)
+    try:
+        res = eng._fwd_bwd(item_d, epoch)
+        torch.cuda.synchronize()
+        assert not K.TOPS.forced, "not all imposed selections were consumed"
+    finally:
+        K.TOPS.forced, K._seqstack_bwd_launch = None, real
+    assert calls, "the fused encoder-stack backward was not taken"
+    e_pos = rel_err(res["future_gps"], G[key + "future_gps"])
+    print(f"[{name}] bf16 train step: future_gps rel err {e_pos:.2e}")
+    assert e_pos < TOL_BF16
+    assert rel_err(res["target_vis"], G[key + "target_vis"]) < 5 * TOL_BF16
+    for k in ("loss", "traj_loss", "dense_loss", "ade", "fde"):
+        ref = float(G[key + k])
+        assert abs(float(res[k]) - ref) < 1e-2 * max(1.0, abs(ref)), (k, float(res[k]), ref)
+    rows = _grad_agreement(dict(model.named_parameters()), ograds)
+    by_cos, by_norm = sorted(rows), sorted(rows, key=lambda r: -r[1])
+    print(f"[{name}] bf16 gradients vs oracle autograd over {len(rows)} parameters: worst cosines "
+          + ", ".join(f"{n} {c_:.4f}" for c_, _, n in by_cos[:5]) + "; worst norm errors "
+          + ", ".join(f"{n} {e:.3f}" for _, e, n in by_norm[:5]))
+    flat_o = torch.cat([ograds[n].double().reshape(-1) for n in sorted(ograds)])
+    flat_g = torch.cat([dict(model.named_parameters())[n].grad.detach().cpu().double().reshape(-1) for n in sorted(ograds)])
+    whole = float(flat_g @ flat_o / (flat_g.norm() * flat_o.norm()))
+    print(f"[{name}] whole-gradient cosine {whole:.5f}, norm ratio {float(flat_g.norm() / flat_o.norm()):.4f}")
+    assert whole > 0.999 and abs(float(flat_g.norm() / flat_o.norm()) - 1) < 2e-2
+    assert by_cos[0][0] >= BF16_GRAD_COS, by_cos[:5]
+    assert by_norm[0][1] <= BF16_GRAD_NORM, by_norm[:5]
 
 
 def test_model_vs_oracle_seeded():
@@ -811,6 +922,18 @@ def test_token_cache_in_model_and_engine():
             n_graphs = len(eng._graphs)
             eng.step(items[1], epoch=10, next_item=items[0])
             assert not replays and len(eng._graphs) == n_graphs, "a cached batch must not run the trunk"
+            eng.verify_ids()  # honest ids: the content check passes
+            # an id REUSED for other frames (ids restarting each epoch / a shuffling loader keyed by batch
+            # index) is caught by the device-side content check, reported at the latest by the next step
+            other = synthetic.synth_item(c["B"], c["T"], c["P"], 13, c["H"], c["W"], streams=c["streams"], gaze=c["gaze"])
+            liar = {"train": _to_dev(other["train"]), "target": _to_dev(other["target"]), "id": 11}
+            eng.step(liar, epoch=10)
+            torch.cuda.synchronize()
+            with pytest.raises(RuntimeError, match="differ from the ones cached"):
+                eng.step(items[1], epoch=10)
+            assert not eng._cached_ids  # forgotten: the next steps re-hash and re-learn
+            eng.step(items[1], epoch=10)
+            eng.verify_ids()
         SAMPLER.drop_static()
     assert all(abs(a - b) < 5e-4 * max(1.0, abs(a)) for a, b in zip(losses["eager"], losses["graph_cached"])), losses
 
