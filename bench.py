@@ -92,6 +92,14 @@ def cpu_baseline(cfg, sd, c, steps=10, warm=3):
                       f"workload, fp32, torch CPU oracle, {dt:.2f} s/step (min {timed[0]:.2f}, max {timed[-1]:.2f})"}
 
 
+def site_len_stack(site, cfg):
+    """L_Q of a ProbSparse call site (L_Q, sample_k) if it belongs to a Perceive encoder / decoder stack (their factor is
+    always 5, cross_modal_transformer.py:379; the paper's Informer uses 4), else -1."""
+    import math
+    L = site[0]
+    return L if site[1] == min(5 * int(math.ceil(math.log(L))), L) and cfg.gps_backbone_config.factor != 5 else -1
+
+
 def ade_vs_cpu_ref(model, cfg, items, precision, n=16, seeds=(1234, 4321)):
     """BASELINE.json's second metric, "ADE vs CPU ref": the L2 distance in METRES between the trajectories this model
     (HIP kernels, its current weights) and the CPU oracle (same weights, same seed -> same host-RNG key samples)
@@ -145,11 +153,19 @@ def ade_vs_cpu_ref(model, cfg, items, precision, n=16, seeds=(1234, 4321)):
                     if mode == "imposed":
                         shadow, K.TOPS.shadow = K.TOPS.shadow, None
                         f = acc.setdefault((prec, "flips"), {})
-                        for site, mine, ref in zip(sites, shadow, src.tops):
+                        run = 0
+                        for ci, (site, mine, ref) in enumerate(zip(sites, shadow, src.tops)):
+                            run = run + 1 if (ci > 0 and sites[ci - 1] == site) else 0
                             diff = (mine.cpu().long().sort(dim=-1).values != ref.long().sort(dim=-1).values)
-                            e = f.setdefault(f"L{site[0]}xk{site[1]}", [0, 0, 0, 0])
-                            e[0] += diff.any(dim=-1).numel(); e[1] += int(diff.any(dim=-1).sum())
-                            e[2] += diff.numel(); e[3] += int(diff.sum())
+                            names = [f"L{site[0]}xk{site[1]}"]
+                            # first layer of an encoder stack: the one call of a fused stack whose INPUT is teacher-forced
+                            # (the free pass of a fused stack runs all its layers on its own selections)
+                            if site[0] == site_len_stack(site, cfg) and run % cfg.encoder_layers == 0:
+                                names.append(names[0] + ".first_layer")
+                            for nm in names:
+                                e = f.setdefault(nm, [0, 0, 0, 0])
+                                e[0] += diff.any(dim=-1).numel(); e[1] += int(diff.any(dim=-1).sum())
+                                e[2] += diff.numel(); e[3] += int(diff.sum())
     finally:
         K.TOPS.forced, K.TOPS.shadow = None, None
         K.set_precision(precision)
@@ -157,7 +173,7 @@ def ade_vs_cpu_ref(model, cfg, items, precision, n=16, seeds=(1234, 4321)):
     res["cpu_forward_s"] = round(t_cpu / len(seeds), 2)
     for (prec, mode), a in acc.items():
         if mode == "flips":
-            tot = [sum(e[i] for e in a.values()) for i in range(4)]
+            tot = [sum(e[i] for k, e in a.items() if not k.endswith(".first_layer")) for i in range(4)]
             res[f"{prec}_flips"] = {"selections": tot[0], "flipped": tot[1], "rate": tot[1] / max(tot[0], 1),
                                     "rows": tot[2], "rows_flipped": tot[3],
                                     "by_site": {k: {"selections": e[0], "flipped": e[1]} for k, e in a.items()}}
@@ -172,23 +188,30 @@ def ade_vs_cpu_ref(model, cfg, items, precision, n=16, seeds=(1234, 4321)):
 def batch_independence(model, item, precision, seed=4321):
     """Eval-mode `future_gps` of sample 0 of the bench batch vs the same sample forwarded alone with the same seed
     (per-sample ops, BatchNorm on running statistics, one shared key-sample table per call as in the reference):
-    max |difference| relative to the trajectory scale.  The timed weights, the timed batch; exact-fp32 matrix-core
-    mode, where the discontinuous top-u selection does not amplify bf16 rounding into a different set of queries."""
+    max |difference| relative to the trajectory scale, for the timed weights and the timed batch.  -> {"f32": ...,
+    <timed precision>: ...}.  In exact-fp32 mode the two forwards agree to rounding (bound 1e-3 = north_star's fp32
+    tolerance).  In bf16 mode a batch of 1 and a batch of 8 take different launch shapes (row-block height, skinny vs
+    tiled GEMM, split-K depth): their fp32 accumulation orders differ at 1e-7, which the discontinuous top-u selection
+    can turn into a different set of active queries -- reported, bounded by 5e-2 (see ade_vs_cpu_ref for the
+    distribution of such selection effects)."""
     from routeformer_amd import kernels as K
     was_training = model.training
     model.eval()
-    K.set_precision("f32")
+    res = {}
     try:
-        outs = []
-        for bt in (item["train"], {k: v[:1] for k, v in item["train"].items()}):
-            torch.manual_seed(seed)
-            with torch.no_grad():
-                o = model(bt)
-            outs.append((o[0] if isinstance(o, tuple) else o)[0].double())
+        for prec in dict.fromkeys(("f32", precision)):
+            K.set_precision(prec)
+            outs = []
+            for bt in (item["train"], {k: v[:1] for k, v in item["train"].items()}):
+                torch.manual_seed(seed)
+                with torch.no_grad():
+                    o = model(bt)
+                outs.append((o[0] if isinstance(o, tuple) else o)[0].double())
+            res[prec] = float((outs[0] - outs[1]).abs().max() / max(1.0, float(outs[0].abs().max())))
     finally:
         K.set_precision(precision)
         model.train(was_training)
-    return float((outs[0] - outs[1]).abs().max() / max(1.0, float(outs[0].abs().max())))
+    return res
 
 
 def self_launch(args) -> int:
@@ -380,7 +403,8 @@ def main():
     # more than "finite": the timed model must treat the samples of its batch independently (eval forward of sample
     # 0 inside the batch == the same sample alone, same seed; fp32 mode, bound 1e-3 = north_star's fp32 tolerance)
     indep = batch_independence(model, item, args.precision)
-    assert indep < 1e-3, f"sample 0 of the bench batch depends on its batch mates: rel diff {indep:.3e}"
+    assert indep["f32"] < 1e-3, f"sample 0 of the bench batch depends on its batch mates: rel diff {indep['f32']:.3e}"
+    assert indep[args.precision] < 5e-2, f"batch dependence in the timed mode: rel diff {indep[args.precision]:.3e}"
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -472,7 +496,7 @@ def main():
                        "step": "fwd + target-feature fwd + losses + bwd + grad all-reduce + clip + AdamW",
                        "launch": ("hipGraph replay of fwd+bwd" + (" (+ the previous step's clip/AdamW at its head)" if defer else ""))
                        if use_graph else "eager launches"},
-            "loss": float(res["loss"].detach()), "rccl_ranks": rccl_ranks, "batch_independence_rel": indep,
+            "loss": float(res["loss"].detach()), "rccl_ranks": rccl_ranks, "batch_independence_rel": indep["f32"], "batch_independence_rel_timed_mode": indep[args.precision],
             "roofline": roof, "roofline_top": top or None, "roofline_fused_encoder_stack": fused or None,
         }
         if rehearse:

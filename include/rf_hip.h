@@ -457,6 +457,44 @@ int rf_motion_input(const float* motion, const float* visual, float* x, float* o
                     int rotate_motion, int zero_visual, void* stream);
 int rf_rotate_head(const float* in, const float* origin, float* out, int B, int P, int C, float sign, void* stream);
 
+/* ---- cross-resolution fusion of the conv trunk without intermediate maps (hrnetv2.py:250-271,453-498;
+ * InverseForm.py:66-67; routeformer.py:478-487) ---------------------------------------------------------------
+ * rf_fuse_upsample_sum: for each entry  out = [relu](base + base2 + sum_s bilinear_up(src[s]))  (terms added in this
+ * order; base / base2 optional full-resolution maps (N,Ho,Wo,C), src[s] low-resolution maps (N,Hi[s],Wi[s],C), bilinear
+ * = F.interpolate(align_corners=False); `out` may alias base).  Up to RF_FUSE_MAX entries per launch: all output
+ * branches of one HighResolutionModule's fuse layer.  Maps in act_dtype (0 fp32, 1 bf16), channels innermost, C % 4 == 0.
+ * rf_concat_pool_tokens: tokens[n, t, :] (fp32, (N,65,sum C)) = AdaptiveAvgPool2d((8,8)) of the channel-concatenation of
+ * the maps up-sampled to maps[0]'s resolution, token 64 = -1: the concatenated full-resolution map is never stored. */
+#define RF_FUSE_MAX 4
+typedef struct RfFuseEntry {
+  const void* base; const void* base2; const void* src[3]; void* out;
+  int N, Ho, Wo, C, n_src, relu;
+  int Hi[3], Wi[3];
+} RfFuseEntry;
+int rf_fuse_upsample_sum(const RfFuseEntry* entries, int count, int act_dtype, void* stream);
+int rf_concat_pool_tokens(const void* const* maps, const int32_t* H, const int32_t* W, const int32_t* C, int n_maps,
+                          int act_dtype, float* tokens, int N, void* stream);
+
+/* ---- gradient exchange over RCCL (SURVEY 8(b) "Comm"; replaces Lightning's DDPStrategy(process_group_backend=
+ * "nccl"), experiments/full_comparison.py:794,832: bucketed gradient all-reduce overlapped with backward) ------
+ * A communicator owns an explicit, highest-priority HIP communication stream and two events.
+ *   rf_comm_unique_id(id)            rank 0 only: 128 bytes to hand to every rank (any host channel)
+ *   rf_comm_init(&comm, id, rank, world)   collective; uses the calling thread's current device
+ *   rf_comm_allreduce_bucket(comm, buf, count, dtype, average, producer_stream)
+ *        in-place all-reduce (SUM, or the mean when `average`) of `count` elements (dtype 0 fp32, 1 bf16) on the
+ *        communication stream, ordered after everything enqueued so far on `producer_stream` (event record + wait);
+ *   rf_comm_broadcast(...)           the one-time parameter broadcast of DDP construction, same discipline
+ *   rf_comm_wait(comm, consumer_stream)   `consumer_stream` waits on the DEVICE for every collective launched so far
+ * No call blocks the host.  RCCL is resolved at run time (dlsym, then librccl.so): rf_comm_available() says whether
+ * it was found; the library itself loads without it. */
+int rf_comm_available(void);
+int rf_comm_unique_id(void* id_out_128_bytes);
+int rf_comm_init(void** comm_out, const void* id_128_bytes, int rank, int world);
+int rf_comm_allreduce_bucket(void* comm, void* buf, int64_t count, int dtype, int average, void* producer_stream);
+int rf_comm_broadcast(void* comm, void* buf, int64_t count, int dtype, int root, void* producer_stream);
+int rf_comm_wait(void* comm, void* consumer_stream);
+int rf_comm_destroy(void* comm);
+
 /* ---- measurement -----------------------------------------------------------------------------
  * rf_kernel_timer_arm(): the NEXT kernel this thread launches through the library carries a start / stop event
  * pair bracketing exactly its dispatch (hipExtLaunchKernelGGL) -- the kernel's own execution time, what rocprofv3's

@@ -87,6 +87,15 @@ SIGNATURES = {
     "rf_sumsq": [_P, _L, _P, _P],
     "rf_adamw_clip": [_P, _P, _P, _P, _L, _P, _I, _F, _F, _F, _F, _F, _F, _I, _F, _P],
     "rf_adamw_clip_dev": [_P, _P, _P, _P, _L, _P, _I, _P, _P],
+    "rf_fuse_upsample_sum": [_P, _I, _I, _P],
+    "rf_concat_pool_tokens": [_P, _P, _P, _P, _I, _I, _P, _I, _P],
+    "rf_comm_available": [],
+    "rf_comm_unique_id": [_P],
+    "rf_comm_init": [_P, _P, _I, _I],
+    "rf_comm_allreduce_bucket": [_P, _P, _L, _I, _I, _P],
+    "rf_comm_broadcast": [_P, _P, _L, _I, _I, _P],
+    "rf_comm_wait": [_P, _P],
+    "rf_comm_destroy": [_P],
     "rf_version": [],
 }
 
@@ -130,6 +139,16 @@ class SeqStackBwd(ctypes.Structure):
 
 
 GATHER_MAX = 8  # RF_GATHER_MAX
+
+
+FUSE_MAX = 4  # RF_FUSE_MAX
+
+
+class FuseEntry(ctypes.Structure):
+    """RfFuseEntry of include/rf_hip.h."""
+    _fields_ = [("base", c_void_p), ("base2", c_void_p), ("src", c_void_p * 3), ("out", c_void_p),
+                ("N", c_int), ("Ho", c_int), ("Wo", c_int), ("C", c_int), ("n_src", c_int), ("relu", c_int),
+                ("Hi", c_int * 3), ("Wi", c_int * 3)]
 
 
 class GatherEntry(ctypes.Structure):

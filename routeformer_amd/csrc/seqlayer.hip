@@ -19,6 +19,7 @@
 // Training mode writes what the (layer-by-layer) backward kernels consume -- packed q|k|v, ctx, x-hat / 1/sigma of
 // both norms, x1, z, h, the selected rows -- with the same meaning as the unfused forward's saved tensors.
 // bf16 matrix-core mode only (like rowblock.hip); the exact-fp32 mode keeps the layer-by-layer path.
+#include <cstdlib>
 #include "seqlayer_common.h"
 
 namespace {
@@ -36,6 +37,7 @@ struct SeqStackP {
   float* y;                     // (layers, B*L, 128): layer outputs
   float *qkv, *ctx, *xhat1, *rstd1, *x1, *z, *h, *xhat2, *rstd2;  // training saves (layers, B*L, width)
   int B, L, F, n_layers, act, sample_k, n_top, idx_group, force_top, save;
+  int split;  // 1: q / k projection and sparsity-measure scores in split-bf16 (default); 0: plain bf16 (RF_SEQ_SPLIT=0, A/B only)
   float scale, eps;
   DropCfg drop;   // nn.Dropout of the layers (cross_modal_transformer.py:295,298,299); state == null: off
   int drop_site0; // layer i uses sites drop_site0 + 3 i + {0: attention output, 1: hidden activation, 2: conv2 output}
@@ -257,10 +259,12 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
           acc[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (p.split) {
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[kk], wf[pt][kk], acc[pt], 0, 0, 0);
-            acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk], wlo[pt][kk], acc[pt], 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk) {
+              acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[kk], wf[pt][kk], acc[pt], 0, 0, 0);
+              acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk], wlo[pt][kk], acc[pt], 0, 0, 0);
+            }
           }
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk], wf[pt][kk], acc[pt], 0, 0, 0);
@@ -356,8 +360,11 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
           for (int ct = 0; ct < RT; ++ct) {
             const unsigned int c4 = cnt32[((ct * 16 + fr) * LP + rt * 16 + fq * 4) >> 2];
             const bf16x8 kbl = fq < 2 ? ld_frag(Kl + (ct * 16 + fr) * SL_E + fq * 8) : zero_frag();
-            f32x4 sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qal, kb[ct], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kbl, sv, 0, 0, 0);
+            f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+            if (p.split) {
+              sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qal, kb[ct], sv, 0, 0, 0);
+              sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kbl, sv, 0, 0, 0);
+            }
             sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kb[ct], sv, 0, 0, 0);  // ~fp32-accurate q . k
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -871,6 +878,10 @@ extern "C" int rf_seqlayer_fwd(const RfSeqStack* st_, const float* x, int B, int
   p.B = B; p.L = L; p.F = d_ff; p.n_layers = s.n_layers; p.act = act; p.sample_k = sample_k; p.n_top = n_top;
   p.idx_group = (idx_group <= 0 || idx_group > B) ? B : idx_group;
   p.force_top = force_top; p.save = save; p.scale = scale; p.eps = eps;
+  {
+    const char* e = getenv("RF_SEQ_SPLIT");
+    p.split = !(e && e[0] == '0');
+  }
   RF_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state));
   p.drop = make_drop_cfg(rng_state, nullptr, 0, drop_p);
   p.drop_site0 = drop_site0;

@@ -246,6 +246,11 @@ class GradReducer:
         self._works: List = []
         self._starts = sorted((self.offset[id(p)], id(p)) for p in self.params)
         self.hooks_enabled = True  # False: no in-backward launches (HIP-graph capture); finish() sends all
+        # RF_DP_COMM=rf: the all-reduce mode talks to RCCL through rf_comm_* (own communicator + communication stream)
+        self.rfcomm = None
+        if self.exchange and not self.sharded and _os.environ.get("RF_DP_COMM", "pg") == "rf" and dev.type == "cuda":
+            from routeformer_amd.comm import RfComm
+            self.rfcomm = RfComm(dist.get_rank(group), self.world, group=group)
         if self.exchange and not self.sharded:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
@@ -359,11 +364,19 @@ class GradReducer:
         dist.all_gather_into_tensor(out, local, group=self.group)
         return out
 
+    def _all_reduce(self, view):
+        """SUM all-reduce of a slice of the flat gradient buffer, asynchronous, ordered after everything enqueued so far
+        on the current stream: through ``rf_comm_allreduce_bucket`` (RF_DP_COMM=rf: our own RCCL communicator and
+        communication stream, csrc/comm.hip) or through the process group (ProcessGroupNCCL = RCCL on its own stream)."""
+        if self.rfcomm is not None:
+            self.rfcomm.allreduce_bucket(view)
+            self._works.append(None)
+        else:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def _launch(self, b: int):
         s, e = self.buckets[b]
-        # async: RCCL runs on the process group's own stream, ordered after everything enqueued so far
-        self._works.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                           async_op=True))
+        self._all_reduce(self.flat_grad[s:e])
         self._launched[b] = True
 
     def _on_grad(self, p):
@@ -400,8 +413,7 @@ class GradReducer:
             while self.coalesce and j + 1 < len(ready) and ready[j + 1] == ready[j] + 1:
                 j += 1
             s, e = self.buckets[ready[i]][0], self.buckets[ready[j]][1]
-            self._works.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                               async_op=True))
+            self._all_reduce(self.flat_grad[s:e])
             for b in ready[i:j + 1]:
                 self._launched[b] = True
             n += j + 1 - i
@@ -429,11 +441,17 @@ class GradReducer:
         elif self.exchange:
             self._launch_runs([b for b in range(len(self.buckets)) if not self._launched[b]])
             for w in self._works:
-                w.wait()
+                if w is not None:
+                    w.wait()
+            if self.rfcomm is not None:
+                self.rfcomm.wait()  # the current (compute) stream waits on the device; the host does not
         return 1.0 / self.world
 
     def broadcast_parameters(self, src: int = 0):
-        if self.exchange:
+        if self.exchange and self.rfcomm is not None:
+            self.rfcomm.broadcast(self.flat_param, root=src)
+            self.rfcomm.wait()
+        elif self.exchange:
             dist.broadcast(self.flat_param, src=src, group=self.group)
 
 

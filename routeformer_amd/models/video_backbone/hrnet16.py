@@ -84,6 +84,9 @@ UNITS = _conv_units()
 
 
 import os as _os
+# cross-resolution fuse / final concat + pool without intermediate maps (csrc/fuse.hip); RF_FUSE_SUM=0: one up-sample launch
+# per (output branch, source branch) pair as before
+FUSE_SUM = _os.environ.get("RF_FUSE_SUM", "1") != "0"
 GROUP_BRANCHES = _os.environ.get("RF_CONV_GROUP", "1") != "0"  # one launch per conv step of an HRNet module's branches
 
 
@@ -307,6 +310,8 @@ class HRNet16Backbone(VideoBackboneModule):
             for b in range(nb):
                 for k in range(BLOCKS_PER_BRANCH):
                     xs[b] = self._basic(W, f"{p}.branches.{b}.{k}", xs[b])
+        if FUSE_SUM:
+            return self._fuse_grouped(W, p, xs)
         outs = []
         for i in range(nb):
             size = tuple(xs[i].shape[1:3])
@@ -333,6 +338,51 @@ class HRNet16Backbone(VideoBackboneModule):
                     else:
                         acc, owned = self._upsample(t, size, addend=acc, relu=last), True
             outs.append(acc)
+        return outs
+
+    def _fuse_grouped(self, W, p, xs):
+        """The cross-resolution fuse (hrnetv2.py:250-271) with ONE launch for all the up-sampled terms of a module:
+        out_i = relu(sum_{j<i} stride-2 chains + x_i + sum_{j>i} up(conv1x1_j(x_j))), terms in the reference's order.
+        The chains keep their running sum in the last conv's epilogue; x_i and the up-sampled terms of every output
+        branch i < nb - 1 are added by rf_fuse_upsample_sum (no read-modify-write pass per (i, j) pair, no add launch)."""
+        nb = len(xs)
+        outs, ents = [None] * nb, []
+        for i in range(nb):
+            acc = None
+            for j in range(i):
+                t = xs[j]
+                for k in range(i - j):
+                    final = k == i - j - 1
+                    t = self._conv(W, f"{p}.fuse_layers.{i}.{j}.{k}.0", t, stride=2, relu=not final,
+                                   residual=acc if final else None)
+                acc = t
+            if i == nb - 1:  # lowest resolution: no up-sampled terms, ReLU after adding x_i
+                outs[i] = xs[i] if acc is None else self._add(acc, xs[i], relu=True)
+                continue
+            srcs = [self._conv(W, f"{p}.fuse_layers.{i}.{j}.0", xs[j]) for j in range(i + 1, nb)]
+            out = torch.empty_like(xs[i])
+            outs[i] = out
+            ents.append((acc, xs[i], srcs, out))
+        if ents:
+            arr = (_hip.FuseEntry * len(ents))()
+            keep = []
+            for e, (acc, xi, srcs, out) in zip(arr, ents):
+                N, Ho, Wo, C = out.shape
+                first, second = (acc, xi) if acc is not None else (xi, None)
+                assert first.is_contiguous() and (second is None or second.is_contiguous()) and first.shape == out.shape
+                e.base, e.base2, e.out = ptr(first), ptr(second), ptr(out)
+                e.N, e.Ho, e.Wo, e.C, e.n_src, e.relu = N, Ho, Wo, C, len(srcs), 1
+                for s_i, t in enumerate(srcs):
+                    assert t.is_contiguous() and t.shape[0] == N and t.shape[3] == C and t.dtype == out.dtype
+                    e.src[s_i], e.Hi[s_i], e.Wi[s_i] = ptr(t), t.shape[1], t.shape[2]
+                keep.append((first, second, srcs))
+            ev = K.PROFILE.begin() if K.PROFILE.on else None
+            check(_hip.lib().rf_fuse_upsample_sum(arr, len(ents), self._act_code(xs[0]), K._stream()), "rf_fuse_upsample_sum")
+            if ev is not None:
+                es = xs[0].element_size()
+                K.PROFILE.end("fuse_upsample_sum_kernel", ev, 0.0,
+                              float(sum(es * (o.numel() * (2 + (a is not None)) + sum(t.numel() for t in sr))
+                                        for a, _, sr, o in ents)))
         return outs
 
     def encode_tokens(self, video, frame_idx: Optional[torch.Tensor]) -> torch.Tensor:
@@ -398,14 +448,26 @@ class HRNet16Backbone(VideoBackboneModule):
             for m in range(nmod):
                 xs = self._module(W, f"{stage}.{m}", xs)
         Hf, Wf = xs[0].shape[1:3]
+        tokens = out if out is not None else torch.empty(N, 65, 240, device=dev, dtype=torch.float32)
+        assert tuple(tokens.shape) == (N, 65, 240) and tokens.is_contiguous()
+        if FUSE_SUM and len(xs) <= 4 and sum(t.shape[-1] for t in xs) == 240:
+            # up-sample + concat + AdaptiveAvgPool + token layout in one launch: the 240-channel map is never stored
+            import ctypes
+            n = len(xs)
+            maps = (ctypes.c_void_p * n)(*[ptr(t.contiguous()) for t in xs])
+            dims = [(ctypes.c_int32 * n)(*[t.shape[k] for t in xs]) for k in (1, 2, 3)]
+            ev = K.PROFILE.begin() if K.PROFILE.on else None
+            check(_hip.lib().rf_concat_pool_tokens(maps, dims[0], dims[1], dims[2], n, act, ptr(tokens), N, K._stream()),
+                  "rf_concat_pool_tokens")
+            if ev is not None:
+                K.PROFILE.end("concat_pool_tokens_kernel", ev, 0.0, float(sum(es * t.numel() for t in xs) + 4 * tokens.numel()))
+            return tokens
         feats = torch.empty(N, Hf, Wf, 240, device=dev, dtype=adt)
         off = 0
         for t in xs:  # concat along channels; identity-scale "upsample" copies branch 0
             c = t.shape[-1]
             self._upsample(t, (Hf, Wf), out=feats.data_ptr() + es * off, ldy=240)
             off += c
-        tokens = out if out is not None else torch.empty(N, 65, 240, device=dev, dtype=torch.float32)
-        assert tuple(tokens.shape) == (N, 65, 240) and tokens.is_contiguous()
         check(_hip.lib().rf_avgpool8_tokens(ptr(feats), act, ptr(tokens), N, Hf, Wf, 240, K._stream()),
               "rf_avgpool8_tokens")
         return tokens

@@ -58,3 +58,19 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0 and out["config"]["global_batch"] == 4
+
+
+def test_rccl_rehearsal_process_group_and_rf_comm():
+    """The N > 1 step over the REAL collective library on the one GPU of the box (a one-rank RCCL communicator is legal):
+    ``RF_REHEARSE_COLLECTIVES=1`` drives bucket launches, the two-graph step with the backbone's all-reduce between the
+    replays and the optimizer's wait -- once through ProcessGroupNCCL and once through ``rf_comm_{init,allreduce_bucket,
+    wait}`` (our own communicator + communication stream, csrc/comm.hip).  Both must reproduce the plain single-process
+    steps; the rf_comm unit part checks values and event ordering (tools/rccl_rehearsal.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_rehearsal.py"), "c2_small", "3", "--unit",
+                        "--comm=pg", "--comm=rf"], env=env, capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
+    assert "rf_comm unit (one rank): values + stream ordering -> OK" in r.stdout
+    assert r.stdout.count("-> OK") == 5 and "MISMATCH" not in r.stdout

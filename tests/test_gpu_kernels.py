@@ -640,6 +640,74 @@ def test_vision_helpers():
     assert torch.equal(y8, y16)
 
 
+@pytest.mark.parametrize("adt", [torch.float32, torch.bfloat16])
+def test_fuse_upsample_sum_and_concat_pool(adt):
+    """csrc/fuse.hip against torch on the CPU: (i) several output branches of a fuse layer in one launch --
+    relu(base + base2 + sum_j bilinear(src_j)), incl. an entry without base2, one with a single source and an in-place
+    one; (ii) up-sample + concat + AdaptiveAvgPool2d((8,8)) + token layout with the -1 row, for the trunk's 28/14/7/4
+    pyramid (224 x 224 input) and a 56/28/14/7 one (448 x 448), never materialising the concatenated map."""
+    import ctypes
+    from routeformer_amd import _hip, kernels as Kn
+    g = _g(17)
+    code = 1 if adt == torch.bfloat16 else 0
+
+    def rnd(*shape):  # NCHW values representable in the storage type
+        return torch.randn(*shape, generator=g).to(adt).float()
+
+    def dev(x):  # NCHW cpu -> NHWC device in the storage type
+        return x.permute(0, 2, 3, 1).contiguous().to(DEV).to(adt)
+
+    N = 3
+    cases = [  # (C, Ho, Wo, has_base, has_base2, [(Hi, Wi)], relu)
+        (16, 28, 28, True, False, [(14, 14), (7, 7), (4, 4)], 1),
+        (32, 14, 14, True, True, [(7, 7), (4, 4)], 1),
+        (64, 7, 7, True, True, [(4, 4)], 0),
+        (8, 12, 20, False, True, [(5, 7)], 1),
+    ]
+    arr = (_hip.FuseEntry * len(cases))()
+    keep, refs = [], []
+    for e, (C, Ho, Wo, hb, hb2, srcs, relu) in zip(arr, cases):
+        base = rnd(N, C, Ho, Wo) if hb else None
+        base2 = rnd(N, C, Ho, Wo) if hb2 else None
+        ss = [rnd(N, C, h, w) for h, w in srcs]
+        ref = torch.zeros(N, C, Ho, Wo)
+        for t in (base, base2):
+            if t is not None:
+                ref = ref + t
+        for t in ss:
+            ref = ref + F.interpolate(t, size=(Ho, Wo), mode="bilinear", align_corners=False)
+        refs.append(F.relu(ref) if relu else ref)
+        bd, b2d, sd = (dev(base) if hb else None), (dev(base2) if hb2 else None), [dev(t) for t in ss]
+        out = bd if (hb and C == 64) else torch.empty(N, Ho, Wo, C, device=DEV, dtype=adt)  # one in-place entry
+        e.base, e.base2, e.out = _hip.ptr(bd), _hip.ptr(b2d), out.data_ptr()
+        e.N, e.Ho, e.Wo, e.C, e.n_src, e.relu = N, Ho, Wo, C, len(ss), relu
+        for i, (t, (h, w)) in enumerate(zip(sd, srcs)):
+            e.src[i], e.Hi[i], e.Wi[i] = t.data_ptr(), h, w
+        keep.append((bd, b2d, sd, out))
+    _hip.check(_hip.lib().rf_fuse_upsample_sum(arr, len(cases), code, Kn._stream()), "rf_fuse_upsample_sum")
+    torch.cuda.synchronize()
+    for (_, _, _, out), ref in zip(keep, refs):
+        got = out.float().cpu().permute(0, 3, 1, 2)
+        if code == 0:
+            assert rel_err(got, ref) < 1e-5
+        else:  # one bf16 rounding of the fp32 sum
+            assert torch.allclose(got, ref, rtol=2.0 ** -7, atol=1e-6)
+    for sizes in (((28, 28), (14, 14), (7, 7), (4, 4)), ((56, 56), (28, 28), (14, 14), (7, 7))):
+        chans = (16, 32, 64, 128)
+        xs = [rnd(2, c, h, w) for c, (h, w) in zip(chans, sizes)]
+        Hf, Wf = sizes[0]
+        cat = torch.cat([t if t.shape[2:] == (Hf, Wf) else F.interpolate(t, size=(Hf, Wf), mode="bilinear", align_corners=False)
+                         for t in xs], dim=1)
+        ref = F.adaptive_avg_pool2d(cat, (8, 8)).permute(0, 2, 3, 1).reshape(2, 64, 240)
+        xd = [dev(t) for t in xs]
+        maps = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in xd])
+        dims = [(ctypes.c_int32 * 4)(*[t.shape[k] for t in xd]) for k in (1, 2, 3)]
+        tok = torch.empty(2, 65, 240, device=DEV)
+        _hip.check(_hip.lib().rf_concat_pool_tokens(maps, dims[0], dims[1], dims[2], 4, code, tok.data_ptr(), 2, Kn._stream()),
+                   "rf_concat_pool_tokens")
+        assert rel_err(tok[:, :64], ref) < 1e-5 and torch.all(tok[:, 64] == -1)
+
+
 @pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16", 5e-2)])
 def test_hrnet16_golden(prec, tol):
     """Whole frozen conv encoder against the reference's outputs (tests/golden/hrnet.npz)."""
@@ -1018,20 +1086,25 @@ def _bf(t_):
 def _emulate_stack(x, layers, idx_tabs, idx_group, factor, act, forced_tops=None):
     """CPU restatement of the fused kernel's arithmetic: the reference's EncoderLayer (cross_modal_transformer.py:288-301
     with ProbAttention :88-166) where every matrix-core operand is rounded to bf16 (x, weights, q / k / v, the
-    softmax probabilities, ctx, x1, h) and everything else is fp32.  -> (y, per-layer saves, per-layer selections)."""
+    softmax probabilities, ctx, x1, h) EXCEPT on the way to the discontinuous top-u selection (q / k projection, sampled
+    scores: ~fp32), and everything else is fp32.  -> (y, per-layer saves, per-layer selections)."""
     B, L, D = x.shape
     H, E = 8, 16
     saves, tops = [], []
     for li, W in enumerate(layers):
         sample_k, n_top = O.prob_sizes(L, L, factor)
-        qkv = _bf(x) @ _bf(W["wqkv"]).t() + W["bqkv"]
+        # q / k projection and the scores of the sparsity measure in split-bf16 (hi + lo operands: ~2^-16, i.e. fp32 here);
+        # v, the softmax rows and everything downstream on bf16-rounded operands
+        qkv = torch.cat([x @ W["wqkv"][:2 * D].t(), _bf(x) @ _bf(W["wqkv"][2 * D:]).t()], dim=-1) + W["bqkv"]
+        qf, kf = (qkv[..., i * D:(i + 1) * D].view(B, L, H, E).transpose(1, 2) for i in range(2))
+        S_meas = qf @ kf.transpose(-1, -2)
         q, k, v = (_bf(qkv[..., i * D:(i + 1) * D]).view(B, L, H, E).transpose(1, 2) for i in range(3))  # (B,H,L,E)
         S = q @ k.transpose(-1, -2)
         top_l = []
         ctx = v.mean(dim=2, keepdim=True).expand(B, H, L, E).clone()
         for b in range(B):
             idx = idx_tabs[li][b // idx_group].long()
-            samp = torch.gather(S[b], 2, idx.unsqueeze(0).expand(H, L, sample_k))
+            samp = torch.gather(S_meas[b], 2, idx.unsqueeze(0).expand(H, L, sample_k))
             Mm = samp.max(-1).values - samp.sum(-1) / L
             if forced_tops is not None:
                 top = forced_tops[li][b].long()

@@ -18,7 +18,15 @@ from oracle import routeformer_oracle as O  # noqa: E402
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL_F32, TOL_BF16 = 1e-3, 1e-2
-BF16_GRAD_COS, BF16_GRAD_NORM = 0.99, 5e-2  # per-parameter gradient agreement with the oracle in bf16 mode
+# Per-parameter agreement of bf16-mode gradients with the fp32 CPU oracle.  What bounds it is the arithmetic mode itself,
+# not a kernel: profiles/r03/bf16_grad_report.txt (tools/bf16_grad_report.py) shows the same figures for the fused
+# stacks, the layer-by-layer kernels and the plain tiled GEMMs (whole-gradient cosine 0.985 / 0.985 / 0.983 on c2_paper,
+# 1.00000 in fp32 mode): bf16 operand rounding moves ReLU masks, MaxPool arg-maxes of the distilling layers and the
+# nearly-uniform softmax rows of the first Informer layer (dS cancels 3-4 digits: dWq / dWk there carry 25 % norm error
+# at 1e-6 of the gradient energy).  The reference itself trains with torch.set_float32_matmul_precision("medium")
+# (full_comparison.py:48), i.e. bf16 operand rounding inside its fp32 matmuls on a GPU.  Observed worst cases over the
+# three fixtures: cosine 0.956, norm error 0.24 (the two ill-conditioned parameters), whole-gradient cosine 0.985.
+BF16_GRAD_COS, BF16_GRAD_NORM, BF16_GRAD_WHOLE = 0.94, 0.27, 0.98
 
 
 @pytest.fixture(autouse=True)
@@ -254,7 +262,11 @@ def test_model_eval_forward_bf16(name):
         out = model(_to_dev(item["train"]))
     free = rel_err(out[0] if isinstance(out, tuple) else out, G["eval.future_gps"])
     print(f"[{name}] bf16 free-running rel err {free:.2e}")
-    assert free < 0.2
+    # free-running: the selections leave the oracle's path (bench.py ade_vs_cpu_ref: 40 % of the teacher-forced selections
+    # differ in bf16 mode -- 13 % already in the first layer of the frame encoder, whose input is the bf16 conv trunk's --
+    # against 5e-5 in fp32 mode); a different-but-valid set of active queries moves a trajectory by up to 2.7e-2 over
+    # 32 bench samples (median 5e-3, 2/3 within 1e-2: profiles/r03/bench_n1_*.json).  Bound = 2 x the observed maximum.
+    assert free < 5e-2
 
 
 @pytest.mark.parametrize("name", ["c1_default", "c1_recursive", "c2_small", "c4_small", "c2_paper"])
@@ -364,7 +376,7 @@ def test_model_train_step_bf16(name):
     flat_g = torch.cat([dict(model.named_parameters())[n].grad.detach().cpu().double().reshape(-1) for n in sorted(ograds)])
     whole = float(flat_g @ flat_o / (flat_g.norm() * flat_o.norm()))
     print(f"[{name}] whole-gradient cosine {whole:.5f}, norm ratio {float(flat_g.norm() / flat_o.norm()):.4f}")
-    assert whole > 0.999 and abs(float(flat_g.norm() / flat_o.norm()) - 1) < 2e-2
+    assert whole > BF16_GRAD_WHOLE and abs(float(flat_g.norm() / flat_o.norm()) - 1) < 2e-2
     assert by_cos[0][0] >= BF16_GRAD_COS, by_cos[:5]
     assert by_norm[0][1] <= BF16_GRAD_NORM, by_norm[:5]
 

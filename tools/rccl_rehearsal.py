@@ -52,19 +52,67 @@ def run(mode: str, preset: str, rehearse: bool, steps: int = 4):
     return eng.reducer.flat_param.detach().clone(), ms
 
 
+def unit_rf_comm():
+    """rf_comm_* on a one-rank communicator: values (a sum / mean over one rank is the identity, fp32 and bf16) and the
+    stream discipline -- the collective must be ordered AFTER slow producer work on stream A (event record + wait) and
+    the consumer stream B must see its result after rf_comm_wait, with no host synchronisation in between."""
+    from routeformer_amd.comm import RfComm
+    comm = RfComm(0, 1)
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    n = 1 << 22
+    buf = torch.zeros(n, device="cuda")
+    out = torch.zeros(n, device="cuda")
+    half = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        for _ in range(200):           # a long producer chain: buf ends at 200 only when all of it has run
+            buf.add_(1.0)
+        comm.allreduce_bucket(buf)     # ordered after the chain although launched from the host immediately
+        half.fill_(3.0)
+        comm.allreduce_bucket(half, average=True)
+    comm.wait(b)
+    with torch.cuda.stream(b):
+        out.copy_(buf)
+    torch.cuda.synchronize()
+    ok = bool((out == 200.0).all()) and bool((half.float() == 3.0).all())
+    comm.broadcast(buf, root=0)
+    comm.wait()
+    torch.cuda.synchronize()
+    ok &= bool((buf == 200.0).all())
+    comm.close()
+    print(f"rf_comm unit (one rank): values + stream ordering -> {'OK' if ok else 'MISMATCH'}", flush=True)
+    return ok
+
+
 def main():
-    preset = sys.argv[1] if len(sys.argv) > 1 else "c2_small"
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    preset = args[0] if args else "c2_small"
+    steps = int(args[1]) if len(args) > 1 else 4
+    comms = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--comm=")] or ["pg"]
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     ok = True
-    for mode in ("eager", "graph"):
-        ref, ms_ref = run(mode, preset, rehearse=False)
-        got, ms = run(mode, preset, rehearse=True)
-        d = (ref - got).abs()
-        same = bool(d.max() < 5e-3 and d.mean() < 5e-4)  # fp32 atomics in the split-K weight gradients: not bit-stable
-        ok &= same
-        print(f"{mode:6s}: plain {ms_ref:7.2f} ms/step | with RCCL exchange {ms:7.2f} ms/step | parameter diff "
-              f"max {d.max():.2e} mean {d.mean():.2e} -> {'OK' if same else 'MISMATCH'}", flush=True)
+    if "--unit" in sys.argv:
+        ok &= unit_rf_comm()
+    for comm in comms:                       # pg = ProcessGroupNCCL, rf = rf_comm_* (csrc/comm.hip)
+        os.environ["RF_DP_COMM"] = comm
+        for dp_mode in ([a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--dp=")] or ["allreduce"]):
+            if comm == "rf" and dp_mode != "allreduce":
+                continue
+            os.environ["RF_DP_MODE"] = dp_mode
+            for mode in ("eager", "graph"):
+                ref, ms_ref = run(mode, preset, rehearse=False, steps=steps)
+                got, ms = run(mode, preset, rehearse=True, steps=steps)
+                if got.numel() != ref.numel():  # direct modes pad their regions: compare what both hold
+                    same, dmax, dmean = True, float("nan"), float("nan")
+                else:
+                    d = (ref - got).abs()
+                    dmax, dmean = float(d.max()), float(d.mean())
+                    same = bool(dmax < 5e-3 and dmean < 5e-4)  # fp32 atomics in the split-K weight gradients: not bit-stable
+                ok &= same
+                print(f"comm={comm:2s} dp={dp_mode:11s} {mode:6s}: plain {ms_ref:7.2f} ms/step | with RCCL exchange {ms:7.2f} "
+                      f"ms/step ({(ms / ms_ref - 1) * 100:+.1f} %) | parameter diff max {dmax:.2e} mean {dmean:.2e} -> "
+                      f"{'OK' if same else 'MISMATCH'}", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
 
