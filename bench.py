@@ -392,10 +392,15 @@ def main():
         engine._eager_fwd_bwd(engine._static_item, 10)
         K.PROFILE.disable()
         SAMPLER.drop_static()  # the legs below run the model outside the engine: ordinary host draws again
+    rank_ms = None
     if multi:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax)
+        mine = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t) for t in every]
+        elapsed = max(per_rank)  # the MAX over ranks is what counts
+        rank_ms = {"min": min(per_rank) / args.steps * 1e3, "max": max(per_rank) / args.steps * 1e3,
+                   "per_rank": [round(t / args.steps * 1e3, 4) for t in per_rank]}
     assert torch.isfinite(res["loss"]).item(), "loss is not finite"
     for k in ("ade", "fde"):
         assert torch.isfinite(res[k]).all().item(), f"{k} is not finite"
@@ -420,7 +425,7 @@ def main():
             # the dispatch, and the largest refined total wins -- the raw eager event times include the Python launch
             # path between kernels
             best = None
-            for cand, st in [kv for kv in ranked if "+" not in kv[0]][:8]:
+            for cand, st in [kv for kv in ranked if "+" not in kv[0]][:14]:
                 fine = K.PROFILE.refine(cand)
                 if fine is None:  # no replayable launches recorded for this symbol: its eager figure is not comparable
                     continue
@@ -448,7 +453,7 @@ def main():
             # separately, gfx950 x2 read correction applied; bench.py itself cannot collect counters)
             traffic, traffic_src = None, None
             try:
-                for rnd in ("r02", "r01"):  # the newest committed PMC pass that knows this kernel
+                for rnd in ("r03", "r02", "r01"):  # the newest committed PMC pass that knows this kernel
                     path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
                     if os.path.exists(path):
                         with open(path) as fh:
@@ -499,6 +504,13 @@ def main():
             "loss": float(res["loss"].detach()), "rccl_ranks": rccl_ranks, "batch_independence_rel": indep["f32"], "batch_independence_rel_timed_mode": indep[args.precision],
             "roofline": roof, "roofline_top": top or None, "roofline_fused_encoder_stack": fused or None,
         }
+        if multi:
+            out["config"]["gradient_exchange"] = {
+                "mode": os.environ.get("RF_DP_MODE", "allreduce"),
+                "transport": "rf_comm_* (own RCCL communicator + communication stream)" if os.environ.get("RF_DP_COMM") == "rf"
+                else f"torch.distributed process group ({backend})",
+                "two_graph_step": bool(getattr(engine, "split", False)), "deferred_update": bool(defer)}
+            out["ms_per_step_by_rank"] = rank_ms
         if rehearse:
             out["config"]["rehearsal"] = "one-rank RCCL group, N>1 code path (RF_REHEARSE_COLLECTIVES=1)"
         if world == 1 and not rehearse and not args.no_ade and cfg.with_video:

@@ -496,9 +496,18 @@ class FusedAdamW:
         if hi <= lo:
             return
         o = 4 * lo
-        _hip.check(_hip.lib().rf_adamw_clip_dev(self.p.data_ptr() + o, self.g.data_ptr() + o, self.m.data_ptr() + o,
-                                                self.v.data_ptr() + o, hi - lo, self.sumsq.data_ptr(), self.parts,
-                                                hyper_dev.data_ptr(), K._stream()), "rf_adamw_clip_dev")
+        ev = K.PROFILE.begin() if K.PROFILE.on else None
+        args = (self.p.data_ptr() + o, self.g.data_ptr() + o, self.m.data_ptr() + o, self.v.data_ptr() + o, hi - lo,
+                self.sumsq.data_ptr(), self.parts, hyper_dev.data_ptr())
+        _hip.check(_hip.lib().rf_adamw_clip_dev(*args, K._stream()), "rf_adamw_clip_dev")
+        if ev is not None:
+            # algorithmic bytes: p, m, v read + written, g read (28 B per parameter).  The timing replay (bench.py, after
+            # the timed region) streams the same bytes with lr = wd = 0: parameters stay, only the moments decay
+            probe = hyper_dev.clone()
+            probe[0], probe[2], probe[6] = 1.0, 0.0, 0.0
+            K.PROFILE.end("adamw_clip_kernel<true>", ev, 12.0 * (hi - lo), 28.0 * (hi - lo),
+                          replay=lambda a=args[:-1], h=probe, kp=(self.p, self.g, self.m, self.v): _hip.lib().rf_adamw_clip_dev(
+                              *a, h.data_ptr(), K._stream()))
         K.WEIGHTS_EPOCH += 1
 
     def _segments(self, lo: int, hi: int, skip):
@@ -1121,7 +1130,12 @@ class GraphedTrainEngine(TrainEngine):
         if not self.split:
             with torch.cuda.graph(g, **_capture_kw()):
                 cur = torch.cuda.current_stream()
+
                 if la:
+                    # (the branch forks at the HEAD of the step: forking it after the camera streams' frame encoder, so that
+                    #  it runs underneath the latency-bound middle of the step only, was measured at 8.1 instead of 6.8 ms;
+                    #  stream priorities -- range (0, -1) on this stack -- make no difference under graph replay:
+                    #  profiles/r03/overlap_experiments.txt)
                     self._tstream.wait_stream(cur)
                     with torch.cuda.stream(self._tstream):
                         self._encode(clips, out=self._tok_next)

@@ -218,23 +218,25 @@ class HRNet16Backbone(VideoBackboneModule):
         fast = wb is not None and k == 3 and stride == 1 and K._PRECISION == 1
         pw = wb is not None and k == 1 and stride == 1 and K._PRECISION == 1 and act == 1
         if pw:  # 1x1 over bf16 maps: streaming GEMM, weights in registers
-            check(_hip.lib().rf_pointwise_bf16(ptr(x), ptr(wb), ptr(b), ptr(residual), ptr(y), N * H * Wd, cin, cout,
-                                               1 if relu else 0, K._stream()), "rf_pointwise_bf16")
+            fn, cargs = _hip.lib().rf_pointwise_bf16, (ptr(x), ptr(wb), ptr(b), ptr(residual), ptr(y), N * H * Wd, cin, cout,
+                                                       1 if relu else 0)
         elif fast:  # 3x3/s1 on the bf16 matrix cores straight out of an LDS raster window
-            check(_hip.lib().rf_conv3x3_bf16(ptr(x), ptr(wb), ptr(b), ptr(residual), ptr(y), act, N, H, Wd, cin, cout,
-                                             1 if relu else 0, K._stream()), "rf_conv3x3_bf16")
+            fn, cargs = _hip.lib().rf_conv3x3_bf16, (ptr(x), ptr(wb), ptr(b), ptr(residual), ptr(y), act, N, H, Wd, cin, cout,
+                                                     1 if relu else 0)
         else:
-            check(_hip.lib().rf_conv2d_nhwc(ptr(x), ptr(w), ptr(b), ptr(residual), ptr(y), act, N, H, Wd, cin, cout, k,
-                                            stride, pad, Ho, Wo, cout, cout, 1 if relu else 0, K._PRECISION,
-                                            K._stream()), "rf_conv2d_nhwc")
+            fn, cargs = _hip.lib().rf_conv2d_nhwc, (ptr(x), ptr(w), ptr(b), ptr(residual), ptr(y), act, N, H, Wd, cin, cout, k,
+                                                    stride, pad, Ho, Wo, cout, cout, 1 if relu else 0, K._PRECISION)
+        check(fn(*cargs, K._stream()), "trunk convolution")
         if ev is not None:  # algorithmic work: one read of x / w (/ residual), one write of y
             M = N * Ho * Wo
             tag = f"pointwise_kernel<{cin}, {cout}>" if pw else \
                 f"conv3x3_kernel<{cin}, {cout}, {'__bf16' if act else 'float'}>" if fast else \
                 f"gemm2_kernel<{K._PRECISION}, 3, 0, {1 if cout <= 16 else (2 if cout <= 32 else 0)}>"
             es = x.element_size()
+            keep = (x, w, b, wb, residual, y)
             K.PROFILE.end(tag, ev, 2.0 * M * cout * k * k * cin,
-                          es * (x.numel() + M * cout * (2 if residual is not None else 1)) + 4.0 * w.numel())
+                          es * (x.numel() + M * cout * (2 if residual is not None else 1)) + 4.0 * w.numel(),
+                          replay=lambda f=fn, a=cargs, kp=keep: f(*a, K._stream()))
         return y
 
     def _conv_group(self, W, units, xs, residuals):
@@ -253,7 +255,16 @@ class HRNet16Backbone(VideoBackboneModule):
             e.x, e.w_packed, e.bias, e.residual, e.y = ptr(x), ptr(wb), ptr(b), ptr(r), ptr(y)
             e.N, e.H, e.W, e.cin, e.cout, e.relu = N, H, Wd, cin, cout, 1
             ys.append(y)
-        check(_hip.lib().rf_conv3x3_group_bf16(arr, n, self._act_code(xs[0]), K._stream()), "rf_conv3x3_group_bf16")
+        ev = K.PROFILE.begin() if K.PROFILE.on else None
+        code = self._act_code(xs[0])
+        check(_hip.lib().rf_conv3x3_group_bf16(arr, n, code, K._stream()), "rf_conv3x3_group_bf16")
+        if ev is not None:
+            es = xs[0].element_size()
+            keep = (arr, list(xs), ys, residuals)
+            K.PROFILE.end("conv3x3_group_kernel", ev,
+                          float(sum(2.0 * y.numel() * 9 * x.shape[-1] for x, y in zip(xs, ys))),
+                          float(sum(es * (x.numel() + y.numel() * (2 if residuals is not None else 1)) for x, y in zip(xs, ys))),
+                          replay=lambda a=arr, n_=n, c_=code, kp=keep: _hip.lib().rf_conv3x3_group_bf16(a, n_, c_, K._stream()))
         return ys
 
     @classmethod
@@ -380,9 +391,12 @@ class HRNet16Backbone(VideoBackboneModule):
             check(_hip.lib().rf_fuse_upsample_sum(arr, len(ents), self._act_code(xs[0]), K._stream()), "rf_fuse_upsample_sum")
             if ev is not None:
                 es = xs[0].element_size()
+                code = self._act_code(xs[0])
                 K.PROFILE.end("fuse_upsample_sum_kernel", ev, 0.0,
                               float(sum(es * (o.numel() * (2 + (a is not None)) + sum(t.numel() for t in sr))
-                                        for a, _, sr, o in ents)))
+                                        for a, _, sr, o in ents)),
+                              replay=lambda a_=arr, n_=len(ents), c_=code, kp=(keep, ents): _hip.lib().rf_fuse_upsample_sum(
+                                  a_, n_, c_, K._stream()))
         return outs
 
     def encode_tokens(self, video, frame_idx: Optional[torch.Tensor]) -> torch.Tensor:
@@ -436,6 +450,18 @@ class HRNet16Backbone(VideoBackboneModule):
                                            x.data_ptr() + es * off * (H // 2) * (Wd // 2) * 4, act, v.shape[0], v.shape[1],
                                            fi.numel(), H, Wd, K._stream()), "rf_stem_conv0")
             off += n
+        tokens = out if out is not None else torch.empty(N, 65, 240, device=dev, dtype=torch.float32)
+        assert tuple(tokens.shape) == (N, 65, 240) and tokens.is_contiguous()
+        # (Measured dead end, profiles/r03/trunk_chunks.txt: running the rest of the trunk over 2 / 4 / 8 image slices, so
+        #  that its chip-filling launches leave wave slots to the latency-bound transformer chain on the other streams of
+        #  the step: 6.79 -> 6.77 / 8.19 / 13.3 ms per step -- the low-resolution half of the trunk is latency-bound
+        #  itself and every slice pays its ~90 launches again.)
+        self._trunk_body(W, x, tokens, adt, act, es)
+        return tokens
+
+    def _trunk_body(self, W, x, tokens, adt, act, es):
+        """Everything after conv0 for a contiguous slice of images: (n, H/2, W/2, 4) maps -> tokens (n, 65, 240)."""
+        N, dev = x.shape[0], x.device
         x = self._conv(W, "conv1", x, stride=2, relu=True)
         x = self._conv(W, "conv2", x, stride=2, relu=True)
         x = self._bottleneck(W, "layer1.0", x)
@@ -448,8 +474,6 @@ class HRNet16Backbone(VideoBackboneModule):
             for m in range(nmod):
                 xs = self._module(W, f"{stage}.{m}", xs)
         Hf, Wf = xs[0].shape[1:3]
-        tokens = out if out is not None else torch.empty(N, 65, 240, device=dev, dtype=torch.float32)
-        assert tuple(tokens.shape) == (N, 65, 240) and tokens.is_contiguous()
         if FUSE_SUM and len(xs) <= 4 and sum(t.shape[-1] for t in xs) == 240:
             # up-sample + concat + AdaptiveAvgPool + token layout in one launch: the 240-channel map is never stored
             import ctypes
