@@ -457,6 +457,25 @@ int rf_motion_input(const float* motion, const float* visual, float* x, float* o
                     int rotate_motion, int zero_visual, void* stream);
 int rf_rotate_head(const float* in, const float* origin, float* out, int B, int P, int C, float sign, void* stream);
 
+/* ---- small tensor plumbing of the hot path as single launches (csrc/smallops.hip) ---------------------------
+ * rf_median_windows: y (B,target,C) = lower median (torch.median: NaN wins) of the consecutive windows of T / target
+ *   samples of x (B,T,C) -- `median_downsampler`, routeformer/utils/filter.py:5-43 (gaze 200 Hz -> seq_len).
+ * rf_motion_diff: motion (B,T,2): row 0 = 0, row t = normalise(gps[t] - gps[t-1]) (routeformer.py:284-292).
+ * rf_time_table / _bwd: out[l,c] = l * w[c] + pe[l,c] (DataEmbedding's time feature + positional table,
+ *   gps_backbone/layers/Embedding.py:99-126) and dw[c] (+)= sum_l l * dout[l,c].
+ * rf_timeline_scatter / _gather: out (N,T,E) = zeros with out[:, idx[f]] = feats[:, f] (routeformer.py:443-459) and the
+ *   gradient gather; idx int64 (F).
+ * rf_smart_tail_fwd / _bwd: y (B,L+P,C) = cat(x, x[:, L-1] repeated P times (smart) or zeros) -- the Informer decoder
+ *   input (gps_backbone/Informer.py:125-136); dx = dy[:, :L] (+ extra) with the tail's gradients added to the last row. */
+int rf_median_windows(const float* x, float* y, int B, int T, int C, int target, void* stream);
+int rf_motion_diff(const float* gps, float* motion, int B, int T, int normalize, float mean, float std_, void* stream);
+int rf_time_table(const float* w, const float* pe, float* out, int L, int d, void* stream);
+int rf_time_table_bwd(const float* dout, float* dw, int L, int d, int accumulate, void* stream);
+int rf_timeline_scatter(const float* feats, const int64_t* idx, float* out, int64_t N, int T, int F, int E, void* stream);
+int rf_timeline_gather(const float* dout, const int64_t* idx, float* dfeats, int64_t N, int T, int F, int E, void* stream);
+int rf_smart_tail_fwd(const float* x, float* y, int B, int L, int P, int C, int smart, void* stream);
+int rf_smart_tail_bwd(const float* dy, const float* extra, float* dx, int B, int L, int P, int C, int smart, void* stream);
+
 /* ---- cross-resolution fusion of the conv trunk without intermediate maps (hrnetv2.py:250-271,453-498;
  * InverseForm.py:66-67; routeformer.py:478-487) ---------------------------------------------------------------
  * rf_fuse_upsample_sum: for each entry  out = [relu](base + base2 + sum_s bilinear_up(src[s]))  (terms added in this

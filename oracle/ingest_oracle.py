@@ -4,8 +4,8 @@
 ``routeformer/io/dataset.py:1463-1492`` (``cv2.resize(frame, target, None, None, None, cv2.INTER_AREA)``).
 **Parity unpinned**: OpenCV (``cv2``, a third-party dependency of the reference, ``opencv-python`` in its
 ``pyproject.toml``) is not installed in the build container and the reference holds no fixture for this path, so the
-restatement follows OpenCV's documented algorithm (area-weighted mean of the covered source pixels, result rounded to
-nearest-even and saturated) and is checked only against itself and against exact integer-factor block means.
+restatement follows OpenCV's published algorithm (area-weighted mean of the covered source pixels, result rounded to
+nearest-even and saturated; the exact-half scale takes OpenCV's integer 2 x 2 fast path, which rounds a half up) and is checked only against itself and against exact integer-factor block means.
 ``TokenCacheModel``: what the device hash table must do, as a dict."""
 import numpy as np
 
@@ -14,6 +14,9 @@ def resize_area(frames: np.ndarray, factor: float) -> np.ndarray:
     """uint8 (..., H, W) -> uint8 (..., int(H*factor), int(W*factor)); float64 accumulation."""
     H, W = frames.shape[-2:]
     h, w = int(H * factor), int(W * factor)
+    if H == 2 * h and W == 2 * w:  # OpenCV's 2 x 2 fast path (resize.cpp, ResizeAreaFastVec): rounds a half UP
+        f = frames.astype(np.int32)
+        return ((f[..., 0::2, 0::2] + f[..., 0::2, 1::2] + f[..., 1::2, 0::2] + f[..., 1::2, 1::2] + 2) >> 2).astype(np.uint8)
     sy, sx = H / h, W / w
 
     def weights(n_src, n_dst, s):

@@ -87,6 +87,14 @@ SIGNATURES = {
     "rf_sumsq": [_P, _L, _P, _P],
     "rf_adamw_clip": [_P, _P, _P, _P, _L, _P, _I, _F, _F, _F, _F, _F, _F, _I, _F, _P],
     "rf_adamw_clip_dev": [_P, _P, _P, _P, _L, _P, _I, _P, _P],
+    "rf_median_windows": [_P, _P, _I, _I, _I, _I, _P],
+    "rf_motion_diff": [_P, _P, _I, _I, _I, _F, _F, _P],
+    "rf_time_table": [_P, _P, _P, _I, _I, _P],
+    "rf_time_table_bwd": [_P, _P, _I, _I, _I, _P],
+    "rf_timeline_scatter": [_P, _P, _P, _L, _I, _I, _I, _P],
+    "rf_timeline_gather": [_P, _P, _P, _L, _I, _I, _I, _P],
+    "rf_smart_tail_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "rf_smart_tail_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "rf_fuse_upsample_sum": [_P, _I, _I, _P],
     "rf_concat_pool_tokens": [_P, _P, _P, _P, _I, _I, _P, _I, _P],
     "rf_comm_available": [],

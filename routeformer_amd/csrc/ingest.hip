@@ -24,6 +24,14 @@ __global__ __launch_bounds__(256) void resize_area_kernel(const uint8_t* __restr
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int x = (int)(i % w), y = (int)((i / w) % h);
     const long n = i / ((long)w * h);
+    if (H == 2 * h && W == 2 * w) {
+      // exact factor 1/2: OpenCV takes its 2 x 2 fast path here (resize.cpp, ResizeAreaFastVec: (a + b + c + d + 2) >> 2),
+      // which rounds a half UP, where the general path's saturate_cast rounds it to even -- a quarter of the pixels of a
+      // natural frame sit on such a half
+      const uint8_t* p0 = src + n * (long)H * W + (long)(2 * y) * W + 2 * x;
+      dst[i] = (uint8_t)(((int)p0[0] + (int)p0[1] + (int)p0[W] + (int)p0[W + 1] + 2) >> 2);
+      continue;
+    }
     const double fy0 = y * sy, fy1 = (y + 1) * sy, fx0 = x * sx, fx1 = (x + 1) * sx;
     const int y0 = (int)fy0, y1 = min(H, (int)ceil(fy1 - 1e-9)), x0 = (int)fx0, x1 = min(W, (int)ceil(fx1 - 1e-9));
     const uint8_t* img = src + n * (long)H * W;

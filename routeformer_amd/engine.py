@@ -849,14 +849,17 @@ class GraphedTrainEngine(TrainEngine):
         if rng is not None:
             lo, hi = rng
             side = K.side_stream("update")
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                opt.launch_update_dev(lo, hi, self._hyper)
-                r.flat_grad[lo:hi].zero_()
+            # the encoders' 5 % first and ALONE, then the fork: launched next to the backbone's 2-GB streaming update the
+            # small slices were starved by it (rocprofv3 trace, profiles/r03/step_trace_before.txt: 394 us for 98 MB of
+            # traffic, both launches ending together) -- and the camera / gaze / fusion encoders wait for exactly them
             for a, b in ((0, lo), (hi, n)):
                 if b > a:
                     opt.launch_update_dev(a, b, self._hyper)
                     r.flat_grad[a:b].zero_()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                opt.launch_update_dev(lo, hi, self._hyper)
+                r.flat_grad[lo:hi].zero_()
             self.model.__dict__["_before_gps_backbone"] = lambda: torch.cuda.current_stream().wait_stream(side)
         else:
             opt.launch_update_dev(0, n, self._hyper)

@@ -1364,6 +1364,123 @@ class _RotateHead(torch.autograd.Function):
         return dout, None
 
 
+# ---------------------------------------------------------------------------------------------------
+# small tensor plumbing as single launches (csrc/smallops.hip)
+# ---------------------------------------------------------------------------------------------------
+def median_windows(x: torch.Tensor, target: int) -> torch.Tensor:
+    """``median_downsampler`` (utils/filter.py:5-43) of a (B,T,C) fp32 device tensor in one launch."""
+    _req(x, "median_windows.x")
+    x = x.contiguous()
+    B, T, C = x.shape
+    y = torch.empty(B, target, C, device=x.device, dtype=torch.float32)
+    check(_hip.lib().rf_median_windows(ptr(x), ptr(y), B, T, C, target, _stream()), "rf_median_windows")
+    return y
+
+
+def motion_diff(gps: torch.Tensor, normalize: bool, mean: float, std: float) -> torch.Tensor:
+    """(B,T,2) positions -> (B,T,2) motion with the zero row in front (routeformer.py:284-292); no gradient."""
+    _req(gps, "motion_diff.gps")
+    gps = gps.contiguous()
+    B, T, C = gps.shape
+    assert C == 2
+    out = torch.empty_like(gps)
+    check(_hip.lib().rf_motion_diff(ptr(gps), ptr(out), B, T, 1 if normalize else 0, float(mean), float(std), _stream()),
+          "rf_motion_diff")
+    return out
+
+
+class _TimeTable(torch.autograd.Function):
+    """(L, d) table  l * w + pe[l]  of DataEmbedding (time feature of the position index + positional embedding)."""
+
+    @staticmethod
+    def forward(ctx, w, pe, L, gw):
+        d = w.numel()
+        wv = w.reshape(d).contiguous()
+        pe2 = pe.reshape(-1, d)[:L].contiguous()
+        out = torch.empty(L, d, device=w.device, dtype=torch.float32)
+        check(_hip.lib().rf_time_table(ptr(wv), ptr(pe2), ptr(out), L, d, _stream()), "rf_time_table")
+        ctx.cfg = (L, d, w.shape, gw)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L, d, wshape, gw = ctx.cfg
+        dout = dout.contiguous()
+        if gw is not None:
+            check(_hip.lib().rf_time_table_bwd(ptr(dout), ptr(gw), L, d, 1, _stream()), "rf_time_table_bwd")
+            _wrote(gw)
+            return None, None, None, None
+        dw = torch.empty(d, device=dout.device, dtype=torch.float32)
+        check(_hip.lib().rf_time_table_bwd(ptr(dout), ptr(dw), L, d, 0, _stream()), "rf_time_table_bwd")
+        return dw.view(wshape), None, None, None
+
+
+def time_table(w, pe, L: int):
+    _req(w, "time_table.w")
+    return _TimeTable.apply(w, pe, L, _slot(w))
+
+
+class _Timeline(torch.autograd.Function):
+    """(N,F,E) features of the sub-sampled frames -> (N,T,E) zero timeline with row idx[f] = feature f, one launch."""
+
+    @staticmethod
+    def forward(ctx, feats, idx, T):
+        feats = feats.contiguous()
+        N, F_, E = feats.shape
+        out = torch.empty(N, T, E, device=feats.device, dtype=torch.float32)
+        check(_hip.lib().rf_timeline_scatter(ptr(feats), ptr(idx), ptr(out), N, T, F_, E, _stream()), "rf_timeline_scatter")
+        ctx.save_for_backward(idx)
+        ctx.dims = (N, T, F_, E)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        N, T, F_, E = ctx.dims
+        dout = dout.contiguous()
+        dfeats = torch.empty(N, F_, E, device=dout.device, dtype=torch.float32)
+        check(_hip.lib().rf_timeline_gather(ptr(dout), ptr(idx), ptr(dfeats), N, T, F_, E, _stream()), "rf_timeline_gather")
+        return dfeats, None, None
+
+
+def timeline(feats, idx, T: int):
+    """``idx``: int64 (F) device tensor of distinct time steps."""
+    _req(feats, "timeline.feats")
+    assert idx.dtype == torch.int64 and idx.is_cuda and idx.is_contiguous()
+    return _Timeline.apply(feats, idx, T)
+
+
+class _SmartTail(torch.autograd.Function):
+    """x (B,L,C) -> (decoder input (B,L+P,C) = cat(x, last row repeated | zeros), alias of x for the encoder): both
+    gradients of x meet in ONE backward launch instead of slice + sum + add + autograd's add."""
+
+    @staticmethod
+    def forward(ctx, x, P, smart):
+        x = x.contiguous()
+        B, L, C = x.shape
+        y = torch.empty(B, L + P, C, device=x.device, dtype=torch.float32)
+        check(_hip.lib().rf_smart_tail_fwd(ptr(x), ptr(y), B, L, P, C, 1 if smart else 0, _stream()), "rf_smart_tail_fwd")
+        ctx.dims = (B, L, P, C, smart)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dalias):
+        B, L, P, C, smart = ctx.dims
+        if dy is None:
+            return dalias, None, None
+        dy = dy.contiguous()
+        extra = dalias.contiguous() if dalias is not None else None
+        dx = torch.empty(B, L, C, device=dy.device, dtype=torch.float32)
+        check(_hip.lib().rf_smart_tail_bwd(ptr(dy), ptr(extra), ptr(dx), B, L, P, C, 1 if smart else 0, _stream()),
+              "rf_smart_tail_bwd")
+        return dx, None, None
+
+
+def smart_tail(x, P: int, smart: bool):
+    _req(x, "smart_tail.x")
+    return _SmartTail.apply(x, P, smart)
+
+
 def motion_input(motion, visual, rotate_motion: bool, zero_visual: bool = False):
     return _MotionInput.apply(motion, visual, rotate_motion, zero_visual)
 

@@ -215,13 +215,10 @@ class DataEmbedding(nn.Module):
 
     def forward(self, x):
         L = x.shape[1]
-        cache = self.__dict__.setdefault("_mark_cache", {})
-        mark = cache.get((L, x.device))
-        if mark is None:  # (position indices: a constant per length -- no arange launch per forward)
-            mark = cache[(L, x.device)] = torch.arange(L, device=x.device, dtype=torch.float32).view(1, L, 1)
-        # rank-1 time feature + table: (1,L,d) host-side plumbing, broadcast over the batch
-        offset = mark * self.temporal_embedding.embed.weight.view(1, 1, -1) + self.position_embedding(L)
-        return _dropout(self.value_embedding(x, residual=offset[0]), self.p, self.training)
+        # rank-1 time feature (the position index l as the one "timeF" feature) + positional table: an (L, d) table built
+        # in one launch, added to every sequence in the token convolution's epilogue
+        offset = K.time_table(self.temporal_embedding.embed.weight, self.position_embedding.pe, L)
+        return _dropout(self.value_embedding(x, residual=offset), self.p, self.training)
 
 
 class AttentionLayer(nn.Module):

@@ -41,12 +41,9 @@ class Informer(nn.Module):
             projection=nn.Linear(c.d_model, c.c_out, bias=True))
 
     def forward(self, x):
-        B, L, C = x.shape
-        if self.smart_decoder:  # decoder sees the history followed by its last row repeated
-            tail = x[:, -1:, :].expand(B, self.pred_len, C)
-        else:
-            tail = torch.zeros(B, self.pred_len, C, device=x.device, dtype=torch.float32)
-        x_dec = torch.cat([x, tail], dim=1)
+        # decoder input: the history followed by its last row repeated ("smart") or by zeros; one launch, and the two
+        # gradients of x (encoder path, decoder path) meet in one backward launch
+        x_dec, x = K.smart_tail(x, self.pred_len, self.smart_decoder)
         fork = None
         if (K.OVERLAP and (K.OVERLAP_MASK & 8) and x.is_cuda and not K.on_side_stream() and len(self.decoder.layers) > 0):
             # the decoder's embedding and the self-attention block of its first layer do not depend on the encoder:

@@ -178,10 +178,13 @@ class Routeformer(nn.Module):
         gps = batch["gps"].to(torch.float32)
         if self.motion_noise > 0.0 and self.training:
             gps = gps + torch.randn_like(gps) * self.motion_noise
-        mv = gps[:, 1:, :] - gps[:, :-1, :]
-        if c.normalize_motion:
-            mv = (mv - c.motion_mean) / c.motion_std
-        motion = F.pad(mv, (0, 0, 1, 0))  # zero row in front aligns motion with the frames
+        if gps.is_cuda:  # diff + normalise + the zero row in front: one launch (inputs carry no gradient)
+            motion = K.motion_diff(gps, c.normalize_motion, c.motion_mean, c.motion_std)
+        else:
+            mv = gps[:, 1:, :] - gps[:, :-1, :]
+            if c.normalize_motion:
+                mv = (mv - c.motion_mean) / c.motion_std
+            motion = F.pad(mv, (0, 0, 1, 0))  # zero row in front aligns motion with the frames
         visual = []
         if self.with_video:
             # Plan the per-frame encoder calls in the reference's order (right, left, then front) and make
@@ -406,9 +409,8 @@ class Routeformer(nn.Module):
             emb = self.frame_encoder(tokens.to(dtype), idx_list, n_per).view(len(members), B, -1, E)
             K.TOPS.split_record(len(members), len(idx_list))
             idx_dev = self._device_index(idx, dev)
-            # one zero-fill + one scatter for all member streams (per-stream timelines are views of it)
-            timelines = torch.zeros(len(members), B, T, E, device=dev, dtype=emb.dtype)
-            timelines[:, :, idx_dev] = emb
+            # zero-fill + scatter for all member streams in one launch (per-stream timelines are views of it)
+            timelines = K.timeline(emb.reshape(len(members) * B, -1, E), idx_dev, T).view(len(members), B, T, E)
             for s_i, m in enumerate(members):
                 out.append((m[0], timelines[s_i]))
         return out

@@ -163,6 +163,32 @@ class HRNet16Backbone(VideoBackboneModule):
         return len(picked)
 
     # ---- weight preparation (BN folding, NHWC filter layout) ------------------------------------
+    # ---- backbone-feature cache ----------------------------------------------------------------------
+    def fingerprint(self) -> int:
+        """63-bit digest of the trunk's weights and buffers (what the cached tokens depend on besides the frames and the
+        arithmetic mode): cache keys are namespaced with it, as the reference's torchcache keys on the module hash."""
+        import hashlib
+        key = (tuple(p._version for p in self._Backbone.parameters()), tuple(b._version for b in self._Backbone.buffers()),
+               id(next(self._Backbone.parameters())))
+        hit = self.__dict__.get("_fingerprint")
+        if hit is None or hit[0] != key:
+            h = hashlib.blake2b(digest_size=8)
+            for name, t in sorted(self._Backbone.state_dict().items()):
+                h.update(name.encode())
+                h.update(t.detach().cpu().contiguous().numpy().tobytes())
+            hit = self.__dict__["_fingerprint"] = (key, int.from_bytes(h.digest(), "little") & 0x7FFFFFFFFFFFFFFF)
+        return hit[1]
+
+    @property
+    def token_cache(self):
+        return self.__dict__.get("_token_cache_obj")
+
+    @token_cache.setter
+    def token_cache(self, cache):
+        if cache is not None:
+            cache.bind(self.fingerprint())  # (re-attach the cache after loading other weights into the trunk)
+        self.__dict__["_token_cache_obj"] = cache
+
     def _prepare(self, device):
         key = (str(device), tuple(p._version for p in self._Backbone.parameters()),
                tuple(b._version for b in self._Backbone.buffers()), id(next(self._Backbone.parameters())))
@@ -411,9 +437,10 @@ class HRNet16Backbone(VideoBackboneModule):
         the reference's ``@torchcache(persistent=True)``, video_backbone/__init__.py:14-32): frames whose content has
         been seen are served from HBM, a pass with unknown frames runs the trunk once and stores its tokens.  Inside a
         stream capture (the engine's trunk graphs) the trunk always runs: the engine consults the cache itself."""
-        cache = getattr(self, "token_cache", None)
+        cache = self.token_cache
         if cache is None or torch.cuda.is_current_stream_capturing():
             return self._encode_clips_uncached(clips, out)
+        cache.bind(self.fingerprint())  # (cheap when the weights have not changed)
         clips = [((v if v.dtype in (torch.float16, torch.float32, torch.uint8) else v.float()).contiguous(), fi) for v, fi in clips]
         return cache.tokens_for(clips, self._encode_clips_uncached, out)
 

@@ -37,7 +37,24 @@ class TokenCache:
         self.store = torch.empty(self.capacity, tokens_per_frame, channels, dtype=dtype, device=dev)
         self._misses = torch.zeros(1, dtype=torch.int32, device=dev)
         self.seed = seed
+        self.fingerprint = 0  # digest of the producing trunk's weights (bind): part of every key's namespace
         self.hits = self.lookups = 0
+
+    def bind(self, fingerprint: int):
+        """Namespace the keys with the producing backbone's weight digest (HRNet16Backbone.fingerprint): tokens stored
+        under other weights are never served.  A cache that already holds tokens of another fingerprint refuses."""
+        fingerprint = int(fingerprint) & 0x7FFFFFFFFFFFFFFF
+        if self.fingerprint not in (0, fingerprint) and int(self.next_slot.item()) > 0:
+            raise ValueError("TokenCache holds tokens computed with other backbone weights; use a fresh cache (or load one "
+                             "saved with these weights)")
+        self.fingerprint = fingerprint
+
+    def _key_seed(self) -> int:
+        """seed ^ weight digest ^ arithmetic mode: the stored tokens depend on all three (a cache filled in bf16 mode must
+        not answer an fp32-mode forward and vice versa)."""
+        from routeformer_amd import kernels as K
+        mode = 0x5BF16BF16BF16BF1 if K.get_precision() == "bf16" else 0
+        return (int(self.seed) ^ self.fingerprint ^ mode) & 0x7FFFFFFFFFFFFFFF
 
     # -- keys -------------------------------------------------------------------------------------------------------
     def keys_of(self, clips) -> torch.Tensor:
@@ -54,7 +71,7 @@ class TokenCache:
                 ids = (torch.arange(B, device=v.device).view(B, 1) * T + idx.to(v.device).view(1, -1)).reshape(-1).contiguous()
                 n = ids.numel()
             keys = torch.empty(n, dtype=torch.int64, device=v.device)
-            check(_hip.lib().rf_frame_hash(ptr(v), ptr(ids), n, nbytes, ptr(keys), self.seed, _stream()), "rf_frame_hash")
+            check(_hip.lib().rf_frame_hash(ptr(v), ptr(ids), n, nbytes, ptr(keys), self._key_seed(), _stream()), "rf_frame_hash")
             out.append(keys)
         return torch.cat(out)
 
@@ -110,10 +127,14 @@ class TokenCache:
     def state_dict(self):
         n = int(self.next_slot.item())
         return {"table_keys": self.table_keys.cpu(), "table_slots": self.table_slots.cpu(), "n": n,
-                "store": self.store[:min(n, self.capacity)].cpu(), "seed": self.seed}
+                "store": self.store[:min(n, self.capacity)].cpu(), "seed": self.seed, "fingerprint": self.fingerprint}
 
     def load_state_dict(self, sd):
         assert sd["table_keys"].numel() == self.table_keys.numel(), "cache saved with another capacity"
+        saved = int(sd.get("fingerprint", 0))
+        if self.fingerprint and saved and saved != self.fingerprint:
+            raise ValueError("this cache file was written with other backbone weights (fingerprint mismatch)")
+        self.fingerprint = self.fingerprint or saved
         self.table_keys.copy_(sd["table_keys"])
         self.table_slots.copy_(sd["table_slots"])
         n = min(int(sd["n"]), self.capacity)

@@ -30,5 +30,8 @@ def median_downsampler(tensor: torch.Tensor, target_length: int) -> torch.Tensor
     if target_length >= T:
         raise ValueError("Target length must be less than the current time steps.")
     w = T // target_length
+    if tensor.is_cuda and tensor.dtype == torch.float32 and w <= 1024:  # one selection launch instead of a sort + gather
+        from routeformer_amd import kernels as K
+        return K.median_windows(tensor, target_length)
     win = tensor[:, : w * target_length].reshape(B, target_length, w, C)
     return win.sort(dim=2).values[:, :, (w - 1) // 2, :]

@@ -640,6 +640,72 @@ def test_vision_helpers():
     assert torch.equal(y8, y16)
 
 
+def test_small_ops_match_torch():
+    """csrc/smallops.hip (one launch each) against the torch expressions they replace: windowed lower median (incl. ties,
+    NaN windows, a window count that does not divide T), motion differencing with / without normalisation, the time-
+    feature table and its gradient, the frame timeline scatter / gather, the smart-decoder tail and its gradient."""
+    from routeformer_amd import kernels as Kn
+    from routeformer_amd.utils.tensor import median_downsampler
+    g = _g(23)
+    # median: (B,T,C) -> (B,target,C); reference = torch.median per window (lower median)
+    for (B, T, C, target) in ((3, 1600, 2, 40), (2, 1203, 3, 30), (1, 64, 1, 5), (2, 50, 2, 49)):
+        x = torch.randn(B, T, C, generator=g)
+        x[0, : T // 2, 0] = x[0, : T // 2, 0].round()            # ties
+        if T > 100:
+            x[B - 1, 7, C - 1] = float("nan")                    # a NaN window
+        w = T // target
+        ref = torch.stack([x[:, i * w:(i + 1) * w].median(dim=1).values for i in range(target)], dim=1)
+        got = median_downsampler(x.to(DEV), target).cpu()
+        assert got.shape == ref.shape and torch.equal(torch.nan_to_num(got, nan=123.0), torch.nan_to_num(ref, nan=123.0))
+    # motion
+    gps = torch.randn(4, 40, 2, generator=g).cumsum(dim=1)
+    for norm in (False, True):
+        mv = gps[:, 1:] - gps[:, :-1]
+        if norm:
+            mv = (mv - 1.83) / 0.91
+        ref = F.pad(mv, (0, 0, 1, 0))
+        assert rel_err(Kn.motion_diff(gps.to(DEV), norm, 1.83, 0.91), ref) < 1e-6
+    # time table + gradient
+    d, L = 832, 70
+    w = torch.randn(d, 1, generator=g, requires_grad=True)
+    pe = torch.randn(1, 5000, d, generator=g)
+    ref = torch.arange(L, dtype=torch.float32).view(L, 1) * w.view(1, d) + pe[0, :L]
+    wd = w.detach().to(DEV).requires_grad_()
+    got = Kn.time_table(wd, pe.to(DEV), L)
+    assert rel_err(got, ref) < 1e-6
+    up = torch.randn(L, d, generator=g)
+    ref.backward(up)
+    got.backward(up.to(DEV))
+    assert rel_err(wd.grad, w.grad) < 1e-5
+    # timeline scatter / gather
+    N, T, E = 6, 40, 64
+    idx = torch.flip(torch.arange(T - 1, 0, -5), dims=[0])
+    feats = torch.randn(N, idx.numel(), E, generator=g, requires_grad=True)
+    ref = torch.zeros(N, T, E)
+    ref[:, idx] = feats
+    fd = feats.detach().to(DEV).requires_grad_()
+    got = Kn.timeline(fd, idx.to(DEV), T)
+    assert torch.equal(got.cpu(), ref.detach())
+    up = torch.randn(N, T, E, generator=g)
+    ref.backward(up)
+    got.backward(up.to(DEV))
+    assert torch.equal(fd.grad.cpu(), feats.grad)
+    # smart tail (both variants) + the gradient with the alias branch folded in
+    B, L, P, C = 3, 40, 30, 69
+    for smart in (True, False):
+        x = torch.randn(B, L, C, generator=g, requires_grad=True)
+        tail = x[:, -1:, :].expand(B, P, C) if smart else torch.zeros(B, P, C)
+        ref = torch.cat([x, tail], dim=1)
+        xd = x.detach().to(DEV).requires_grad_()
+        y, alias = Kn.smart_tail(xd, P, smart)
+        assert torch.equal(y.cpu(), ref.detach()) and torch.equal(alias, xd)
+        u1, u2 = torch.randn(B, L + P, C, generator=g), torch.randn(B, L, C, generator=g)
+        (ref * u1).sum().backward()
+        x.grad += u2
+        ((y * u1.to(DEV)).sum() + (alias * u2.to(DEV)).sum()).backward()
+        assert rel_err(xd.grad, x.grad) < 1e-5
+
+
 @pytest.mark.parametrize("adt", [torch.float32, torch.bfloat16])
 def test_fuse_upsample_sum_and_concat_pool(adt):
     """csrc/fuse.hip against torch on the CPU: (i) several output branches of a fuse layer in one launch --
@@ -1204,7 +1270,10 @@ def test_resize_area_vs_restatement(shape, factor):
     if abs(inv - round(inv)) < 1e-9 and shape[-2] % round(inv) == 0 and shape[-1] % round(inv) == 0:
         s = int(round(inv))
         blocks = x.numpy().astype(np.float64).reshape(shape[:-2] + (shape[-2] // s, s, shape[-1] // s, s)).mean(axis=(-3, -1))
-        assert np.array_equal(got, np.rint(blocks).astype(np.uint8))
+        if s == 2:  # OpenCV's 2 x 2 fast path: (a + b + c + d + 2) >> 2, i.e. a half rounds UP (bit-exact here)
+            assert np.array_equal(got, np.floor(blocks + 0.5).astype(np.uint8)) and np.array_equal(got, want)
+        else:
+            assert np.array_equal(got, np.rint(blocks).astype(np.uint8))
 
 
 def test_token_cache_semantics():
@@ -1244,6 +1313,24 @@ def test_token_cache_semantics():
     again.load_state_dict(cache.state_dict())
     s3, m3 = again.lookup(keys)
     assert m3 == 0 and torch.equal(again.gather(s3), tokens)
+    # key namespace: the stored tokens also depend on the trunk's weights and on the arithmetic mode
+    from routeformer_amd import kernels as Kn
+    ns = TokenCache(5, DEV)
+    ns.bind(0x1234567)
+    k_f32 = ns.keys_of([(v, idx)])
+    assert not torch.equal(k_f32, keys), "weight fingerprint must change the keys"
+    Kn.set_precision("bf16")
+    try:
+        assert not torch.equal(ns.keys_of([(v, idx)]), k_f32), "bf16-mode tokens must not answer an fp32-mode lookup"
+    finally:
+        Kn.set_precision("f32")
+    ns.insert(k_f32, ns.lookup(k_f32)[0], tokens)
+    with pytest.raises(ValueError, match="other backbone weights"):
+        ns.bind(0x7654321)
+    foreign = TokenCache(5, DEV)
+    foreign.bind(0x7654321)
+    with pytest.raises(ValueError, match="fingerprint mismatch"):
+        foreign.load_state_dict(ns.state_dict())
 
 
 def test_gather_frames():
