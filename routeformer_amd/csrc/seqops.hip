@@ -411,6 +411,12 @@ __device__ float block_sum(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// Both kernels are ONE workgroup on a few thousand elements -- pure latency, on the critical path between the forward and
+// the backward pass.  The motion channels and the discount table gamma^t go through LDS first (one coalesced round trip),
+// so the horizon-long cumulative sums run out of LDS instead of as P dependent global loads, and no thread calls powf
+// in a loop.
+constexpr int TH_MAXP = 256, TH_MAXROWS = 2048;  // horizon / B * P bounds of the LDS staging (else the direct path)
+
 __global__ __launch_bounds__(256) void traj_head_fwd_kernel(const float* __restrict__ out, const float* __restrict__ last,
                                                             const float* __restrict__ tgt, const float* __restrict__ tvis,
                                                             float* __restrict__ pos, float* __restrict__ gpos,
@@ -418,22 +424,32 @@ __global__ __launch_bounds__(256) void traj_head_fwd_kernel(const float* __restr
                                                             float gamma, float ratio, int dense_on, float mstd,
                                                             float mmean) {
   __shared__ float red[4];
+  __shared__ float disc[TH_MAXP];
+  __shared__ float mot[TH_MAXROWS * 2];
   const int tid = threadIdx.x;
+  const bool staged = P <= TH_MAXP && B * P <= TH_MAXROWS;
+  if (staged) {
+    for (int t = tid; t < P; t += 256) disc[t] = powf(gamma, (float)t);
+    for (int i = tid; i < B * P * 2; i += 256) mot[i] = out[(long)(i >> 1) * C + (i & 1)] * mstd + mmean;
+    __syncthreads();
+  }
   // positions: one thread per (b, coordinate), sequential cumsum over the horizon (P <= a few dozen)
   for (int i = tid; i < B * 2; i += 256) {
     const int b = i >> 1, c = i & 1;
     float run = last[b * 2 + c];
     for (int t = 0; t < P; ++t) {
-      run += out[((long)b * P + t) * C + c] * mstd + mmean;
+      run += staged ? mot[(b * P + t) * 2 + c] : out[((long)b * P + t) * C + c] * mstd + mmean;
       pos[((long)b * P + t) * 2 + c] = run;
+      if (staged) mot[(b * P + t) * 2 + c] = run;  // keep the position: the loss loop below reads it from LDS
     }
   }
   __syncthreads();
   float s_traj = 0.f, s_ade = 0.f, s_fde = 0.f;
   for (int i = tid; i < B * P; i += 256) {
     const int b = i / P, t = i - b * P;
-    const float w = powf(gamma, (float)t);
-    const float dx = pos[i * 2] - tgt[i * 2], dy = pos[i * 2 + 1] - tgt[i * 2 + 1];
+    const float w = staged ? disc[t] : powf(gamma, (float)t);
+    const float px = staged ? mot[i * 2] : pos[i * 2], py = staged ? mot[i * 2 + 1] : pos[i * 2 + 1];
+    const float dx = px - tgt[i * 2], dy = py - tgt[i * 2 + 1];
     s_traj += w * (sl1(dx) + sl1(dy));
     gpos[i * 2] = w * sl1g(dx);
     gpos[i * 2 + 1] = w * sl1g(dy);
@@ -443,10 +459,12 @@ __global__ __launch_bounds__(256) void traj_head_fwd_kernel(const float* __restr
   }
   float s_dense = 0.f;
   if (tvis) {
-    for (long i = tid; i < (long)B * P * E; i += 256) {
-      const long bt = i / E;
-      const int e = (int)(i - bt * E), t = (int)(bt % P);
-      s_dense += powf(gamma, (float)t) * sl1(out[bt * C + 2 + e] - tvis[i]);
+    // one (b, t) row of E channels per 16-lane group pass: the discount is looked up once per row, no div / mod per element
+    for (long bt = tid >> 4; bt < (long)B * P; bt += 16) {
+      const float w = staged ? disc[(int)(bt % P)] : powf(gamma, (float)(bt % P));
+      float a = 0.f;
+      for (int e = tid & 15; e < E; e += 16) a += sl1(out[bt * C + 2 + e] - tvis[bt * E + e]);
+      s_dense += w * a;
     }
   }
   const float traj = block_sum(s_traj, red) / (float)(B * P * 2);
@@ -463,24 +481,31 @@ __global__ __launch_bounds__(256) void traj_head_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gpos, const float* __restrict__ scal,
                                                             const float* __restrict__ gloss, float* __restrict__ dout,
                                                             int B, int P, int C, int E, float gamma, float mstd) {
+  __shared__ float disc[TH_MAXP];
+  __shared__ float gp[TH_MAXROWS * 2];
   const int tid = threadIdx.x;
   const float g = gloss ? gloss[0] : 1.f;
   const float w = scal[5];
+  const bool staged = P <= TH_MAXP && B * P <= TH_MAXROWS;
+  if (staged) {
+    for (int t = tid; t < P; t += 256) disc[t] = powf(gamma, (float)t);
+    for (int i = tid; i < B * P * 2; i += 256) gp[i] = gpos[i];
+    __syncthreads();
+  }
   // d traj / d motion[b,s,c] = mstd * sum_{t>=s} gpos[b,t,c] / (B*P*2)
   for (int i = tid; i < B * 2; i += 256) {
     const int b = i >> 1, c = i & 1;
     float run = 0.f;
     for (int t = P - 1; t >= 0; --t) {
-      run += gpos[((long)b * P + t) * 2 + c];
+      run += staged ? gp[(b * P + t) * 2 + c] : gpos[((long)b * P + t) * 2 + c];
       dout[((long)b * P + t) * C + c] = g * mstd * run / (float)(B * P * 2);
     }
   }
   if (tvis) {
     const float k = g * w / (float)((long)B * P * E);
-    for (long i = tid; i < (long)B * P * E; i += 256) {
-      const long bt = i / E;
-      const int e = (int)(i - bt * E), t = (int)(bt % P);
-      dout[bt * C + 2 + e] = k * powf(gamma, (float)t) * sl1g(out[bt * C + 2 + e] - tvis[i]);
+    for (long bt = tid >> 4; bt < (long)B * P; bt += 16) {
+      const float kw = k * (staged ? disc[(int)(bt % P)] : powf(gamma, (float)(bt % P)));
+      for (int e = tid & 15; e < E; e += 16) dout[bt * C + 2 + e] = kw * sl1g(out[bt * C + 2 + e] - tvis[bt * E + e]);
     }
   }
 }
