@@ -187,6 +187,12 @@ int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const float* x, c
                        const float* var, const float* gamma, const float* beta, float* dx,
                        float* dgamma, float* dbeta, int accumulate, int B, int L, int C, float eps,
                        int training, void* stream);
+/* Train-mode forward of the same tail in ONE launch (batch statistics + running-statistics update + BatchNorm -> ELU ->
+ * MaxPool; mean / var = the biased batch statistics, kept for the backward pass): a workgroup holds a 32-channel slab of
+ * all B * L rows in LDS.  RF_EUNSUPPORTED when the slab does not fit (then: rf_bn_stats + rf_bn_elu_pool_fwd). */
+int rf_bn_train_elu_pool_fwd(const float* x, const float* gamma, const float* beta, float* mean, float* var,
+                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float* y,
+                             int32_t* argmax, int B, int L, int C, float eps, void* stream);
 
 /* Grouped weight gradients (the dW / db GEMMs of nn.Linear / Conv1d(k=1) backward, autograd's
  * `grad_weight = grad_out^T @ input`): for each entry  dw[N,K] += dy[M,N]^T x[M,K]  and, if db != NULL,

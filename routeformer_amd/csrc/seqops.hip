@@ -291,6 +291,128 @@ __global__ __launch_bounds__(256) void bn_elu_pool_bwd_kernel(const float* __res
   }
 }
 
+// ---- distilling tail with the channel slab in LDS (layers/TransformerEncoderDecoder.py:9-29) -----------------------
+// The Informer's ConvLayer tail works on (B * L) <= a few hundred rows x d_model channels: a workgroup takes a slab of
+// BNS_CH channels x ALL rows into LDS with one coalesced pass and does everything else from there -- train-mode batch
+// statistics (two-pass variance), the running-statistics update, BatchNorm -> ELU -> MaxPool1d(3, 2, 1); backward: the
+// pre-BN gradient through the pool routing and ELU', the two batch sums of BatchNorm's backward and dx.  One launch each
+// way instead of statistics + apply launches whose threads walked the rows with strided global loads.
+constexpr int BNS_CH = 32, BNS_RL = 8;  // channels per workgroup x row lanes (256 threads)
+
+__global__ __launch_bounds__(256) void bn_train_elu_pool_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean_out,
+    float* __restrict__ var_out, float* __restrict__ run_mean, float* __restrict__ run_var, long long* __restrict__ batches,
+    float momentum, float* __restrict__ y, int32_t* __restrict__ argmax, int B, int L, int C, int Lout, float eps) {
+  extern __shared__ float slab[];  // [rows][BNS_CH]
+  __shared__ float red[BNS_RL][BNS_CH];
+  const int tx = threadIdx.x % BNS_CH, ty = threadIdx.x / BNS_CH;
+  const int c = blockIdx.x * BNS_CH + tx, cc = min(c, C - 1);
+  const int rows = B * L;
+  float s = 0.f;
+  for (int r = ty; r < rows; r += BNS_RL) {
+    const float v = x[(long)r * C + cc];
+    slab[r * BNS_CH + tx] = v;
+    s += v;
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < BNS_RL; ++k) m += red[k][tx];
+  m /= (float)rows;
+  __syncthreads();
+  float q = 0.f;
+  for (int r = ty; r < rows; r += BNS_RL) { const float d = slab[r * BNS_CH + tx] - m; q += d * d; }
+  red[ty][tx] = q;
+  __syncthreads();
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < BNS_RL; ++k) v += red[k][tx];
+  v /= (float)rows;
+  if (ty == 0 && c < C) {
+    mean_out[c] = m;
+    var_out[c] = v;
+    if (run_mean) {  // nn.BatchNorm1d running statistics (unbiased variance)
+      const float keep = 1.0f - momentum;
+      const float unbias = momentum * ((float)rows / (float)max(rows - 1, 1));
+      run_mean[c] = run_mean[c] * keep + momentum * m;
+      run_var[c] = run_var[c] * keep + unbias * v;
+    }
+  }
+  if (batches && blockIdx.x == 0 && threadIdx.x == 0) *batches += 1;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(v + eps), sh = beta[c] - m * sc;
+  for (int o = ty; o < B * Lout; o += BNS_RL) {
+    const int b = o / Lout, lo = o - b * Lout;
+    float best = -INFINITY;
+    int arg = -1;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int li = 2 * lo - 1 + t;
+      if (li < 0 || li >= L) continue;
+      const float z = elu(fmaf(slab[(b * L + li) * BNS_CH + tx], sc, sh));
+      if (z > best || arg < 0) { best = z; arg = li; }
+    }
+    y[(long)o * C + c] = best;
+    argmax[(long)o * C + c] = arg;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_elu_pool_bwd_slab_kernel(
+    const float* __restrict__ dy, const int32_t* __restrict__ argmax, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dx,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int L, int C, int Lout, float eps, int training, int accumulate) {
+  extern __shared__ float slab[];  // xh [rows][BNS_CH], then d [rows][BNS_CH]
+  __shared__ float red[2][BNS_RL][BNS_CH];
+  const int tx = threadIdx.x % BNS_CH, ty = threadIdx.x / BNS_CH;
+  const int c = blockIdx.x * BNS_CH + tx, cc = min(c, C - 1);
+  const int rows = B * L;
+  float* xh = slab;
+  float* dd = slab + (long)rows * BNS_CH;
+  const float g = gamma[cc], istd = 1.0f / sqrtf(var[cc] + eps), mu = mean[cc], bt = beta[cc];
+  for (int r = ty; r < rows; r += BNS_RL) {
+    xh[r * BNS_CH + tx] = (x[(long)r * C + cc] - mu) * istd;
+    dd[r * BNS_CH + tx] = 0.f;
+  }
+  __syncthreads();
+  // pool routing: every pooled output sends its gradient to its arg-max row (windows overlap in one row: two outputs of a
+  // channel may name the same row -- the (b, lo) loop of one thread column runs over lo with stride BNS_RL, so the adds
+  // of a column go through LDS atomics)
+  for (int o = ty; o < B * Lout; o += BNS_RL) {
+    const int b = o / Lout;
+    const int li = argmax[(long)o * C + cc];
+    atomicAdd(&dd[(b * L + li) * BNS_CH + tx], dy[(long)o * C + cc]);
+  }
+  __syncthreads();
+  float s1 = 0.f, s2 = 0.f;
+  for (int r = ty; r < rows; r += BNS_RL) {
+    const float h = xh[r * BNS_CH + tx];
+    const float z = fmaf(h, g, bt);
+    const float d = dd[r * BNS_CH + tx] * (z > 0.f ? 1.f : expf(z));  // through ELU'
+    dd[r * BNS_CH + tx] = d;
+    s1 += d;
+    s2 += d * h;
+  }
+  red[0][ty][tx] = s1;
+  red[1][ty][tx] = s2;
+  __syncthreads();
+  float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < BNS_RL; ++k) { S1 += red[0][k][tx]; S2 += red[1][k][tx]; }
+  if (c >= C) return;
+  if (ty == 0) {
+    if (accumulate) { dbeta[c] += S1; dgamma[c] += S2; }
+    else { dbeta[c] = S1; dgamma[c] = S2; }
+  }
+  const float m1 = S1 / (float)rows, m2 = S2 / (float)rows;
+  for (int r = ty; r < rows; r += BNS_RL) {
+    const float d = dd[r * BNS_CH + tx], h = xh[r * BNS_CH + tx];
+    dx[(long)r * C + c] = training ? g * istd * (d - m1 - h * m2) : g * istd * d;
+  }
+}
+
+constexpr int BNS_MAX_LDS = 96 * 1024;
+
 inline int grid_for(long total, int block = 256, int cap = 4096) {
   long g = (total + block - 1) / block;
   return (int)(g > cap ? cap : (g < 1 ? 1 : g));
@@ -384,8 +506,47 @@ extern "C" int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const 
                                   void* stream) {
   RF_REQUIRE(dy && argmax && x && mean && var && gamma && beta && dx && dgamma && dbeta && B > 0 && L > 0 && C > 0);
   const int Lout = (L - 1) / 2 + 1;
+  const size_t lds = (size_t)2 * B * L * BNS_CH * sizeof(float);
+  if (lds <= (size_t)BNS_MAX_LDS) {  // channel slab in LDS (the Informer's distilling layers: B * L <= a few hundred rows)
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_elu_pool_bwd_slab_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, BNS_MAX_LDS);
+      attr = true;
+    }
+    RF_LAUNCH(bn_elu_pool_bwd_slab_kernel, dim3((C + BNS_CH - 1) / BNS_CH), dim3(256), lds, static_cast<hipStream_t>(stream), dy,
+              argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, B, L, C, Lout, eps, training, accumulate);
+    RF_CHECK_LAUNCH();
+    return RF_OK;
+  }
   RF_LAUNCH(bn_elu_pool_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), dy,
                      argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, B, L, C, Lout, eps, training, accumulate);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+// Train-mode forward in ONE launch: batch statistics (+ running-statistics update) -> BatchNorm -> ELU -> MaxPool; mean / var
+// (biased) are written for the backward pass.  Returns RF_EUNSUPPORTED when the row slab does not fit LDS (the caller then
+// uses rf_bn_stats + rf_bn_elu_pool_fwd).
+extern "C" int rf_bn_train_elu_pool_fwd(const float* x, const float* gamma, const float* beta, float* mean, float* var,
+                                        float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                        float* y, int32_t* argmax, int B, int L, int C, float eps, void* stream) {
+  RF_REQUIRE(x && gamma && beta && mean && var && y && argmax && B > 0 && L > 0 && C > 0 && (!running_mean == !running_var));
+  const int Lout = (L - 1) / 2 + 1;
+  const size_t lds = (size_t)B * L * BNS_CH * sizeof(float);
+  if (lds > (size_t)BNS_MAX_LDS) {
+    rf_g_last_error = "rf_bn_train_elu_pool_fwd: B * L rows do not fit the LDS slab";
+    return RF_EUNSUPPORTED;
+  }
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_train_elu_pool_fwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, BNS_MAX_LDS);
+    attr = true;
+  }
+  RF_LAUNCH(bn_train_elu_pool_fwd_kernel, dim3((C + BNS_CH - 1) / BNS_CH), dim3(256), lds, static_cast<hipStream_t>(stream), x,
+            gamma, beta, mean, var, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, y,
+            argmax, B, L, C, Lout, eps);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

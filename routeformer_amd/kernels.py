@@ -1043,14 +1043,22 @@ class _BnEluPool(torch.autograd.Function):
     """BatchNorm1d -> ELU -> MaxPool1d(3,2,1) over (B,L,C) (Informer distilling tail)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, mean, var, eps, training, gg=None, gb=None):
+    def forward(ctx, x, gamma, beta, mean, var, eps, training, gg=None, gb=None, running=None):
+        """``running`` = (running_mean, running_var, num_batches_tracked, momentum) with ``mean`` / ``var`` empty buffers:
+        train mode, statistics computed by the same launch (rf_bn_train_elu_pool_fwd)."""
         x = x.contiguous()
         B, L, C = x.shape
         Lout = (L - 1) // 2 + 1
         y = torch.empty(B, Lout, C, device=x.device, dtype=torch.float32)
         arg = torch.empty(B, Lout, C, device=x.device, dtype=torch.int32)
-        check(_hip.lib().rf_bn_elu_pool_fwd(ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(y),
-                                            ptr(arg), B, L, C, eps, _stream()), "rf_bn_elu_pool_fwd")
+        if running is not None:
+            rm, rv, nbt, momentum = running
+            check(_hip.lib().rf_bn_train_elu_pool_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(var), ptr(rm), ptr(rv),
+                                                      ptr(nbt), momentum, ptr(y), ptr(arg), B, L, C, eps, _stream()),
+                  "rf_bn_train_elu_pool_fwd")
+        else:
+            check(_hip.lib().rf_bn_elu_pool_fwd(ptr(x), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(y),
+                                                ptr(arg), B, L, C, eps, _stream()), "rf_bn_elu_pool_fwd")
         ctx.save_for_backward(x, gamma, beta, mean, var, arg)
         ctx.eps, ctx.training = eps, training
         ctx.sinks = (gg, gb)
@@ -1072,7 +1080,7 @@ class _BnEluPool(torch.autograd.Function):
         if sink:
             _wrote(gg, gb)
             dg = db = None
-        return dx, dg, db, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, None
 
 
 def bn_stats(x3: torch.Tensor, running_mean=None, running_var=None, num_batches_tracked=None, momentum: float = 0.1):
@@ -1091,6 +1099,14 @@ def bn_stats(x3: torch.Tensor, running_mean=None, running_var=None, num_batches_
 def bn_elu_pool(x, gamma, beta, running_mean, running_var, num_batches_tracked, training: bool,
                 momentum: float = 0.1, eps: float = 1e-5):
     x = x.contiguous()
+    B, L, C = x.shape
+    if training and B * L * 32 * 4 <= 96 * 1024:  # statistics + apply in one launch (a 32-channel slab of all rows in LDS)
+        if num_batches_tracked is not None:
+            assert num_batches_tracked.dtype == torch.int64 and num_batches_tracked.is_cuda
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        var = torch.empty(C, device=x.device, dtype=torch.float32)
+        return _BnEluPool.apply(x, gamma, beta, mean, var, eps, training, _slot(gamma), _slot(beta),
+                                (running_mean, running_var, num_batches_tracked, momentum))
     if training:
         mean, var = bn_stats(x.detach(), running_mean, running_var, num_batches_tracked, momentum)
     else:
