@@ -463,6 +463,19 @@ int rf_motion_input(const float* motion, const float* visual, float* x, float* o
                     int rotate_motion, int zero_visual, void* stream);
 int rf_rotate_head(const float* in, const float* origin, float* out, int B, int P, int C, float sign, void* stream);
 
+/* ---- row-tile half of a ProbSparse encoder layer (csrc/enclayer.hip) -- for sequences beyond the fused stack's L <= 80
+ * (the fusion `video_encoder`, routeformer.py:85-92,346: L = 160 / 320).  One launch takes the attention output of layer l
+ * through out-projection + residual + LayerNorm1 -> conv1 -> act -> conv2 + residual + LayerNorm2 AND the packed q | k | v
+ * projection of layer l + 1 (cross_modal_transformer.py:288-301), 32 / 48 rows of the flattened (B L, 128) activations per
+ * workgroup; rf_attn_fwd runs between two of them: a layer = 2 launches instead of 4.  Weights: the per-layer blobs of
+ * rf_seqlayer_pack.  ctx == NULL: projection only (first layer's q | k | v from x); wpack_next == NULL: no projection
+ * (last layer).  save = 1: also write what the layer-by-layer backward consumes (z only for GELU). */
+int rf_enclayer_tile_supported(int d_model, int n_heads, int d_ff);
+int rf_enclayer_tile_fwd(const float* ctx, const float* x, const void* wpack, const void* wpack_next, float* y,
+                         float* qkv_next, float* xhat1, float* rstd1, float* x1, float* z, float* h, float* xhat2,
+                         float* rstd2, int M, int d_model, int n_heads, int d_ff, int act, int save, float eps,
+                         void* stream);
+
 /* ---- small tensor plumbing of the hot path as single launches (csrc/smallops.hip) ---------------------------
  * rf_median_windows: y (B,target,C) = lower median (torch.median: NaN wins) of the consecutive windows of T / target
  *   samples of x (B,T,C) -- `median_downsampler`, routeformer/utils/filter.py:5-43 (gaze 200 Hz -> seq_len).

@@ -1,0 +1,311 @@
+// Row-tile half of a ProbSparse encoder layer for sequences too long for the one-workgroup-per-sequence stack
+// (csrc/seqlayer.hip stops at L = 80; the fusion `video_encoder` of routeformer.py:85-92,346 runs L = 160 / 320):
+//
+//   attention output of layer l  ->  out-projection + residual + LayerNorm1 -> conv1 -> act -> conv2 + residual + LayerNorm2
+//                                ->  packed q | k | v projection of layer l + 1              (cross_modal_transformer.py:288-301)
+//
+// is ROW-LOCAL, so a workgroup (8 waves) owns 16 RT rows of the flattened (B L, 128) activations, whatever sequence they
+// belong to; the only step that needs a whole sequence -- ProbSparse attention -- stays its own launch (rf_attn_fwd) between
+// two of these.  A layer is 2 launches instead of 4 (QKV row-block, attention, out-projection + LN row-block, FFN + LN
+// row-block), for any L and any batch, and the activations between out-projection and the next layer's q | k | v never leave
+// the chip.  Same arithmetic contract and the same packed weight blobs as the fused stack: bf16 matrix-core operands
+// (fragment-ordered weights read straight from global / L2), fp32 accumulation, fp32 residual stream in registers (wave w
+// holds columns 16 w .. 16 w + 15 of every row), q and k in split-bf16 (x = hi + lo, W = hi + lo: three MFMAs per product)
+// because they feed the discontinuous top-u selection.  Training mode stores what the layer-by-layer backward consumes
+// (x-hat / 1/sigma of both norms, x1, z, h, the layer output) with the meaning of the unfused forward's saved tensors.
+#include "seqlayer_common.h"
+
+namespace {
+
+struct EncTileP {
+  const float* ctx;            // (M, 128) attention output of this layer; null: projection-only launch (first layer's q | k | v)
+  const float* x;              // (M, 128) input of this layer (residual stream)
+  const unsigned char* wl;     // this layer's packed blob (pack_offsets)
+  const unsigned char* wnext;  // next layer's blob (its [Wq; Wk; Wv], low halves, bias) or null after the last layer
+  float* y;                    // (M, 128) layer output
+  float* qkv_next;             // (M, 384) packed q | k | v for the next attention launch
+  float *xhat1, *rstd1, *x1, *z, *h, *xhat2, *rstd2;  // training saves (M, width) or null
+  int M, F, act;
+  float eps;
+};
+
+template <int RT, bool SAVE>
+__global__ __launch_bounds__(SL_NT) void enc_tile_fwd_kernel(const EncTileP p) {
+  constexpr int LP = 16 * RT, TB = 320;  // TB: floats of one staged 16 x 16 tile (pitch 20)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* xb = reinterpret_cast<__bf16*>(smem);                 // [LP][SL_XP]  ctx / x1 / y as MFMA A operand
+  __bf16* hb = xb + LP * SL_XP;                                 // [LP][F + 8]  hidden activation; later the low half of y
+  const int F = p.F, HP = F + 8;
+  float* stage_base = reinterpret_cast<float*>(hb + LP * HP);   // per wave RT staged tiles
+  float2* part = reinterpret_cast<float2*>(stage_base + SL_NW * RT * TB);
+  float2* stat = part + LP * SL_NW;
+  __bf16* xlo = hb;  // (pitch SL_XP <= HP)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int srow = lane >> 2, sc4 = (lane & 3) * 4;
+  const long row0 = (long)blockIdx.x * LP;
+  const int L = (int)min((long)LP, (long)p.M - row0);  // valid rows of this tile
+  float* sc_f = stage_base + wave * RT * TB;
+  const PackOff po = pack_offsets(F);
+
+  // one 16 x 16 fp32 tile set (RT tiles, accumulator layout) -> global rows, 16-B stores through the wave's staging patch
+  auto store_tiles = [&](const f32x4 (&v)[RT], float* g, int ld) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc_f[rt * TB + (fq * 4 + r) * 20 + fr] = v[rt][r];
+    wave_sync_lds();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      if (rt * 16 + srow < L)
+        *reinterpret_cast<float4*>(g + (long)(rt * 16 + srow) * ld + sc4) = *reinterpret_cast<const float4*>(sc_f + rt * TB + srow * 20 + sc4);
+    wave_sync_lds();
+  };
+
+  // ---- residual stream slice of this wave ----
+  f32x4 xres[RT];
+  {
+    const float* xg = p.x + row0 * SL_D + wave * 16 + fr;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xres[rt][r] = xg[(long)min(rt * 16 + fq * 4 + r, L - 1) * SL_D];
+  }
+
+  if (p.ctx) {
+    const unsigned char* wl = p.wl;
+    const __bf16* w_o = reinterpret_cast<const __bf16*>(wl + po.wo);
+    const __bf16* w_1 = reinterpret_cast<const __bf16*>(wl + po.w1);
+    const __bf16* w_2 = reinterpret_cast<const __bf16*>(wl + po.w2);
+    const float* vec = reinterpret_cast<const float*>(wl + po.vec);
+    bf16x8 wfo[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wfo[kk] = ld_wfrag(w_o, wave * 4 + kk, lane);
+    // ---- attention output of the tile -> bf16 A image (coalesced 16-B loads) ----
+    for (int i = tid; i < LP * (SL_D / 4); i += SL_NT) {
+      const int row = i >> 5, c4 = (i & 31) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(p.ctx + (row0 + min(row, L - 1)) * SL_D + c4);
+      const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      *reinterpret_cast<bf16x4*>(xb + row * SL_XP + c4) = o;
+    }
+    __syncthreads();
+
+    // ================= out-projection + residual + LayerNorm 1 (wave = 16 output columns) =================
+    {
+      const int col = wave * 16 + fr;
+      const float bo = vec[384 + col], g1 = vec[640 + F + col], be1 = vec[768 + F + col];
+      f32x4 v[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8), wfo[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[rt][r] = acc[r] + bo + xres[rt][r];
+      }
+      stack_layer_norm<RT>(v, SAVE ? p.rstd1 + row0 : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the ctx reads)
+      if (SAVE) store_tiles(v, p.xhat1 + row0 * SL_D + wave * 16, SL_D);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y1 = v[rt][r] * g1 + be1;
+          xres[rt][r] = y1;
+          xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)y1;
+        }
+      if (SAVE) store_tiles(xres, p.x1 + row0 * SL_D + wave * 16, SL_D);
+    }
+    __syncthreads();  // x1 image complete
+
+    // ================= conv1 + activation (wave = column tiles wave, wave + 8, ...) =================
+    {
+      float* z_g = (SAVE && p.z) ? p.z + row0 * F : nullptr;
+      float* h_g = SAVE ? p.h + row0 * F : nullptr;
+#pragma unroll 1
+      for (int ct = wave; ct < F / 16; ct += SL_NW) {
+        bf16x8 wf1[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) wf1[kk] = ld_wfrag(w_1, ct * 4 + kk, lane);
+        const int col = ct * 16 + fr;
+        const float b1 = vec[512 + col];
+        f32x4 zz[RT], hh[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          zz[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            zz[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8), wf1[kk], zz[rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zz[rt][r] += b1;
+        if (p.act == RF_ACT_GELU) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hh[rt][r] = sl_gelu(zz[rt][r]);
+        } else {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hh[rt][r] = p.act == RF_ACT_RELU ? fmaxf(zz[rt][r], 0.f) : zz[rt][r];
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hb[(rt * 16 + fq * 4 + r) * HP + col] = (__bf16)hh[rt][r];
+        if (z_g) store_tiles(zz, z_g + ct * 16, F);
+        if (h_g) store_tiles(hh, h_g + ct * 16, F);
+      }
+    }
+    __syncthreads();  // hidden activation image complete
+
+    // ================= conv2 + residual + LayerNorm 2 =================
+    {
+      const int col = wave * 16 + fr;
+      const float b2 = vec[512 + F + col], g2 = vec[896 + F + col], be2 = vec[1024 + F + col];
+      f32x4 v[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) v[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int nk = F / 32;  // <= 8
+      bf16x8 wf2[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) wf2[kk] = ld_wfrag(w_2, wave * nk + min(kk, nk - 1), lane);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        if (kk < nk) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            v[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(hb + (rt * 16 + fr) * HP + kk * 32 + fq * 8), wf2[kk], v[rt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[rt][r] += b2 + xres[rt][r];
+      stack_layer_norm<RT>(v, SAVE ? p.rstd2 + row0 : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the hb / xb reads)
+      if (SAVE) store_tiles(v, p.xhat2 + row0 * SL_D + wave * 16, SL_D);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xres[rt][r] = v[rt][r] * g2 + be2;
+      store_tiles(xres, p.y + row0 * SL_D + wave * 16, SL_D);
+    }
+  }
+  if (!p.wnext) return;
+
+  // ================= packed q | k | v projection of the next layer on this tile's rows =================
+  // (hi / lo images of the residual stream: q and k feed the ProbSparse selection -> split-bf16, v plain bf16)
+  {
+    const int col = wave * 16 + fr;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const __bf16 hi = (__bf16)xres[rt][r];
+        xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = hi;
+        xlo[(rt * 16 + fq * 4 + r) * SL_XP + col] = bf16_lo(xres[rt][r], hi);
+      }
+  }
+  const unsigned char* wn = p.wnext;
+  const __bf16* w_qkv = reinterpret_cast<const __bf16*>(wn + po.wqkv);
+  const __bf16* w_lo = reinterpret_cast<const __bf16*>(wn + po.lo);
+  const float* vecn = reinterpret_cast<const float*>(wn + po.vec);
+  bf16x8 wf[3][4], wlo[2][4];
+  float bias[3];
+#pragma unroll
+  for (int pt = 0; pt < 3; ++pt) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wf[pt][kk] = ld_wfrag(w_qkv, (pt * 8 + wave) * 4 + kk, lane);
+    bias[pt] = vecn[pt * SL_D + wave * 16 + fr];
+  }
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wlo[pt][kk] = ld_wfrag(w_lo, (pt * 8 + wave) * 4 + kk, lane);
+  __syncthreads();  // hi / lo images complete
+  f32x4 acc[3][RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    bf16x8 a[4], al[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      a[kk] = ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8);
+      al[kk] = ld_frag(xlo + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8);
+    }
+#pragma unroll
+    for (int pt = 0; pt < 3; ++pt) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+      if (pt < 2) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[kk], wf[pt][kk], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk], wlo[pt][kk], c, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk], wf[pt][kk], c, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r] += bias[pt];
+      acc[pt][rt] = c;
+    }
+  }
+#pragma unroll
+  for (int pt = 0; pt < 3; ++pt) store_tiles(acc[pt], p.qkv_next + row0 * (3 * SL_D) + pt * SL_D + wave * 16, 3 * SL_D);
+}
+
+template <int RT>
+size_t tile_lds_bytes(int F) {
+  const int LP = 16 * RT;
+  return (size_t)LP * SL_XP * 2 + (size_t)LP * (F + 8) * 2 + (size_t)SL_NW * RT * 320 * 4 + (size_t)LP * SL_NW * 8 + (size_t)LP * 8;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int rf_enclayer_tile_supported(int d_model, int n_heads, int d_ff) {
+  return d_model == SL_D && n_heads == SL_H && d_ff >= 128 && d_ff <= 256 && d_ff % 32 == 0;
+}
+
+// One row-tile launch (see the head of this file).  `wpack` / `wpack_next`: per-layer blobs of rf_seqlayer_pack
+// (rf_seqlayer_pack_bytes(d_ff) each).  ctx == NULL: projection only (q | k | v of the first layer from x);
+// wpack_next == NULL: no projection (last layer).  save: 1 = write the training saves (all seven pointers required; z only
+// for GELU).  Rows per workgroup: 32 (M <= 4096) or 48.
+extern "C" int rf_enclayer_tile_fwd(const float* ctx, const float* x, const void* wpack, const void* wpack_next, float* y,
+                                    float* qkv_next, float* xhat1, float* rstd1, float* x1, float* z, float* h, float* xhat2,
+                                    float* rstd2, int M, int d_model, int n_heads, int d_ff, int act, int save, float eps,
+                                    void* stream) {
+  RF_REQUIRE(x && M > 0 && (ctx || wpack_next) && rf_enclayer_tile_supported(d_model, n_heads, d_ff));
+  RF_REQUIRE(!ctx || (wpack && y && al16(ctx) && al16(y) && al16(wpack)));
+  RF_REQUIRE(!wpack_next || (qkv_next && al16(qkv_next) && al16(wpack_next)));
+  RF_REQUIRE(!save || !ctx || (xhat1 && rstd1 && x1 && h && xhat2 && rstd2 && (z || act != RF_ACT_GELU)));
+  RF_REQUIRE(al16(x));
+  EncTileP p{};
+  p.ctx = ctx; p.x = x; p.wl = static_cast<const unsigned char*>(wpack); p.wnext = static_cast<const unsigned char*>(wpack_next);
+  p.y = y; p.qkv_next = qkv_next; p.xhat1 = xhat1; p.rstd1 = rstd1; p.x1 = x1; p.z = z; p.h = h; p.xhat2 = xhat2; p.rstd2 = rstd2;
+  p.M = M; p.F = d_ff; p.act = act; p.eps = eps;
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool sv = save && ctx;
+#define RF_ET_GO(RT_, SAVE_)                                                                                          \
+  do {                                                                                                                \
+    const size_t lds = tile_lds_bytes<RT_>(d_ff);                                                                     \
+    static bool attr = false;                                                                                         \
+    if (!attr) {                                                                                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_tile_fwd_kernel<RT_, SAVE_>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                               \
+      attr = true;                                                                                                    \
+    }                                                                                                                 \
+    RF_LAUNCH((enc_tile_fwd_kernel<RT_, SAVE_>), dim3((M + 16 * RT_ - 1) / (16 * RT_)), dim3(SL_NT), lds, st, p);     \
+  } while (0)
+  if (M <= 4096) {
+    if (sv) RF_ET_GO(2, true); else RF_ET_GO(2, false);
+  } else {
+    if (sv) RF_ET_GO(3, true); else RF_ET_GO(3, false);
+  }
+#undef RF_ET_GO
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}

@@ -43,66 +43,6 @@ struct SeqStackP {
   int drop_site0; // layer i uses sites drop_site0 + 3 i + {0: attention output, 1: hidden activation, 2: conv2 output}
 };
 
-// byte offsets inside a layer's packed blob
-struct PackOff { long wqkv, wo, w1, w2, vec, lo, total; };
-__host__ __device__ inline PackOff pack_offsets(int F) {
-  PackOff o;
-  o.wqkv = 0;
-  o.wo = o.wqkv + 24L * 4 * 1024;          // 24 column tiles x 4 k-steps x 1 KB
-  o.w1 = o.wo + 8L * 4 * 1024;
-  o.w2 = o.w1 + (long)(F / 16) * 4 * 1024;
-  o.vec = o.w2 + 8L * (F / 32) * 1024;     // fp32: bqkv[384] bo[128] b1[F] b2[128] g1 be1 g2 be2 [128 each]
-  o.lo = (o.vec + (1152L + F) * 4 + 255) & ~255L;  // bf16 residuals W - bf16(W) of Wq | Wk: 16 column tiles x 4 k-steps
-  o.total = o.lo + 16L * 4 * 1024;
-  return o;
-}
-
-// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): two bf16 numbers carry ~16 mantissa bits of x (split-bf16).  A product
-// of two such operands is the sum of three bf16 MFMAs (hi hi + lo hi + hi lo; lo lo is below fp32 rounding).
-__device__ __forceinline__ __bf16 bf16_lo(float x, __bf16 hi) { return (__bf16)(x - (float)hi); }
-
-// LayerNorm over the 128 columns of every row, the columns of a row being spread over the 8 waves (16 each, MFMA
-// accumulator layout: v[rt][r] = row 16 rt + 4 (lane >> 4) + r, column 16 wave + (lane & 15)).  Per-wave partial
-// (sum, sum of squares) meet in part[row][wave]; one thread per row folds them into stat[row] = (mean, 1/sigma)
-// (biased variance: nn.LayerNorm); two workgroup barriers.  v becomes x-hat.
-template <int RT>
-__device__ __forceinline__ void stack_layer_norm(f32x4 (&v)[RT], float* __restrict__ rstd_g, int L, float2* __restrict__ part,
-                                                 float2* __restrict__ stat, int wave, int lane, float eps) {
-  const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float s1 = row16_sum(v[rt][r]), s2 = row16_sum(v[rt][r] * v[rt][r]);
-      if (fr == 0) part[(rt * 16 + fq * 4 + r) * SL_NW + wave] = make_float2(s1, s2);
-    }
-  __syncthreads();
-  {
-    const int row = wave * 64 + lane;
-    if (row < 16 * RT) {
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < SL_NW; w += 2) {
-        const float4 a = *reinterpret_cast<const float4*>(part + row * SL_NW + w);
-        s1 += a.x + a.z;
-        s2 += a.y + a.w;
-      }
-      const float mean = s1 * (1.f / 128.f);
-      const float rs = __builtin_amdgcn_rsqf(fmaxf(s2 * (1.f / 128.f) - mean * mean, 0.f) + eps);
-      stat[row] = make_float2(mean, rs);
-      if (rstd_g && row < L) rstd_g[row] = rs;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float2 st = stat[rt * 16 + fq * 4 + r];
-      v[rt][r] = (v[rt][r] - st.x) * st.y;
-    }
-}
-
 // Phase timing aid (tools/seqlayer_probe.py builds a private copy with -DRF_SL_TIMING): lane 0 of every wave stamps
 // the shader clock at the phase boundaries of the FIRST layer into rf_sl_timing[workgroup][wave][16].
 #ifdef RF_SL_TIMING

@@ -1828,6 +1828,15 @@ class _SeqStack(torch.autograd.Function):
             ctx.sv = None
             return dx.view(B, L, D), None, None, None, None, None
 
+        ctx.sv = None
+        return _stack_backward_layerwise(sv, stack, x2, dy2, B, L, F_, n_top, drop_p, site0).view(B, L, D), None, None, None, None, None
+
+
+def _stack_backward_layerwise(sv, stack, x2, dy2, B, L, F_, n_top, drop_p, site0):
+    """Backward of a stack of ProbSparse encoder layers on the tensors its fused / row-tiled forward saved, layer by layer
+    with the row-block and attention backward kernels (the unfused backward's launches).  -> d input (M, 128)."""
+    M, D, H, E = B * L, 128, 8, 16
+    if True:
         def masked(t, site):  # t * keep / (1 - p) with the mask the fused forward drew for `site` (new tensor)
             out = torch.empty_like(t)
             _drop_launch(t, out, drop_p, site, None)
@@ -1911,5 +1920,106 @@ class _SeqStack(torch.autograd.Function):
             else:
                 dy2 = _input_grad(dqkv, pk["w"], residual=dpre1, ldr=D, res_rows=M)
             _wrote(pk["gw"], pk["gb"])
+    return dy2
+
+
+def tiled_stack_supported(L: int, d_model: int, n_heads: int, d_ff: int) -> bool:
+    """Row-tiled encoder stack (csrc/enclayer.hip): sequences beyond the one-workgroup stack's L <= 80, bf16 mode."""
+    return bool(TILED_STACK and _PRECISION == 1 and 2 <= L <= 320
+                and _hip.lib().rf_enclayer_tile_supported(d_model, n_heads, d_ff))
+
+
+TILED_STACK = os.environ.get("RF_TILED_STACK", "1") != "0"
+
+
+class _TiledStack(torch.autograd.Function):
+    """A stack of ProbSparse encoder layers whose sequences are too long for ``_SeqStack`` (the fusion `video_encoder`,
+    L = 160 / 320): per layer ONE attention launch (rf_attn_fwd, needs the whole sequence) and ONE row-tile launch
+    (rf_enclayer_tile_fwd: out-projection + LN1 + conv pair + LN2 + the NEXT layer's packed q | k | v) instead of four;
+    the first q | k | v comes from a projection-only launch.  Same weight blobs as the fused stack.  Backward: the
+    layer-by-layer kernels on the saved tensors (``_stack_backward_layerwise``)."""
+
+    @staticmethod
+    def forward(ctx, x, stack, idx_list, idx_group, save):
+        B, L, D = x.shape
+        M, H, E = B * L, 8, 16
+        x2 = x.reshape(M, D).contiguous()
+        lay0 = stack.layers[0]
+        F_ = lay0.conv1.weight.shape[0]
+        n = len(stack.layers)
+        sample_k, n_top = prob_sizes(L, L, lay0.attention.factor)
+        dev = x.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        gelu = lay0.act == "gelu"
+        sv = {"y": torch.empty(n if save else 2, M, D, **f32), "qkv": torch.empty(n if save else 2, M, 3 * D, **f32),
+              "ctx": torch.empty(n if save else 1, M, D, **f32), "top": torch.empty(n, B, H, n_top, device=dev, dtype=torch.int32)}
+        if save:
+            for name, width in (("xhat1", D), ("x1", D), ("xhat2", D), ("h", F_)) + ((("z", F_),) if gelu else ()):
+                sv[name] = torch.empty(n, M, width, **f32)
+            sv["rstd1"], sv["rstd2"] = torch.empty(n, M, **f32), torch.empty(n, M, **f32)
+        lib = _hip.lib()
+        wp, stride = stack.wpack.data_ptr(), stack.stride
+        slab = (lambda name, li: ptr(sv[name][li]) if save else None)
+
+        def tile(ctx_t, x_t, li, y_t, qkv_t):
+            """row-tile launch of layer li (ctx_t None: projection only), q | k | v of layer li + 1 -> qkv_t (None: none)"""
+            check(lib.rf_enclayer_tile_fwd(ptr(ctx_t), ptr(x_t), wp + li * stride if ctx_t is not None else None,
+                                           wp + (li + 1) * stride if qkv_t is not None else None, ptr(y_t), ptr(qkv_t),
+                                           slab("xhat1", li) if ctx_t is not None else None, slab("rstd1", li) if ctx_t is not None else None,
+                                           slab("x1", li) if ctx_t is not None else None,
+                                           (slab("z", li) if gelu else None) if ctx_t is not None else None,
+                                           slab("h", li) if ctx_t is not None else None, slab("xhat2", li) if ctx_t is not None else None,
+                                           slab("rstd2", li) if ctx_t is not None else None, M, D, H, F_, ACT[lay0.act],
+                                           1 if (save and ctx_t is not None) else 0, lay0.norm1.eps, _stream()), "rf_enclayer_tile_fwd")
+
+        qkv = sv["qkv"][0]
+        check(lib.rf_enclayer_tile_fwd(None, ptr(x2), None, wp, None, ptr(qkv), None, None, None, None, None, None, None, M, D, H,
+                                       F_, ACT[lay0.act], 0, lay0.norm1.eps, _stream()), "rf_enclayer_tile_fwd(projection)")
+        x_in = x2
+        for li in range(n):
+            idx = idx_list[li]
+            forced = None
+            if TOPS.forced is not None:
+                forced = TOPS.forced.pop(0).to(device=dev, dtype=torch.int32).contiguous()
+                assert tuple(forced.shape) == (B, H, n_top)
+            top = forced if forced is not None else sv["top"][li]
+            c_t = sv["ctx"][li if save else 0]
+            istride = idx.stride(0) if (idx.dim() == 3 and idx.shape[0] > 1) else 0
+            fargs = (qkv.data_ptr(), qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D, 3 * D, 3 * D, 3 * D, ptr(c_t), 0, ptr(idx),
+                     idx_group if idx.dim() == 3 else 0, istride if idx.dim() == 3 else 0)
+            if forced is not None and TOPS.shadow is not None:  # free selection on the same (teacher-forced) q / k
+                free = torch.empty(B, H, n_top, device=dev, dtype=torch.int32)
+                check(lib.rf_attn_fwd(*fargs, ptr(free), 0, B, H, L, L, E, sample_k, n_top, 1, 1.0 / math.sqrt(E), _stream()),
+                      "rf_attn_fwd(shadow)")
+                TOPS.shadow.append(free)
+            ev = PROFILE.begin() if PROFILE.on else None
+            aargs = (*fargs, ptr(top), 1 if forced is not None else 0, B, H, L, L, E, sample_k, n_top, 1, 1.0 / math.sqrt(E))
+            check(lib.rf_attn_fwd(*aargs, _stream()), "rf_attn_fwd")
+            if ev is not None:
+                full = lib.rf_attn_fwd_full_scores(B, H, L, L, E, sample_k, n_top, 1)
+                PROFILE.end("attn_fwd_kernel<true, true>" if full else "attn_fwd_kernel<true, false>", ev,
+                            B * H * (2.0 * L * sample_k * E + 4.0 * n_top * L * E), 4.0 * B * H * E * 4 * L + 4.0 * L * sample_k,
+                            replay=lambda a=aargs, k=(qkv, c_t, idx, top): lib.rf_attn_fwd(*a, _stream()))
+            if forced is not None:
+                sv["top"][li].copy_(forced)
+            if TOPS.record is not None:
+                TOPS.record.append(sv["top"][li].clone())
+            y_t = sv["y"][li if save else li % 2]
+            qkv_next = None if li == n - 1 else sv["qkv"][li + 1 if save else (li + 1) % 2]
+            ev = PROFILE.begin() if PROFILE.on else None
+            tile(c_t, x_in, li, y_t, qkv_next)
+            if ev is not None:
+                PROFILE.end(f"enc_tile_fwd_kernel<{2 if M <= 4096 else 3}, {'true' if save else 'false'}>", ev,
+                            2.0 * M * D * (D + 2 * F_ + (3 * D if qkv_next is not None else 0)),
+                            4.0 * M * (D * 3 + (3 * D if qkv_next is not None else 0) + ((4 * D + 2 * F_) if save else 0)))
+            x_in, qkv = y_t, qkv_next
+        if save:
+            ctx.sv, ctx.stack, ctx.x2, ctx.dims = sv, stack, x2, (B, L, F_, n_top)
+        return x_in.view(B, L, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        sv, stack, x2, (B, L, F_, n_top) = ctx.sv, ctx.stack, ctx.x2, ctx.dims
+        dy2 = dy.reshape(B * L, 128).contiguous()
         ctx.sv = None
-        return dy2.view(B, L, D), None, None, None, None, None
+        return _stack_backward_layerwise(sv, stack, x2, dy2, B, L, F_, n_top, 0.0, 0).view(B, L, 128), None, None, None, None

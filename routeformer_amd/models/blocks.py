@@ -479,8 +479,12 @@ class Encoder(nn.Module):
         if drop_p > 0.0 and (K.RNG.forced is not None or any(lay.p != lay0.p for lay in self.attn_layers)):
             return None  # injected masks (parity tests) go through the layer-by-layer path
         sample_k, n_top = K.prob_sizes(L, L, lay0.attention.factor)
+        tiled = False
         if not K.seqstack_supported(L, D, 8, lay0.conv1.weight.shape[0], sample_k, n_top):
-            return None
+            # longer sequences (the fusion encoder's L = 160 / 320): attention launch + row-tile launch per layer
+            tiled = drop_p == 0.0 and K.tiled_stack_supported(L, D, 8, lay0.conv1.weight.shape[0])
+            if not tiled:
+                return None
         need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in st._params()))
         if need_grad:  # backward = layer-by-layer kernels writing parameter gradients through the engine's sinks
             if not (K.SINK.active and x.requires_grad and all("_packed" in lay.attention.__dict__ for lay in self.attn_layers)
@@ -496,6 +500,8 @@ class Encoder(nn.Module):
             st.refresh()  # (the training engine re-packs at the head of every step instead)
         elif st.wpack is None:
             st.refresh(force=True)
+        if tiled:
+            return K._TiledStack.apply(x, st, idx_list, idx_group or B, need_grad)
         return K._SeqStack.apply(x, st, idx_list, idx_group or B, need_grad, drop_p)
 
     def forward(self, x, idx_list=None, idx_group: int = 0):

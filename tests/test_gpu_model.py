@@ -1104,6 +1104,70 @@ def test_fused_stack_backward_vs_layerwise(shape):
     assert worst[0] < 3e-2, worst
 
 
+@pytest.mark.parametrize("B,L,layers,act", [(3, 160, 3, "gelu"), (2, 320, 2, "gelu"), (5, 120, 2, "relu"), (1, 97, 2, "gelu")])
+def test_tiled_stack_vs_layerwise(B, L, layers, act):
+    """The row-tiled encoder stack for sequences beyond the fused stack's L <= 80 (csrc/enclayer.hip: one attention launch
+    + one row-tile launch per layer; the fusion encoder's L = 160 / 320, a ragged L, a tile spanning two sequences)
+    against the layer-by-layer kernels (RF_TILED_STACK off) in one PerceiveEncoder: same host draws, the layer-by-layer
+    run's selections imposed (q / k are split-bf16 in the tiled path, plain bf16-operand products in the other: a near-tie
+    may resolve differently) -- forward output, input gradient and every parameter gradient (both backward passes run the
+    same layer-by-layer kernels, on the two forwards' saved tensors); and the tiled path was really taken."""
+    from conftest import fro_err
+    from routeformer_amd import kernels as K
+    from routeformer_amd.engine import GradReducer
+    from routeformer_amd.models.blocks import PerceiveEncoder
+    K.set_precision("bf16")
+    g = torch.Generator().manual_seed(B * 100 + L)
+    x_cpu = torch.randn(B, L, 64, generator=g)
+    w_cpu = torch.randn(B, 40, 64, generator=g)
+    out, calls = {}, []
+    real = K._TiledStack.forward
+    try:
+        for tiled in (False, True):
+            K.TILED_STACK = tiled
+            enc = _load(PerceiveEncoder(in_channels=64, out_channels=64, out_len=40, n_heads=8, layers=layers, d_ff=256,
+                                        dropout=0.0, activation=act))
+            enc.train()
+            mods = [m for m in enc.modules() if hasattr(m, "packing_groups")]
+            red = GradReducer(list(enc.parameters()), groups=[g_ for m in mods for g_ in m.packing_groups()])
+            for m in mods:
+                gw, gb = m.packing_groups()
+                vw, vb = red.packed_view(gw), red.packed_view(gb)
+                m._packed = {"w": vw[0], "gw": vw[1], "b": vb[0], "gb": vb[1]}
+            K.SINK.active = True
+            red.zero()
+            if tiled:
+                K.TOPS.forced = [t_.clone() for t_ in out[False]["tops"]]
+                K._TiledStack.forward = staticmethod(lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+            else:
+                K.TOPS.record = []
+            x = x_cpu.to(DEV).requires_grad_()
+            torch.manual_seed(11)
+            y = enc(x)
+            (y * w_cpu.to(DEV)).sum().backward()
+            K.flush_weight_grads()
+            torch.cuda.synchronize()
+            if tiled:
+                assert not K.TOPS.forced
+            grads = {n: p._rf_grad.detach().cpu().clone() for n, p in enc.named_parameters()}
+            out[tiled] = dict(y=y.detach().cpu(), dx=x.grad.detach().cpu(), grads=grads, tops=K.TOPS.record)
+            K.TOPS.record, K.TOPS.forced = None, None
+            K.SINK.active = False
+    finally:
+        K.TILED_STACK, K._TiledStack.forward = True, real
+        K.TOPS.record, K.TOPS.forced = None, None
+        K.SINK.active = False
+    assert calls, "the row-tiled stack was not taken"
+    t_, u = out[True], out[False]
+    e_y, e_dx = rel_err(t_["y"], u["y"]), fro_err(t_["dx"], u["dx"])
+    rms = float(torch.cat([v.flatten() for v in u["grads"].values()]).square().mean().sqrt())
+    worst = max((float((t_["grads"][n].double() - u["grads"][n].double()).norm()
+                       / max(float(u["grads"][n].double().norm()), rms * u["grads"][n].numel() ** 0.5 * 0.05)), n) for n in u["grads"])
+    print(f"tiled stack B={B} L={L}: y rel err {e_y:.2e}, dx fro err {e_dx:.2e}, worst parameter gradient {worst[0]:.2e} ({worst[1]})")
+    # (ReLU stack: a handful of mask flips between the two bf16 roundings of the forward -- 4.9e-2 observed)
+    assert e_y < TOL_BF16 and e_dx < 5e-2 and worst[0] < 8e-2, (e_y, e_dx, worst)
+
+
 def test_side_stream_branches_change_nothing():
     """Every sub-graph the engine moves to a side stream (target-side pass, gaze encoder, the GPS backbone decoder's
     encoder-independent block) computes what it computes on the main stream: one train step with all forks on
