@@ -476,6 +476,17 @@ int rf_enclayer_tile_fwd(const float* ctx, const float* x, const void* wpack, co
                          float* rstd2, int M, int d_model, int n_heads, int d_ff, int act, int save, float eps,
                          void* stream);
 
+/* Backward counterpart: between two rf_attn_bwd launches one row-tile launch does the packed q | k | v projection^T of
+ * layer l + 1 (+ skip = its d pre-norm-1) -> LayerNorm-2 backward -> conv2^T -> act' -> conv1^T + skip -> LayerNorm-1 backward
+ * -> out-projection^T of layer l (2 launches per layer instead of 5).  Weights: the transposed blobs of rf_seqlayer_bwd
+ * (rf_seqlayer_bwd_pack_bytes each).  dy: the stack's output gradient (last layer; then dqkv / skip / wpack_next_t NULL);
+ * wpack_t NULL: projection^T only -> dx (the stack's input gradient).  Outputs per layer: dpre2, dz (weight-gradient
+ * operands, bf16-rounded), dpre1 (fp32), dctx (for rf_attn_bwd); dgamma / dbeta of both norms are ACCUMULATED (atomics). */
+int rf_enclayer_tile_bwd(const float* dy, const float* dqkv, const float* skip, const void* wpack_t, const void* wpack_next_t,
+                         const float* xhat1, const float* rstd1, const float* zsrc, const float* xhat2, const float* rstd2,
+                         float* dpre2, float* dz, float* dpre1, float* dctx, float* dx, float* dgamma1, float* dbeta1,
+                         float* dgamma2, float* dbeta2, int M, int d_model, int n_heads, int d_ff, int act, void* stream);
+
 /* ---- small tensor plumbing of the hot path as single launches (csrc/smallops.hip) ---------------------------
  * rf_median_windows: y (B,target,C) = lower median (torch.median: NaN wins) of the consecutive windows of T / target
  *   samples of x (B,T,C) -- `median_downsampler`, routeformer/utils/filter.py:5-43 (gaze 200 Hz -> seq_len).

@@ -256,6 +256,212 @@ __global__ __launch_bounds__(SL_NT) void enc_tile_fwd_kernel(const EncTileP p) {
   for (int pt = 0; pt < 3; ++pt) store_tiles(acc[pt], p.qkv_next + row0 * (3 * SL_D) + pt * SL_D + wave * 16, 3 * SL_D);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward counterpart: between two attention-backward launches ONE row-tile launch does
+//     packed q | k | v projection^T of layer l + 1 (+ its skip gradient)  =  gradient of layer l's output
+//     -> LayerNorm-2 backward -> conv2^T -> activation' -> conv1^T + skip -> LayerNorm-1 backward -> out-projection^T
+// and hands rf_attn_bwd the gradient of layer l's attention output: 2 launches per layer instead of 5.  Weights: the
+// TRANSPOSED fragment blobs of the fused stack's backward (rf_seqlayer_pack, transpose = 1).  What leaves the launch per
+// layer: d pre-norm-2 and dz (bf16-rounded: weight-gradient operands only), d pre-norm-1 in full fp32 (it is also the skip
+// gradient the next launch adds), the LayerNorm parameter gradients (atomics), d ctx.
+// ---------------------------------------------------------------------------------------------------------------------
+struct EncTileBwdP {
+  const float* dy;             // (M, 128) gradient of this layer's output (last layer), or null with dqkv
+  const float* dqkv;           // (M, 384) gradient of the NEXT layer's packed q | k | v, or null
+  const float* skip;           // (M, 128) d pre-norm-1 of the next layer (with dqkv)
+  const unsigned char* wl;     // this layer's transposed blob; null: projection^T only (the stack's input gradient)
+  const unsigned char* wnext;  // next layer's transposed blob (with dqkv)
+  const float *xhat1, *rstd1, *zsrc, *xhat2, *rstd2;
+  float *dpre2, *dz, *dpre1, *dctx, *dx;
+  float *dg1, *db1, *dg2, *db2;
+  int M, F, act;
+};
+
+template <int RT>
+__global__ __launch_bounds__(SL_NT) void enc_tile_bwd_kernel(const EncTileBwdP p) {
+  constexpr int LP = 16 * RT, QP = 3 * SL_D + 8, TB = 320;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* xb = reinterpret_cast<__bf16*>(smem);
+  __bf16* hb = xb + LP * SL_XP;
+  __bf16* dqi = xb;  // projection phase alias of xb + hb
+  const int F = p.F, HP = F + 8;
+  const int region = max(LP * SL_XP + LP * HP, LP * QP) * 2;
+  float* stage_base = reinterpret_cast<float*>(smem + ((region + 15) & ~15));
+  float2* part = reinterpret_cast<float2*>(stage_base + SL_NW * RT * TB);
+  float4* stat = reinterpret_cast<float4*>(part + LP * SL_NW);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int srow = lane >> 2, sc4 = (lane & 3) * 4, col = wave * 16 + fr;
+  const long row0 = (long)blockIdx.x * LP;
+  const int L = (int)min((long)LP, (long)p.M - row0);
+  float* sc_f = stage_base + wave * RT * TB;
+  const BwdPackOff po = bwd_pack_offsets(F);
+
+  auto store_tiles = [&](const f32x4 (&v)[RT], float* g, int ld) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc_f[rt * TB + (fq * 4 + r) * 20 + fr] = v[rt][r];
+    wave_sync_lds();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      if (rt * 16 + srow < L)
+        *reinterpret_cast<float4*>(g + (long)(rt * 16 + srow) * ld + sc4) = *reinterpret_cast<const float4*>(sc_f + rt * TB + srow * 20 + sc4);
+    wave_sync_lds();
+  };
+  auto load_tile = [&](const float* g, f32x4 (&v)[RT]) {  // (M, 128) rows of this tile, accumulator layout, rows >= L -> 0
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + fq * 4 + r;
+        const float x = g[(row0 + min(row, L - 1)) * SL_D + col];
+        v[rt][r] = row < L ? x : 0.f;
+      }
+  };
+
+  f32x4 dyres[RT];
+  if (p.dqkv) {
+    // ================= packed q | k | v projection^T of the next layer + its skip gradient =================
+    const __bf16* w_qkvt = reinterpret_cast<const __bf16*>(p.wnext + po.wqkvt);
+    bf16x8 wfp[12];
+#pragma unroll
+    for (int kk = 0; kk < 12; ++kk) wfp[kk] = ld_wfrag(w_qkvt, wave * 12 + kk, lane);
+    for (int i = tid; i < LP * (3 * SL_D / 4); i += SL_NT) {
+      const int row = i / 96, c4 = (i - row * 96) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < L) v = *reinterpret_cast<const float4*>(p.dqkv + (row0 + row) * (3 * SL_D) + c4);
+      const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      *reinterpret_cast<bf16x4*>(dqi + row * QP + c4) = o;
+    }
+    load_tile(p.skip, dyres);
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      f32x4 acc = dyres[rt];
+#pragma unroll
+      for (int kk = 0; kk < 12; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(dqi + (rt * 16 + fr) * QP + kk * 32 + fq * 8), wfp[kk], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dyres[rt][r] = rt * 16 + fq * 4 + r < L ? acc[r] : 0.f;
+    }
+  } else {
+    load_tile(p.dy, dyres);
+  }
+  if (!p.wl) {  // the stack's input gradient
+    store_tiles(dyres, p.dx + row0 * SL_D + wave * 16, SL_D);
+    return;
+  }
+  const unsigned char* wl = p.wl;
+  const __bf16* w_2t = reinterpret_cast<const __bf16*>(wl + po.w2t);
+  const __bf16* w_1t = reinterpret_cast<const __bf16*>(wl + po.w1t);
+  const __bf16* w_ot = reinterpret_cast<const __bf16*>(wl + po.wot);
+  const float* vec = reinterpret_cast<const float*>(wl + po.vec);
+  f32x4 res[RT];
+
+  // ================= norm2 backward (its first barrier also fences the dq image reads above) =================
+  stack_ln_bwd<RT>(dyres, p.xhat2 + row0 * SL_D + col, p.rstd2 + row0, vec[SL_D + col], p.dg2 + col, p.db2 + col, L, part, stat,
+                   wave, lane);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    res[rt] = dyres[rt];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)dyres[rt][r];
+  }
+  __syncthreads();  // d pre-norm-2 image complete
+  save_image(xb, SL_XP, SL_D, p.dpre2 + row0 * SL_D, L, tid);
+
+  // ================= conv2^T + activation' : dz =================
+  {
+    const float* zs = p.zsrc + row0 * F;
+#pragma unroll 1
+    for (int ct = wave; ct < F / 16; ct += SL_NW) {
+      bf16x8 wf[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) wf[kk] = ld_wfrag(w_2t, ct * 4 + kk, lane);
+      f32x4 zz[RT], acc[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zz[rt][r] = zs[(long)min(rt * 16 + fq * 4 + r, L - 1) * F + ct * 16 + fr];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8), wf[kk], acc[rt], 0, 0, 0);
+      }
+      if (p.act == RF_ACT_GELU) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[rt][r] *= sl_gelu_grad(zz[rt][r]);
+      } else if (p.act == RF_ACT_RELU) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[rt][r] = zz[rt][r] > 0.f ? acc[rt][r] : 0.f;
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hb[(rt * 16 + fq * 4 + r) * HP + ct * 16 + fr] = (__bf16)acc[rt][r];
+    }
+  }
+  __syncthreads();  // dz image complete
+  save_image(hb, HP, F, p.dz + row0 * F, L, tid);
+
+  // ================= conv1^T + skip, norm1 backward =================
+  {
+    const int nk = F / 32;  // <= 8
+    bf16x8 wf[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) wf[kk] = ld_wfrag(w_1t, wave * nk + min(kk, nk - 1), lane);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) dyres[rt] = res[rt];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      if (kk < nk) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          dyres[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(hb + (rt * 16 + fr) * HP + kk * 32 + fq * 8), wf[kk], dyres[rt], 0, 0, 0);
+      }
+    }
+  }
+  stack_ln_bwd<RT>(dyres, p.xhat1 + row0 * SL_D + col, p.rstd1 + row0, vec[col], p.dg1 + col, p.db1 + col, L, part, stat, wave,
+                   lane);  // (its barriers fence the xb reads of the dz phase)
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)dyres[rt][r];
+  store_tiles(dyres, p.dpre1 + row0 * SL_D + wave * 16, SL_D);  // fp32: also the next launch's skip gradient
+  __syncthreads();  // d pre-norm-1 image complete
+
+  // ================= out-projection^T: gradient of the attention output =================
+  {
+    bf16x8 wf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wf[kk] = ld_wfrag(w_ot, wave * 4 + kk, lane);
+    f32x4 dc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      dc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        dc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8), wf[kk], dc[rt], 0, 0, 0);
+    }
+    store_tiles(dc, p.dctx + row0 * SL_D + wave * 16, SL_D);
+  }
+}
+
+template <int RT>
+size_t tile_bwd_lds_bytes(int F) {
+  const int LP = 16 * RT;
+  const int a = LP * SL_XP + LP * (F + 8), q = LP * (3 * SL_D + 8);
+  const int region = (((a > q ? a : q) * 2) + 15) & ~15;
+  return (size_t)region + (size_t)SL_NW * RT * 320 * 4 + (size_t)LP * SL_NW * 8 + (size_t)LP * 16;
+}
+
 template <int RT>
 size_t tile_lds_bytes(int F) {
   const int LP = 16 * RT;
@@ -306,6 +512,44 @@ extern "C" int rf_enclayer_tile_fwd(const float* ctx, const float* x, const void
     if (sv) RF_ET_GO(3, true); else RF_ET_GO(3, false);
   }
 #undef RF_ET_GO
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+// Backward row-tile launch (see above).  dqkv / skip / wpack_next_t: projection^T part (null for the stack's last layer, whose
+// output gradient comes in `dy`); wpack_t == NULL: projection^T only -> dx (the stack's input gradient, after the first layer).
+extern "C" int rf_enclayer_tile_bwd(const float* dy, const float* dqkv, const float* skip, const void* wpack_t,
+                                    const void* wpack_next_t, const float* xhat1, const float* rstd1, const float* zsrc,
+                                    const float* xhat2, const float* rstd2, float* dpre2, float* dz, float* dpre1, float* dctx,
+                                    float* dx, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, int M, int d_model,
+                                    int n_heads, int d_ff, int act, void* stream) {
+  RF_REQUIRE(M > 0 && rf_enclayer_tile_supported(d_model, n_heads, d_ff));
+  RF_REQUIRE((dqkv != nullptr) != (dy != nullptr));
+  RF_REQUIRE(!dqkv || (skip && wpack_next_t && al16(dqkv) && al16(skip) && al16(wpack_next_t)));
+  RF_REQUIRE(wpack_t || (dx && al16(dx)));
+  RF_REQUIRE(!wpack_t || (xhat1 && rstd1 && zsrc && xhat2 && rstd2 && dpre2 && dz && dpre1 && dctx && dgamma1 && dbeta1 && dgamma2 &&
+                          dbeta2 && al16(wpack_t) && al16(dpre2) && al16(dz) && al16(dpre1) && al16(dctx)));
+  EncTileBwdP p{};
+  p.dy = dy; p.dqkv = dqkv; p.skip = skip; p.wl = static_cast<const unsigned char*>(wpack_t);
+  p.wnext = static_cast<const unsigned char*>(wpack_next_t);
+  p.xhat1 = xhat1; p.rstd1 = rstd1; p.zsrc = zsrc; p.xhat2 = xhat2; p.rstd2 = rstd2;
+  p.dpre2 = dpre2; p.dz = dz; p.dpre1 = dpre1; p.dctx = dctx; p.dx = dx;
+  p.dg1 = dgamma1; p.db1 = dbeta1; p.dg2 = dgamma2; p.db2 = dbeta2;
+  p.M = M; p.F = d_ff; p.act = act;
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+#define RF_ETB_GO(RT_)                                                                                               \
+  do {                                                                                                               \
+    static bool attr = false;                                                                                        \
+    if (!attr) {                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_tile_bwd_kernel<RT_>),                             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                              \
+      attr = true;                                                                                                   \
+    }                                                                                                                \
+    RF_LAUNCH((enc_tile_bwd_kernel<RT_>), dim3((M + 16 * RT_ - 1) / (16 * RT_)), dim3(SL_NT), tile_bwd_lds_bytes<RT_>(d_ff), st, p); \
+  } while (0)
+  if (M <= 4096) RF_ETB_GO(2);
+  else RF_ETB_GO(3);
+#undef RF_ETB_GO
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

@@ -41,108 +41,6 @@ struct SeqStackBwdP {
   int drop_site0; // layer i: sites drop_site0 + 3 i + {0: attention output, 1: hidden activation, 2: conv2 output}
 };
 
-struct BwdPackOff { long w2t, w1t, wot, wqkvt, vec, total; };
-__host__ __device__ inline BwdPackOff bwd_pack_offsets(int F) {
-  BwdPackOff o;
-  o.w2t = 0;                                   // B[k = d][n = f] = W2[d][f]:   F/16 column tiles x 4 k-steps
-  o.w1t = o.w2t + (long)(F / 16) * 4 * 1024;   // B[k = f][n = d] = W1[f][d]:   8 column tiles x F/32 k-steps
-  o.wot = o.w1t + 8L * (F / 32) * 1024;        // B[k = o][n = i] = Wo[o][i]:   8 x 4
-  o.wqkvt = o.wot + 8L * 4 * 1024;             // B[k = j][n = d] = Wqkv[j][d]: 8 x 12
-  o.vec = o.wqkvt + 8L * 12 * 1024;            // fp32: gamma1[128] gamma2[128]
-  o.total = (o.vec + 256L * 4 + 255) & ~255L;
-  return o;
-}
-
-__device__ __forceinline__ bf16x8 pack8(const float4& a, const float4& b) {
-  bf16x8 o;
-  o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
-  o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
-  return o;
-}
-
-__device__ __forceinline__ float sl_gelu_grad(float x) {  // Phi(x) + x phi(x), the forward's erf approximation
-  const float u = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float e = __expf(-u * u);
-  const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * t * e, x));
-  return fmaf(x * 0.39894228040143267794f, e, cdf);
-}
-
-// LayerNorm backward over the 128 columns of every row (columns spread over the 8 waves as in stack_layer_norm):
-//   g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  dgamma += sum_rows dy * xhat;  dbeta += sum_rows dy.
-// In: g = dy (rows >= L hold zeros).  Out: g = dx (rows >= L stay zero).  Two workgroup barriers.
-template <int RT>
-__device__ __forceinline__ void stack_ln_bwd(f32x4 (&g)[RT], const float* __restrict__ xhat_g, const float* __restrict__ rstd_g,
-                                             float gamma, float* __restrict__ dgam, float* __restrict__ dbet, int L,
-                                             float2* __restrict__ part, float4* __restrict__ stat, int wave, int lane) {
-  const int fr = lane & 15, fq = lane >> 4;
-  f32x4 xh[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xh[rt][r] = xhat_g[min(rt * 16 + fq * 4 + r, L - 1) * SL_D];
-  float dg = 0.f, db = 0.f;
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      dg = fmaf(g[rt][r], xh[rt][r], dg);
-      db += g[rt][r];
-    }
-  dg += __shfl_xor(dg, 16); db += __shfl_xor(db, 16);
-  dg += __shfl_xor(dg, 32); db += __shfl_xor(db, 32);
-  if (fq == 0) {
-    atomicAdd(dgam, dg);
-    atomicAdd(dbet, db);
-  }
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float gm = g[rt][r] * gamma;
-      g[rt][r] = gm;
-      const float s1 = row16_sum(gm), s2 = row16_sum(gm * xh[rt][r]);
-      if (fr == 0) part[(rt * 16 + fq * 4 + r) * SL_NW + wave] = make_float2(s1, s2);
-    }
-  __syncthreads();
-  {
-    const int row = wave * 64 + lane;
-    if (row < 16 * RT) {
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < SL_NW; w += 2) {
-        const float4 a = *reinterpret_cast<const float4*>(part + row * SL_NW + w);
-        s1 += a.x + a.z;
-        s2 += a.y + a.w;
-      }
-      stat[row] = make_float4(s1 * (1.f / 128.f), s2 * (1.f / 128.f), row < L ? rstd_g[row] : 0.f, 0.f);
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float4 st = stat[rt * 16 + fq * 4 + r];
-      g[rt][r] = st.z * (g[rt][r] - st.x - xh[rt][r] * st.y);
-    }
-}
-
-// rows 0..L-1 of a bf16 LDS image -> fp32 global rows of `cols` floats (16-B stores, the whole workgroup)
-__device__ __forceinline__ void save_image(const __bf16* __restrict__ img, int pitch, int cols, float* __restrict__ dst, int L,
-                                           int tid) {
-  const int c4n = cols >> 2;
-  for (int i = tid; i < L * c4n; i += SL_NT) {
-    const int row = i / c4n, c4 = (i - row * c4n) * 4;
-    const bf16x4 c = *reinterpret_cast<const bf16x4*>(img + row * pitch + c4);
-    *reinterpret_cast<float4*>(dst + (long)row * cols + c4) = make_float4((float)c[0], (float)c[1], (float)c[2], (float)c[3]);
-  }
-}
-
 // Phase timing aid (tools/seqlayer_probe.py: private -DRF_SL_TIMING build): lane 0 of every wave stamps the shader
 // clock at the phase boundaries of the LAST layer (the first one processed) into rf_slb_timing[workgroup][wave][16].
 #ifdef RF_SL_TIMING

@@ -1930,6 +1930,7 @@ def tiled_stack_supported(L: int, d_model: int, n_heads: int, d_ff: int) -> bool
 
 
 TILED_STACK = os.environ.get("RF_TILED_STACK", "1") != "0"
+TILED_STACK_BWD = os.environ.get("RF_TILED_STACK_BWD", "1") != "0"  # row-tile backward launches (else layer by layer)
 
 
 class _TiledStack(torch.autograd.Function):
@@ -2020,6 +2021,58 @@ class _TiledStack(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         sv, stack, x2, (B, L, F_, n_top) = ctx.sv, ctx.stack, ctx.x2, ctx.dims
-        dy2 = dy.reshape(B * L, 128).contiguous()
+        M, D, H, E = B * L, 128, 8, 16
+        dy2 = dy.reshape(M, D).contiguous()
         ctx.sv = None
-        return _stack_backward_layerwise(sv, stack, x2, dy2, B, L, F_, n_top, 0.0, 0).view(B, L, 128), None, None, None, None
+        if not (TILED_STACK_BWD and not DETERMINISTIC and stack.wpack_bwd is not None):
+            return _stack_backward_layerwise(sv, stack, x2, dy2, B, L, F_, n_top, 0.0, 0).view(B, L, D), None, None, None, None
+        # ---- per layer: ONE row-tile launch (the next layer's q | k | v projection^T + skip, norm2 backward, conv pair^T, norm1
+        # backward, out-projection^T) and ONE attention-backward launch; the weight gradients follow as grouped GEMMs ----
+        lib, dev, n = _hip.lib(), dy2.device, len(stack.layers)
+        f32 = dict(device=dev, dtype=torch.float32)
+        g = {"dpre2": torch.empty(n, M, D, **f32), "dz": torch.empty(n, M, F_, **f32), "dpre1": torch.empty(n, M, D, **f32),
+             "dqkv": torch.empty(n, M, 3 * D, **f32)}
+        dctx = torch.empty(M, D, **f32)
+        dx = torch.empty(M, D, **f32)
+        wt, st = stack.wpack_bwd.data_ptr(), stack.stride_bwd
+        act = ACT[stack.layers[0].act]
+        slots = [(_slot(l.norm1.weight), _slot(l.norm1.bias), _slot(l.norm2.weight), _slot(l.norm2.bias)) for l in stack.layers]
+        zsrc = sv["z"] if "z" in sv else sv["h"]
+        scale = 1.0 / math.sqrt(E)
+        for li in reversed(range(n)):
+            last = li == n - 1
+            g1, b1, g2, b2 = slots[li]
+            ev = PROFILE.begin() if PROFILE.on else None
+            check(lib.rf_enclayer_tile_bwd(ptr(dy2) if last else None, None if last else ptr(g["dqkv"][li + 1]),
+                                           None if last else ptr(g["dpre1"][li + 1]), wt + li * st, None if last else wt + (li + 1) * st,
+                                           ptr(sv["xhat1"][li]), ptr(sv["rstd1"][li]), ptr(zsrc[li]), ptr(sv["xhat2"][li]),
+                                           ptr(sv["rstd2"][li]), ptr(g["dpre2"][li]), ptr(g["dz"][li]), ptr(g["dpre1"][li]), ptr(dctx),
+                                           None, ptr(g1), ptr(b1), ptr(g2), ptr(b2), M, D, H, F_, act, _stream()), "rf_enclayer_tile_bwd")
+            if ev is not None:
+                PROFILE.end(f"enc_tile_bwd_kernel<{2 if M <= 4096 else 3}>", ev, 2.0 * M * D * (D + 2 * F_ + (0 if last else 3 * D)),
+                            4.0 * M * (D * 6 + 2 * F_ + (0 if last else 4 * D)))
+            qkv, dq = sv["qkv"][li], g["dqkv"][li]
+            ev = PROFILE.begin() if PROFILE.on else None
+            bargs = (qkv.data_ptr(), qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D, 3 * D, 3 * D, 3 * D, ptr(dctx), 0,
+                     ptr(sv["top"][li]), dq.data_ptr(), dq.data_ptr() + 4 * D, dq.data_ptr() + 8 * D, 3 * D, 3 * D, 3 * D, B, H, L, L, E,
+                     n_top, 1, scale)
+            check(lib.rf_attn_bwd(*bargs, _stream()), "rf_attn_bwd")
+            if ev is not None:
+                PROFILE.end("attn_bwd_kernel<true>", ev, B * H * 10.0 * n_top * L * E, 4.0 * B * H * E * 8 * L,
+                            replay=lambda fa=bargs, k=(qkv, dq, dctx, sv): lib.rf_attn_bwd(*fa, _stream()))
+        check(lib.rf_enclayer_tile_bwd(None, ptr(g["dqkv"][0]), ptr(g["dpre1"][0]), None, wt, None, None, None, None, None, None, None,
+                                       None, None, ptr(dx), None, None, None, None, M, D, H, F_, act, _stream()),
+              "rf_enclayer_tile_bwd(projection)")
+        for li in reversed(range(n)):
+            lay = stack.layers[li]
+            att, pk = lay.attention, lay.attention._packed
+            _wrote(*slots[li])
+            for gy, xin, w_into, b_into in (
+                    (g["dpre2"][li], sv["h"][li], _slot(lay.conv2.weight).view(D, F_), _slot(lay.conv2.bias)),
+                    (g["dz"][li], sv["x1"][li], _slot(lay.conv1.weight).view(F_, D), _slot(lay.conv1.bias)),
+                    (g["dpre1"][li], sv["ctx"][li], _slot(att.out_projection.weight), _slot(att.out_projection.bias)),
+                    (g["dqkv"][li], x2 if li == 0 else sv["y"][li - 1], pk["gw"], pk["gb"])):
+                if _weight_grad(gy, xin, into=w_into, bias_into=b_into) is not True:
+                    colsum(gy, into=b_into)
+                _wrote(w_into, b_into)
+        return dx.view(B, L, D), None, None, None, None

@@ -1106,12 +1106,13 @@ def test_fused_stack_backward_vs_layerwise(shape):
 
 @pytest.mark.parametrize("B,L,layers,act", [(3, 160, 3, "gelu"), (2, 320, 2, "gelu"), (5, 120, 2, "relu"), (1, 97, 2, "gelu")])
 def test_tiled_stack_vs_layerwise(B, L, layers, act):
-    """The row-tiled encoder stack for sequences beyond the fused stack's L <= 80 (csrc/enclayer.hip: one attention launch
-    + one row-tile launch per layer; the fusion encoder's L = 160 / 320, a ragged L, a tile spanning two sequences)
-    against the layer-by-layer kernels (RF_TILED_STACK off) in one PerceiveEncoder: same host draws, the layer-by-layer
-    run's selections imposed (q / k are split-bf16 in the tiled path, plain bf16-operand products in the other: a near-tie
-    may resolve differently) -- forward output, input gradient and every parameter gradient (both backward passes run the
-    same layer-by-layer kernels, on the two forwards' saved tensors); and the tiled path was really taken."""
+    """The row-tiled encoder stack for sequences beyond the fused stack's L <= 80 (csrc/enclayer.hip: per layer one
+    attention launch + one row-tile launch, forward and backward; the fusion encoder's L = 160 / 320, a ragged L, a tile
+    spanning two sequences) in one PerceiveEncoder against the layer-by-layer kernels (RF_TILED_STACK off): same host draws,
+    the layer-by-layer run's selections imposed (q / k are split-bf16 in the tiled path, plain bf16-operand products in
+    the other: a near-tie may resolve differently) -- forward output, input gradient, every parameter gradient.  A third
+    run takes the tiled forward with the layer-by-layer backward kernels on ITS saved tensors: the two backward
+    implementations on identical inputs."""
     from conftest import fro_err
     from routeformer_amd import kernels as K
     from routeformer_amd.engine import GradReducer
@@ -1120,11 +1121,13 @@ def test_tiled_stack_vs_layerwise(B, L, layers, act):
     g = torch.Generator().manual_seed(B * 100 + L)
     x_cpu = torch.randn(B, L, 64, generator=g)
     w_cpu = torch.randn(B, 40, 64, generator=g)
-    out, calls = {}, []
-    real = K._TiledStack.forward
+    out, fwd_calls, lw_calls = {}, [], []
+    real_fwd, real_lw = K._TiledStack.forward, K._stack_backward_layerwise
+    K._stack_backward_layerwise = lambda *a, **k: (lw_calls.append(1), real_lw(*a, **k))[1]
     try:
-        for tiled in (False, True):
-            K.TILED_STACK = tiled
+        for mode in ("layerwise", "tiled", "tiled_fwd_only"):
+            K.TILED_STACK = mode != "layerwise"
+            K.TILED_STACK_BWD = mode == "tiled"
             enc = _load(PerceiveEncoder(in_channels=64, out_channels=64, out_len=40, n_heads=8, layers=layers, d_ff=256,
                                         dropout=0.0, activation=act))
             enc.train()
@@ -1136,36 +1139,47 @@ def test_tiled_stack_vs_layerwise(B, L, layers, act):
                 m._packed = {"w": vw[0], "gw": vw[1], "b": vb[0], "gb": vb[1]}
             K.SINK.active = True
             red.zero()
-            if tiled:
-                K.TOPS.forced = [t_.clone() for t_ in out[False]["tops"]]
-                K._TiledStack.forward = staticmethod(lambda *a, **k: (calls.append(1), real(*a, **k))[1])
-            else:
+            if mode == "layerwise":
                 K.TOPS.record = []
+            else:
+                K.TOPS.forced = [t_.clone() for t_ in out["layerwise"]["tops"]]
+                K._TiledStack.forward = staticmethod(lambda *a, **k: (fwd_calls.append(mode), real_fwd(*a, **k))[1])
+            n_lw = len(lw_calls)
             x = x_cpu.to(DEV).requires_grad_()
             torch.manual_seed(11)
             y = enc(x)
             (y * w_cpu.to(DEV)).sum().backward()
             K.flush_weight_grads()
             torch.cuda.synchronize()
-            if tiled:
+            if mode != "layerwise":
                 assert not K.TOPS.forced
+                assert (len(lw_calls) > n_lw) == (mode == "tiled_fwd_only"), "wrong backward path"
             grads = {n: p._rf_grad.detach().cpu().clone() for n, p in enc.named_parameters()}
-            out[tiled] = dict(y=y.detach().cpu(), dx=x.grad.detach().cpu(), grads=grads, tops=K.TOPS.record)
+            out[mode] = dict(y=y.detach().cpu(), dx=x.grad.detach().cpu(), grads=grads, tops=K.TOPS.record)
             K.TOPS.record, K.TOPS.forced = None, None
             K.SINK.active = False
     finally:
-        K.TILED_STACK, K._TiledStack.forward = True, real
+        K.TILED_STACK, K.TILED_STACK_BWD, K._TiledStack.forward, K._stack_backward_layerwise = True, True, real_fwd, real_lw
         K.TOPS.record, K.TOPS.forced = None, None
         K.SINK.active = False
-    assert calls, "the row-tiled stack was not taken"
-    t_, u = out[True], out[False]
-    e_y, e_dx = rel_err(t_["y"], u["y"]), fro_err(t_["dx"], u["dx"])
-    rms = float(torch.cat([v.flatten() for v in u["grads"].values()]).square().mean().sqrt())
-    worst = max((float((t_["grads"][n].double() - u["grads"][n].double()).norm()
-                       / max(float(u["grads"][n].double().norm()), rms * u["grads"][n].numel() ** 0.5 * 0.05)), n) for n in u["grads"])
-    print(f"tiled stack B={B} L={L}: y rel err {e_y:.2e}, dx fro err {e_dx:.2e}, worst parameter gradient {worst[0]:.2e} ({worst[1]})")
+    assert "tiled" in fwd_calls and "tiled_fwd_only" in fwd_calls, "the row-tiled stack was not taken"
+
+    def compare(a, b_):
+        rms = float(torch.cat([v.flatten() for v in b_["grads"].values()]).square().mean().sqrt())
+        worst = max((float((a["grads"][n].double() - b_["grads"][n].double()).norm()
+                           / max(float(b_["grads"][n].double().norm()), rms * b_["grads"][n].numel() ** 0.5 * 0.05)), n)
+                    for n in b_["grads"])
+        return rel_err(a["y"], b_["y"]), fro_err(a["dx"], b_["dx"]), worst
+
+    e_y, e_dx, worst = compare(out["tiled"], out["layerwise"])
+    print(f"tiled stack B={B} L={L} vs layer-by-layer: y rel err {e_y:.2e}, dx fro err {e_dx:.2e}, worst parameter gradient "
+          f"{worst[0]:.2e} ({worst[1]})")
     # (ReLU stack: a handful of mask flips between the two bf16 roundings of the forward -- 4.9e-2 observed)
     assert e_y < TOL_BF16 and e_dx < 5e-2 and worst[0] < 8e-2, (e_y, e_dx, worst)
+    e_y, e_dx, worst = compare(out["tiled"], out["tiled_fwd_only"])
+    print(f"   row-tile backward vs layer-by-layer backward on the same saves: dx fro err {e_dx:.2e}, worst parameter gradient "
+          f"{worst[0]:.2e} ({worst[1]})")
+    assert e_y == 0.0 and e_dx < 2e-2 and worst[0] < 3e-2, (e_y, e_dx, worst)
 
 
 def test_side_stream_branches_change_nothing():
