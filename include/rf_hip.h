@@ -156,6 +156,11 @@ int rf_avgpool8_tokens(const void* x, int act_dtype, float* tokens, int N, int H
  * cross_modal_transformer.py:352-369; layers/Embedding.py:28-46; TransformerEncoderDecoder.py:12-18. */
 int rf_unfold3_circular(const float* x, float* cols, int B, int L, int C, int pad, void* stream);
 int rf_fold3_circular(const float* dcols, float* dx, int B, int L, int C, int pad, void* stream);
+/* The same with a row pitch `ld` >= 3 C for the unfolded matrix: unfold zero-fills columns 3 C .. ld - 1, fold ignores them.
+ * A c_in whose 3 C is not a multiple of 4 (the GPS backbone's 69 input channels) is unfolded with ld = 208 so that the
+ * token-embedding GEMM and its backward stay on the 16-B vector path (weights zero-padded to the same K). */
+int rf_unfold3_circular_ld(const float* x, float* cols, int B, int L, int C, int pad, int ld, void* stream);
+int rf_fold3_circular_ld(const float* dcols, float* dx, int B, int L, int C, int pad, int ld, void* stream);
 
 /* LayerNorm over the last dim (eps 1e-5) of s = x (+ residual); saves xhat and rstd for backward.
  * cross_modal_transformer.py:283-284,297,301,421. cols <= 1024. */

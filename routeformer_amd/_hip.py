@@ -38,6 +38,8 @@ SIGNATURES = {
     "rf_avgpool8_tokens": [_P, _I, _P, _I, _I, _I, _I, _P],
     "rf_unfold3_circular": [_P, _P, _I, _I, _I, _I, _P],
     "rf_fold3_circular": [_P, _P, _I, _I, _I, _I, _P],
+    "rf_unfold3_circular_ld": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "rf_fold3_circular_ld": [_P, _P, _I, _I, _I, _I, _I, _P],
     "rf_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "rf_layernorm_bwd_parts": [_I],
     "rf_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P],

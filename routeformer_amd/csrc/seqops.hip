@@ -140,13 +140,16 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
   }
 }
 
+// `ld` = row pitch of cols (>= 3 C): columns 3 C .. ld - 1 are written as zeros (a K padded to a multiple of 4 keeps the
+// consuming GEMM on its 16-B vector path: c_in = 69 -> 207 columns would otherwise take the scalar kernel)
 __global__ void unfold3_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int L, int C, int pad,
-                               int Lout) {
-  const long total = (long)B * Lout * 3 * C;
+                               int Lout, int ld) {
+  const long total = (long)B * Lout * ld;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int t = (int)(i % 3);
-    long r = i / 3;
-    const int c = (int)(r % C); r /= C;
+    const int k = (int)(i % ld);
+    long r = i / ld;
+    if (k >= 3 * C) { cols[i] = 0.f; continue; }
+    const int t = k % 3, c = k / 3;
     const int l = (int)(r % Lout);
     const int b = (int)(r / Lout);
     int src = (l + t - pad) % L;
@@ -156,7 +159,7 @@ __global__ void unfold3_kernel(const float* __restrict__ x, float* __restrict__ 
 }
 
 __global__ void fold3_kernel(const float* __restrict__ dcols, float* __restrict__ dx, int B, int L, int C, int pad,
-                             int Lout) {
+                             int Lout, int ld) {
   const long total = (long)B * L * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
@@ -168,7 +171,7 @@ __global__ void fold3_kernel(const float* __restrict__ dcols, float* __restrict_
     for (int t = 0; t < 3; ++t) {
       int lo = (l - t + pad) % L;
       if (lo < 0) lo += L;
-      for (; lo < Lout; lo += L) s += dcols[(((long)b * Lout + lo) * C + c) * 3 + t];
+      for (; lo < Lout; lo += L) s += dcols[((long)b * Lout + lo) * ld + c * 3 + t];
     }
     dx[i] = s;
   }
@@ -461,22 +464,30 @@ extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float*
   return RF_OK;
 }
 
-extern "C" int rf_unfold3_circular(const float* x, float* cols, int B, int L, int C, int pad, void* stream) {
-  RF_REQUIRE(x && cols && B > 0 && L > 0 && C > 0 && pad >= 1 && pad <= 2);
+extern "C" int rf_unfold3_circular_ld(const float* x, float* cols, int B, int L, int C, int pad, int ld, void* stream) {
+  RF_REQUIRE(x && cols && B > 0 && L > 0 && C > 0 && pad >= 1 && pad <= 2 && ld >= 3 * C);
   const int Lout = L + 2 * pad - 2;
-  RF_LAUNCH(unfold3_kernel, dim3(grid_for((long)B * Lout * 3 * C)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, cols, B, L, C, pad, Lout);
+  RF_LAUNCH(unfold3_kernel, dim3(grid_for((long)B * Lout * ld)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, cols, B, L, C, pad, Lout, ld);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_unfold3_circular(const float* x, float* cols, int B, int L, int C, int pad, void* stream) {
+  return rf_unfold3_circular_ld(x, cols, B, L, C, pad, 3 * C, stream);
+}
+
+extern "C" int rf_fold3_circular_ld(const float* dcols, float* dx, int B, int L, int C, int pad, int ld, void* stream) {
+  RF_REQUIRE(dcols && dx && B > 0 && L > 0 && C > 0 && pad >= 1 && pad <= 2 && ld >= 3 * C);
+  const int Lout = L + 2 * pad - 2;
+  RF_LAUNCH(fold3_kernel, dim3(grid_for((long)B * L * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     dcols, dx, B, L, C, pad, Lout, ld);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
 
 extern "C" int rf_fold3_circular(const float* dcols, float* dx, int B, int L, int C, int pad, void* stream) {
-  RF_REQUIRE(dcols && dx && B > 0 && L > 0 && C > 0 && pad >= 1 && pad <= 2);
-  const int Lout = L + 2 * pad - 2;
-  RF_LAUNCH(fold3_kernel, dim3(grid_for((long)B * L * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     dcols, dx, B, L, C, pad, Lout);
-  RF_CHECK_LAUNCH();
-  return RF_OK;
+  return rf_fold3_circular_ld(dcols, dx, B, L, C, pad, 3 * C, stream);
 }
 
 extern "C" int rf_bn_stats(const float* x, float* mean, float* var, int rows, int C, float* running_mean,

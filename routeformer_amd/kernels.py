@@ -1008,33 +1008,43 @@ def add_layer_norm(x, residual, gamma, beta, eps: float = 1e-5):
 
 
 class _Unfold3(torch.autograd.Function):
-    """(B,L,C) -> (B,L+2p-2,3C) circular im2col for the k=3 sequence convolutions."""
+    """(B,L,C) -> (B,L+2p-2,ld) circular im2col for the k=3 sequence convolutions (ld >= 3C, extra columns zero)."""
 
     @staticmethod
-    def forward(ctx, x, pad: int):
+    def forward(ctx, x, pad: int, ld: int = 0):
         _req(x, "unfold3.x")
         x = x.contiguous()
         B, L, C = x.shape
-        cols = torch.empty(B, L + 2 * pad - 2, 3 * C, device=x.device, dtype=torch.float32)
-        check(_hip.lib().rf_unfold3_circular(ptr(x), ptr(cols), B, L, C, pad, _stream()), "rf_unfold3")
-        ctx.dims = (B, L, C, pad)
+        ld = ld or 3 * C
+        cols = torch.empty(B, L + 2 * pad - 2, ld, device=x.device, dtype=torch.float32)
+        check(_hip.lib().rf_unfold3_circular_ld(ptr(x), ptr(cols), B, L, C, pad, ld, _stream()), "rf_unfold3")
+        ctx.dims = (B, L, C, pad, ld)
         return cols
 
     @staticmethod
     def backward(ctx, dcols):
-        B, L, C, pad = ctx.dims
+        B, L, C, pad, ld = ctx.dims
         dcols = dcols.contiguous()
         dx = torch.empty(B, L, C, device=dcols.device, dtype=torch.float32)
-        check(_hip.lib().rf_fold3_circular(ptr(dcols), ptr(dx), B, L, C, pad, _stream()), "rf_fold3")
-        return dx, None
+        check(_hip.lib().rf_fold3_circular_ld(ptr(dcols), ptr(dx), B, L, C, pad, ld, _stream()), "rf_fold3")
+        return dx, None, None
 
 
 def circular_conv3(x, weight, bias=None, pad: int = 1, residual=None):
     """Conv1d(k=3, padding_mode='circular') on channels-last sequences: weight (d, c, 3), used in place as
     a (d, 3c) matrix (the unfold emits columns in the weight's own (c, t) memory order).
     ``residual`` (L_out, d): added to every sequence (positional / time-feature table)."""
+    d, c = weight.shape[0], weight.shape[1]
+    if (3 * c) % 4 != 0 and x.is_cuda:
+        # 3 c not a multiple of 4 (the GPS backbone's 69 input channels -> K = 207): neither operand of the embedding GEMM
+        # is 16-B addressable and it (and both backward GEMMs) would take the scalar tile kernel -- 37 us for 0.1 GFLOP on
+        # the critical path.  One zero column: the unfold writes a pitch of 208, the weight is padded to match (autograd
+        # slices its gradient back), all three GEMMs stay on the vector path.
+        ld = (3 * c + 3) // 4 * 4
+        cols = _Unfold3.apply(x, pad, ld)
+        wp = torch.nn.functional.pad(weight.reshape(d, 3 * c), (0, ld - 3 * c))
+        return _Linear.apply(cols, wp, bias, residual, None, _slot(bias))
     cols = _Unfold3.apply(x, pad)
-    d = weight.shape[0]
     return _Linear.apply(cols, weight.view(d, -1), bias, residual, _slot(weight, (d, weight.shape[1] * 3)),
                          _slot(bias))
 
