@@ -177,7 +177,10 @@ class Routeformer(nn.Module):
             training = self.training
         gps = batch["gps"].to(torch.float32)
         if self.motion_noise > 0.0 and self.training:
-            gps = gps + torch.randn_like(gps) * self.motion_noise
+            # drawn from the HOST generator, where the reference's CPU run draws it (the first draw of a train-mode forward,
+            # SURVEY Appendix D), so that a seed reproduces the reference's noise; note `self.training`, not `training`: the
+            # target-side pass of a train step draws (and discards) its own noise too
+            gps = gps + torch.randn(gps.shape, dtype=gps.dtype).to(gps.device) * self.motion_noise
         if gps.is_cuda:  # diff + normalise + the zero row in front: one launch (inputs carry no gradient)
             motion = K.motion_diff(gps, c.normalize_motion, c.motion_mean, c.motion_std)
         else:

@@ -59,6 +59,9 @@ CASES = {
                          rf=dict(RF_DEFAULT, with_video=False, rotate_motion=True,
                                  decoder_mode="recursive", normalize_motion=True,
                                  motion_mean=1.8332362885457094, motion_std=0.9090128501056961)),
+    # motion_noise > 0 (routeformer.py:281-282): torch.randn_like(gps) is the FIRST host draw of a train-mode forward
+    "c1_noise": dict(B=3, T=10, P=15, H=0, W=0, streams=(), gaze=False, gps=GPS_TINY,
+                     rf=dict(RF_DEFAULT, with_video=False, motion_noise=0.25, decoder_mode="smart")),
     # configs[4] at reduced size: long horizon (fusion length 320), GELU Informer.
     "c5_small": dict(B=1, T=80, P=25, H=96, W=96,
                      streams=("left_video", "right_video", "front_video"), gaze=True, gps=GPS_TINY,

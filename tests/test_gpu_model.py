@@ -167,7 +167,7 @@ def test_informer_golden(tag, preset, B, T, P, cin):
                 assert rel_err(sd["encoder.conv_layers.0.norm.running_var"], G[key + "bn0_running_var"]) < 1e-4
 
 
-CASES = ["c1_default", "c1_paper", "c1_recursive", "c2_small", "c4_small", "c5_small", "ar_small", "c2_paper"]
+CASES = ["c1_default", "c1_paper", "c1_recursive", "c1_noise", "c2_small", "c4_small", "c5_small", "ar_small", "c2_paper"]
 
 
 def _first_flip(tops_gpu, src):
@@ -269,7 +269,7 @@ def test_model_eval_forward_bf16(name):
     assert free < 5e-2
 
 
-@pytest.mark.parametrize("name", ["c1_default", "c1_recursive", "c2_small", "c4_small", "c2_paper"])
+@pytest.mark.parametrize("name", ["c1_default", "c1_recursive", "c1_noise", "c2_small", "c4_small", "c2_paper"])
 def test_model_train_step_golden(name):
     """The train-step recipe (loss, ADE, FDE, gradients) vs the reference, epochs 0 and 10, with the
     oracle's top-u selections imposed (train-mode oracle run with the same seed)."""

@@ -154,7 +154,7 @@ def test_helpers():
         O.median_downsampler(t(G["gaze"])[:, :10], 10)
 
 
-CASES = ["c1_default", "c1_paper", "c1_recursive", "c2_small", "c4_small", "c5_small", "ar_small", "c2_paper"]
+CASES = ["c1_default", "c1_paper", "c1_recursive", "c1_noise", "c2_small", "c4_small", "c5_small", "ar_small", "c2_paper"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -171,7 +171,7 @@ def test_model_eval_forward(name):
         assert rel_err(vis, G["eval.future_vis"]) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["c1_default", "c1_recursive", "c2_small", "c4_small"])
+@pytest.mark.parametrize("name", ["c1_default", "c1_recursive", "c1_noise", "c2_small", "c4_small"])
 def test_model_train_step(name):
     model, cfg, sd, c = build_product_model(name)
     G = golden(name)
