@@ -452,10 +452,12 @@ int rf_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const
                   float grad_scale, void* stream);
 /* Same update with the scalars read from device memory, for a launch replayed from a HIP graph:
  * hyper[10] = {pending (0: leave everything untouched), max_norm, lr, beta1, beta2, eps, wd, 1-beta1^t,
- * sqrt(1-beta2^t), grad_scale}.  `sumsq` may cover a larger buffer than [p, p+n): the clip coefficient is global. */
+ * sqrt(1-beta2^t), grad_scale}.  `sumsq` may cover a larger buffer than [p, p+n): the clip coefficient is global.
+ * max_blocks > 0 caps the grid (0: 4096 workgroups): a slice updated on a side stream underneath other work is
+ * throttled this way so that its 28 B/parameter stream does not starve the kernels it runs next to. */
 #define RF_ADAMW_HYPER 10
 int rf_adamw_clip_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, int sumsq_parts,
-                      const float* hyper, void* stream);
+                      const float* hyper, int max_blocks, void* stream);
 
 /* ---- backbone input / output head (routeformer.py:210-233,279-292) ------------------------------
  * rf_motion_input: x[b,t,:] = [R(-origin_b) motion | (angle - origin_b)/pi | |motion| | |motion|_t - |motion|_{t-1}

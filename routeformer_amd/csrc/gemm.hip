@@ -1024,7 +1024,10 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
   if (a_rowsum && am != 1) { rf_g_last_error = "a_rowsum needs a row-contiguous, aligned A"; return RF_EUNSUPPORTED; }
   bool in_kernel_reduce = false;
   if (am <= 1 && bm <= 1) {  // both operands vectorizable: pipelined kernel
-    const bool tall = M >= 4096 && N >= 64;
+    // 128-row tiles only while they still fill the chip: M = 12 480, N = 128 (the camera-token embedding) is 196 of them --
+    // one four-wave workgroup on 3/4 of the CUs, 12 dependent K-steps each (67 us); 64 x 64 tiles give 390
+    static const long tall_min = [] { const char* e = getenv("RF_GEMM_TALL_MIN"); return e ? atol(e) : 0L; }();
+    const bool tall = M >= 4096 && N >= 64 && (long)((M + 127) / 128) * ((N + 63) / 64) * splitk >= tall_min;
     if (splitk > 1 && !atomic_accumulate && tile_counters) {
       const long tiles = (long)((M + (tall ? 127 : 63)) / (tall ? 128 : 64)) * ((N + 63) / 64);
       if (tiles <= 4096) { p.tile_cnt = tile_counters; in_kernel_reduce = true; }  // counter buffer: 4096 tiles

@@ -9,6 +9,11 @@ namespace {
 constexpr int LN_MAXV = 16;  // cols <= 64 * 16
 constexpr int LN_WAVES = 4;
 
+// NV = number of 64-column groups a lane walks (cols <= 64 NV), a template parameter so that the unrolled loads carry
+// no branches: with a wave-uniform `if (group < cols)` around each of them (the previous form) the compiler waited for
+// every load before the next branch -- 13 dependent memory round trips per row at cols = 832 (10-12 us for a 20-row
+// launch; 4.5 us at cols = 128, where there are two).  Loads at a clamped column, masked by a select.
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
@@ -18,103 +23,117 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   const int row = blockIdx.x * LN_WAVES + wave;
   if (row >= rows) return;
   const long off = (long)row * cols;
-  float v[LN_MAXV];
+  float v[NV], gm[NV], bt[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = x[off + min(i * 64 + lane, cols - 1)];
+  if (res) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] += res[off + min(i * 64 + lane, cols - 1)];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int cc = min(i * 64 + lane, cols - 1);
+    gm[i] = gamma[cc];
+    bt[i] = beta[cc];
+  }
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    // unconditional loads at a clamped column, masked by a select (a predicated load is an exec-mask branch)
-    const int c = i * 64 + lane, cc = min(c, cols - 1);
-    float t = 0.f;
-    if (i * 64 < cols) {  // wave-uniform (scalar branch): skip the 64-column groups beyond the row
-      t = x[off + cc];
-      if (res) t += res[off + cc];
-      t = c < cols ? t : 0.f;
-    }
-    v[i] = t;
-    s += t;
+  for (int i = 0; i < NV; ++i) {
+    v[i] = (i * 64 + lane < cols) ? v[i] : 0.f;
+    s += v[i];
   }
   const float mean = wave_sum(s) / (float)cols;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = i * 64 + lane;
-    const float d = (c < cols) ? v[i] - mean : 0.f;
+  for (int i = 0; i < NV; ++i) {
+    const float d = (i * 64 + lane < cols) ? v[i] - mean : 0.f;
     q += d * d;
   }
   const float var = wave_sum(q) / (float)cols;
   const float rstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = i * 64 + lane;
     if (c < cols) {
       const float h = (v[i] - mean) * rstd;
       if (xhat) xhat[off + c] = h;
-      y[off + c] = h * gamma[c] + beta[c];
+      y[off + c] = h * gm[i] + bt[i];
     }
   }
   if (rstd_out && lane == 0) rstd_out[row] = rstd;
 }
 
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
                                                             float* __restrict__ ws, int rows, int cols,
                                                             float* __restrict__ agamma, float* __restrict__ abeta) {
-  __shared__ float red[LN_WAVES][64];
+  __shared__ float red[2][LN_WAVES][NV * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float dg[LN_MAXV], db[LN_MAXV];
+  float dg[NV], db[NV], gm[NV];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+  for (int i = 0; i < NV; ++i) {
+    dg[i] = 0.f; db[i] = 0.f;
+    gm[i] = gamma[min(i * 64 + lane, cols - 1)];
+  }
   for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
     const long off = (long)row * cols;
-    float g[LN_MAXV], h[LN_MAXV];
+    float g[NV], h[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int cc = min(i * 64 + lane, cols - 1);  // clamped, unconditional; masked below
+      g[i] = dy[off + cc];
+      h[i] = xhat[off + cc];
+    }
+    const float r = rstd[row];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = i * 64 + lane, cc = min(c, cols - 1);  // clamped, unconditional; masked below
-      float d = 0.f, hh = 0.f, gm = 0.f;
-      if (i * 64 < cols) {  // wave-uniform (scalar branch): skip the 64-column groups beyond the row
-        d = dy[off + cc]; hh = xhat[off + cc]; gm = gamma[cc];
-        d = c < cols ? d : 0.f;
-        hh = c < cols ? hh : 0.f;
-      }
-      dg[i] += d * hh;
+    for (int i = 0; i < NV; ++i) {
+      const bool in = i * 64 + lane < cols;
+      const float d = in ? g[i] : 0.f;
+      h[i] = in ? h[i] : 0.f;
+      dg[i] += d * h[i];
       db[i] += d;
-      g[i] = d * gm;
-      h[i] = hh;
+      g[i] = d * gm[i];
       s1 += g[i];
-      s2 += g[i] * hh;
+      s2 += g[i] * h[i];
     }
     const float m1 = wave_sum(s1) / (float)cols, m2 = wave_sum(s2) / (float)cols;
-    const float r = rstd[row];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = i * 64 + lane;
       if (c < cols) dx[off + c] = r * (g[i] - m1 - h[i] * m2);
     }
   }
-  // block partials -> ws[block][0][cols] (dgamma), ws[block][1][cols] (dbeta)
-  float* wg = agamma ? nullptr : ws + (long)blockIdx.x * 2 * cols;
+  // block partials -> ws[block][0][cols] (dgamma), ws[block][1][cols] (dbeta), or atomics into the running sums: the four
+  // waves' sums meet in LDS behind ONE barrier (was four barriers per 64-column group)
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    if (i * 64 >= cols) break;
-    const int c = i * 64 + lane;
-    red[wave][lane] = dg[i];
-    __syncthreads();
-    if (wave == 0 && c < cols) {
-      const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-      if (agamma) atomicAdd(&agamma[c], t); else wg[c] = t;
-    }
-    __syncthreads();
-    red[wave][lane] = db[i];
-    __syncthreads();
-    if (wave == 0 && c < cols) {
-      const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-      if (abeta) atomicAdd(&abeta[c], t); else wg[cols + c] = t;
-    }
-    __syncthreads();
+  for (int i = 0; i < NV; ++i) {
+    red[0][wave][i * 64 + lane] = dg[i];
+    red[1][wave][i * 64 + lane] = db[i];
+  }
+  __syncthreads();
+  float* wg = agamma ? nullptr : ws + (long)blockIdx.x * 2 * cols;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const float tg = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    const float tb = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    if (agamma) { atomicAdd(&agamma[c], tg); atomicAdd(&abeta[c], tb); }
+    else { wg[c] = tg; wg[cols + c] = tb; }
   }
 }
+
+// smallest instantiated NV >= the 64-column groups of a row
+#define RF_LN_DISPATCH(KERNEL, cols, ...)                                                     \
+  do {                                                                                        \
+    const int nv__ = ((cols) + 63) / 64;                                                      \
+    if (nv__ <= 1) RF_LAUNCH(KERNEL<1>, __VA_ARGS__);                                         \
+    else if (nv__ <= 2) RF_LAUNCH(KERNEL<2>, __VA_ARGS__);                                    \
+    else if (nv__ <= 4) RF_LAUNCH(KERNEL<4>, __VA_ARGS__);                                    \
+    else if (nv__ <= 8) RF_LAUNCH(KERNEL<8>, __VA_ARGS__);                                    \
+    else if (nv__ <= 13) RF_LAUNCH(KERNEL<13>, __VA_ARGS__);                                  \
+    else RF_LAUNCH(KERNEL<16>, __VA_ARGS__);                                                  \
+  } while (0)
 
 // block = 64 columns x 4 part-lanes: sums the per-block partials of layernorm_bwd_kernel
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ ws, int parts, int cols,
@@ -142,19 +161,29 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
 
 // `ld` = row pitch of cols (>= 3 C): columns 3 C .. ld - 1 are written as zeros (a K padded to a multiple of 4 keeps the
 // consuming GEMM on its 16-B vector path: c_in = 69 -> 207 columns would otherwise take the scalar kernel)
-__global__ void unfold3_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int L, int C, int pad,
-                               int Lout, int ld) {
-  const long total = (long)B * Lout * ld;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % ld);
-    long r = i / ld;
-    if (k >= 3 * C) { cols[i] = 0.f; continue; }
-    const int t = k % 3, c = k / 3;
-    const int l = (int)(r % Lout);
-    const int b = (int)(r / Lout);
-    int src = (l + t - pad) % L;
-    if (src < 0) src += L;
-    cols[i] = x[((long)b * L + src) * C + c];
+// One workgroup iteration per output row, 32-bit index arithmetic (the element-indexed form spent its time in 64-bit
+// divisions by run-time values: 66 us for the 12 480 x 720 camera-token unfold, now HBM time).
+__global__ __launch_bounds__(256) void unfold3_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int L,
+                                                      int C, int pad, int Lout, int ld) {
+  const int rows = B * Lout, kc = 3 * C;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int l = r % Lout, b = r / Lout;
+    int s0 = (l - pad) % L;
+    if (s0 < 0) s0 += L;
+    const int s1 = s0 + 1 == L ? 0 : s0 + 1, s2 = s1 + 1 == L ? 0 : s1 + 1;
+    const float* base = x + (long)b * L * C;
+    const float* x0 = base + (long)s0 * C;
+    const float* x1 = base + (long)s1 * C;
+    const float* x2 = base + (long)s2 * C;
+    float* out = cols + (long)r * ld;
+    for (int k = threadIdx.x; k < ld; k += 256) {
+      float v = 0.f;
+      if (k < kc) {
+        const int c = k / 3, t = k - 3 * c;
+        v = (t == 0 ? x0 : (t == 1 ? x1 : x2))[c];
+      }
+      out[k] = v;
+    }
   }
 }
 
@@ -426,8 +455,8 @@ inline int grid_for(long total, int block = 256, int cap = 4096) {
 extern "C" int rf_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
                                 float* y, float* xhat, float* rstd, int rows, int cols, float eps, void* stream) {
   RF_REQUIRE(x && gamma && beta && y && rows > 0 && cols > 0 && cols <= 64 * LN_MAXV);
-  RF_LAUNCH(layernorm_fwd_kernel, dim3((rows + LN_WAVES - 1) / LN_WAVES), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, residual, gamma, beta, y, xhat, rstd, rows, cols, eps);
+  RF_LN_DISPATCH(layernorm_fwd_kernel, cols, dim3((rows + LN_WAVES - 1) / LN_WAVES), dim3(256), 0,
+                 static_cast<hipStream_t>(stream), x, residual, gamma, beta, y, xhat, rstd, rows, cols, eps);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
@@ -449,14 +478,14 @@ extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float*
     // launches are latency-bound), then grid-stride
     int blocks = (rows + LN_WAVES - 1) / LN_WAVES;
     blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
-    RF_LAUNCH(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, xhat, rstd, gamma, dx,
-                       static_cast<float*>(nullptr), rows, cols, dgamma, dbeta);
+    RF_LN_DISPATCH(layernorm_bwd_kernel, cols, dim3(blocks), dim3(256), 0, st, dy, xhat, rstd, gamma, dx,
+                   static_cast<float*>(nullptr), rows, cols, dgamma, dbeta);
     RF_CHECK_LAUNCH();
     return RF_OK;
   }
   const int parts = rf_layernorm_bwd_parts(rows);
-  RF_LAUNCH(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, st, dy, xhat, rstd, gamma, dx, workspace, rows,
-                     cols, static_cast<float*>(nullptr), static_cast<float*>(nullptr));
+  RF_LN_DISPATCH(layernorm_bwd_kernel, cols, dim3(parts), dim3(256), 0, st, dy, xhat, rstd, gamma, dx, workspace, rows,
+                 cols, static_cast<float*>(nullptr), static_cast<float*>(nullptr));
   RF_CHECK_LAUNCH();
   RF_LAUNCH(ln_param_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, workspace, parts, cols,
                      dgamma, dbeta, accumulate);
@@ -467,7 +496,9 @@ extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float*
 extern "C" int rf_unfold3_circular_ld(const float* x, float* cols, int B, int L, int C, int pad, int ld, void* stream) {
   RF_REQUIRE(x && cols && B > 0 && L > 0 && C > 0 && pad >= 1 && pad <= 2 && ld >= 3 * C);
   const int Lout = L + 2 * pad - 2;
-  RF_LAUNCH(unfold3_kernel, dim3(grid_for((long)B * Lout * ld)), dim3(256), 0,
+  RF_REQUIRE((long)B * Lout < (1L << 31));
+  const long rows = (long)B * Lout;
+  RF_LAUNCH(unfold3_kernel, dim3((unsigned)(rows > 16384 ? 16384 : rows)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, cols, B, L, C, pad, Lout, ld);
   RF_CHECK_LAUNCH();
   return RF_OK;

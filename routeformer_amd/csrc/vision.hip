@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 // HYPER: the scalars come from a device array (rf_adamw_clip_dev) -- a launch replayed from a HIP graph cannot
 // take new by-value arguments, and the bias corrections / learning rate change every step.
 template <bool HYPER>
-__global__ void adamw_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                   float* __restrict__ v, long n, const float* __restrict__ sumsq, float max_norm,
                                   float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
                                   float grad_scale, int sumsq_parts, const float* __restrict__ hyper) {
@@ -169,8 +169,17 @@ __global__ void adamw_clip_kernel(float* __restrict__ p, const float* __restrict
   }
   float coef = grad_scale;
   if (max_norm > 0.f) {
-    float ss = 0.f;
-    for (int k = 0; k < sumsq_parts; ++k) ss += sumsq[k];  // uniform, ascending: same value in every workgroup
+    // the norm from the per-workgroup partials: every workgroup adds them in the SAME fixed order (thread t takes k = t,
+    // t + 256, ...; DPP wave sums; four wave totals) -- bit-identical in every workgroup, on every rank and run.  (One
+    // thread walking all 1024 partials cost ~50 us of dependent loads at the head of every workgroup: the 3.5-M
+    // parameter slice of the encoders took 170 us.)
+    __shared__ float red[4];
+    float part = 0.f;
+    for (int k = threadIdx.x; k < sumsq_parts; k += 256) part += sumsq[k];
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const float ss = (red[0] + red[1]) + (red[2] + red[3]);
     const float total = grad_scale * sqrtf(ss);
     const float c = max_norm / (total + 1e-6f);
     if (c < 1.f) coef *= c;
@@ -316,9 +325,9 @@ extern "C" int rf_adamw_clip(float* p, const float* g, float* m, float* v, int64
 }
 
 extern "C" int rf_adamw_clip_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
-                                 int sumsq_parts, const float* hyper, void* stream) {
-  RF_REQUIRE(p && g && m && v && n > 0 && hyper && sumsq && sumsq_parts >= 1);
-  RF_LAUNCH(adamw_clip_kernel<true>, dim3(grid_for(n, 256, 4096)), dim3(256), 0,
+                                 int sumsq_parts, const float* hyper, int max_blocks, void* stream) {
+  RF_REQUIRE(p && g && m && v && n > 0 && hyper && sumsq && sumsq_parts >= 1 && max_blocks >= 0);
+  RF_LAUNCH(adamw_clip_kernel<true>, dim3(grid_for(n, 256, max_blocks > 0 ? max_blocks : 4096)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p, g, m, v, (long)n, sumsq, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f,
                      1.f, sumsq_parts, hyper);
   RF_CHECK_LAUNCH();

@@ -489,9 +489,10 @@ class FusedAdamW:
         from routeformer_amd import _hip, kernels as K
         _hip.check(_hip.lib().rf_sumsq(self.g.data_ptr(), self.p.numel(), self.sumsq.data_ptr(), K._stream()), "rf_sumsq")
 
-    def launch_update_dev(self, lo: int, hi: int, hyper_dev: torch.Tensor):
+    def launch_update_dev(self, lo: int, hi: int, hyper_dev: torch.Tensor, max_blocks: int = 0):
         """AdamW over the slice [lo, hi) of the flat buffers on the current stream, scalars from ``hyper_dev``
-        (the clip coefficient still comes from the norm of the WHOLE gradient buffer: launch_sumsq first)."""
+        (the clip coefficient still comes from the norm of the WHOLE gradient buffer: launch_sumsq first).
+        ``max_blocks`` > 0 throttles the launch (a side-stream update with slack)."""
         from routeformer_amd import _hip, kernels as K
         if hi <= lo:
             return
@@ -499,7 +500,7 @@ class FusedAdamW:
         ev = K.PROFILE.begin() if K.PROFILE.on else None
         args = (self.p.data_ptr() + o, self.g.data_ptr() + o, self.m.data_ptr() + o, self.v.data_ptr() + o, hi - lo,
                 self.sumsq.data_ptr(), self.parts, hyper_dev.data_ptr())
-        _hip.check(_hip.lib().rf_adamw_clip_dev(*args, K._stream()), "rf_adamw_clip_dev")
+        _hip.check(_hip.lib().rf_adamw_clip_dev(*args, max_blocks, K._stream()), "rf_adamw_clip_dev")
         if ev is not None:
             # algorithmic bytes: p, m, v read + written, g read (28 B per parameter).  The timing replay (bench.py, after
             # the timed region) streams the same bytes with lr = wd = 0: parameters stay, only the moments decay
@@ -507,7 +508,7 @@ class FusedAdamW:
             probe[0], probe[2], probe[6] = 1.0, 0.0, 0.0
             K.PROFILE.end("adamw_clip_kernel<true>", ev, 12.0 * (hi - lo), 28.0 * (hi - lo),
                           replay=lambda a=args[:-1], h=probe, kp=(self.p, self.g, self.m, self.v): _hip.lib().rf_adamw_clip_dev(
-                              *a, h.data_ptr(), K._stream()))
+                              *a, h.data_ptr(), max_blocks, K._stream()))
         K.WEIGHTS_EPOCH += 1
 
     def _segments(self, lo: int, hi: int, skip):
@@ -794,6 +795,7 @@ class GraphedTrainEngine(TrainEngine):
         self._out = None
         self._trunk_g = None
         self._ready_id = None
+        self._ready_checked = None
         self._cached_ids = {}     # batch id -> (cache slots, content keys) of its frames
         self._uncached_ids = set()  # ids whose frames did not fit into the cache
         self._id_bad = self._id_bad_host = self._id_checked = None
@@ -858,7 +860,7 @@ class GraphedTrainEngine(TrainEngine):
                     r.flat_grad[a:b].zero_()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                opt.launch_update_dev(lo, hi, self._hyper)
+                opt.launch_update_dev(lo, hi, self._hyper, int(__import__("os").environ.get("RF_ADAMW_SIDE_BLOCKS", "0")))
                 r.flat_grad[lo:hi].zero_()
             self.model.__dict__["_before_gps_backbone"] = lambda: torch.cuda.current_stream().wait_stream(side)
         else:
@@ -956,6 +958,10 @@ class GraphedTrainEngine(TrainEngine):
             return False  # cannot be hashed in place: take the trunk path
         cache.gather(hit[0], self._tok_next)
         return True
+
+    @staticmethod
+    def _clip_ptrs(item):
+        return tuple(v.data_ptr() for part in ("train", "target") for v in item[part].values() if v.dim() == 5)
 
     def _check_id_content(self, item) -> bool:
         """Device-side check that the frames of ``item`` are the ones remembered under its id (no host synchronisation;
@@ -1246,7 +1252,10 @@ class GraphedTrainEngine(TrainEngine):
             iid = item.get("id")
             cache = self._cache()
             if self._ready_id is not None and iid is not None and iid == self._ready_id:
-                self._check_id_content(item)  # tokens were computed ahead under this id: same frames? (cache attached)
+                # tokens were prepared under this id by the previous call: by its look-ahead trunk pass (cache attached:
+                # are these the frames remembered for the id?) or from the cache (already checked when they were gathered)
+                if self._ready_checked != self._clip_ptrs(item):
+                    self._check_id_content(item)
             else:
                 if not self._cached_tokens_into_next(item):  # cold start / no look-ahead: run this batch's trunk now
                     self._stage_clips(item)
@@ -1259,8 +1268,10 @@ class GraphedTrainEngine(TrainEngine):
             self._ready_id = None
             # (a next_item without an id could not be recognised by the following call: its trunk pass would be wasted)
             lookahead = next_item is not None and next_item.get("id") is not None
+            self._ready_checked = None
             if lookahead and self._cached_tokens_into_next(next_item):
                 lookahead = False  # tokens of the next batch are already in _tok_next: no trunk branch this step
+                self._ready_checked = self._clip_ptrs(next_item)  # these very tensors have just been hashed
             elif lookahead:
                 self._stage_clips(next_item)
                 if cache is not None:

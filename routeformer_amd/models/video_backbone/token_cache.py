@@ -38,6 +38,7 @@ class TokenCache:
         self._misses = torch.zeros(1, dtype=torch.int32, device=dev)
         self.seed = seed
         self.fingerprint = 0  # digest of the producing trunk's weights (bind): part of every key's namespace
+        self._ids_cache = {}
         self.hits = self.lookups = 0
 
     def bind(self, fingerprint: int):
@@ -68,7 +69,13 @@ class TokenCache:
             if idx is None:
                 ids, n = None, B * T
             else:
-                ids = (torch.arange(B, device=v.device).view(B, 1) * T + idx.to(v.device).view(1, -1)).reshape(-1).contiguous()
+                # frame ids of the selection, built once per (B, T, selection): a per-call `idx.to(device)` is a pageable
+                # host-to-device copy, i.e. a host stall in the middle of every step that consults the cache
+                key = (B, T, tuple(int(i) for i in idx.tolist()), str(v.device))
+                ids = self._ids_cache.get(key)
+                if ids is None:
+                    ids = (torch.arange(B, device=v.device).view(B, 1) * T + idx.to(v.device).view(1, -1)).reshape(-1).contiguous()
+                    self._ids_cache[key] = ids
                 n = ids.numel()
             keys = torch.empty(n, dtype=torch.int64, device=v.device)
             check(_hip.lib().rf_frame_hash(ptr(v), ptr(ids), n, nbytes, ptr(keys), self._key_seed(), _stream()), "rf_frame_hash")
