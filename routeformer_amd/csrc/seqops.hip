@@ -341,10 +341,17 @@ __global__ __launch_bounds__(256) void bn_train_elu_pool_fwd_kernel(
   const int c = blockIdx.x * BNS_CH + tx, cc = min(c, C - 1);
   const int rows = B * L;
   float s = 0.f;
-  for (int r = ty; r < rows; r += BNS_RL) {
-    const float v = x[(long)r * C + cc];
-    slab[r * BNS_CH + tx] = v;
-    s += v;
+  // eight rows in flight per thread (clamped, unconditional loads): a load -> LDS store -> next load loop is one memory
+  // round trip per row, 40 of them at B L = 320 (27 us for a 1-MB tensor)
+  for (int r0 = ty; r0 < rows; r0 += BNS_RL * 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = x[(long)min(r0 + j * BNS_RL, rows - 1) * C + cc];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = r0 + j * BNS_RL;
+      if (r < rows) { slab[r * BNS_CH + tx] = v[j]; s += v[j]; }
+    }
   }
   red[ty][tx] = s;
   __syncthreads();
@@ -402,18 +409,35 @@ __global__ __launch_bounds__(256) void bn_elu_pool_bwd_slab_kernel(
   float* xh = slab;
   float* dd = slab + (long)rows * BNS_CH;
   const float g = gamma[cc], istd = 1.0f / sqrtf(var[cc] + eps), mu = mean[cc], bt = beta[cc];
-  for (int r = ty; r < rows; r += BNS_RL) {
-    xh[r * BNS_CH + tx] = (x[(long)r * C + cc] - mu) * istd;
-    dd[r * BNS_CH + tx] = 0.f;
+  for (int r0 = ty; r0 < rows; r0 += BNS_RL * 8) {  // eight rows in flight per thread (see the forward kernel)
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = x[(long)min(r0 + j * BNS_RL, rows - 1) * C + cc];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = r0 + j * BNS_RL;
+      if (r < rows) { xh[r * BNS_CH + tx] = (v[j] - mu) * istd; dd[r * BNS_CH + tx] = 0.f; }
+    }
   }
   __syncthreads();
   // pool routing: every pooled output sends its gradient to its arg-max row (windows overlap in one row: two outputs of a
   // channel may name the same row -- the (b, lo) loop of one thread column runs over lo with stride BNS_RL, so the adds
   // of a column go through LDS atomics)
-  for (int o = ty; o < B * Lout; o += BNS_RL) {
-    const int b = o / Lout;
-    const int li = argmax[(long)o * C + cc];
-    atomicAdd(&dd[(b * L + li) * BNS_CH + tx], dy[(long)o * C + cc]);
+  const int outs = B * Lout;
+  for (int o0 = ty; o0 < outs; o0 += BNS_RL * 4) {
+    int li[4];
+    float gy[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long at = (long)min(o0 + j * BNS_RL, outs - 1) * C + cc;
+      li[j] = argmax[at];
+      gy[j] = dy[at];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = o0 + j * BNS_RL;
+      if (o < outs) atomicAdd(&dd[((o / Lout) * L + li[j]) * BNS_CH + tx], gy[j]);
+    }
   }
   __syncthreads();
   float s1 = 0.f, s2 = 0.f;
@@ -663,11 +687,26 @@ __global__ __launch_bounds__(256) void traj_head_fwd_kernel(const float* __restr
   float s_dense = 0.f;
   if (tvis) {
     // one (b, t) row of E channels per 16-lane group pass: the discount is looked up once per row, no div / mod per element
-    for (long bt = tid >> 4; bt < (long)B * P; bt += 16) {
-      const float w = staged ? disc[(int)(bt % P)] : powf(gamma, (float)(bt % P));
-      float a = 0.f;
-      for (int e = tid & 15; e < E; e += 16) a += sl1(out[bt * C + 2 + e] - tvis[bt * E + e]);
-      s_dense += w * a;
+    // flat over the (b, t, e) elements, eight loads of each operand in flight per thread (this single workgroup sits
+    // between the forward and the backward pass: a dependent load per row pass cost 15 us here)
+    const int total = B * P * E;
+    for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+      float o[8], tv[8];
+      int bt[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = min(i0 + 256 * j, total - 1);
+        bt[j] = i / E;
+        o[j] = out[(long)bt[j] * C + 2 + (i - bt[j] * E)];
+        tv[j] = tvis[i];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (i0 + 256 * j < total) {
+          const int t = bt[j] % P;
+          s_dense += (staged ? disc[t] : powf(gamma, (float)t)) * sl1(o[j] - tv[j]);
+        }
+      }
     }
   }
   const float traj = block_sum(s_traj, red) / (float)(B * P * 2);
@@ -706,9 +745,25 @@ __global__ __launch_bounds__(256) void traj_head_bwd_kernel(const float* __restr
   }
   if (tvis) {
     const float k = g * w / (float)((long)B * P * E);
-    for (long bt = tid >> 4; bt < (long)B * P; bt += 16) {
-      const float kw = k * (staged ? disc[(int)(bt % P)] : powf(gamma, (float)(bt % P)));
-      for (int e = tid & 15; e < E; e += 16) dout[bt * C + 2 + e] = kw * sl1g(out[bt * C + 2 + e] - tvis[bt * E + e]);
+    const int total = B * P * E;
+    for (int i0 = tid; i0 < total; i0 += 256 * 8) {  // (see the forward kernel)
+      float o[8], tv[8];
+      int bt[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = min(i0 + 256 * j, total - 1);
+        bt[j] = i / E;
+        o[j] = out[(long)bt[j] * C + 2 + (i - bt[j] * E)];
+        tv[j] = tvis[i];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + 256 * j;
+        if (i < total) {
+          const int t = bt[j] % P;
+          dout[(long)bt[j] * C + 2 + (i - bt[j] * E)] = k * (staged ? disc[t] : powf(gamma, (float)t)) * sl1g(o[j] - tv[j]);
+        }
+      }
     }
   }
 }
@@ -778,11 +833,17 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(AsmP p) {
   const int s = blockIdx.x, c = threadIdx.x & 63, rl = threadIdx.x >> 6;
   if (!p.demb[s]) return;
   float a = 0.f;
-  if (c < p.E)
-    for (int r = rl; r < p.B * p.T; r += 4) {
-      const int b = r / p.T, t = r - b * p.T;
-      a += p.dout[(((long)b * p.S + s) * p.T + t) * p.E + c];
+  const int BT = p.B * p.T, cc = min(c, p.E - 1);
+  for (int r0 = rl; r0 < BT; r0 += 32) {  // eight rows in flight per thread
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = min(r0 + 4 * j, BT - 1), b = r / p.T, t = r - b * p.T;
+      v[j] = p.dout[(((long)b * p.S + s) * p.T + t) * p.E + cc];
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a += (r0 + 4 * j < BT) ? v[j] : 0.f;
+  }
   red[rl][c] = a;
   __syncthreads();
   if (rl == 0 && c < p.E) p.demb[s][c] += red[0][c] + red[1][c] + red[2][c] + red[3][c];

@@ -23,7 +23,7 @@ from routeformer_amd.losses import FutureDiscountedLoss
 from routeformer_amd.score import ade, fde
 
 
-WGRAD_SIDE = os.environ.get("RF_WGRAD_SIDE", "0") == "1"  # weight-gradient groups that fill up mid-backward on a side stream
+WGRAD_SIDE = os.environ.get("RF_WGRAD_SIDE", "1") == "1"  # weight-gradient groups that fill up mid-backward on a side stream
 
 
 def _capture_kw() -> dict:

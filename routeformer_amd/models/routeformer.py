@@ -414,6 +414,8 @@ class Routeformer(nn.Module):
             idx_dev = self._device_index(idx, dev)
             # zero-fill + scatter for all member streams in one launch (per-stream timelines are views of it)
             timelines = K.timeline(emb.reshape(len(members) * B, -1, E), idx_dev, T).view(len(members), B, T, E)
-            for s_i, m in enumerate(members):
-                out.append((m[0], timelines[s_i]))
+            # (unbind, not indexing: its backward is ONE stack of the member gradients instead of a zero-fill + copy per member
+            # and their sums)
+            for m, tl in zip(members, timelines.unbind(0)):
+                out.append((m[0], tl))
         return out
