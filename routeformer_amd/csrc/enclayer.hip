@@ -470,6 +470,13 @@ size_t tile_lds_bytes(int F) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// 16-row tiles while they are what fills the chip (the launch is latency-bound: a workgroup's time is its weight stream
+// and its dependent phases, not its MFMA count)
+inline int tile16_max_rows() {
+  static const int v = [] { const char* e = getenv("RF_ENC_TILE16_ROWS"); return e ? atoi(e) : 2048; }();
+  return v;
+}
+
 }  // namespace
 
 extern "C" int rf_enclayer_tile_supported(int d_model, int n_heads, int d_ff) {
@@ -506,7 +513,9 @@ extern "C" int rf_enclayer_tile_fwd(const float* ctx, const float* x, const void
     }                                                                                                                 \
     RF_LAUNCH((enc_tile_fwd_kernel<RT_, SAVE_>), dim3((M + 16 * RT_ - 1) / (16 * RT_)), dim3(SL_NT), lds, st, p);     \
   } while (0)
-  if (M <= 4096) {
+  if (M <= tile16_max_rows()) {
+    if (sv) RF_ET_GO(1, true); else RF_ET_GO(1, false);
+  } else if (M <= 4096) {
     if (sv) RF_ET_GO(2, true); else RF_ET_GO(2, false);
   } else {
     if (sv) RF_ET_GO(3, true); else RF_ET_GO(3, false);
@@ -547,7 +556,8 @@ extern "C" int rf_enclayer_tile_bwd(const float* dy, const float* dqkv, const fl
     }                                                                                                                \
     RF_LAUNCH((enc_tile_bwd_kernel<RT_>), dim3((M + 16 * RT_ - 1) / (16 * RT_)), dim3(SL_NT), tile_bwd_lds_bytes<RT_>(d_ff), st, p); \
   } while (0)
-  if (M <= 4096) RF_ETB_GO(2);
+  if (M <= tile16_max_rows()) RF_ETB_GO(1);
+  else if (M <= 4096) RF_ETB_GO(2);
   else RF_ETB_GO(3);
 #undef RF_ETB_GO
   RF_CHECK_LAUNCH();

@@ -858,14 +858,19 @@ class GraphedTrainEngine(TrainEngine):
                 if b > a:
                     opt.launch_update_dev(a, b, self._hyper)
                     r.flat_grad[a:b].zero_()
+            # the encoders' slots are final: pack their bf16 fragments BEFORE the streaming update is let loose (next to it
+            # the 16-us pack kernel ran for as long as the update did -- kernel trace, profiles/r03/overlap_experiments.txt)
+            self._repack_fused()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                opt.launch_update_dev(lo, hi, self._hyper, int(__import__("os").environ.get("RF_ADAMW_SIDE_BLOCKS", "0")))
+                opt.launch_update_dev(lo, hi, self._hyper)
                 r.flat_grad[lo:hi].zero_()
             self.model.__dict__["_before_gps_backbone"] = lambda: torch.cuda.current_stream().wait_stream(side)
-        else:
-            opt.launch_update_dev(0, n, self._hyper)
-            r.flat_grad.zero_()
+            r.begin_step()
+            K.WGRAD.begin_step()
+            return
+        opt.launch_update_dev(0, n, self._hyper)
+        r.flat_grad.zero_()
         r.begin_step()
         K.WGRAD.begin_step()
         self._repack_fused()  # after the (deferred) update of the encoders' slots, on this stream
