@@ -457,7 +457,13 @@ def main():
                     path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
                     if os.path.exists(path):
                         with open(path) as fh:
-                            traffic = json.load(fh)["kernels"].get(name, {}).get("hbm_bytes_per_launch")
+                            kern = json.load(fh)["kernels"]
+                        traffic = kern.get(name, {}).get("hbm_bytes_per_launch")
+                        if traffic is None and name == "adamw_clip_kernel<true>" and "adamw_clip_kernel<false>" in kern:
+                            # the PMC passes run the eager engine, whose update is ONE launch of the by-value variant over
+                            # the whole buffer; the replayed step covers the same buffer with `launches` slices of the
+                            # device-scalar variant (same loop body): per launch = the whole-buffer figure / launches
+                            traffic = kern["adamw_clip_kernel<false>"]["hbm_bytes_per_launch"] / launches
                         if traffic is not None:
                             traffic_src = f"profiles/{rnd}/pmc_traffic.json"
                             break
