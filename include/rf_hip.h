@@ -210,8 +210,10 @@ int rf_bn_train_elu_pool_fwd(const float* x, const float* gamma, const float* be
  * instead of fp32 atomics (most of the bytes of a backward pass: the large weights have shallow reductions). */
 #define RF_WGRAD_MAX_GROUP 48
 typedef struct RfWgradEntry {
-  const float* dy; const float* x; float* dw; float* db;
+  const void* dy; const void* x; float* dw; float* db;
   int M, N, K, ld_dy, ld_x, splits, kchunk, exclusive;
+  int dy_bf16, x_bf16; /* both != 0: the operands lie in memory as bf16 (rf_wgrad_tr only; ld in elements; both or neither).
+                          The fused encoder stacks write their dy slabs / activation saves that way. */
 } RfWgradEntry;
 int rf_wgrad_grouped(const RfWgradEntry* entries, int count, int prec, void* stream);
 /* The bf16 matrix-core path of rf_wgrad_grouped (prec = 1 routes here; RF_WGRAD_TR=0 in the environment keeps the tiled
@@ -330,7 +332,11 @@ typedef struct RfSeqStack {
   int32_t* top;
   float* y;
   float *qkv, *ctx, *xhat1, *rstd1, *x1, *z, *h, *xhat2, *rstd2;
-  int n_layers, pad;
+  void* xin; /* optional (save != 0): bf16 [layers, B*L, 128], the INPUT of every layer as the projection consumes it (layer
+                0: x, layer i: y[i - 1], rounded to bf16) -- the `x` operand of the packed projection's weight gradient */
+  int n_layers;
+  int flags; /* bit 0: ctx, x1 and (when z is given) h are bf16 slabs -- they are bf16-rounded MFMA operands in the kernel
+                anyway, and only the weight-gradient GEMMs (RfWgradEntry.x_bf16) read them again */
 } RfSeqStack;
 typedef struct RfSeqPackEntry {
   const float* w; void* out; int64_t ldw; int N, K, transpose;
@@ -376,7 +382,8 @@ typedef struct RfSeqStackBwd {
   float *dpre2, *dz, *dpre1, *dqkv;
   float* dgamma1[RF_SEQLAYER_MAX_LAYERS]; float* dbeta1[RF_SEQLAYER_MAX_LAYERS];
   float* dgamma2[RF_SEQLAYER_MAX_LAYERS]; float* dbeta2[RF_SEQLAYER_MAX_LAYERS];
-  int n_layers, pad;
+  int n_layers;
+  int flags; /* bit 0: dpre2 / dz / dpre1 / dqkv are bf16 slabs (RfWgradEntry.dy_bf16 for the weight-gradient GEMMs) */
 } RfSeqStackBwd;
 int64_t rf_seqlayer_bwd_pack_bytes(int d_ff);
 int rf_seqlayer_bwd(const RfSeqStackBwd* stack, const float* dy, float* dx, int B, int L, int d_model, int n_heads,

@@ -123,7 +123,7 @@ class WgradEntry(ctypes.Structure):
     """RfWgradEntry of include/rf_hip.h."""
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("db", c_void_p), ("M", c_int), ("N", c_int),
                 ("K", c_int), ("ld_dy", c_int), ("ld_x", c_int), ("splits", c_int), ("kchunk", c_int),
-                ("exclusive", c_int)]
+                ("exclusive", c_int), ("dy_bf16", c_int), ("x_bf16", c_int)]
 
 
 class ConvEntry(ctypes.Structure):
@@ -139,8 +139,8 @@ class SeqStack(ctypes.Structure):
     """RfSeqStack of include/rf_hip.h."""
     _fields_ = ([("wpack", c_void_p), ("wpack_stride", c_int64), ("idx", c_void_p * SEQLAYER_MAX_LAYERS),
                  ("idx_stride", c_int64), ("top", c_void_p), ("y", c_void_p)]
-                + [(n, c_void_p) for n in ("qkv", "ctx", "xhat1", "rstd1", "x1", "z", "h", "xhat2", "rstd2")]
-                + [("n_layers", c_int), ("pad", c_int)])
+                + [(n, c_void_p) for n in ("qkv", "ctx", "xhat1", "rstd1", "x1", "z", "h", "xhat2", "rstd2", "xin")]
+                + [("n_layers", c_int), ("flags", c_int)])
 
 
 class SeqStackBwd(ctypes.Structure):
@@ -149,7 +149,7 @@ class SeqStackBwd(ctypes.Structure):
                 + [(n, c_void_p) for n in ("qkv", "xhat1", "rstd1", "zsrc", "xhat2", "rstd2", "top", "dpre2", "dz", "dpre1",
                                            "dqkv")]
                 + [(n, c_void_p * SEQLAYER_MAX_LAYERS) for n in ("dgamma1", "dbeta1", "dgamma2", "dbeta2")]
-                + [("n_layers", c_int), ("pad", c_int)])
+                + [("n_layers", c_int), ("flags", c_int)])
 
 
 GATHER_MAX = 8  # RF_GATHER_MAX

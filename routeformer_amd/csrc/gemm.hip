@@ -921,8 +921,8 @@ __global__ __launch_bounds__(NT) void wgrad_grouped_kernel(const WgradTable t) {
   }
   const RfWgradEntry& e = t.e[lo];
   GemmP p{};
-  p.A = e.dy; p.lda_m = 1; p.lda_k = e.ld_dy;     // A = dY^T: "row" m = output feature, contiguous across m
-  p.B = e.x; p.ldb_k = e.ld_x; p.ldb_n = 1;
+  p.A = static_cast<const float*>(e.dy); p.lda_m = 1; p.lda_k = e.ld_dy;     // A = dY^T: "row" m = output feature, contiguous across m
+  p.B = static_cast<const float*>(e.x); p.ldb_k = e.ld_x; p.ldb_n = 1;
   p.C = e.dw; p.ldc = e.K;
   p.M = e.N; p.N = e.K; p.K = e.M;
   p.res_rows = 1; p.atomic = (e.exclusive && e.splits == 1) ? 2 : 1; p.a_rowsum = e.db;
@@ -1146,6 +1146,7 @@ extern "C" int rf_wgrad_grouped(const RfWgradEntry* entries, int count, int prec
     RfWgradEntry e = entries[i];
     RF_REQUIRE(e.dy && e.x && e.dw && e.M > 0 && e.N > 0 && e.K > 0 && e.splits >= 1);
     RF_REQUIRE(aligned16(e.dy) && aligned16(e.x) && e.ld_dy % 4 == 0 && e.ld_x % 4 == 0 && e.N % 4 == 0 && e.K % 4 == 0);
+    RF_REQUIRE(!e.dy_bf16 && !e.x_bf16);  // bf16 operands: the transposed-read kernel only
     const int ktiles = (e.M + KQ - 1) / KQ;
     int splits = e.splits > ktiles ? ktiles : e.splits;
     e.kchunk = ((ktiles + splits - 1) / splits) * KQ;

@@ -36,6 +36,8 @@ struct SeqStackP {
   int32_t* top;                 // (layers, B, 8, n_top): written (read when force_top); may be null without save
   float* y;                     // (layers, B*L, 128): layer outputs
   float *qkv, *ctx, *xhat1, *rstd1, *x1, *z, *h, *xhat2, *rstd2;  // training saves (layers, B*L, width)
+  int bf16_saves;  // ctx, x1 and (with z) h are bf16 slabs (RfSeqStack.flags & 1)
+  __bf16* xin;     // optional bf16 (layers, B*L, 128): every layer's input image
   int B, L, F, n_layers, act, sample_k, n_top, idx_group, force_top, save;
   int split;  // 1: q / k projection and sparsity-measure scores in split-bf16 (default); 0: plain bf16 (RF_SEQ_SPLIT=0, A/B only)
   float scale, eps;
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
     SL_MARK(1);
 
     SL_LOCAL();
+    if (SAVE && p.xin) save_image_bf16(xb, SL_XP, SL_D, p.xin + lrow * SL_D, L, tid);
     // ================= phase 1: q | k | v of head `wave` =================
     // q and k feed the ProbSparse sparsity measure, whose top-u ranking is DISCONTINUOUS: a bf16-level rounding of the
     // projection or of q / k flips selections that the fp32 reference makes the other way (SURVEY section 7 "ProbSparse
@@ -483,14 +486,8 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
           for (int r = 0; r < 4; ++r) v[rt][r] = acc[r] + bo + xres[rt][r];
         }
       }
-      if (SAVE) {  // the context as the out-projection (and its weight gradient) consumes it: the bf16 image, widened
-        float* ctx_g = p.ctx + lrow * SL_D;
-        for (int i = tid; i < L * (SL_D / 4); i += SL_NT) {
-          const int row = i >> 5, c4 = (i & 31) * 4;
-          const bf16x4 c = *reinterpret_cast<const bf16x4*>(xb + row * SL_XP + c4);
-          *reinterpret_cast<float4*>(ctx_g + row * SL_D + c4) = make_float4((float)c[0], (float)c[1], (float)c[2], (float)c[3]);
-        }
-      }
+      if (SAVE)  // the context as the out-projection (and its weight gradient) consumes it: the bf16 image (widened, or as it is)
+        save_image_as(xb, SL_XP, SL_D, p.ctx, lrow * SL_D, L, tid, p.bf16_saves != 0);
       stack_layer_norm<RT>(v, SAVE ? p.rstd1 + lrow : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the ctx reads)
       if (SAVE) {  // x-hat of norm1: RT staged tiles, one sync pair
         float* xh_g = p.xhat1 + lrow * SL_D + wave * 16;
@@ -513,7 +510,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
           xres[rt][r] = y1;
           xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)y1;
         }
-      if (SAVE) {
+      if (SAVE && !p.bf16_saves) {  // (bf16 saves: the x1 IMAGE is copied out once it is complete, below)
         float* x1_g = p.x1 + lrow * SL_D + wave * 16;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -532,10 +529,12 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
     SL_MARK(10);
 
     SL_LOCAL();
+    if (SAVE && p.bf16_saves) save_image_bf16(xb, SL_XP, SL_D, reinterpret_cast<__bf16*>(p.x1) + lrow * SL_D, L, tid);
     // ================= phase 4: conv1 + activation (wave = column tiles wave, wave + 8) =================
+    const bool h_img = SAVE && p.bf16_saves && p.z;  // h leaves as the bf16 image it is for conv2 (z stays fp32: GELU' reads it)
     {
       float* z_g = (SAVE && p.z) ? p.z + lrow * F : nullptr;
-      float* h_g = SAVE ? p.h + lrow * F : nullptr;
+      float* h_g = (SAVE && !h_img) ? p.h + lrow * F : nullptr;
 #pragma unroll 1
       for (int ct = wave; ct < F / 16; ct += SL_NW) {
         bf16x8 wf1[4];
@@ -578,7 +577,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) hb[(rt * 16 + fq * 4 + r) * HP + col] = (__bf16)hh[rt][r];
-        if (h_g) {
+        if (h_g || z_g) {
 #pragma unroll
           for (int which = 0; which < 2; ++which) {
             float* dst = which == 0 ? z_g : h_g;
@@ -603,6 +602,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
     SL_MARK(12);
 
     SL_LOCAL();
+    if (h_img) save_image_bf16(hb, HP, F, reinterpret_cast<__bf16*>(p.h) + lrow * F, L, tid);
     // ================= phase 5: conv2 + residual + LayerNorm 2 =================
     {
       const int col = wave * 16 + fr;
@@ -814,7 +814,9 @@ extern "C" int rf_seqlayer_fwd(const RfSeqStack* st_, const float* x, int B, int
   p.idx_stride = s.idx_stride > 0 ? s.idx_stride : (long)L * sample_k;
   p.top = s.top; p.y = s.y;
   p.qkv = s.qkv; p.ctx = s.ctx; p.xhat1 = s.xhat1; p.rstd1 = s.rstd1; p.x1 = s.x1; p.z = s.z; p.h = s.h;
-  p.xhat2 = s.xhat2; p.rstd2 = s.rstd2;
+  p.xhat2 = s.xhat2; p.rstd2 = s.rstd2; p.bf16_saves = (save && (s.flags & 1)) ? 1 : 0;
+  p.xin = save ? static_cast<__bf16*>(s.xin) : nullptr;
+  RF_REQUIRE(!p.xin || al16(p.xin));
   p.B = B; p.L = L; p.F = d_ff; p.n_layers = s.n_layers; p.act = act; p.sample_k = sample_k; p.n_top = n_top;
   p.idx_group = (idx_group <= 0 || idx_group > B) ? B : idx_group;
   p.force_top = force_top; p.save = save; p.scale = scale; p.eps = eps;

@@ -36,6 +36,7 @@ struct SeqStackBwdP {
   float* dg2[RF_SEQLAYER_MAX_LAYERS];
   float* db2[RF_SEQLAYER_MAX_LAYERS];
   int B, L, F, n_layers, act, n_top;
+  int bf16_grads;  // dpre2 / dz / dpre1 / dqkv are bf16 slabs (RfSeqStackBwd.flags & 1)
   float scale;
   DropCfg drop;   // the forward's nn.Dropout masks are regenerated from (seed, step, site, element); state == null: off
   int drop_site0; // layer i: sites drop_site0 + 3 i + {0: attention output, 1: hidden activation, 2: conv2 output}
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
     SLB_MARK(1);
     __syncthreads();  // d pre-norm-2 image complete
     SLB_MARK(2);
-    save_image(xb, SL_XP, SL_D, p.dpre2 + lrow * SL_D, L, tid);
+    save_image_as(xb, SL_XP, SL_D, p.dpre2, lrow * SL_D, L, tid, p.bf16_grads);
 
     // ================= conv2^T + activation' : dz (wave = column tiles wave, wave + 8, ...) =================
     SLB_LOCAL();
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
     SLB_MARK(3);
     __syncthreads();  // dz image complete
     SLB_MARK(4);
-    save_image(hb, HP, F, p.dz + lrow * F, L, tid);
+    save_image_as(hb, HP, F, p.dz, lrow * F, L, tid, p.bf16_grads);
 
     // ================= conv1^T + skip, norm1 backward =================
     SLB_LOCAL();
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
     SLB_MARK(5);
     __syncthreads();  // d pre-norm-1 image complete
     SLB_MARK(6);
-    save_image(xb, SL_XP, SL_D, p.dpre1 + lrow * SL_D, L, tid);
+    save_image_as(xb, SL_XP, SL_D, p.dpre1, lrow * SL_D, L, tid, p.bf16_grads);
 
     // ================= out-projection^T: dC of head `wave` =================
     SLB_LOCAL();
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
     SLB_MARK(13);
     __syncthreads();  // d q|k|v image complete
     SLB_MARK(14);
-    save_image(dqi, QP, 3 * SL_D, p.dqkv + lrow * (3 * SL_D), L, tid);
+    save_image_as(dqi, QP, 3 * SL_D, p.dqkv, lrow * (3 * SL_D), L, tid, p.bf16_grads);
 
     // ================= packed q|k|v projection^T + skip =================
     SLB_LOCAL();
@@ -565,6 +566,7 @@ extern "C" int rf_seqlayer_bwd(const RfSeqStackBwd* st_, const float* dy, float*
     p.dg1[i] = s.dgamma1[i]; p.db1[i] = s.dbeta1[i]; p.dg2[i] = s.dgamma2[i]; p.db2[i] = s.dbeta2[i];
   }
   p.B = B; p.L = L; p.F = d_ff; p.n_layers = s.n_layers; p.act = act; p.n_top = n_top; p.scale = scale;
+  p.bf16_grads = s.flags & 1;
   RF_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state));
   p.drop = make_drop_cfg(rng_state, nullptr, 0, drop_p);
   p.drop_site0 = drop_site0;

@@ -244,5 +244,20 @@ __device__ __forceinline__ void save_image(const __bf16* __restrict__ img, int p
   }
 }
 
+// the same rows kept as bf16 (16-B copies; cols % 8 == 0, 16-B aligned rows on both sides)
+__device__ __forceinline__ void save_image_bf16(const __bf16* __restrict__ img, int pitch, int cols, __bf16* __restrict__ dst, int L,
+                                                int tid) {
+  const int c8n = cols >> 3;
+  for (int i = tid; i < L * c8n; i += SL_NT) {
+    const int row = i / c8n, c8 = (i - row * c8n) * 8;
+    *reinterpret_cast<uint4*>(dst + (long)row * cols + c8) = *reinterpret_cast<const uint4*>(img + row * pitch + c8);
+  }
+}
+// dst is [rows][cols] fp32 or (as_bf16) bf16, `off` its element offset
+__device__ __forceinline__ void save_image_as(const __bf16* __restrict__ img, int pitch, int cols, float* __restrict__ dst, long off,
+                                              int L, int tid, bool as_bf16) {
+  if (as_bf16) save_image_bf16(img, pitch, cols, reinterpret_cast<__bf16*>(dst) + off, L, tid);
+  else save_image(img, pitch, cols, dst + off, L, tid);
+}
 
 }  // namespace

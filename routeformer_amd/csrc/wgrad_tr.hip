@@ -64,17 +64,38 @@ __device__ unsigned long long rf_wt_timing[64 * 8 * 8];
 #define WT_MARK(k) do {} while (0)
 #endif
 
-struct Staged { float4 y[4], x[2]; };  // one thread's share of a 32-row step: dY 32 x 256, X 32 x 128
+// one thread's share of a 32-row step: dY 32 x 256 (4 x 4 columns), X 32 x 128 (2 x 4 columns); an operand that already
+// lies in memory as bf16 (YBF / XBF: the fused encoder stacks write their `dy` slabs and activation saves that way -- the
+// values were bf16-rounded MFMA operands all along) travels as 8-B groups and reaches LDS without a conversion
+template <bool BF> struct Quad;
+template <> struct Quad<false> { typedef float4 T; };
+template <> struct Quad<true> { typedef uint2 T; };
+__device__ __forceinline__ float4 quad_f32(const float4& v) { return v; }
+__device__ __forceinline__ float4 quad_f32(const uint2& v) {
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ bf16x4 quad_bf16(const float4& v) { return bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w}; }
+__device__ __forceinline__ bf16x4 quad_bf16(const uint2& v) {
+  union { uint2 u; bf16x4 b; } c;
+  c.u = v;
+  return c.b;
+}
+__device__ __forceinline__ void quad_zero(float4& v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void quad_zero(uint2& v) { v = make_uint2(0u, 0u); }
 
-__global__ __launch_bounds__(WT_NT) void wgrad_tr_kernel(const TrTable t) {
-  // buffers: [2 stages][dY half 0 | dY half 1 | X] images of 8 KB each; then the bias reduction scratch
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 3 * WT_HALF + 8 * 256 * 4];
+template <bool YBF, bool XBF>
+struct Staged { typename Quad<YBF>::T y[4]; typename Quad<XBF>::T x[2]; };
+
+// The block of one (problem, chunk, tile): instantiated per operand-type combination; the kernel below picks the
+// instantiation with ONE workgroup-uniform branch at its top (straight-line code inside: the compiler keeps counting the
+// outstanding loads of the ring), so fp32-operand and bf16-operand problems share a launch.
+template <bool YBF, bool XBF>
+__device__ __forceinline__ void wgrad_tr_block(const TrTable& t, const int lo, unsigned char* lds) {
+  typedef typename Quad<YBF>::T YQ;
+  typedef typename Quad<XBF>::T XQ;
+  typedef Staged<YBF, XBF> StagedT;
   const int b = blockIdx.x;
-  int lo = 0, hi = t.count - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (t.first_block[mid] <= b) lo = mid; else hi = mid - 1;
-  }
   const RfWgradEntry& e = t.e[lo];
   const int M = e.M, N = e.N, K = e.K;
   const int gn = (N + WT_BN - 1) / WT_BN, gk = (K + WT_BK - 1) / WT_BK;
@@ -92,48 +113,50 @@ __global__ __launch_bounds__(WT_NT) void wgrad_tr_kernel(const TrTable t) {
   const int yc4 = tid & 63, yr = tid >> 6;         // float4 column, first row (rows yr + 8 u)
   const int xc4 = tid & 31, xr = tid >> 5;         // rows xr + 16 u
   const bool ycol_ok = n0 + 4 * yc4 < N, xcol_ok = k0 + 4 * xc4 < K;
-  const float* yg = e.dy + (ycol_ok ? n0 + 4 * yc4 : 0);  // (columns beyond N / K: a valid address, the value is dropped)
-  const float* xg = e.x + (xcol_ok ? k0 + 4 * xc4 : 0);
-  const long ldy = e.ld_dy, ldx = e.ld_x;
+  // (columns beyond N / K: a valid address, the value is dropped); pointers / pitches in units of 4-column groups' bytes
+  const unsigned char* yg = reinterpret_cast<const unsigned char*>(e.dy) + (long)(ycol_ok ? n0 + 4 * yc4 : 0) * (YBF ? 2 : 4);
+  const unsigned char* xg = reinterpret_cast<const unsigned char*>(e.x) + (long)(xcol_ok ? k0 + 4 * xc4 : 0) * (XBF ? 2 : 4);
+  const long ldy = (long)e.ld_dy * (YBF ? 2 : 4), ldx = (long)e.ld_x * (XBF ? 2 : 4);
   // LDS store offsets (row-dependent part added per u): chunk = column / 8, 8-byte half = (column / 4) & 1
   const int y_half = (yc4 >> 5), y_ch = (yc4 & 31) >> 1, y_hb = 8 * (yc4 & 1);
   const int x_ch = xc4 >> 1, x_hb = 8 * (xc4 & 1);
 
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 bsum = zero4;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool bias = e.db != nullptr && bk == 0;
 
   // UNCONDITIONAL loads at clamped addresses, zeroed by a select afterwards: a predicated load is a branch, and behind
   // control flow the compiler can no longer count outstanding loads -- every use then waits with vmcnt(0), i.e. for
   // the loads issued a moment ago as well, and the ring hides nothing (measured: 1.5 us per step either way).
-  auto gload = [&](Staged& r, int step) {
+  YQ zero_y; quad_zero(zero_y);
+  XQ zero_x; quad_zero(zero_x);
+  auto gload = [&](StagedT& r, int step) {
     const int m0 = m_lo + step * WT_MS;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int m = m0 + yr + 8 * u;
-      const float4 v = *reinterpret_cast<const float4*>(yg + (long)min(m, m_hi - 1) * ldy);
-      r.y[u] = (ycol_ok && m < m_hi) ? v : zero4;
+      const YQ v = *reinterpret_cast<const YQ*>(yg + (long)min(m, m_hi - 1) * ldy);
+      r.y[u] = (ycol_ok && m < m_hi) ? v : zero_y;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int m = m0 + xr + 16 * u;
-      const float4 v = *reinterpret_cast<const float4*>(xg + (long)min(m, m_hi - 1) * ldx);
-      r.x[u] = (xcol_ok && m < m_hi) ? v : zero4;
+      const XQ v = *reinterpret_cast<const XQ*>(xg + (long)min(m, m_hi - 1) * ldx);
+      r.x[u] = (xcol_ok && m < m_hi) ? v : zero_x;
     }
   };
-  auto lstore = [&](const Staged& r, int stage) {
+  auto lstore = [&](const StagedT& r, int stage) {
     unsigned char* base = lds + stage * 3 * WT_HALF;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const bf16x4 o = {(__bf16)r.y[u].x, (__bf16)r.y[u].y, (__bf16)r.y[u].z, (__bf16)r.y[u].w};
-      *reinterpret_cast<bf16x4*>(base + y_half * WT_HALF + img_off(yr + 8 * u, y_ch) + y_hb) = o;
-      if (bias) { bsum.x += r.y[u].x; bsum.y += r.y[u].y; bsum.z += r.y[u].z; bsum.w += r.y[u].w; }
+      *reinterpret_cast<bf16x4*>(base + y_half * WT_HALF + img_off(yr + 8 * u, y_ch) + y_hb) = quad_bf16(r.y[u]);
+      if (bias) {
+        const float4 f = quad_f32(r.y[u]);
+        bsum.x += f.x; bsum.y += f.y; bsum.z += f.z; bsum.w += f.w;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const bf16x4 o = {(__bf16)r.x[u].x, (__bf16)r.x[u].y, (__bf16)r.x[u].z, (__bf16)r.x[u].w};
-      *reinterpret_cast<bf16x4*>(base + 2 * WT_HALF + img_off(xr + 16 * u, x_ch) + x_hb) = o;
-    }
+    for (int u = 0; u < 2; ++u)
+      *reinterpret_cast<bf16x4*>(base + 2 * WT_HALF + img_off(xr + 16 * u, x_ch) + x_hb) = quad_bf16(r.x[u]);
   };
 
   f32x4 acc[4][4];
@@ -145,7 +168,7 @@ __global__ __launch_bounds__(WT_NT) void wgrad_tr_kernel(const TrTable t) {
 
   // ring of register sets: set s % 3 holds the operands of step s from the moment they are requested (three steps
   // ahead) until they are written to LDS stage s & 1 at the bottom of step s - 1
-  Staged ring[WT_RING];
+  StagedT ring[WT_RING];
 #pragma unroll
   for (int r = 0; r < WT_RING; ++r) gload(ring[r], r);
   lstore(ring[0], 0);
@@ -244,6 +267,19 @@ __global__ __launch_bounds__(WT_NT) void wgrad_tr_kernel(const TrTable t) {
   }
 }
 
+__global__ __launch_bounds__(WT_NT) void wgrad_tr_kernel(const TrTable t) {
+  // buffers: [2 stages][dY half 0 | dY half 1 | X] images of 8 KB each; then the bias reduction scratch
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 3 * WT_HALF + 8 * 256 * 4];
+  const int b = blockIdx.x;
+  int lo = 0, hi = t.count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.first_block[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  if (t.e[lo].dy_bf16) wgrad_tr_block<true, true>(t, lo, lds);  // (rf_wgrad_tr: both operands bf16, or both fp32)
+  else wgrad_tr_block<false, false>(t, lo, lds);
+}
+
 }  // namespace
 
 #ifdef RF_WT_TIMING
@@ -265,6 +301,7 @@ extern "C" int rf_wgrad_tr(const RfWgradEntry* entries, int count, void* stream)
     RF_REQUIRE(e.dy && e.x && e.dw && e.M > 0 && e.N > 0 && e.K > 0 && e.splits >= 1);
     RF_REQUIRE((reinterpret_cast<uintptr_t>(e.dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(e.x) & 15) == 0 &&
                e.ld_dy % 4 == 0 && e.ld_x % 4 == 0 && e.N % 4 == 0 && e.K % 4 == 0);
+    RF_REQUIRE((e.dy_bf16 != 0) == (e.x_bf16 != 0));  // both operands of a problem in the same storage type
     // chunks of the reduction: at least 1 024 rows each (whole 32-row steps), never more than the caller asked for
     int chunks = (e.M + 1023) / 1024;
     if (chunks > e.splits) chunks = e.splits;

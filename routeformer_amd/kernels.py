@@ -390,6 +390,8 @@ def gemm(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, *, bias=None, residu
 def colsum(X2d: torch.Tensor, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Column sums; ``into`` = slot of the flat gradient buffer to ACCUMULATE into (returns None then)."""
     M, N = X2d.shape
+    if X2d.dtype != torch.float32:
+        X2d = X2d.float()
     out = into if into is not None else torch.empty(N, device=X2d.device, dtype=torch.float32)
     parts = _hip.lib().rf_colsum_parts(M, N)
     ws = torch.empty(parts * N, device=X2d.device, dtype=torch.float32)
@@ -412,6 +414,12 @@ def _weight_grad(dy2: torch.Tensor, x2: torch.Tensor, into: Optional[torch.Tenso
     M, N = dy2.shape
     K = x2.shape[1]
     tiles = -(-N // 64) * -(-K // 64)
+    if dy2.dtype == torch.bfloat16 or x2.dtype == torch.bfloat16:
+        # operands a fused stack kept as bf16: only the grouped transposed-read kernel takes them as they are (both or neither)
+        if not (dy2.dtype == x2.dtype and into is not None and not DETERMINISTIC and WGRAD.active and into.is_contiguous() and _PRECISION == 1
+                and os.environ.get("RF_WGRAD_TR", "1") != "0" and _vec_ok(dy2) and _vec_ok(x2)
+                and into.data_ptr() % 16 == 0 and N % 4 == 0 and K % 4 == 0):
+            dy2, x2 = dy2.float(), x2.float()
     if (into is not None and not DETERMINISTIC and _vec_ok(dy2) and _vec_ok(x2) and into.data_ptr() % 16 == 0
             and N % 4 == 0 and K % 4 == 0):
         if WGRAD.active and into.is_contiguous():
@@ -488,6 +496,7 @@ class _WgradQueue:
                 splits = max(1, min(splits, -(-M // 1024)))
             e.dy, e.x, e.dw, e.db = ptr(dy2), ptr(x2), ptr(into), ptr(bias_into)
             e.M, e.N, e.K, e.ld_dy, e.ld_x, e.splits = M, N, K, dy2.stride(0), x2.stride(0), splits
+            e.dy_bf16, e.x_bf16 = int(dy2.dtype == torch.bfloat16), int(x2.dtype == torch.bfloat16)
             e.exclusive = 1 if (uses[into.data_ptr()] == 1 and into.data_ptr() not in self.written) else 0
         self.written.update(uses)
         ev = PROFILE.begin() if PROFILE.on else None
@@ -506,8 +515,8 @@ class _WgradQueue:
                 PROFILE.end(tag, ev, sum(2.0 * i[4] * i[5] * i[6] for i in q),
                             # algorithmic bytes: both operands once, dW written once (plain exclusive stores) or read +
                             # written (atomic accumulation into a slot another launch also writes)
-                            sum(4.0 * (i[4] * i[5] + i[4] * i[6] + (1 if e_.exclusive else 2) * i[5] * i[6])
-                                for i, e_ in zip(q, arr)),
+                            sum(i[0].element_size() * i[4] * i[5] + i[1].element_size() * i[4] * i[6]
+                                + 4.0 * (1 if e_.exclusive else 2) * i[5] * i[6] for i, e_ in zip(q, arr)),
                             replay=lambda a=arr, n_=n, pr=_PRECISION, k=keep: _hip.lib().rf_wgrad_grouped(a, n_, pr, _stream()))
             for _, _, into, bias_into, *_ in q:
                 self.pending.discard(into.data_ptr())
@@ -1693,11 +1702,15 @@ def _seqstack_bwd_launch(dy2, sv, wpack, stride, ln_slots, B, L, F_, act, n_top,
     import ctypes
     n, M, dev = len(ln_slots), B * L, dy2.device
     f32 = dict(device=dev, dtype=torch.float32)
-    out = {"dpre2": torch.empty(n, M, 128, **f32), "dz": torch.empty(n, M, F_, **f32),
-           "dpre1": torch.empty(n, M, 128, **f32), "dqkv": torch.empty(n, M, 384, **f32)}
+    # the `dy` operands of the weight-gradient GEMMs: bf16-rounded values either way (they are LDS images of the kernel);
+    # kept as bf16 they cost half the bytes to write here and to read in the grouped weight-gradient launch
+    gdt = dict(device=dev, dtype=torch.bfloat16 if BF16_SAVES else torch.float32)
+    out = {"dpre2": torch.empty(n, M, 128, **gdt), "dz": torch.empty(n, M, F_, **gdt),
+           "dpre1": torch.empty(n, M, 128, **gdt), "dqkv": torch.empty(n, M, 384, **gdt)}
     dx = torch.empty(M, 128, **f32)
     st = _hip.SeqStackBwd()
     st.wpack, st.wpack_stride, st.n_layers = wpack.data_ptr(), stride, n
+    st.flags = 1 if BF16_SAVES else 0
     for name in ("qkv", "xhat1", "rstd1", "xhat2", "rstd2", "top"):
         setattr(st, name, ptr(sv[name]))
     st.zsrc = ptr(sv["z"] if "z" in sv else sv["h"])
@@ -1713,7 +1726,9 @@ def _seqstack_bwd_launch(dy2, sv, wpack, stride, ln_slots, B, L, F_, act, n_top,
     check(_hip.lib().rf_seqlayer_bwd(*args, _stream()), "rf_seqlayer_bwd")
     if ev is not None:
         flops = n * B * (2.0 * L * 128 * (384 + 128 + 2 * F_) + 8 * 10.0 * n_top * L * 16)
-        nbytes = 4.0 * M * 128 * 2 + n * (2.0 * (4 * 128 * 128 + 2 * 128 * F_) + 4.0 * M * (384 * 2 + 128 * 4 + 2 * F_ + 2))
+        gb = 2.0 if BF16_SAVES else 4.0  # bytes per element of the four gradient slabs (384 + 128 + 128 + F_ wide)
+        nbytes = (4.0 * M * 128 * 2 + n * (2.0 * (4 * 128 * 128 + 2 * 128 * F_) + 4.0 * M * (384 + 128 * 2 + F_ + 2)
+                                           + gb * M * (384 + 128 * 2 + F_)))
         keep = (dy2, dx, sv, out, wpack, st, ln_slots)
         PROFILE.end(f"seq_stack_bwd_kernel<{3 if L <= 48 else 5}, {'true' if drop_p > 0 else 'false'}>", ev, flops, nbytes,
                     replay=lambda a=args, k=keep: _hip.lib().rf_seqlayer_bwd(*a, _stream()))
@@ -1722,6 +1737,13 @@ def _seqstack_bwd_launch(dy2, sv, wpack, stride, ln_slots, B, L, F_, act, n_top,
 
 def seqstack_pack_bytes(d_ff: int) -> int:
     return int(_hip.lib().rf_seqlayer_pack_bytes(d_ff))
+
+
+# bf16 storage for what only the weight-gradient GEMMs read again (fused per-sequence stacks, bf16 mode): ctx / x1 / h of
+# the forward and the four `dy` slabs of the backward.  Lossless with respect to the arithmetic (they are bf16 MFMA operands
+# in those GEMMs, rounded the same way) and half the bytes: 601 -> 447 MB written by the camera-token stack's forward,
+# 732 -> 550 MB moved by its backward, 613 -> 330 MB read by its weight-gradient group.
+BF16_SAVES = os.environ.get("RF_BF16_SAVES", "1") != "0"
 
 
 def _seqstack_launch(x2, wpack, stride, idx_list, idx_group, B, L, F_, act, sample_k, n_top, save, forced_tops, eps,
@@ -1736,15 +1758,23 @@ def _seqstack_launch(x2, wpack, stride, idx_list, idx_group, B, L, F_, act, samp
     if save or force:
         sv["top"] = (torch.stack([t.to(device=dev, dtype=torch.int32) for t in forced_tops]).contiguous() if force
                      else torch.empty(n, B, 8, n_top, device=dev, dtype=torch.int32))
+    half = save and BF16_SAVES
     if save:
+        # ctx, x1 and (GELU: z is there for the activation gradient) h are read again by the weight-gradient GEMMs only,
+        # as bf16 MFMA operands -- BF16_SAVES keeps them as the bf16 images the kernel holds anyway
+        bf = dict(device=dev, dtype=torch.bfloat16)
         for name, width in (("qkv", 384), ("ctx", 128), ("xhat1", 128), ("x1", 128), ("xhat2", 128), ("h", F_)):
-            sv[name] = torch.empty(n, M, width, **f32)
+            as_bf = half and (name in ("ctx", "x1") or (name == "h" and act == "gelu"))
+            sv[name] = torch.empty(n, M, width, **(bf if as_bf else f32))
         if act == "gelu":
             sv["z"] = torch.empty(n, M, F_, **f32)
+        if half:  # every layer's input as the projection consumed it: the x operand of its weight gradient
+            sv["xin"] = torch.empty(n, M, 128, **bf)
         sv["rstd1"] = torch.empty(n, M, **f32)
         sv["rstd2"] = torch.empty(n, M, **f32)
     st = _hip.SeqStack()
     st.wpack, st.wpack_stride, st.n_layers = wpack.data_ptr(), stride, n
+    st.flags = 1 if half else 0
     idx_stride = 0
     for i, t in enumerate(idx_list):
         assert t.dim() == 3 and t.dtype == torch.int32 and t.stride(2) == 1 and t.stride(1) == t.shape[2], "key-sample table"
@@ -1753,7 +1783,7 @@ def _seqstack_launch(x2, wpack, stride, idx_list, idx_group, B, L, F_, act, samp
         assert i == 0 or s_ == idx_stride, "the layers' key-sample tables must share one group stride"
         idx_stride = s_
     st.idx_stride = idx_stride
-    for name in ("top", "y", "qkv", "ctx", "xhat1", "rstd1", "x1", "z", "h", "xhat2", "rstd2"):
+    for name in ("top", "y", "qkv", "ctx", "xhat1", "rstd1", "x1", "z", "h", "xhat2", "rstd2", "xin"):
         setattr(st, name, ptr(sv.get(name)))
     ev = PROFILE.begin() if PROFILE.on else None
     args = (ctypes.byref(st), ptr(x2), B, L, 128, 8, F_, ACT[act], sample_k, n_top, idx_group, 1 if force else 0,
@@ -1831,7 +1861,8 @@ class _SeqStack(torch.autograd.Function):
                         (g["dpre2"][li], sv["h"][li], _slot(lay.conv2.weight).view(D, F_), _slot(lay.conv2.bias)),
                         (g["dz"][li], sv["x1"][li], _slot(lay.conv1.weight).view(F_, D), _slot(lay.conv1.bias)),
                         (g["dpre1"][li], sv["ctx"][li], _slot(att.out_projection.weight), _slot(att.out_projection.bias)),
-                        (g["dqkv"][li], x2 if li == 0 else sv["y"][li - 1], pk["gw"], pk["gb"])):
+                        (g["dqkv"][li], sv["xin"][li] if "xin" in sv else (x2 if li == 0 else sv["y"][li - 1]), pk["gw"],
+                         pk["gb"])):
                     if _weight_grad(gy, xin, into=w_into, bias_into=b_into) is not True:
                         colsum(gy, into=b_into)
                     _wrote(w_into, b_into)
@@ -1846,6 +1877,8 @@ def _stack_backward_layerwise(sv, stack, x2, dy2, B, L, F_, n_top, drop_p, site0
     """Backward of a stack of ProbSparse encoder layers on the tensors its fused / row-tiled forward saved, layer by layer
     with the row-block and attention backward kernels (the unfused backward's launches).  -> d input (M, 128)."""
     M, D, H, E = B * L, 128, 8, 16
+    if any(t.dtype == torch.bfloat16 for t in sv.values()):  # (BF16_SAVES of the fused forward: these kernels read fp32)
+        sv = {k: (t.float() if t.dtype == torch.bfloat16 else t) for k, t in sv.items()}
     if True:
         def masked(t, site):  # t * keep / (1 - p) with the mask the fused forward drew for `site` (new tensor)
             out = torch.empty_like(t)

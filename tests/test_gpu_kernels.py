@@ -888,6 +888,56 @@ def test_wgrad_grouped(prec, tol):
         assert rel_err(d[3], db) < 1e-4, sh
 
 
+@pytest.mark.parametrize("ybf,xbf", [(True, True)])
+def test_wgrad_grouped_bf16_operands(ybf, xbf):
+    """rf_wgrad_tr with operands that already lie in memory as bf16 (the fused encoder stacks' dy slabs / activation saves,
+    kernels.BF16_SAVES): BIT-identical to the fp32-operand launch on the same (bf16-representable) values -- the kernel rounds
+    fp32 operands to bf16 on the way into LDS, so nothing but the bytes read changes."""
+    from routeformer_amd import _hip, kernels as Kn
+    from routeformer_amd._hip import ptr
+    g = _g(33)
+    shapes = [(12480, 384, 128, True), (4160, 128, 512, True), (325, 512, 128, True), (1030, 128, 128, False), (40, 384, 128, True)]
+    results = []
+    for as_bf in (False, True):
+        arr = (_hip.WgradEntry * len(shapes))()
+        keep = []
+        gg = _g(34)
+        for e, (M, N, K, with_bias) in zip(arr, shapes):
+            dy, x = _bf(torch.randn(M, N, generator=gg)), _bf(torch.randn(M, K, generator=gg))
+            dyd = dy.to(DEV).to(torch.bfloat16 if (as_bf and ybf) else torch.float32)
+            xd = x.to(DEV).to(torch.bfloat16 if (as_bf and xbf) else torch.float32)
+            dw, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+            keep.append((dyd, xd, dw, db, dy, x))
+            e.dy, e.x, e.dw, e.db = ptr(dyd), ptr(xd), ptr(dw), (ptr(db) if with_bias else None)
+            e.M, e.N, e.K, e.ld_dy, e.ld_x = M, N, K, N, K
+            e.splits, e.exclusive = 1, 1   # one chunk, plain stores: a fixed summation order, so the two runs can be compared bit by bit
+            e.dy_bf16, e.x_bf16 = int(as_bf and ybf), int(as_bf and xbf)
+        rc = _hip.lib().rf_wgrad_grouped(arr, len(shapes), 1, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, _hip.lib().rf_last_error()
+        torch.cuda.synchronize()
+        results.append(keep)
+    for (_, _, dw32, db32, dy, x), (_, _, dw16, db16, _, _), sh in zip(results[0], results[1], shapes):
+        assert torch.equal(dw32, dw16), sh
+        assert rel_err(db16.cpu(), db32.cpu()) < 1e-6, sh
+        assert rel_err(dw16.cpu(), dy.T @ x) < 1e-3, sh
+    # fp32- and bf16-operand problems may share a launch (a workgroup-uniform branch picks the loader) ...
+    arr = (_hip.WgradEntry * 2)()
+    for e, kp, flag in zip(arr, (results[1][1], results[0][2]), (1, 0)):
+        kp[2].zero_()
+        e.dy, e.x, e.dw, e.db = ptr(kp[0]), ptr(kp[1]), ptr(kp[2]), None
+        e.M, e.N, e.K = kp[4].shape[0], kp[4].shape[1], kp[5].shape[1]
+        e.ld_dy, e.ld_x, e.splits, e.exclusive, e.dy_bf16, e.x_bf16 = e.N, e.K, 1, 1, flag, flag
+    assert _hip.lib().rf_wgrad_grouped(arr, 2, 1, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    for kp in (results[1][1], results[0][2]):
+        assert rel_err(kp[2].cpu(), kp[4].T @ kp[5]) < 1e-3
+    # ... but one problem's operands share a type, and the fp32 tiled path takes fp32 operands only
+    arr[0].x_bf16 = 0
+    assert _hip.lib().rf_wgrad_grouped(arr, 2, 1, torch.cuda.current_stream().cuda_stream) != 0
+    arr[0].x_bf16 = 1
+    assert _hip.lib().rf_wgrad_grouped(arr, 1, 0, torch.cuda.current_stream().cuda_stream) != 0
+
+
 @pytest.mark.parametrize("M,N,K,res,ln", [(12480, 384, 128, False, False), (325, 128, 128, True, True),
                                           (64, 128, 256, True, True), (1300, 68, 256, True, False),
                                           (7, 128, 128, False, True), (130, 200, 128, False, False)])
@@ -1238,12 +1288,16 @@ def test_fused_encoder_stack_forward(B, L, F_, n_layers, groups, act):
     M = B * L
     for li in range(n_layers):
         for name in ("qkv", "ctx", "x1", "xhat1", "h", "xhat2", "y") + (("z",) if act == "gelu" else ()):
-            got, want = forced[name][li].cpu(), saves[li][name].reshape(M, -1)
-            # ctx is saved as the bf16 image the out-projection consumes: one bf16 ulp (2^-8) when a rounding flips
-            tol = 1e-2 if name == "ctx" else 4e-3 * (li + 1)
+            got, want = forced[name][li].float().cpu(), saves[li][name].reshape(M, -1)
+            # ctx is saved as the bf16 image the out-projection consumes: one bf16 ulp (2^-8) when a rounding flips; the
+            # same holds for whatever kernels.BF16_SAVES keeps as bf16 (x1, h: the images conv1 / conv2 consume)
+            tol = 1e-2 if (name == "ctx" or forced[name].dtype == torch.bfloat16) else 4e-3 * (li + 1)
             assert rel_err(got, want) < tol, (li, name, rel_err(got, want))
         assert forced["rstd1"][li].shape == (M,) and bool(torch.isfinite(forced["rstd1"][li]).all())
         assert bool((forced["rstd2"][li] > 0).all())
+        if "xin" in forced:  # every layer's input as the projection consumed it (bf16): x, then the previous layer's output
+            want = (x if li == 0 else saves[li - 1]["y"]).reshape(M, -1)
+            assert rel_err(forced["xin"][li].float().cpu(), want) < 1e-2, (li, "xin")
     assert rel_err(forced["y"][-1].cpu(), y_ref.reshape(M, D)) < 4e-3 * n_layers
     assert torch.equal(nosave["y"][0], forced["y"][-1]), "the no-save variant must compute the same output"
     if all(same):
