@@ -1307,6 +1307,31 @@ def attention(a, b, offs, dims, mode: int, *, index_sample=None, n_top: int = 0,
     return _Attention.apply(a, b, offs, index_sample, dims, mode, n_top, out_layout, scale, forced_top, idx_group, drop)
 
 
+def attention_map(a, b, offs, dims, mode: int, tops, scale: Optional[float] = None):
+    """The dense (B, H, L_Q, L_K) attention map the reference returns with ``output_attention=True`` -- a debugging output,
+    built with torch ops OUTSIDE the attention kernel from the projections it consumed and the rows it selected:
+    FullAttention (mode 0): softmax(scale Q K^T) (cross_modal_transformer.py:60-66, SelfAttentionFamily.py:59-66);
+    ProbAttention (mode 1 / 2): every row 1 / L_V except the selected queries, whose rows are their (mode 2: causally masked,
+    ProbMask) softmax rows (cross_modal_transformer.py:134-138, SelfAttentionFamily.py:133-137)."""
+    B, H, LQ, LK, E = dims
+    scale = scale or 1.0 / math.sqrt(E)
+    HE = H * E
+    with torch.no_grad():
+        q = a[:, offs[0]:offs[0] + HE].reshape(B, LQ, H, E).permute(0, 2, 1, 3).float()
+        k = b[:, offs[1]:offs[1] + HE].reshape(B, LK, H, E).permute(0, 2, 1, 3).float()
+        if mode == 0:
+            return torch.softmax(scale * (q @ k.transpose(-1, -2)), dim=-1)
+        idx = tops.long()  # (B, H, u)
+        qs = torch.gather(q, 2, idx.unsqueeze(-1).expand(-1, -1, -1, E))
+        scores = scale * (qs @ k.transpose(-1, -2))  # (B, H, u, L_K)
+        if mode == 2:  # ProbMask: key j > query position is masked
+            scores = scores.masked_fill(torch.arange(LK, device=a.device).view(1, 1, 1, LK) > idx.unsqueeze(-1), float("-inf"))
+        rows = torch.softmax(scores, dim=-1)
+        full = torch.full((B, H, LK, LK), 1.0 / LK, device=a.device, dtype=rows.dtype)
+        full.scatter_(2, idx.unsqueeze(-1).expand(-1, -1, -1, LK), rows)
+        return full
+
+
 class _TrajHead(torch.autograd.Function):
     """postprocess_batch + discounted SmoothL1 losses + ADE/FDE in one launch (and one for backward)."""
 

@@ -288,6 +288,11 @@ class AttentionLayer(nn.Module):
         layout = 1 if self.gps_variant else 0
         # nn.Dropout on the softmax probabilities (FullAttention only, cross_modal_transformer.py:63): in-kernel
         drop_p = self.attn_dropout if self.training else 0.0
+        want_map = self.__dict__.get("output_attention", False)
+        if want_map:  # the dense map is rebuilt from the kernel's own selection (recorded for this one call)
+            if drop_p > 0.0:
+                raise NotImplementedError("output_attention with attention dropout in train mode (the dropped map)")
+            rec_outer, K.TOPS.record = K.TOPS.record, []
         if self.kind == "full":
             ctx = K.attention(a, bm, offs, dims, 0, out_layout=layout, drop_p=drop_p)
         elif self.kind == "full_masked":
@@ -301,6 +306,12 @@ class AttentionLayer(nn.Module):
                 idx = SAMPLER.draw(S, L, sample_k, x.device)
             ctx = K.attention(a, bm, offs, dims, 2 if self.kind == "prob_masked" else 1, index_sample=idx,
                               n_top=n_top, out_layout=layout, idx_group=idx_group)
+        if want_map:
+            mine, K.TOPS.record = K.TOPS.record, rec_outer
+            if rec_outer is not None:
+                rec_outer.extend(mine)
+            mode = {"full": 0, "full_masked": 2, "prob": 1, "prob_masked": 2}[self.kind]
+            self.__dict__["attention_map"] = K.attention_map(a, bm, offs, dims, mode, mine[-1] if mine else None)
         if self.mix and not self.gps_variant:
             ctx = ctx.transpose(2, 1).contiguous()
         ctx = ctx.view(B, L, HE)  # GPS variant: (B,H,L,D) memory reinterpreted -- the head scramble
@@ -504,13 +515,27 @@ class Encoder(nn.Module):
             return K._TiledStack.apply(x, st, idx_list, idx_group or B, need_grad)
         return K._SeqStack.apply(x, st, idx_list, idx_group or B, need_grad, drop_p)
 
+    def set_output_attention(self, on: bool = True):
+        """``output_attention=True`` of the reference encoders: after a forward, ``self.attentions`` holds the dense
+        (B, H, L, L) map of every layer (kernels.attention_map); the layers then run one by one (no fused stack)."""
+        self.__dict__["output_attention"] = bool(on)
+        for lay in self.attn_layers:
+            lay.attention.__dict__["output_attention"] = bool(on)
+        return self
+
     def forward(self, x, idx_list=None, idx_group: int = 0):
+        x = self._forward(x, idx_list, idx_group)
+        if self.__dict__.get("output_attention", False):
+            self.__dict__["attentions"] = [lay.attention.__dict__.pop("attention_map") for lay in self.attn_layers]
+        return x
+
+    def _forward(self, x, idx_list=None, idx_group: int = 0):
         if self.conv_layers is not None:
             for attn, conv in zip(self.attn_layers, self.conv_layers):
                 x = conv(attn(x))
             x = self.attn_layers[-1](x)
         else:
-            y = self._fused_forward(x, idx_list, idx_group)
+            y = None if self.__dict__.get("output_attention", False) else self._fused_forward(x, idx_list, idx_group)
             if y is not None:
                 x = y
             else:
@@ -545,8 +570,7 @@ class PerceiveEncoder(nn.Module):
     def __init__(self, in_channels, out_channels, out_len, factor=5, d_model=128, n_heads=8, layers=3,
                  d_ff=None, dropout=0.1, activation="gelu", output_attention=False):
         super().__init__()
-        if output_attention:
-            raise NotImplementedError("output_attention is not produced by the fused attention kernel")
+        self.output_attention = bool(output_attention)
         self.pred_len = out_len
         d_ff = d_ff if d_ff is not None else 4 * d_model
         self.value_embedding = TokenEmbedding(in_channels, d_model, bias=True)
@@ -556,6 +580,8 @@ class PerceiveEncoder(nn.Module):
              for _ in range(layers)],
             None, norm_layer=nn.LayerNorm(d_model))
         self.projection = nn.Linear(d_model, out_channels, bias=True)
+        if self.output_attention:  # (cross_modal_transformer.py:430-433: returns (output, attentions))
+            self.encoder.set_output_attention()
 
     def predraw(self, L: int, device):
         """The draws one forward over length-L sequences makes, in layer order ((L,k) int32 on device)."""
@@ -571,7 +597,8 @@ class PerceiveEncoder(nn.Module):
         h = self.value_embedding(x_enc, residual=self.position_embedding(x_enc.shape[1])[0])
         h = self.encoder(h, idx_list, idx_group)
         # only the last pred_len tokens are consumed: project just those rows
-        return K.linear(h[:, -self.pred_len:, :], self.projection.weight, self.projection.bias)
+        y = K.linear(h[:, -self.pred_len:, :], self.projection.weight, self.projection.bias)
+        return (y, self.encoder.attentions) if self.output_attention else y
 
 
 class PerceiveDecoder(nn.Module):

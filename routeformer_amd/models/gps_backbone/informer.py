@@ -17,12 +17,10 @@ class Informer(nn.Module):
     def __init__(self, configs: GPSBackboneConfig):
         super().__init__()
         c = configs
-        if c.output_attention:
-            raise NotImplementedError("output_attention is not produced by the fused attention kernel")
         if c.embed != "timeF":
             raise NotImplementedError("only the timeF embedding used by Routeformer is implemented")
         self.pred_len = c.pred_len
-        self.output_attention = False
+        self.output_attention = bool(c.output_attention)
         self.smart_decoder = c.smart_decoder
         self.enc_embedding = DataEmbedding(c.enc_in, c.d_model, c.dropout)
         self.dec_embedding = DataEmbedding(c.dec_in, c.d_model, c.dropout)
@@ -39,6 +37,8 @@ class Informer(nn.Module):
              for _ in range(c.d_layers)],
             norm_layer=nn.LayerNorm(c.d_model),
             projection=nn.Linear(c.d_model, c.c_out, bias=True))
+        if self.output_attention:  # the ENCODER's maps (Informer.py:53,164); decoder attentions are never returned
+            self.encoder.set_output_attention()
 
     def forward(self, x):
         # decoder input: the history followed by its last row repeated ("smart") or by zeros; one launch, and the two
@@ -59,4 +59,5 @@ class Informer(nn.Module):
             out = self.decoder(None, memory, first=first)
         else:
             out = self.decoder(self.dec_embedding(x_dec), memory)
-        return out[:, -self.pred_len:, :]
+        out = out[:, -self.pred_len:, :]
+        return (out, self.encoder.attentions) if self.output_attention else out

@@ -14,12 +14,10 @@ class Transformer(nn.Module):
     def __init__(self, configs: GPSBackboneConfig):
         super().__init__()
         c = configs
-        if c.output_attention:
-            raise NotImplementedError("output_attention is not produced by the fused attention kernel")
         if c.embed != "timeF":
             raise NotImplementedError("only the timeF embedding used by Routeformer is implemented")
         self.pred_len = c.pred_len
-        self.output_attention = False
+        self.output_attention = bool(c.output_attention)
         self.enc_embedding = DataEmbedding(c.enc_in, c.d_model, c.dropout)
         self.dec_embedding = DataEmbedding(c.dec_in, c.d_model, c.dropout)
 
@@ -34,10 +32,12 @@ class Transformer(nn.Module):
              for _ in range(c.d_layers)],
             norm_layer=nn.LayerNorm(c.d_model),
             projection=nn.Linear(c.d_model, c.c_out, bias=True))
+        if self.output_attention:  # the ENCODER's maps (Transformer.py:45,138)
+            self.encoder.set_output_attention()
 
     def forward(self, x):
         B, L, C = x.shape
         x_dec = torch.cat([x, torch.zeros(B, self.pred_len, C, device=x.device, dtype=torch.float32)], dim=1)
         memory = self.encoder(self.enc_embedding(x))
-        out = self.decoder(self.dec_embedding(x_dec), memory)
-        return out[:, -self.pred_len:, :]
+        out = self.decoder(self.dec_embedding(x_dec), memory)[:, -self.pred_len:, :]
+        return (out, self.encoder.attentions) if self.output_attention else out

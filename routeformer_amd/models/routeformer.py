@@ -143,11 +143,14 @@ class Routeformer(nn.Module):
         if hook is not None:  # engine: the backbone's parameters may still be in flight on another stream
             hook()
         out = self.gps_backbone(x)
+        attention = None
+        if c.output_attention:  # (routeformer.py:237-252: the backbone's encoder attention maps ride along)
+            out, attention = out
         if c.decoder_mode == "recursive":
             out = out + (x[:, -1:, :] if c.dense_prediction else x[:, -1:, :2])
         if c.rotate_motion:
             out = torch.cat([rotate(out[:, :, :2], origin), out[:, :, 2:]], dim=-1)
-        return out, None
+        return out, attention
 
     def _forward_fused(self, motion, visual):
         """``_forward`` with the motion featurisation + concat and the output un-rotation as one launch each
@@ -163,11 +166,14 @@ class Routeformer(nn.Module):
         if hook is not None:  # engine: the backbone's parameters may still be in flight on another stream
             hook()
         out = self.gps_backbone(x)
+        attention = None
+        if c.output_attention:  # (routeformer.py:237-252: the backbone's encoder attention maps ride along)
+            out, attention = out
         if c.decoder_mode == "recursive":
             out = out + (x[:, -1:, :] if c.dense_prediction else x[:, -1:, :2])
         if c.rotate_motion:
             out = K.rotate_head(out, origin)
-        return out, None
+        return out, attention
 
     # ------------------------------------------------------------------------------------------
     def preprocess_batch(self, batch, training: bool = None):

@@ -628,7 +628,68 @@ def gen_dropout():
     save("dropout", **out)
 
 
-GENERATORS = {"dropout": gen_dropout, "widen": gen_widen, "attention": gen_attention, "blocks": gen_blocks, "informer": gen_informer,
+def gen_attn_out():
+    """``output_attention=True``: the dense attention maps the reference hands back next to its outputs -- the Informer's
+    and the Transformer's encoder maps (ProbAttention: uniform rows + the selected queries' softmax rows; FullAttention:
+    the softmax), a PerceiveEncoder's, and Routeformer._forward's second return value."""
+    out = {}
+    g = torch.Generator().manual_seed(17)
+    B, T, P, cin = 3, 20, 10, 69
+    x = torch.randn(B, T, cin, generator=g)
+    out["x"] = x
+    for tag, cls in (("informer", REF.gps.Informer), ("transformer", REF.gps.Transformer)):
+        gcfg = REF.gps.GPSBackboneConfig(seq_len=T, label_len=T, pred_len=P, **presets.GPS_TINY)
+        gcfg.output_attention, gcfg.smart_decoder, gcfg._enc_in, gcfg._c_out = True, True, cin, cin - 3
+        torch.manual_seed(0)
+        net = cls(gcfg)
+        load_synth(net)
+        net.eval()
+        log = []
+        torch.manual_seed(RSEED)
+        with record_randint(log), torch.no_grad():
+            y, attns = net(x)
+        out[f"{tag}.y"] = y
+        for i, a in enumerate(attns):
+            out[f"{tag}.attn{i}"] = a
+        out[f"{tag}.n"] = np.array(len(attns))
+        out.update({f"{tag}.{k}": v for k, v in pack_draws(log).items()})
+    # a PerceiveEncoder with output_attention (cross_modal_transformer.py:385-433)
+    torch.manual_seed(0)
+    enc = REF.cmt.PerceiveEncoder(24, 16, 7, factor=5, d_model=128, n_heads=8, layers=3, dropout=0.0, output_attention=True)
+    load_synth(enc)
+    enc.eval()
+    xe = torch.randn(2, 21, 24, generator=g)
+    log = []
+    torch.manual_seed(RSEED)
+    with record_randint(log), torch.no_grad():
+        y, attns = enc(xe)
+    out["perceive.x"], out["perceive.y"], out["perceive.n"] = xe, y, np.array(len(attns))
+    for i, a in enumerate(attns):
+        out[f"perceive.attn{i}"] = a
+    out.update({f"perceive.{k}": v for k, v in pack_draws(log).items()})
+    # Routeformer._forward's (output, attention)
+    c = dict(presets.case("c1_default"))
+    gps_cfg, rf_cfg = presets.build_configs(c, REF.gps.GPSBackboneConfig, REF.cfg.RouteformerConfig, REF.vbc.VideoBackboneConfig)
+    rf_cfg.output_attention = True
+    rf_cfg.gps_backbone_config.output_attention = True
+    torch.manual_seed(0)
+    model = REF.rf.Routeformer(rf_cfg, gps_backbone=REF.gps.Informer, video_backbone=None)
+    load_synth(model)
+    model.eval()
+    item = synthetic.synth_item(c["B"], c["T"], c["P"], DSEED, c["H"], c["W"], streams=c["streams"], gaze=c["gaze"])
+    log = []
+    torch.manual_seed(RSEED)
+    with record_randint(log), torch.no_grad():
+        motion, visual = model.preprocess_batch(item["train"])[:2]
+        y, attns = model._forward(motion, visual)
+    out["model.y"], out["model.n"] = y, np.array(len(attns))
+    for i, a in enumerate(attns):
+        out[f"model.attn{i}"] = a
+    out.update({f"model.{k}": v for k, v in pack_draws(log).items()})
+    save("attn_out", **out)
+
+
+GENERATORS = {"attn_out": gen_attn_out, "dropout": gen_dropout, "widen": gen_widen, "attention": gen_attention, "blocks": gen_blocks, "informer": gen_informer,
               "hrnet": gen_hrnet, "helpers": gen_helpers}
 
 if __name__ == "__main__":

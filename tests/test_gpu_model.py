@@ -167,6 +167,60 @@ def test_informer_golden(tag, preset, B, T, P, cin):
                 assert rel_err(sd["encoder.conv_layers.0.norm.running_var"], G[key + "bn0_running_var"]) < 1e-4
 
 
+def test_output_attention_golden():
+    """``output_attention=True`` (cross_modal_transformer.py:66,134-138,430; gps_backbone Informer.py:164, Transformer.py:138;
+    routeformer.py:237-252): the dense maps handed back next to the outputs, against the reference's own -- uniform 1 / L rows
+    with the SELECTED queries' softmax rows scattered in (so the kernel's top-u selection is checked too), the dense softmax of
+    FullAttention, and Routeformer._forward's second return value."""
+    from routeformer_amd import presets, synthetic
+    from routeformer_amd.models import Routeformer, RouteformerConfig
+    from routeformer_amd.models.blocks import SAMPLER, PerceiveEncoder
+    from routeformer_amd.models.gps_backbone import GPSBackboneConfig, Informer, Transformer
+    from routeformer_amd.models.video_backbone import VideoBackboneConfig
+    G = golden("attn_out")
+    x = t(G["x"]).to(DEV)
+    B, T, P, cin = 3, 20, 10, 69
+
+    def check(tag, y, attns, tol=2e-4):
+        assert len(attns) == int(G[tag + ".n"])
+        assert rel_err(y, G[tag + ".y"]) < tol, tag
+        for i, a in enumerate(attns):
+            want = t(G[f"{tag}.attn{i}"])
+            assert tuple(a.shape) == tuple(want.shape), (tag, i, a.shape, want.shape)
+            assert float((a.sum(-1) - 1).abs().max()) < 1e-5  # rows are distributions
+            assert rel_err(a, want) < tol, (tag, i)
+
+    for tag, cls in (("informer", Informer), ("transformer", Transformer)):
+        gcfg = GPSBackboneConfig(seq_len=T, label_len=T, pred_len=P, **presets.GPS_TINY)
+        gcfg.output_attention, gcfg.smart_decoder, gcfg._enc_in, gcfg._c_out = True, True, cin, cin - 3
+        net = _load(cls(gcfg)).eval()
+        SAMPLER.replay = draws(G, tag + ".")
+        with torch.no_grad():
+            y, attns = net(x)
+        check(tag, y, attns)
+    enc = _load(PerceiveEncoder(24, 16, 7, factor=5, d_model=128, n_heads=8, layers=3, dropout=0.0, output_attention=True)).eval()
+    SAMPLER.replay = draws(G, "perceive.")
+    with torch.no_grad():
+        y, attns = enc(t(G["perceive.x"]).to(DEV))
+    check("perceive", y, attns)
+    # the whole model: _forward returns (output, attention) as routeformer.py:252 does
+    c = dict(presets.case("c1_default"))
+    gps_cfg, cfg = presets.build_configs(c, GPSBackboneConfig, RouteformerConfig, VideoBackboneConfig)
+    cfg.output_attention = True
+    cfg.gps_backbone_config.output_attention = True
+    model = _load(Routeformer(cfg, gps_backbone=Informer, video_backbone=None)).eval()
+    item = synthetic.synth_item(c["B"], c["T"], c["P"], 11, c["H"], c["W"], streams=c["streams"], gaze=c["gaze"])
+    SAMPLER.replay = draws(G, "model.")
+    with torch.no_grad():
+        motion, visual = model.preprocess_batch(_to_dev(item["train"]))
+        y, attns = model._forward(motion, visual)
+        check("model", y, attns)
+        SAMPLER.replay = draws(G, "model.")
+        pos = model(_to_dev(item["train"]))  # forward() itself is unchanged by the flag (routeformer.py:157)
+    assert pos.shape[-1] == 2 and bool(torch.isfinite(pos).all())
+    SAMPLER.replay = None
+
+
 CASES = ["c1_default", "c1_paper", "c1_recursive", "c1_noise", "c2_small", "c4_small", "c5_small", "ar_small", "c2_paper"]
 
 
