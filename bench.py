@@ -316,11 +316,10 @@ def main():
     # ms/step: the streaming update slows the latency-bound encoder kernels by more than it saves), so it is off.
     # clip + AdamW of step k at the head of step k + 1's replay, the GPS backbone's share on a side stream underneath
     # the camera / gaze / fusion encoders (same arithmetic, same order; the flush() calls below keep exactly K updates
-    # inside the timed region).  Measured A/B at N = 1: 7.00 / 6.95 -> 6.84 / 6.80 ms.  Not available with gaze dropout
-    # (the skipped optimizer slots are decided per step) or the sharded gradient exchange.
+    # inside the timed region).  Measured A/B at N = 1: 7.00 / 6.95 -> 6.84 / 6.80 ms.  With gaze dropout the update is launched per
+    # segment, each with its own device-side "pending" flag and update count.  Not available with the sharded gradient exchange.
     want = os.environ.get("RF_DEFER_UPDATE", "auto")
-    defer = (want == "1") or (want == "auto" and args.dropout == "none"
-                              and os.environ.get("RF_DP_MODE", "allreduce") == "allreduce")
+    defer = (want == "1") or (want == "auto" and os.environ.get("RF_DP_MODE", "allreduce") == "allreduce")
     engine = GraphedTrainEngine(model, defer_update=defer) if use_graph else TrainEngine(model)
     if use_graph:
         # capture once up front; fall back step by step: two-graph step (N > 1) -> one graph -> eager launches.

@@ -479,9 +479,10 @@ class FusedAdamW:
     def lr(self, value: float):
         self.param_groups[0]["lr"] = value
 
-    def hyper(self, grad_scale: float, pending: bool = True) -> List[float]:
-        """The scalar arguments of update number ``self.t`` as rf_adamw_clip_dev reads them from device memory."""
-        t = max(self.t, 1)
+    def hyper(self, grad_scale: float, pending: bool = True, t: Optional[int] = None) -> List[float]:
+        """The scalar arguments of update number ``t`` (default ``self.t``) as rf_adamw_clip_dev reads them from device
+        memory."""
+        t = max(self.t if t is None else t, 1)
         return [1.0 if pending else 0.0, self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                 1.0 - self.betas[0] ** t, (1.0 - self.betas[1] ** t) ** 0.5, grad_scale]
 
@@ -659,6 +660,10 @@ class TrainEngine:
             if not prefixes and self._flag_group is not None:
                 agree_unused(False, self._flag_group)  # every rank takes part in the exchange every step
             return ()
+        return self._prefix_ranges(prefixes)
+
+    def _prefix_ranges(self, prefixes):
+        """The merged [lo, hi) slices of the parameters whose names start with one of ``prefixes`` (no rank agreement)."""
         hit = self._skip_cache.get(tuple(prefixes))
         if hit is not None:
             return hit
@@ -787,7 +792,8 @@ class GraphedTrainEngine(TrainEngine):
         # order -- the bandwidth-bound update just no longer sits alone on the critical path.  ``flush()`` applies a
         # still-pending update (call it before reading parameters or saving a checkpoint).
         self.defer_update = defer_update
-        self._pending = None          # hyper-parameters of the update the next replay has to apply
+        self._pending = None          # per-segment scalars of the update the next replay has to apply
+        self._segments = None         # [(lo, hi, on the side stream)]: fixed launch plan of a deferred update
         self._hyper = self._hyper_pinned = None
         self._gps_range = None
         self.graph = None
@@ -810,8 +816,6 @@ class GraphedTrainEngine(TrainEngine):
         c = model.configs
         if c.motion_noise > 0:
             raise ValueError("GraphedTrainEngine: motion_noise > 0 (torch.randn_like on the inputs) is not supported")
-        if defer_update and c.gaze_dropout > 0:
-            raise ValueError("defer_update cannot skip the optimizer slots of a dropped gaze branch; use defer_update=False")
         if defer_update and self.reducer.sharded:
             raise ValueError("defer_update replays the whole-buffer update; use RF_DP_MODE=allreduce with it")
 
@@ -844,44 +848,74 @@ class GraphedTrainEngine(TrainEngine):
             self.reducer.zero()
             return
         r, opt = self.reducer, self.opt
-        n = r.flat_param.numel()
         opt.launch_sumsq()
-        rng = self._gps_range if (self.overlap and __import__("os").environ.get("RF_DEFER_SIDE", "1") != "0") else None
+        use_side = self._gps_range is not None and self.overlap and __import__("os").environ.get("RF_DEFER_SIDE", "1") != "0"
         cur = torch.cuda.current_stream()
-        if rng is not None:
-            lo, hi = rng
+
+        def run(segments):  # one launch per segment (its own scalars), one zero per contiguous run of segments
+            runs = []
+            for i, (a, b, _) in segments:
+                opt.launch_update_dev(a, b, self._hyper[i])
+                if runs and runs[-1][1] == a:
+                    runs[-1][1] = b
+                else:
+                    runs.append([a, b])
+            for a, b in runs:
+                r.flat_grad[a:b].zero_()
+
+        seg = list(enumerate(self._segments))
+        # the encoders' 5 % first and ALONE, then the fork: launched next to the backbone's 2-GB streaming update the
+        # small slices were starved by it (rocprofv3 trace, profiles/r03/step_trace_before.txt: 394 us for 98 MB of
+        # traffic, both launches ending together) -- and the camera / gaze / fusion encoders wait for exactly them
+        run([x for x in seg if not (use_side and x[1][2])])
+        # the encoders' slots are final: pack their bf16 fragments BEFORE the streaming update is let loose (next to it
+        # the 16-us pack kernel ran for as long as the update did -- kernel trace, profiles/r03/overlap_experiments.txt)
+        self._repack_fused()
+        if use_side:
             side = K.side_stream("update")
-            # the encoders' 5 % first and ALONE, then the fork: launched next to the backbone's 2-GB streaming update the
-            # small slices were starved by it (rocprofv3 trace, profiles/r03/step_trace_before.txt: 394 us for 98 MB of
-            # traffic, both launches ending together) -- and the camera / gaze / fusion encoders wait for exactly them
-            for a, b in ((0, lo), (hi, n)):
-                if b > a:
-                    opt.launch_update_dev(a, b, self._hyper)
-                    r.flat_grad[a:b].zero_()
-            # the encoders' slots are final: pack their bf16 fragments BEFORE the streaming update is let loose (next to it
-            # the 16-us pack kernel ran for as long as the update did -- kernel trace, profiles/r03/overlap_experiments.txt)
-            self._repack_fused()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                opt.launch_update_dev(lo, hi, self._hyper)
-                r.flat_grad[lo:hi].zero_()
+                run([x for x in seg if x[1][2]])
             self.model.__dict__["_before_gps_backbone"] = lambda: torch.cuda.current_stream().wait_stream(side)
-            r.begin_step()
-            K.WGRAD.begin_step()
-            return
-        opt.launch_update_dev(0, n, self._hyper)
-        r.flat_grad.zero_()
         r.begin_step()
         K.WGRAD.begin_step()
-        self._repack_fused()  # after the (deferred) update of the encoders' slots, on this stream
+
+    def _plan_segments(self):
+        """The fixed segmentation of the flat buffers a deferred update is launched in: cut at the GPS backbone's range
+        (its share runs on the side stream) and at every range a step may leave untouched (a dropped gaze branch:
+        routeformer.py:299-310) -- such a segment is switched off for that update by its own "pending" flag on the
+        device, and carries its own update count (torch.optim.AdamW's per-parameter ``state['step']``)."""
+        n = self.reducer.flat_param.numel()
+        cuts = {0, n}
+        rng = self._gps_range
+        if rng is not None:
+            cuts.update(rng)
+        if self.model.configs.gaze_dropout > 0 and getattr(self.model, "with_gaze", False):
+            for a, b in self._prefix_ranges(("gaze_encoder.", "gaze_video_decoder.")):
+                cuts.update((a, b))
+        cuts = sorted(cuts)
+        return [(a, b, rng is not None and rng[0] <= a and b <= rng[1]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+
+    def _pending_rows(self, scale: float, skip):
+        """Per segment the scalars of update ``opt.t`` (call after ``opt.t += 1`` and ``opt._note_skipped(skip)``)."""
+        opt, rows = self.opt, []
+        for a, b, _ in self._segments:
+            skipped = any(x <= a and b <= y for x, y in skip)
+            lag = max([k for (x, y), k in opt._lag.items() if x <= a and b <= y] + [0])
+            rows.append(opt.hyper(scale, pending=not skipped, t=opt.t - lag))
+        return rows
 
     def _set_hyper(self):
         """Ship the pending update's scalars (or "nothing pending") ahead of the replay."""
-        vals = self._pending if self._pending is not None else self.opt.hyper(1.0, pending=False)
+        rows = self._pending if self._pending is not None else [self.opt.hyper(1.0, pending=False)] * len(self._segments)
+        self._ship_hyper(rows)
+
+    def _ship_hyper(self, rows):
         ev = self.__dict__.get("_hyper_copied")
         if ev is not None:
             ev.synchronize()  # the previous copy must have left the pinned buffer before it is rewritten
-        self._hyper_pinned[:len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
+        vals = torch.tensor(rows, dtype=torch.float32)
+        self._hyper_pinned[:, :vals.shape[1]].copy_(vals)
         self._hyper.copy_(self._hyper_pinned, non_blocking=True)
         self._hyper_copied = torch.cuda.Event()
         self._hyper_copied.record()
@@ -889,16 +923,11 @@ class GraphedTrainEngine(TrainEngine):
     def flush(self):
         """Apply a still-pending optimizer update now (eagerly, on the current stream)."""
         if self._pending is not None:
-            vals, self._pending = self._pending, None
+            rows, self._pending = self._pending, None
             self.opt.launch_sumsq()
-            ev = self.__dict__.get("_hyper_copied")
-            if ev is not None:
-                ev.synchronize()
-            self._hyper_pinned[:len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
-            self._hyper.copy_(self._hyper_pinned, non_blocking=True)
-            self._hyper_copied = torch.cuda.Event()
-            self._hyper_copied.record()
-            self.opt.launch_update_dev(0, self.reducer.flat_param.numel(), self._hyper)
+            self._ship_hyper(rows)
+            for i, (a, b, _) in enumerate(self._segments):
+                self.opt.launch_update_dev(a, b, self._hyper[i])
             self.reducer.flat_grad.zero_()
         return self
 
@@ -1058,9 +1087,11 @@ class GraphedTrainEngine(TrainEngine):
         if self.defer_update:
             self.flush()
             from routeformer_amd._hip import lib as _lib  # noqa: F401  (fail loudly without the extension)
-            self._hyper = torch.zeros(16, device=dev, dtype=torch.float32)  # "nothing pending" during the warm-up passes
-            self._hyper_pinned = torch.zeros(16, dtype=torch.float32).pin_memory()
             self._gps_range = self._backbone_range()
+            self._segments = self._plan_segments()
+            # one row of scalars per segment; all zero = "nothing pending" during the warm-up passes
+            self._hyper = torch.zeros(len(self._segments), 16, device=dev, dtype=torch.float32)
+            self._hyper_pinned = torch.zeros(len(self._segments), 16, dtype=torch.float32).pin_memory()
         self._pipelined = self.overlap and bool(self.model.video_clips([item["train"], item["target"]])[0])
         # static inputs of the main graph: private copies of every tensor.  Pipelined engine: the video tensors are
         # only consulted for shapes / cache keys inside the main graph (the trunk reads the staging buffers), so
@@ -1300,8 +1331,10 @@ class GraphedTrainEngine(TrainEngine):
                 self._remember_tokens(*pending)
         scale = self.reducer.finish()
         if self.defer_update:
+            skip = self._skip_ranges(self._variant_unused[variant])
             self.opt.t += 1
-            self._pending = self.opt.hyper(scale)  # applied at the start of the next replay (or by flush())
+            self.opt._note_skipped(skip)
+            self._pending = self._pending_rows(scale, skip)  # applied at the start of the next replay (or by flush())
         else:
             self._update(scale, self._skip_ranges(self._variant_unused[variant]))
         return out

@@ -880,25 +880,34 @@ def test_graphed_engine_with_dropouts_matches_eager():
         it = synthetic.synth_item(c["B"], c["T"], c["P"], seed, c["H"], c["W"], streams=c["streams"], gaze=c["gaze"])
         items.append({"train": _to_dev(it["train"]), "target": _to_dev(it["target"]), "id": seed})
     runs = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "graph_deferred"):
         model, sd = _dropout_model(cfg)
-        eng = TrainEngine(model, lr=1e-4) if mode == "eager" else GraphedTrainEngine(model, lr=1e-4).capture(items[0], epoch=10)
-        if mode == "graph":
+        eng = (TrainEngine(model, lr=1e-4) if mode == "eager" else
+               GraphedTrainEngine(model, lr=1e-4, defer_update=mode == "graph_deferred").capture(items[0], epoch=10))
+        if mode != "eager":
             assert SAMPLER.n_variants == 6  # view: keep | drop left | drop right, x gaze: keep | drop
+        if mode == "graph_deferred":  # the update is launched per segment: backbone | gaze slots | the rest
+            assert len(eng._segments) >= 3 and sum(side for _, _, side in eng._segments) == 1
         K.RNG.manual_seed(11)   # restarts the device step counter: both engines draw the same masks from here on
         torch.manual_seed(5)
         gaze_w = dict(model.named_parameters())["gaze_encoder.projection.weight"]
         losses, decisions, gaze_moved = [], [], []
         for i in range(14):
             before = gaze_w.detach().clone()
-            res = eng.step(items[i % 2], epoch=10, next_item=items[(i + 1) % 2] if mode == "graph" else None)
+            res = eng.step(items[i % 2], epoch=10, next_item=items[(i + 1) % 2] if mode != "eager" else None)
             losses.append(float(res["loss"].detach()))
             decisions.append(tuple(model.__dict__.get("_unused_prefixes", ())) if mode == "eager"
                              else tuple(eng._variant_unused[SAMPLER._variant]))
             gaze_moved.append(bool((gaze_w.detach() != before).any()))
         torch.cuda.synchronize()
+        if mode == "graph_deferred":
+            before = gaze_w.detach().clone()
+            eng.flush()  # the last step's update is still pending
+            torch.cuda.synchronize()
+            gaze_moved.append(bool((gaze_w.detach() != before).any()))
+            assert eng.opt.t == 14
         runs[mode] = (losses, decisions, gaze_moved, eng.reducer.flat_param.clone(), torch.get_rng_state())
-        if mode == "graph":
+        if mode != "eager":
             assert len({k[1] for k in eng._graphs}) >= 3, "expected several decision variants in 14 steps"
         SAMPLER.drop_static()
     (le, de, me, pe, re_), (lg, dg, mg, pg, rg) = runs["eager"], runs["graph"]
@@ -908,6 +917,14 @@ def test_graphed_engine_with_dropouts_matches_eager():
     assert me == [not d for d in de] and mg == me
     assert all(abs(a - b) < 2e-3 * max(1.0, abs(a)) for a, b in zip(le, lg)), (le, lg)
     assert rel_err(pg, pe) < 14 * 3e-4
+    # deferred update (the step's clip + AdamW replayed at the head of the NEXT step, per segment with device-side
+    # "pending" flags and per-segment update counts): same decisions, the gaze slots move one call later -- or not at all
+    # for a step that dropped the branch --, same parameters after the final flush
+    ld, dd, md, pd, rd = runs["graph_deferred"]
+    assert dd == de and torch.equal(rd, re_)
+    assert md == [False] + [not d for d in de], (md, de)
+    assert all(abs(a - b) < 2e-3 * max(1.0, abs(a)) for a, b in zip(le, ld)), (le, ld)
+    assert rel_err(pd, pe) < 14 * 3e-4
 
 
 def test_fused_stack_matches_layerwise_train_step():
