@@ -488,7 +488,10 @@ int rf_enclayer_tile_supported(int d_model, int n_heads, int d_ff);
 int rf_enclayer_tile_fwd(const float* ctx, const float* x, const void* wpack, const void* wpack_next, float* y,
                          float* qkv_next, float* xhat1, float* rstd1, float* x1, float* z, float* h, float* xhat2,
                          float* rstd2, int M, int d_model, int n_heads, int d_ff, int act, int save, float eps,
-                         void* stream);
+                         float drop_p, const void* rng_state, int drop_site, void* stream);
+/* drop_p > 0: nn.Dropout(p) of the layer in train mode (cross_modal_transformer.py:295,298,299), Philox masks of
+ * sites drop_site + {0: attention output, 1: hidden activation (saved h = the dropped activation), 2: conv2 output}, element
+ * index row * cols + col -- the masks rf_dropout / rf_seqlayer_fwd generate for the same (site, element). */
 
 /* Backward counterpart: between two rf_attn_bwd launches one row-tile launch does the packed q | k | v projection^T of
  * layer l + 1 (+ skip = its d pre-norm-1) -> LayerNorm-2 backward -> conv2^T -> act' -> conv1^T + skip -> LayerNorm-1 backward
@@ -499,7 +502,11 @@ int rf_enclayer_tile_fwd(const float* ctx, const float* x, const void* wpack, co
 int rf_enclayer_tile_bwd(const float* dy, const float* dqkv, const float* skip, const void* wpack_t, const void* wpack_next_t,
                          const float* xhat1, const float* rstd1, const float* zsrc, const float* xhat2, const float* rstd2,
                          float* dpre2, float* dz, float* dpre1, float* dctx, float* dx, float* dgamma1, float* dbeta1,
-                         float* dgamma2, float* dbeta2, int M, int d_model, int n_heads, int d_ff, int act, void* stream);
+                         float* dgamma2, float* dbeta2, int M, int d_model, int n_heads, int d_ff, int act, float* dskip,
+                         float drop_p, const void* rng_state, int drop_site, void* stream);
+/* drop_p > 0: the forward's masks are regenerated (same rng_state step, same drop_site); dpre2 / dpre1 then hold the gradients
+ * BEHIND the conv2-output / attention-output dropout (the weight-gradient operands) and `dskip` (M, 128) receives the unmasked
+ * d pre-norm-1, which is what the next launch takes as `skip`. */
 
 /* ---- small tensor plumbing of the hot path as single launches (csrc/smallops.hip) ---------------------------
  * rf_median_windows: y (B,target,C) = lower median (torch.median: NaN wins) of the consecutive windows of T / target

@@ -91,8 +91,8 @@ SIGNATURES = {
     "rf_adamw_clip": [_P, _P, _P, _P, _L, _P, _I, _F, _F, _F, _F, _F, _F, _I, _F, _P],
     "rf_adamw_clip_dev": [_P, _P, _P, _P, _L, _P, _I, _P, _I, _P],
     "rf_enclayer_tile_supported": [_I, _I, _I],
-    "rf_enclayer_tile_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
-    "rf_enclayer_tile_bwd": [_P] * 19 + [_I, _I, _I, _I, _I, _P],
+    "rf_enclayer_tile_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _I, _P],
+    "rf_enclayer_tile_bwd": [_P] * 19 + [_I, _I, _I, _I, _I, _P, _F, _P, _I, _P],
     "rf_median_windows": [_P, _P, _I, _I, _I, _I, _P],
     "rf_motion_diff": [_P, _P, _I, _I, _I, _F, _F, _P],
     "rf_time_table": [_P, _P, _P, _I, _I, _P],

@@ -27,9 +27,11 @@ struct EncTileP {
   float *xhat1, *rstd1, *x1, *z, *h, *xhat2, *rstd2;  // training saves (M, width) or null
   int M, F, act;
   float eps;
+  DropCfg drop;    // nn.Dropout of the layer in train mode (cross_modal_transformer.py:295,298,299); state == null: off
+  int drop_site;   // sites drop_site + {0: attention output, 1: hidden activation, 2: conv2 output}, element = row * cols + col
 };
 
-template <int RT, bool SAVE>
+template <int RT, bool SAVE, bool DROP>
 __global__ __launch_bounds__(SL_NT) void enc_tile_fwd_kernel(const EncTileP p) {
   constexpr int LP = 16 * RT, TB = 320;  // TB: floats of one staged 16 x 16 tile (pitch 20)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -47,6 +49,13 @@ __global__ __launch_bounds__(SL_NT) void enc_tile_fwd_kernel(const EncTileP p) {
   const int L = (int)min((long)LP, (long)p.M - row0);  // valid rows of this tile
   float* sc_f = stage_base + wave * RT * TB;
   const PackOff po = pack_offsets(F);
+  uint2 dkey = make_uint2(0, 0);
+  uint32_t dstep = 0;
+  if constexpr (DROP) {
+    const unsigned long long sd = p.drop.state->seed;
+    dkey = make_uint2((uint32_t)sd, (uint32_t)(sd >> 32));
+    dstep = (uint32_t)p.drop.state->step;
+  }
 
   // one 16 x 16 fp32 tile set (RT tiles, accumulator layout) -> global rows, 16-B stores through the wave's staging patch
   auto store_tiles = [&](const f32x4 (&v)[RT], float* g, int ld) {
@@ -101,8 +110,14 @@ __global__ __launch_bounds__(SL_NT) void enc_tile_fwd_kernel(const EncTileP p) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * SL_XP + kk * 32 + fq * 8), wfo[kk], acc, 0, 0, 0);
+        if constexpr (DROP) {
+          const f32x4 f = drop_factors(p.drop, dkey, dstep, (uint32_t)p.drop_site, row0 + rt * 16, SL_D, col, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[rt][r] = acc[r] + bo + xres[rt][r];
+          for (int r = 0; r < 4; ++r) v[rt][r] = (acc[r] + bo) * f[r] + xres[rt][r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[rt][r] = acc[r] + bo + xres[rt][r];
+        }
       }
       stack_layer_norm<RT>(v, SAVE ? p.rstd1 + row0 : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the ctx reads)
       if (SAVE) store_tiles(v, p.xhat1 + row0 * SL_D + wave * 16, SL_D);
@@ -152,6 +167,14 @@ __global__ __launch_bounds__(SL_NT) void enc_tile_fwd_kernel(const EncTileP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) hh[rt][r] = p.act == RF_ACT_RELU ? fmaxf(zz[rt][r], 0.f) : zz[rt][r];
         }
+        if constexpr (DROP) {  // conv2 consumes (and the backward needs) the dropped activation
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const f32x4 f = drop_factors(p.drop, dkey, dstep, (uint32_t)(p.drop_site + 1), row0 + rt * 16, F, col, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hh[rt][r] *= f[r];
+          }
+        }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -181,10 +204,19 @@ __global__ __launch_bounds__(SL_NT) void enc_tile_fwd_kernel(const EncTileP p) {
             v[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(hb + (rt * 16 + fr) * HP + kk * 32 + fq * 8), wf2[kk], v[rt], 0, 0, 0);
         }
       }
+      if constexpr (DROP) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < RT; ++rt) {
+          const f32x4 f = drop_factors(p.drop, dkey, dstep, (uint32_t)(p.drop_site + 2), row0 + rt * 16, SL_D, col, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[rt][r] += b2 + xres[rt][r];
+          for (int r = 0; r < 4; ++r) v[rt][r] = (v[rt][r] + b2) * f[r] + xres[rt][r];
+        }
+      } else {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[rt][r] += b2 + xres[rt][r];
+      }
       stack_layer_norm<RT>(v, SAVE ? p.rstd2 + row0 : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the hb / xb reads)
       if (SAVE) store_tiles(v, p.xhat2 + row0 * SL_D + wave * 16, SL_D);
 #pragma unroll
@@ -275,9 +307,13 @@ struct EncTileBwdP {
   float *dpre2, *dz, *dpre1, *dctx, *dx;
   float *dg1, *db1, *dg2, *db2;
   int M, F, act;
+  float* dskip;    // DROP: (M, 128) the UNMASKED d pre-norm-1 (the next launch's skip gradient; dpre1 then holds the gradient
+                   // behind the attention-output dropout, what the out-projection's weight gradient consumes)
+  DropCfg drop;    // the forward's masks are regenerated from (seed, step, site, element); state == null: off
+  int drop_site;
 };
 
-template <int RT>
+template <int RT, bool DROP>
 __global__ __launch_bounds__(SL_NT) void enc_tile_bwd_kernel(const EncTileBwdP p) {
   constexpr int LP = 16 * RT, QP = 3 * SL_D + 8, TB = 320;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -296,6 +332,15 @@ __global__ __launch_bounds__(SL_NT) void enc_tile_bwd_kernel(const EncTileBwdP p
   const int L = (int)min((long)LP, (long)p.M - row0);
   float* sc_f = stage_base + wave * RT * TB;
   const BwdPackOff po = bwd_pack_offsets(F);
+  uint2 dkey = make_uint2(0, 0);
+  uint32_t dstep = 0;
+  if constexpr (DROP) {
+    if (p.drop.state) {  // (the projection-only launch of a dropout stack carries no state)
+      const unsigned long long sd = p.drop.state->seed;
+      dkey = make_uint2((uint32_t)sd, (uint32_t)(sd >> 32));
+      dstep = (uint32_t)p.drop.state->step;
+    }
+  }
 
   auto store_tiles = [&](const f32x4 (&v)[RT], float* g, int ld) {
 #pragma unroll
@@ -365,8 +410,14 @@ __global__ __launch_bounds__(SL_NT) void enc_tile_bwd_kernel(const EncTileBwdP p
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     res[rt] = dyres[rt];
+    f32x4 m = dyres[rt];
+    if constexpr (DROP) {  // the conv pair sees the gradient through the conv2-output dropout; the skip does not
+      const f32x4 f = drop_factors(p.drop, dkey, dstep, (uint32_t)(p.drop_site + 2), row0 + rt * 16, SL_D, col, lane);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)dyres[rt][r];
+      for (int r = 0; r < 4; ++r) m[r] *= f[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)m[r];
   }
   __syncthreads();  // d pre-norm-2 image complete
   save_image(xb, SL_XP, SL_D, p.dpre2 + row0 * SL_D, L, tid);
@@ -402,6 +453,14 @@ __global__ __launch_bounds__(SL_NT) void enc_tile_bwd_kernel(const EncTileBwdP p
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[rt][r] = zz[rt][r] > 0.f ? acc[rt][r] : 0.f;
       }
+      if constexpr (DROP) {  // hidden-activation dropout
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const f32x4 f = drop_factors(p.drop, dkey, dstep, (uint32_t)(p.drop_site + 1), row0 + rt * 16, F, ct * 16 + fr, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[rt][r] *= f[r];
+        }
+      }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -430,11 +489,20 @@ __global__ __launch_bounds__(SL_NT) void enc_tile_bwd_kernel(const EncTileBwdP p
   }
   stack_ln_bwd<RT>(dyres, p.xhat1 + row0 * SL_D + col, p.rstd1 + row0, vec[col], p.dg1 + col, p.db1 + col, L, part, stat, wave,
                    lane);  // (its barriers fence the xb reads of the dz phase)
+  if constexpr (DROP) {
+    store_tiles(dyres, p.dskip + row0 * SL_D + wave * 16, SL_D);  // the skip carries the unmasked gradient
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {  // attention-output dropout
+      const f32x4 f = drop_factors(p.drop, dkey, dstep, (uint32_t)p.drop_site, row0 + rt * 16, SL_D, col, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dyres[rt][r] *= f[r];
+    }
+  }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)dyres[rt][r];
-  store_tiles(dyres, p.dpre1 + row0 * SL_D + wave * 16, SL_D);  // fp32: also the next launch's skip gradient
+  store_tiles(dyres, p.dpre1 + row0 * SL_D + wave * 16, SL_D);  // fp32 (without dropout: also the next launch's skip gradient)
   __syncthreads();  // d pre-norm-1 image complete
 
   // ================= out-projection^T: gradient of the attention output =================
@@ -490,7 +558,7 @@ extern "C" int rf_enclayer_tile_supported(int d_model, int n_heads, int d_ff) {
 extern "C" int rf_enclayer_tile_fwd(const float* ctx, const float* x, const void* wpack, const void* wpack_next, float* y,
                                     float* qkv_next, float* xhat1, float* rstd1, float* x1, float* z, float* h, float* xhat2,
                                     float* rstd2, int M, int d_model, int n_heads, int d_ff, int act, int save, float eps,
-                                    void* stream) {
+                                    float drop_p, const void* rng_state, int drop_site, void* stream) {
   RF_REQUIRE(x && M > 0 && (ctx || wpack_next) && rf_enclayer_tile_supported(d_model, n_heads, d_ff));
   RF_REQUIRE(!ctx || (wpack && y && al16(ctx) && al16(y) && al16(wpack)));
   RF_REQUIRE(!wpack_next || (qkv_next && al16(qkv_next) && al16(wpack_next)));
@@ -500,26 +568,33 @@ extern "C" int rf_enclayer_tile_fwd(const float* ctx, const float* x, const void
   p.ctx = ctx; p.x = x; p.wl = static_cast<const unsigned char*>(wpack); p.wnext = static_cast<const unsigned char*>(wpack_next);
   p.y = y; p.qkv_next = qkv_next; p.xhat1 = xhat1; p.rstd1 = rstd1; p.x1 = x1; p.z = z; p.h = h; p.xhat2 = xhat2; p.rstd2 = rstd2;
   p.M = M; p.F = d_ff; p.act = act; p.eps = eps;
+  RF_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state));
+  p.drop = make_drop_cfg(ctx ? rng_state : nullptr, nullptr, 0, drop_p);  // (the projection-only launch has no dropout site)
+  p.drop_site = drop_site;
   const hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool sv = save && ctx;
-#define RF_ET_GO(RT_, SAVE_)                                                                                          \
+  const bool sv = save && ctx, drop = p.drop.state != nullptr;
+#define RF_ET_GO(RT_, SAVE_, DROP_)                                                                                   \
   do {                                                                                                                \
     const size_t lds = tile_lds_bytes<RT_>(d_ff);                                                                     \
     static bool attr = false;                                                                                         \
     if (!attr) {                                                                                                      \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_tile_fwd_kernel<RT_, SAVE_>),                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_tile_fwd_kernel<RT_, SAVE_, DROP_>),                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                               \
       attr = true;                                                                                                    \
     }                                                                                                                 \
-    RF_LAUNCH((enc_tile_fwd_kernel<RT_, SAVE_>), dim3((M + 16 * RT_ - 1) / (16 * RT_)), dim3(SL_NT), lds, st, p);     \
+    RF_LAUNCH((enc_tile_fwd_kernel<RT_, SAVE_, DROP_>), dim3((M + 16 * RT_ - 1) / (16 * RT_)), dim3(SL_NT), lds, st, p); \
   } while (0)
-  if (M <= tile16_max_rows()) {
-    if (sv) RF_ET_GO(1, true); else RF_ET_GO(1, false);
-  } else if (M <= 4096) {
-    if (sv) RF_ET_GO(2, true); else RF_ET_GO(2, false);
-  } else {
-    if (sv) RF_ET_GO(3, true); else RF_ET_GO(3, false);
-  }
+#define RF_ET_PICK(RT_)                                                                 \
+  do {                                                                                  \
+    if (drop && sv) RF_ET_GO(RT_, true, true);                                          \
+    else if (drop) RF_ET_GO(RT_, false, true);  /* train-mode forward under no_grad (the target-side pass) */ \
+    else if (sv) RF_ET_GO(RT_, true, false);                                            \
+    else RF_ET_GO(RT_, false, false);                                                   \
+  } while (0)
+  if (M <= tile16_max_rows()) RF_ET_PICK(1);
+  else if (M <= 4096) RF_ET_PICK(2);
+  else RF_ET_PICK(3);
+#undef RF_ET_PICK
 #undef RF_ET_GO
   RF_CHECK_LAUNCH();
   return RF_OK;
@@ -531,7 +606,8 @@ extern "C" int rf_enclayer_tile_bwd(const float* dy, const float* dqkv, const fl
                                     const void* wpack_next_t, const float* xhat1, const float* rstd1, const float* zsrc,
                                     const float* xhat2, const float* rstd2, float* dpre2, float* dz, float* dpre1, float* dctx,
                                     float* dx, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, int M, int d_model,
-                                    int n_heads, int d_ff, int act, void* stream) {
+                                    int n_heads, int d_ff, int act, float* dskip, float drop_p, const void* rng_state,
+                                    int drop_site, void* stream) {
   RF_REQUIRE(M > 0 && rf_enclayer_tile_supported(d_model, n_heads, d_ff));
   RF_REQUIRE((dqkv != nullptr) != (dy != nullptr));
   RF_REQUIRE(!dqkv || (skip && wpack_next_t && al16(dqkv) && al16(skip) && al16(wpack_next_t)));
@@ -545,20 +621,27 @@ extern "C" int rf_enclayer_tile_bwd(const float* dy, const float* dqkv, const fl
   p.dpre2 = dpre2; p.dz = dz; p.dpre1 = dpre1; p.dctx = dctx; p.dx = dx;
   p.dg1 = dgamma1; p.db1 = dbeta1; p.dg2 = dgamma2; p.db2 = dbeta2;
   p.M = M; p.F = d_ff; p.act = act;
+  RF_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state));
+  p.drop = make_drop_cfg(wpack_t ? rng_state : nullptr, nullptr, 0, drop_p);
+  p.drop_site = drop_site; p.dskip = dskip;
+  const bool drop = p.drop.state != nullptr;
+  RF_REQUIRE(!drop || (dskip && al16(dskip)));
   const hipStream_t st = static_cast<hipStream_t>(stream);
-#define RF_ETB_GO(RT_)                                                                                               \
+#define RF_ETB_GO(RT_, DROP_)                                                                                        \
   do {                                                                                                               \
     static bool attr = false;                                                                                        \
     if (!attr) {                                                                                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_tile_bwd_kernel<RT_>),                             \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_tile_bwd_kernel<RT_, DROP_>),                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                              \
       attr = true;                                                                                                   \
     }                                                                                                                \
-    RF_LAUNCH((enc_tile_bwd_kernel<RT_>), dim3((M + 16 * RT_ - 1) / (16 * RT_)), dim3(SL_NT), tile_bwd_lds_bytes<RT_>(d_ff), st, p); \
+    RF_LAUNCH((enc_tile_bwd_kernel<RT_, DROP_>), dim3((M + 16 * RT_ - 1) / (16 * RT_)), dim3(SL_NT), tile_bwd_lds_bytes<RT_>(d_ff), st, p); \
   } while (0)
-  if (M <= tile16_max_rows()) RF_ETB_GO(1);
-  else if (M <= 4096) RF_ETB_GO(2);
-  else RF_ETB_GO(3);
+#define RF_ETB_PICK(RT_) do { if (drop) RF_ETB_GO(RT_, true); else RF_ETB_GO(RT_, false); } while (0)
+  if (M <= tile16_max_rows()) RF_ETB_PICK(1);
+  else if (M <= 4096) RF_ETB_PICK(2);
+  else RF_ETB_PICK(3);
+#undef RF_ETB_PICK
 #undef RF_ETB_GO
   RF_CHECK_LAUNCH();
   return RF_OK;

@@ -2009,7 +2009,7 @@ class _TiledStack(torch.autograd.Function):
     layer-by-layer kernels on the saved tensors (``_stack_backward_layerwise``)."""
 
     @staticmethod
-    def forward(ctx, x, stack, idx_list, idx_group, save):
+    def forward(ctx, x, stack, idx_list, idx_group, save, drop_p=0.0):
         B, L, D = x.shape
         M, H, E = B * L, 8, 16
         x2 = x.reshape(M, D).contiguous()
@@ -2029,6 +2029,15 @@ class _TiledStack(torch.autograd.Function):
         lib = _hip.lib()
         wp, stride = stack.wpack.data_ptr(), stack.stride
         slab = (lambda name, li: ptr(sv[name][li]) if save else None)
+        site0 = 0
+        if drop_p > 0.0:  # three dropout sites per layer, numbered in the reference's call order (as _SeqStack does)
+            site0 = RNG.site
+            RNG.site += 3 * n
+            if RNG.record is not None:
+                for li in range(n):
+                    for k, cols in enumerate((D, F_, D)):
+                        RNG.record.append(RNG.materialise(site0 + 3 * li + k, (B, L, cols), drop_p, x.device))
+        rng = ptr(RNG.state(dev)) if drop_p > 0.0 else None
 
         def tile(ctx_t, x_t, li, y_t, qkv_t):
             """row-tile launch of layer li (ctx_t None: projection only), q | k | v of layer li + 1 -> qkv_t (None: none)"""
@@ -2039,11 +2048,12 @@ class _TiledStack(torch.autograd.Function):
                                            (slab("z", li) if gelu else None) if ctx_t is not None else None,
                                            slab("h", li) if ctx_t is not None else None, slab("xhat2", li) if ctx_t is not None else None,
                                            slab("rstd2", li) if ctx_t is not None else None, M, D, H, F_, ACT[lay0.act],
-                                           1 if (save and ctx_t is not None) else 0, lay0.norm1.eps, _stream()), "rf_enclayer_tile_fwd")
+                                           1 if (save and ctx_t is not None) else 0, lay0.norm1.eps, float(drop_p), rng,
+                                           site0 + 3 * li, _stream()), "rf_enclayer_tile_fwd")
 
         qkv = sv["qkv"][0]
         check(lib.rf_enclayer_tile_fwd(None, ptr(x2), None, wp, None, ptr(qkv), None, None, None, None, None, None, None, M, D, H,
-                                       F_, ACT[lay0.act], 0, lay0.norm1.eps, _stream()), "rf_enclayer_tile_fwd(projection)")
+                                       F_, ACT[lay0.act], 0, lay0.norm1.eps, 0.0, None, 0, _stream()), "rf_enclayer_tile_fwd(projection)")
         x_in = x2
         for li in range(n):
             idx = idx_list[li]
@@ -2083,17 +2093,19 @@ class _TiledStack(torch.autograd.Function):
                             4.0 * M * (D * 3 + (3 * D if qkv_next is not None else 0) + ((4 * D + 2 * F_) if save else 0)))
             x_in, qkv = y_t, qkv_next
         if save:
-            ctx.sv, ctx.stack, ctx.x2, ctx.dims = sv, stack, x2, (B, L, F_, n_top)
+            ctx.sv, ctx.stack, ctx.x2, ctx.dims, ctx.drop = sv, stack, x2, (B, L, F_, n_top), (float(drop_p), site0)
         return x_in.view(B, L, D)
 
     @staticmethod
     def backward(ctx, dy):
         sv, stack, x2, (B, L, F_, n_top) = ctx.sv, ctx.stack, ctx.x2, ctx.dims
+        drop_p, site0 = ctx.drop
         M, D, H, E = B * L, 128, 8, 16
         dy2 = dy.reshape(M, D).contiguous()
         ctx.sv = None
         if not (TILED_STACK_BWD and not DETERMINISTIC and stack.wpack_bwd is not None):
-            return _stack_backward_layerwise(sv, stack, x2, dy2, B, L, F_, n_top, 0.0, 0).view(B, L, D), None, None, None, None
+            return (_stack_backward_layerwise(sv, stack, x2, dy2, B, L, F_, n_top, drop_p, site0).view(B, L, D), None, None, None,
+                    None, None)
         # ---- per layer: ONE row-tile launch (the next layer's q | k | v projection^T + skip, norm2 backward, conv pair^T, norm1
         # backward, out-projection^T) and ONE attention-backward launch; the weight gradients follow as grouped GEMMs ----
         lib, dev, n = _hip.lib(), dy2.device, len(stack.layers)
@@ -2102,6 +2114,9 @@ class _TiledStack(torch.autograd.Function):
              "dqkv": torch.empty(n, M, 3 * D, **f32)}
         dctx = torch.empty(M, D, **f32)
         dx = torch.empty(M, D, **f32)
+        # with dropout the skip gradient (unmasked d pre-norm-1) and the out-projection's weight-gradient operand (masked) differ
+        skips = torch.empty(n, M, D, **f32) if drop_p > 0.0 else g["dpre1"]
+        rng = ptr(RNG.state(dev)) if drop_p > 0.0 else None
         wt, st = stack.wpack_bwd.data_ptr(), stack.stride_bwd
         act = ACT[stack.layers[0].act]
         slots = [(_slot(l.norm1.weight), _slot(l.norm1.bias), _slot(l.norm2.weight), _slot(l.norm2.bias)) for l in stack.layers]
@@ -2112,10 +2127,12 @@ class _TiledStack(torch.autograd.Function):
             g1, b1, g2, b2 = slots[li]
             ev = PROFILE.begin() if PROFILE.on else None
             check(lib.rf_enclayer_tile_bwd(ptr(dy2) if last else None, None if last else ptr(g["dqkv"][li + 1]),
-                                           None if last else ptr(g["dpre1"][li + 1]), wt + li * st, None if last else wt + (li + 1) * st,
+                                           None if last else ptr(skips[li + 1]), wt + li * st, None if last else wt + (li + 1) * st,
                                            ptr(sv["xhat1"][li]), ptr(sv["rstd1"][li]), ptr(zsrc[li]), ptr(sv["xhat2"][li]),
                                            ptr(sv["rstd2"][li]), ptr(g["dpre2"][li]), ptr(g["dz"][li]), ptr(g["dpre1"][li]), ptr(dctx),
-                                           None, ptr(g1), ptr(b1), ptr(g2), ptr(b2), M, D, H, F_, act, _stream()), "rf_enclayer_tile_bwd")
+                                           None, ptr(g1), ptr(b1), ptr(g2), ptr(b2), M, D, H, F_, act,
+                                           ptr(skips[li]) if drop_p > 0.0 else None, float(drop_p), rng, site0 + 3 * li, _stream()),
+                  "rf_enclayer_tile_bwd")
             if ev is not None:
                 PROFILE.end(f"enc_tile_bwd_kernel<{2 if M <= 4096 else 3}>", ev, 2.0 * M * D * (D + 2 * F_ + (0 if last else 3 * D)),
                             4.0 * M * (D * 6 + 2 * F_ + (0 if last else 4 * D)))
@@ -2128,8 +2145,8 @@ class _TiledStack(torch.autograd.Function):
             if ev is not None:
                 PROFILE.end("attn_bwd_kernel<true>", ev, B * H * 10.0 * n_top * L * E, 4.0 * B * H * E * 8 * L,
                             replay=lambda fa=bargs, k=(qkv, dq, dctx, sv): lib.rf_attn_bwd(*fa, _stream()))
-        check(lib.rf_enclayer_tile_bwd(None, ptr(g["dqkv"][0]), ptr(g["dpre1"][0]), None, wt, None, None, None, None, None, None, None,
-                                       None, None, ptr(dx), None, None, None, None, M, D, H, F_, act, _stream()),
+        check(lib.rf_enclayer_tile_bwd(None, ptr(g["dqkv"][0]), ptr(skips[0]), None, wt, None, None, None, None, None, None, None,
+                                       None, None, ptr(dx), None, None, None, None, M, D, H, F_, act, None, 0.0, None, 0, _stream()),
               "rf_enclayer_tile_bwd(projection)")
         for li in reversed(range(n)):
             lay = stack.layers[li]
@@ -2143,4 +2160,4 @@ class _TiledStack(torch.autograd.Function):
                 if _weight_grad(gy, xin, into=w_into, bias_into=b_into) is not True:
                     colsum(gy, into=b_into)
                 _wrote(w_into, b_into)
-        return dx.view(B, L, D), None, None, None, None
+        return dx.view(B, L, D), None, None, None, None, None

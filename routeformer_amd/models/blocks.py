@@ -493,7 +493,7 @@ class Encoder(nn.Module):
         tiled = False
         if not K.seqstack_supported(L, D, 8, lay0.conv1.weight.shape[0], sample_k, n_top):
             # longer sequences (the fusion encoder's L = 160 / 320): attention launch + row-tile launch per layer
-            tiled = drop_p == 0.0 and K.tiled_stack_supported(L, D, 8, lay0.conv1.weight.shape[0])
+            tiled = K.tiled_stack_supported(L, D, 8, lay0.conv1.weight.shape[0])
             if not tiled:
                 return None
         need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in st._params()))
@@ -512,7 +512,7 @@ class Encoder(nn.Module):
         elif st.wpack is None:
             st.refresh(force=True)
         if tiled:
-            return K._TiledStack.apply(x, st, idx_list, idx_group or B, need_grad)
+            return K._TiledStack.apply(x, st, idx_list, idx_group or B, need_grad, drop_p)
         return K._SeqStack.apply(x, st, idx_list, idx_group or B, need_grad, drop_p)
 
     def set_output_attention(self, on: bool = True):

@@ -1037,8 +1037,10 @@ def test_token_cache_in_model_and_engine():
     assert all(abs(a - b) < 5e-4 * max(1.0, abs(a)) for a, b in zip(losses["eager"], losses["graph_cached"])), losses
 
 
-def test_fused_stack_dropout_vs_oracle_and_layerwise():
-    """Dropout INSIDE the fused encoder stack (train mode, p = 0.2): the Philox masks the kernel drew are materialised
+@pytest.mark.parametrize("B,L", [(6, 65), (3, 160), (2, 97)])
+def test_fused_stack_dropout_vs_oracle_and_layerwise(B, L):
+    """(L = 65: the one-workgroup-per-sequence stack; L = 160 / 97: the row-tiled stack, csrc/enclayer.hip.)
+    Dropout INSIDE the fused encoder stack (train mode, p = 0.2): the Philox masks the kernel drew are materialised
     (``K.RNG.record``) and handed to the CPU oracle -- outputs must agree (bf16 tolerance, the oracle's selections
     imposed); and the backward (layer-by-layer kernels regenerating the same masks from (seed, step, site)) must agree
     with the layer-by-layer forward + backward run on the same masks and selections."""
@@ -1047,7 +1049,7 @@ def test_fused_stack_dropout_vs_oracle_and_layerwise():
     from routeformer_amd.engine import GradReducer
     from routeformer_amd.models.blocks import SAMPLER, PerceiveEncoder
     K.set_precision("bf16")
-    P, B, L = 0.2, 6, 65
+    P = 0.2
     g = torch.Generator().manual_seed(3)
     x_cpu = torch.randn(B, L, 240, generator=g)
     w_cpu = torch.randn(B, 1, 64, generator=g)
