@@ -2,6 +2,8 @@
 // the k=3 token/distil convolutions, and the Informer distilling tail BatchNorm1d -> ELU -> MaxPool1d.
 // All are HBM/latency-bound streaming kernels: channels innermost, one wave per row where a row
 // reduction is needed (wave-shuffle reductions), coalesced 256-B accesses per wave-instruction.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -189,12 +191,12 @@ __global__ __launch_bounds__(256) void unfold3_kernel(const float* __restrict__ 
 
 __global__ void fold3_kernel(const float* __restrict__ dcols, float* __restrict__ dx, int B, int L, int C, int pad,
                              int Lout, int ld) {
-  const long total = (long)B * L * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const long r = i / C;
-    const int l = (int)(r % L);
-    const int b = (int)(r / L);
+  const int total = B * L * C;  // (< 2^31, checked by the caller: 32-bit index arithmetic, see unfold3_kernel)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const int r = i / C;
+    const int l = r % L;
+    const int b = r / L;
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -501,7 +503,7 @@ extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float*
     // one row per wave until 512 workgroups (M <= 560 layers: 80-140 workgroups instead of 20-35 -- these
     // launches are latency-bound), then grid-stride
     int blocks = (rows + LN_WAVES - 1) / LN_WAVES;
-    blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
+    blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);  // (128 .. 1 024 measured: no difference)
     RF_LN_DISPATCH(layernorm_bwd_kernel, cols, dim3(blocks), dim3(256), 0, st, dy, xhat, rstd, gamma, dx,
                    static_cast<float*>(nullptr), rows, cols, dgamma, dbeta);
     RF_CHECK_LAUNCH();
@@ -534,6 +536,7 @@ extern "C" int rf_unfold3_circular(const float* x, float* cols, int B, int L, in
 
 extern "C" int rf_fold3_circular_ld(const float* dcols, float* dx, int B, int L, int C, int pad, int ld, void* stream) {
   RF_REQUIRE(dcols && dx && B > 0 && L > 0 && C > 0 && pad >= 1 && pad <= 2 && ld >= 3 * C);
+  RF_REQUIRE((long)B * L * C < (1L << 31) - (4096L * 256));
   const int Lout = L + 2 * pad - 2;
   RF_LAUNCH(fold3_kernel, dim3(grid_for((long)B * L * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      dcols, dx, B, L, C, pad, Lout, ld);
