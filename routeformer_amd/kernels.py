@@ -1766,8 +1766,8 @@ def seqstack_pack_bytes(d_ff: int) -> int:
 
 # bf16 storage for what only the weight-gradient GEMMs read again (fused per-sequence stacks, bf16 mode): ctx / x1 / h of
 # the forward and the four `dy` slabs of the backward.  Lossless with respect to the arithmetic (they are bf16 MFMA operands
-# in those GEMMs, rounded the same way) and half the bytes: 601 -> 447 MB written by the camera-token stack's forward,
-# 732 -> 550 MB moved by its backward, 613 -> 330 MB read by its weight-gradient group.
+# in those GEMMs, rounded the same way) and half the bytes (PMC): 645 -> 569 MB moved by the camera-token stack's forward,
+# 732 -> 553 MB by its backward, 355 -> 281 MB per weight-gradient launch.
 BF16_SAVES = os.environ.get("RF_BF16_SAVES", "1") != "0"
 
 
