@@ -508,6 +508,40 @@ int rf_enclayer_tile_bwd(const float* dy, const float* dqkv, const float* skip, 
  * BEHIND the conv2-output / attention-output dropout (the weight-gradient operands) and `dskip` (M, 128) receives the unmasked
  * d pre-norm-1, which is what the next launch takes as `skip`. */
 
+/* ---- row-local chains of a d_model = 64 decoder layer (csrc/rowchain.hip) -- the gaze-video PerceiveDecoder
+ * (cross_modal_transformer.py:304-365,436-476).  ONE launch takes an attention output `a` through
+ *     out-projection + residual x -> LayerNorm  => x1   [-> conv1 -> act -> conv2 + residual x1 -> LayerNorm => y]
+ *     [-> projection of the result (the next attention launch's q, or q | k | v) => proj]
+ * on 16 / 32-row tiles of the flattened (M, 64) activations: a decoder layer is self attention, chain, k | v projection of
+ * the memory, cross attention, chain + FFN + next projection -- 5 launches instead of 13.  Weights are the fp32 masters
+ * (bf16 MFMA fragments are formed from them in registers); saves (xhat / rstd of the norms, z, h) are what rf_rowchain_bwd
+ * and the weight-gradient GEMMs consume.  rf_rowchain_bwd: gradient of the chain output (`dyin`, from other consumers of
+ * it, and / or `dproj` through the projection) -> [LayerNorm-2 backward -> conv2^T -> act' -> conv1^T + skip] -> LayerNorm-1
+ * backward -> out-projection^T: writes da (gradient of `a`), dpre1 (= gradient of the residual input x, and the dy operand
+ * of the out-projection's weight gradient), dpre2 / dz (dy operands of conv2 / conv1), ACCUMULATES dgamma / dbeta (atomics). */
+typedef struct RfRowChain {
+  const float *a, *x;
+  const float *wo, *bo, *g1, *be1;
+  const float *w1, *b1, *w2, *b2, *g2, *be2; /* w1 == NULL: no FFN block */
+  const float *wp, *bp;                      /* wp == NULL: no projection; bp may be NULL */
+  float *x1, *y, *proj;
+  float *xhat1, *rstd1, *z, *h, *xhat2, *rstd2; /* training saves, each may be NULL */
+  int d_model, d_ff, n_proj, act;
+  float eps;
+  int pad;
+} RfRowChain;
+typedef struct RfRowChainBwd {
+  const float *dproj, *dyin, *wp;
+  const float *w1, *w2, *g2, *xhat2, *rstd2, *zsrc; /* zsrc = z (GELU) or h (ReLU) */
+  float *dpre2, *dz, *dg2, *db2;
+  const float *wo, *g1, *xhat1, *rstd1;
+  float *dpre1, *da, *dg1, *db1;
+  int d_model, d_ff, n_proj, act;
+} RfRowChainBwd;
+int rf_rowchain_supported(int d_model, int d_ff, int n_proj);
+int rf_rowchain_fwd(const RfRowChain* chain, int M, void* stream);
+int rf_rowchain_bwd(const RfRowChainBwd* chain, int M, void* stream);
+
 /* ---- small tensor plumbing of the hot path as single launches (csrc/smallops.hip) ---------------------------
  * rf_median_windows: y (B,target,C) = lower median (torch.median: NaN wins) of the consecutive windows of T / target
  *   samples of x (B,T,C) -- `median_downsampler`, routeformer/utils/filter.py:5-43 (gaze 200 Hz -> seq_len).

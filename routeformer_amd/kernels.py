@@ -1332,6 +1332,117 @@ def attention_map(a, b, offs, dims, mode: int, tops, scale: Optional[float] = No
         return full
 
 
+ROWCHAIN = os.environ.get("RF_ROWCHAIN", "1") != "0"  # row-local chains of the d_model = 64 decoder as single launches
+
+
+def rowchain_supported(d_model: int, d_ff: int, n_proj: int) -> bool:
+    return ROWCHAIN and _PRECISION == 1 and bool(_hip.lib().rf_rowchain_supported(d_model, d_ff, n_proj))
+
+
+class _RowChain(torch.autograd.Function):
+    """csrc/rowchain.hip: a (attention output) -> out-projection + residual x -> LayerNorm [-> conv FFN + residual ->
+    LayerNorm] [-> projection for the next attention launch], one launch; backward one launch + the weight-gradient GEMMs
+    (queued).  Only ``a`` and ``x`` are differentiable INPUTS: the parameters are plain arguments whose gradients go to
+    the engine's sinks (the caller checks that every one of them has a slot)."""
+
+    @staticmethod
+    def forward(ctx, a, x, lin, norm1, ffn, proj, act, eps, save):
+        """lin = (Wo, bo); norm1 = (gamma, beta); ffn = None | (W1 (F, D[, 1]), b1, W2 (D, F[, 1]), b2, gamma, beta);
+        proj = None | (Wp (NP, D), bp, grad slot of Wp, grad slot of bp).  -> (x1 or y, proj or None)."""
+        D = a.shape[-1]
+        M = a.numel() // D
+        a2, x2 = a.reshape(M, D).contiguous(), x.reshape(M, D).contiguous()
+        dev = a.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        F_ = ffn[0].shape[0] if ffn is not None else 0
+        NP = proj[0].shape[0] if proj is not None else 0
+        x1 = torch.empty(M, D, **f32)
+        y = torch.empty(M, D, **f32) if ffn is not None else None
+        pr = torch.empty(M, NP, **f32) if proj is not None else None
+        sv = {}
+        if save:
+            sv["xhat1"], sv["rstd1"] = torch.empty(M, D, **f32), torch.empty(M, **f32)
+            if ffn is not None:
+                sv["xhat2"], sv["rstd2"], sv["h"] = torch.empty(M, D, **f32), torch.empty(M, **f32), torch.empty(M, F_, **f32)
+                if act == "gelu":
+                    sv["z"] = torch.empty(M, F_, **f32)
+        c = _hip.RowChain()
+        c.a, c.x, c.wo, c.bo, c.g1, c.be1 = ptr(a2), ptr(x2), ptr(lin[0]), ptr(lin[1]), ptr(norm1[0]), ptr(norm1[1])
+        if ffn is not None:
+            c.w1, c.b1, c.w2, c.b2, c.g2, c.be2 = (ptr(t) for t in ffn)
+        if proj is not None:
+            c.wp, c.bp = ptr(proj[0]), ptr(proj[1])
+        c.x1, c.y, c.proj = ptr(x1), ptr(y), ptr(pr)
+        for name in ("xhat1", "rstd1", "z", "h", "xhat2", "rstd2"):
+            setattr(c, name, ptr(sv.get(name)))
+        c.d_model, c.d_ff, c.n_proj, c.act, c.eps = D, F_, NP, ACT[act], eps
+        import ctypes
+        ev = PROFILE.begin() if PROFILE.on else None
+        check(_hip.lib().rf_rowchain_fwd(ctypes.byref(c), M, _stream()), "rf_rowchain_fwd")
+        if ev is not None:
+            keep = (a2, x2, lin, norm1, ffn, proj, x1, y, pr, sv, c)
+            PROFILE.end(f"rowchain_fwd_kernel<{1 if M <= 1024 else 2}>", ev, 2.0 * M * D * (D + 2 * F_ + NP),
+                        4.0 * M * (D * (3 + (ffn is not None)) + NP + (len(sv) and (2 * D + 2 * F_))),
+                        replay=lambda cc=c, k=keep: _hip.lib().rf_rowchain_fwd(ctypes.byref(cc), M, _stream()))
+        out = y if ffn is not None else x1
+        if save:
+            ctx.sv, ctx.a2, ctx.x1, ctx.out = sv, a2, x1, out
+            ctx.params = (lin, norm1, ffn, proj)
+            ctx.cfg = (M, D, F_, NP, act, a.shape, x.shape)
+        return out.view(x.shape), (pr.view(*x.shape[:-1], NP) if pr is not None else None)
+
+    @staticmethod
+    def backward(ctx, dout, dproj):
+        import ctypes
+        sv, a2, x1, out = ctx.sv, ctx.a2, ctx.x1, ctx.out
+        lin, norm1, ffn, proj = ctx.params
+        M, D, F_, NP, act, ashape, xshape = ctx.cfg
+        ctx.sv = None
+        dev = a2.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        dpre1, da = torch.empty(M, D, **f32), torch.empty(M, D, **f32)
+        c = _hip.RowChainBwd()
+        dproj2 = dproj.reshape(M, NP).contiguous() if (dproj is not None and proj is not None) else None
+        dout2 = dout.reshape(M, D).contiguous() if dout is not None else None
+        c.dproj, c.dyin, c.wp = ptr(dproj2), ptr(dout2), (ptr(proj[0]) if dproj2 is not None else None)
+        dpre2 = dz = None
+        if ffn is not None:
+            dpre2, dz = torch.empty(M, D, **f32), torch.empty(M, F_, **f32)
+            c.w1, c.w2, c.g2 = ptr(ffn[0]), ptr(ffn[2]), ptr(ffn[4])
+            c.xhat2, c.rstd2, c.zsrc = ptr(sv["xhat2"]), ptr(sv["rstd2"]), ptr(sv["z"] if "z" in sv else sv["h"])
+            c.dpre2, c.dz, c.dg2, c.db2 = ptr(dpre2), ptr(dz), ptr(_slot(ffn[4])), ptr(_slot(ffn[5]))
+        c.wo, c.g1, c.xhat1, c.rstd1 = ptr(lin[0]), ptr(norm1[0]), ptr(sv["xhat1"]), ptr(sv["rstd1"])
+        c.dpre1, c.da, c.dg1, c.db1 = ptr(dpre1), ptr(da), ptr(_slot(norm1[0])), ptr(_slot(norm1[1]))
+        c.d_model, c.d_ff, c.n_proj, c.act = D, F_, (NP if dproj2 is not None else 0), ACT[act]
+        ev = PROFILE.begin() if PROFILE.on else None
+        check(_hip.lib().rf_rowchain_bwd(ctypes.byref(c), M, _stream()), "rf_rowchain_bwd")
+        if ev is not None:
+            keep = (dproj2, dout2, sv, dpre1, da, dpre2, dz, c)
+            PROFILE.end(f"rowchain_bwd_kernel<{1 if M <= 1024 else 2}>", ev, 2.0 * M * D * (D + 2 * F_ + NP),
+                        4.0 * M * (D * 6 + 2 * F_ + NP))
+        _wrote(_slot(norm1[0]), _slot(norm1[1]))
+        pairs = []
+        if dproj2 is not None:
+            pairs.append((dproj2, out, proj[2], proj[3]))
+        if ffn is not None:
+            _wrote(_slot(ffn[4]), _slot(ffn[5]))
+            pairs.append((dpre2, sv["h"], _slot(ffn[2]).view(D, F_), _slot(ffn[3])))
+            pairs.append((dz, x1, _slot(ffn[0]).view(F_, D), _slot(ffn[1])))
+        pairs.append((dpre1, a2, _slot(lin[0]), _slot(lin[1])))
+        for gy, xin, w_into, b_into in pairs:
+            if _weight_grad(gy, xin, into=w_into, bias_into=b_into) is not True:
+                colsum(gy, into=b_into)
+            _wrote(w_into, b_into)
+        return da.view(ashape), dpre1.view(xshape), None, None, None, None, None, None, None
+
+
+def rowchain(a, x, lin, norm1, ffn, proj, act: str, eps: float):
+    """See ``_RowChain``.  The caller has checked ``rowchain_supported`` and, when gradients are needed, that the sinks are
+    active and every parameter has a slot."""
+    need_grad = torch.is_grad_enabled() and (a.requires_grad or x.requires_grad)
+    return _RowChain.apply(a, x, lin, norm1, ffn, proj, act, eps, need_grad)
+
+
 class _TrajHead(torch.autograd.Function):
     """postprocess_batch + discounted SmoothL1 losses + ADE/FDE in one launch (and one for backward)."""
 

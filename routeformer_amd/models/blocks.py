@@ -553,10 +553,89 @@ class Decoder(nn.Module):
         self.norm = norm_layer
         self.projection = projection
 
+    def _chain_forward(self, x, memory):
+        """The layers as attention launches + row-local chains (csrc/rowchain.hip: everything between two attention
+        launches in one launch; 5 launches per layer instead of 13) -- d_model 64 decoders in bf16 mode without dropout,
+        i.e. the gaze-video PerceiveDecoder.  None: not applicable, take the layer-by-layer path."""
+        if not (x.is_cuda and x.dtype == torch.float32 and len(self.layers) > 0):
+            return None
+        l0 = self.layers[0]
+        D = x.shape[-1]
+        F_ = l0.conv1.weight.shape[0]
+        for lay in self.layers:
+            sa, ca = lay.self_attention, lay.cross_attention
+            if not (isinstance(lay, DecoderLayer) and sa.kind == "prob_masked" and ca.kind == "full" and not sa.gps_variant
+                    and not ca.gps_variant and not ca.mix and sa.n_heads == ca.n_heads
+                    and sa.query_projection.weight.shape == (D, D) and ca.query_projection.weight.shape == (D, D)
+                    and lay.conv1.weight.shape[0] == F_ and lay.act == l0.act and lay.conv1.bias is not None
+                    and not sa.__dict__.get("output_attention") and not ca.__dict__.get("output_attention")):
+                return None
+            if self.training and (lay.p > 0.0 or ca.attn_dropout > 0.0):
+                return None  # (dropout sites inside the chain: not built; the layer-by-layer path draws them)
+        if not (K.rowchain_supported(D, F_, D) and K.rowchain_supported(D, F_, 3 * D)):
+            return None
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or memory.requires_grad
+                                                 or any(p.requires_grad for p in self.layers.parameters()))
+        if need_grad:  # parameter gradients leave through the engine's sinks only
+            if not (K.SINK.active and not K.DETERMINISTIC and x.requires_grad
+                    and all("_packed" in a.__dict__ for lay in self.layers for a in (lay.self_attention, lay.cross_attention))
+                    and all(K._slot(p) is not None for p in self.layers.parameters())):
+                return None
+        B, L, _ = x.shape
+        S = memory.shape[1]
+        H = l0.self_attention.n_heads
+        E = D // H
+        mem2 = memory.reshape(B * S, -1)
+        qkv = None
+        for i, lay in enumerate(self.layers):
+            sa, ca = lay.self_attention, lay.cross_attention
+            pks, pkc = sa.__dict__.get("_packed"), ca.__dict__.get("_packed")
+            if qkv is None:  # first layer: the packed q | k | v projection as a GEMM (later ones come out of the chain)
+                if pks is not None:
+                    qkv = K.linear_packed(x.reshape(B * L, D), pks["w"], pks["b"], pks["gw"], pks["gb"])
+                else:
+                    qkv = K.linear(x.reshape(B * L, D),
+                                   torch.cat([sa.query_projection.weight, sa.key_projection.weight, sa.value_projection.weight]),
+                                   torch.cat([sa.query_projection.bias, sa.key_projection.bias, sa.value_projection.bias]))
+            qkv = qkv.reshape(B * L, 3 * D)
+            sample_k, n_top = K.prob_sizes(L, L, sa.factor)
+            idx = SAMPLER.draw(L, L, sample_k, x.device)
+            # mix = the (B, H, L, E) context VIEWED as (B, L, H E) (cross_modal_transformer.py:203-205): the kernel's
+            # un-transposed output layout, no transpose copy
+            ctx1 = K.attention(qkv, qkv, (0, D, 2 * D), (B, H, L, L, E), 2, index_sample=idx, n_top=n_top,
+                               out_layout=1 if sa.mix else 0).view(B, L, D)
+            x1, q2 = K.rowchain(ctx1, x, (sa.out_projection.weight, sa.out_projection.bias), (lay.norm1.weight, lay.norm1.bias),
+                                None, (ca.query_projection.weight, ca.query_projection.bias,
+                                       K._slot(ca.query_projection.weight), K._slot(ca.query_projection.bias)),
+                                lay.act, lay.norm1.eps)
+            if pkc is not None:
+                kv = K.linear_packed(mem2, pkc["w"][D:], pkc["b"][D:], pkc["gw"][D:], pkc["gb"][D:])
+            else:
+                kv = K.linear(mem2, torch.cat([ca.key_projection.weight, ca.value_projection.weight]),
+                              torch.cat([ca.key_projection.bias, ca.value_projection.bias]))
+            ctx2 = K.attention(q2.reshape(B * L, D), kv, (0, 0, D), (B, H, L, S, E), 0).view(B, L, D)
+            nxt = self.layers[i + 1].self_attention if i + 1 < len(self.layers) else None
+            proj = None
+            if nxt is not None:
+                pkn = nxt.__dict__.get("_packed")
+                if pkn is not None:
+                    proj = (pkn["w"], pkn["b"], pkn["gw"], pkn["gb"])
+                else:
+                    proj = (torch.cat([nxt.query_projection.weight, nxt.key_projection.weight, nxt.value_projection.weight]),
+                            torch.cat([nxt.query_projection.bias, nxt.key_projection.bias, nxt.value_projection.bias]), None, None)
+            ffn = (lay.conv1.weight, lay.conv1.bias, lay.conv2.weight, lay.conv2.bias, lay.norm3.weight, lay.norm3.bias)
+            x, qkv = K.rowchain(ctx2, x1, (ca.out_projection.weight, ca.out_projection.bias), (lay.norm2.weight, lay.norm2.bias),
+                                ffn, proj, lay.act, lay.norm2.eps)
+        return x
+
     def forward(self, x, memory, first=None):
         """``first``: the first layer's ``self_block`` output, computed by the caller (then ``x`` is not used)."""
-        for i, layer in enumerate(self.layers):
-            x = layer(x, memory, after_self=first if i == 0 else None)
+        y = self._chain_forward(x, memory) if first is None else None
+        if y is not None:
+            x = y
+        else:
+            for i, layer in enumerate(self.layers):
+                x = layer(x, memory, after_self=first if i == 0 else None)
         if self.norm is not None:
             x = K.add_layer_norm(x, None, self.norm.weight, self.norm.bias)
         if self.projection is not None:

@@ -1108,6 +1108,64 @@ def test_fused_stack_dropout_vs_oracle_and_layerwise(B, L):
     assert fro_err(f["dx"], u["dx"]) < 0.1 and fro_err(f["grad"], u["grad"]) < 0.1, (fro_err(f["dx"], u["dx"]), fro_err(f["grad"], u["grad"]))
 
 
+@pytest.mark.parametrize("B,L,S,act", [(8, 40, 40, "gelu"), (3, 21, 40, "gelu"), (2, 70, 33, "relu")])
+def test_rowchain_decoder_vs_layerwise(B, L, S, act):
+    """The d_model = 64 PerceiveDecoder as attention launches + row-local chains (csrc/rowchain.hip: out-projection + residual
+    + LayerNorm [+ FFN + LayerNorm] + the next projection in ONE launch, forward and backward) against the layer-by-layer
+    kernels, bf16 matrix-core mode, same host draws and the layer-by-layer run's selections imposed: output, input gradients
+    (queries and memory) and the whole parameter-gradient buffer; and the chain path was really taken."""
+    from conftest import fro_err
+    from routeformer_amd import kernels as K
+    from routeformer_amd.engine import GradReducer
+    from routeformer_amd.models.blocks import SAMPLER, PerceiveDecoder
+    K.set_precision("bf16")
+    g = torch.Generator().manual_seed(5)
+    q_cpu, m_cpu = torch.randn(B, L, 128, generator=g), torch.randn(B, S, 64, generator=g)
+    w_cpu = torch.randn(B, L, 64, generator=g)
+    out, calls = {}, []
+    real = K._RowChain.apply
+    try:
+        for chain in (False, True):
+            K.ROWCHAIN = chain
+            dec = _load(PerceiveDecoder(query_channels=128, value_channels=64, out_channels=64, out_len=L, n_heads=8, layers=2,
+                                        dropout=0.0, activation=act))
+            dec.train()
+            layers = [m for m in dec.modules() if hasattr(m, "packing_groups")]
+            red = GradReducer(list(dec.parameters()), groups=[g_ for m in layers for g_ in m.packing_groups()])
+            for m in layers:
+                gw, gb = m.packing_groups()
+                vw, vb = red.packed_view(gw), red.packed_view(gb)
+                m._packed = {"w": vw[0], "gw": vw[1], "b": vb[0], "gb": vb[1]}
+            K.SINK.active = True
+            red.zero()
+            q, mem = q_cpu.to(DEV).requires_grad_(), m_cpu.to(DEV).requires_grad_()
+            torch.manual_seed(11)
+            if chain:
+                K.TOPS.forced = [t_.clone() for t_ in out[False]["tops"]]
+                K._RowChain.apply = lambda *a: (calls.append(1), real(*a))[1]
+            else:
+                K.TOPS.record = []
+            y = dec(mem, q)
+            (y * w_cpu.to(DEV)).sum().backward()
+            K.flush_weight_grads()
+            torch.cuda.synchronize()
+            out[chain] = dict(y=y.detach().cpu(), dq=q.grad.detach().cpu(), dm=mem.grad.detach().cpu(),
+                              grad=red.flat_grad.clone().cpu(), tops=K.TOPS.record, rng=torch.get_rng_state())
+            K.TOPS.record, K.TOPS.forced = None, None
+            K.SINK.active = False
+    finally:
+        K.ROWCHAIN = True
+        K._RowChain.apply = real
+        K.SINK.active = False
+        K.TOPS.record, K.TOPS.forced = None, None
+    c, u = out[True], out[False]
+    assert len(calls) == 4, "two chains per decoder layer expected"
+    assert torch.equal(c["rng"], u["rng"]), "host draws differ between the two paths"
+    assert rel_err(c["y"], u["y"]) < 2e-2, rel_err(c["y"], u["y"])
+    for k in ("dq", "dm", "grad"):
+        assert fro_err(c[k], u[k]) < 3e-2, (k, fro_err(c[k], u[k]))
+
+
 @pytest.mark.parametrize("shape", [(6, 65, 8, "gelu", 0.0), (5, 40, 3, "gelu", 0.0), (3, 80, 2, "relu", 0.0),
                                    (4, 17, 2, "gelu", 0.0), (6, 65, 3, "gelu", 0.2), (3, 40, 2, "relu", 0.1)])
 def test_fused_stack_backward_vs_layerwise(shape):
