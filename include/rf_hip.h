@@ -528,7 +528,8 @@ typedef struct RfRowChain {
   float *xhat1, *rstd1, *z, *h, *xhat2, *rstd2; /* training saves, each may be NULL */
   int d_model, d_ff, n_proj, act;
   float eps;
-  int pad;
+  int drop_site; /* drop_p > 0: Philox masks of sites drop_site + {0: out-projection output, 1: hidden activation (saved h = the
+                    dropped activation), 2: conv2 output}, element index row * cols + col -- the masks rf_dropout generates */
 } RfRowChain;
 typedef struct RfRowChainBwd {
   const float *dproj, *dyin, *wp;
@@ -537,10 +538,13 @@ typedef struct RfRowChainBwd {
   const float *wo, *g1, *xhat1, *rstd1;
   float *dpre1, *da, *dg1, *db1;
   int d_model, d_ff, n_proj, act;
+  float* dx;     /* drop_p > 0: (M, 64) the UNMASKED d pre-norm-1 = gradient of the residual input (dpre1 / dpre2 then hold the
+                    gradients behind the out-projection / conv2-output dropout: the weight-gradient operands) */
+  int drop_site, pad;
 } RfRowChainBwd;
 int rf_rowchain_supported(int d_model, int d_ff, int n_proj);
-int rf_rowchain_fwd(const RfRowChain* chain, int M, void* stream);
-int rf_rowchain_bwd(const RfRowChainBwd* chain, int M, void* stream);
+int rf_rowchain_fwd(const RfRowChain* chain, int M, float drop_p, const void* rng_state, void* stream);
+int rf_rowchain_bwd(const RfRowChainBwd* chain, int M, float drop_p, const void* rng_state, void* stream);
 
 /* ---- small tensor plumbing of the hot path as single launches (csrc/smallops.hip) ---------------------------
  * rf_median_windows: y (B,target,C) = lower median (torch.median: NaN wins) of the consecutive windows of T / target

@@ -91,8 +91,8 @@ SIGNATURES = {
     "rf_adamw_clip": [_P, _P, _P, _P, _L, _P, _I, _F, _F, _F, _F, _F, _F, _I, _F, _P],
     "rf_adamw_clip_dev": [_P, _P, _P, _P, _L, _P, _I, _P, _I, _P],
     "rf_rowchain_supported": [_I, _I, _I],
-    "rf_rowchain_fwd": [_P, _I, _P],
-    "rf_rowchain_bwd": [_P, _I, _P],
+    "rf_rowchain_fwd": [_P, _I, _F, _P, _P],
+    "rf_rowchain_bwd": [_P, _I, _F, _P, _P],
     "rf_enclayer_tile_supported": [_I, _I, _I],
     "rf_enclayer_tile_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _I, _P],
     "rf_enclayer_tile_bwd": [_P] * 19 + [_I, _I, _I, _I, _I, _P, _F, _P, _I, _P],
@@ -133,14 +133,16 @@ class RowChain(ctypes.Structure):
     """RfRowChain of include/rf_hip.h."""
     _fields_ = ([(n, c_void_p) for n in ("a", "x", "wo", "bo", "g1", "be1", "w1", "b1", "w2", "b2", "g2", "be2", "wp", "bp",
                                          "x1", "y", "proj", "xhat1", "rstd1", "z", "h", "xhat2", "rstd2")]
-                + [("d_model", c_int), ("d_ff", c_int), ("n_proj", c_int), ("act", c_int), ("eps", ctypes.c_float), ("pad", c_int)])
+                + [("d_model", c_int), ("d_ff", c_int), ("n_proj", c_int), ("act", c_int), ("eps", ctypes.c_float),
+                   ("drop_site", c_int)])
 
 
 class RowChainBwd(ctypes.Structure):
     """RfRowChainBwd of include/rf_hip.h."""
     _fields_ = ([(n, c_void_p) for n in ("dproj", "dyin", "wp", "w1", "w2", "g2", "xhat2", "rstd2", "zsrc", "dpre2", "dz", "dg2",
                                          "db2", "wo", "g1", "xhat1", "rstd1", "dpre1", "da", "dg1", "db1")]
-                + [("d_model", c_int), ("d_ff", c_int), ("n_proj", c_int), ("act", c_int)])
+                + [("d_model", c_int), ("d_ff", c_int), ("n_proj", c_int), ("act", c_int), ("dx", c_void_p), ("drop_site", c_int),
+                   ("pad", c_int)])
 
 
 class ConvEntry(ctypes.Structure):

@@ -21,10 +21,13 @@ constexpr int RC_D = 64, RC_NW = RC_D / 16, RC_NT = 64 * RC_NW, RC_XP = RC_D + 8
 struct RowChainFwdP {
   RfRowChain c;
   int M;
+  DropCfg drop;  // nn.Dropout of the layer in train mode (state == null: off); sites c.drop_site + {0: out-projection output,
+                 // 1: hidden activation, 2: conv2 output}, element index row * cols + col (the numbering of rf_dropout)
 };
 struct RowChainBwdP {
   RfRowChainBwd c;
   int M;
+  DropCfg drop;
 };
 
 // B fragment of a k-contiguous fp32 weight w[n][k] (pitch ld): row n, columns k .. k + 7 (this lane's share of a 32-wide k-step)
@@ -125,10 +128,17 @@ __device__ __forceinline__ void rc_ln_bwd(f32x4 (&g)[RT], const float* __restric
     }
 }
 
-template <int RT>
+template <int RT, bool DROP>
 __global__ __launch_bounds__(RC_NT) void rowchain_fwd_kernel(const RowChainFwdP pp) {
   constexpr int LP = 16 * RT;
   const RfRowChain& p = pp.c;
+  uint2 dkey = make_uint2(0, 0);
+  uint32_t dstep = 0;
+  if constexpr (DROP) {
+    const unsigned long long sd = pp.drop.state->seed;
+    dkey = make_uint2((uint32_t)sd, (uint32_t)(sd >> 32));
+    dstep = (uint32_t)pp.drop.state->step;
+  }
   __shared__ __attribute__((aligned(16))) __bf16 xb[LP * RC_XP];   // A image of the 64-wide operand (a, then x1, then y)
   __shared__ __attribute__((aligned(16))) __bf16 hb[LP * RC_HP];   // hidden activation image
   __shared__ __attribute__((aligned(16))) float patch[RC_NW * 320];
@@ -169,8 +179,14 @@ __global__ __launch_bounds__(RC_NT) void rowchain_fwd_kernel(const RowChainFwdP 
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * RC_XP + kk * 32 + fq * 8), wfo[kk], acc, 0, 0, 0);
+    if constexpr (DROP) {
+      const f32x4 f = drop_factors(pp.drop, dkey, dstep, (uint32_t)p.drop_site, row0 + rt * 16, RC_D, col, lane);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[rt][r] = acc[r] + bo + xres[rt][r];
+      for (int r = 0; r < 4; ++r) v[rt][r] = (acc[r] + bo) * f[r] + xres[rt][r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[rt][r] = acc[r] + bo + xres[rt][r];
+    }
   }
   rc_layer_norm<RT>(v, p.rstd1 ? p.rstd1 + row0 : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the a-image reads)
   if (p.xhat1) store_acc(v, p.xhat1, RC_D, wave * 16);
@@ -201,10 +217,13 @@ __global__ __launch_bounds__(RC_NT) void rowchain_fwd_kernel(const RowChainFwdP 
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
           zz[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * RC_XP + kk * 32 + fq * 8), wf1[kk], zz[rt], 0, 0, 0);
+        f32x4 f = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (DROP) f = drop_factors(pp.drop, dkey, dstep, (uint32_t)(p.drop_site + 1), row0 + rt * 16, F, n, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           zz[rt][r] += b1;
           hh[rt][r] = p.act == RF_ACT_GELU ? sl_gelu(zz[rt][r]) : (p.act == RF_ACT_RELU ? fmaxf(zz[rt][r], 0.f) : zz[rt][r]);
+          hh[rt][r] *= f[r];  // conv2 consumes (and the backward needs) the dropped activation
           hb[(rt * 16 + fq * 4 + r) * RC_HP + n] = (__bf16)hh[rt][r];
         }
       }
@@ -223,9 +242,12 @@ __global__ __launch_bounds__(RC_NT) void rowchain_fwd_kernel(const RowChainFwdP 
         v[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(hb + (rt * 16 + fr) * RC_HP + kk * 32 + fq * 8), wf2, v[rt], 0, 0, 0);
     }
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt) {
+      f32x4 f = {1.f, 1.f, 1.f, 1.f};
+      if constexpr (DROP) f = drop_factors(pp.drop, dkey, dstep, (uint32_t)(p.drop_site + 2), row0 + rt * 16, RC_D, col, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[rt][r] += b2 + xres[rt][r];
+      for (int r = 0; r < 4; ++r) v[rt][r] = (v[rt][r] + b2) * f[r] + xres[rt][r];
+    }
     rc_layer_norm<RT>(v, p.rstd2 ? p.rstd2 + row0 : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the x1 / h reads)
     if (p.xhat2) store_acc(v, p.xhat2, RC_D, wave * 16);
 #pragma unroll
@@ -264,10 +286,17 @@ __global__ __launch_bounds__(RC_NT) void rowchain_fwd_kernel(const RowChainFwdP 
   }
 }
 
-template <int RT>
+template <int RT, bool DROP>
 __global__ __launch_bounds__(RC_NT) void rowchain_bwd_kernel(const RowChainBwdP pp) {
   constexpr int LP = 16 * RT;
   const RfRowChainBwd& p = pp.c;
+  uint2 dkey = make_uint2(0, 0);
+  uint32_t dstep = 0;
+  if constexpr (DROP) {
+    const unsigned long long sd = pp.drop.state->seed;
+    dkey = make_uint2((uint32_t)sd, (uint32_t)(sd >> 32));
+    dstep = (uint32_t)pp.drop.state->step;
+  }
   __shared__ __attribute__((aligned(16))) __bf16 xb[LP * RC_XP];   // 64-wide gradient images (A operands)
   __shared__ __attribute__((aligned(16))) __bf16 hb[LP * RC_HP];   // d proj image, then the dz image
   __shared__ __attribute__((aligned(16))) float patch[RC_NW * 320];
@@ -329,7 +358,14 @@ __global__ __launch_bounds__(RC_NT) void rowchain_bwd_kernel(const RowChainBwdP 
     rc_ln_bwd<RT>(g, p.xhat2 + row0 * RC_D + col, p.rstd2 + row0, p.g2[col], p.dg2 + col, p.db2 + col, L, part, stat, wave,
                   lane);  // (its first barrier also fences the d proj image reads)
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) res[rt] = g[rt];
+    for (int rt = 0; rt < RT; ++rt) {
+      res[rt] = g[rt];  // the skip carries the unmasked gradient
+      if constexpr (DROP) {  // the conv pair sees it through the conv2-output dropout (and so does conv2's weight gradient)
+        const f32x4 f = drop_factors(pp.drop, dkey, dstep, (uint32_t)(p.drop_site + 2), row0 + rt * 16, RC_D, col, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[rt][r] *= f[r];
+      }
+    }
     put_image(g);
     store_acc(g, p.dpre2, RC_D, wave * 16);
     __syncthreads();  // d pre-norm-2 image complete
@@ -352,8 +388,14 @@ __global__ __launch_bounds__(RC_NT) void rowchain_bwd_kernel(const RowChainBwdP 
           const float zs = p.zsrc[(row0 + min(rt * 16 + fq * 4 + r, L - 1)) * F + n];
           const float d = p.act == RF_ACT_GELU ? sl_gelu_grad(zs) : (p.act == RF_ACT_RELU ? (zs > 0.f ? 1.f : 0.f) : 1.f);
           acc[rt][r] *= d;
-          hb[(rt * 16 + fq * 4 + r) * RC_HP + n] = (__bf16)acc[rt][r];
         }
+        if constexpr (DROP) {  // hidden-activation dropout
+          const f32x4 f = drop_factors(pp.drop, dkey, dstep, (uint32_t)(p.drop_site + 1), row0 + rt * 16, F, n, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[rt][r] *= f[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hb[(rt * 16 + fq * 4 + r) * RC_HP + n] = (__bf16)acc[rt][r];
       }
       store_acc(acc, p.dz, F, ct * 16);
     }
@@ -376,8 +418,18 @@ __global__ __launch_bounds__(RC_NT) void rowchain_bwd_kernel(const RowChainBwdP 
 
   // ---- first block backward: LayerNorm, out-projection^T ----
   rc_ln_bwd<RT>(g, p.xhat1 + row0 * RC_D + col, p.rstd1 + row0, p.g1[col], p.dg1 + col, p.db1 + col, L, part, stat, wave, lane);
+  if constexpr (DROP) {
+    store_acc(g, p.dx, RC_D, wave * 16);  // the residual input sees the unmasked gradient
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const f32x4 f = drop_factors(pp.drop, dkey, dstep, (uint32_t)p.drop_site, row0 + rt * 16, RC_D, col, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g[rt][r] *= f[r];
+    }
+  }
   put_image(g);
-  store_acc(g, p.dpre1, RC_D, wave * 16);  // gradient of the residual input AND the out-projection's weight-gradient operand
+  // without dropout: the gradient of the residual input AND the out-projection's weight-gradient operand
+  store_acc(g, p.dpre1, RC_D, wave * 16);
   __syncthreads();
   {
     bf16x8 wf[2];
@@ -404,7 +456,7 @@ extern "C" int rf_rowchain_supported(int d_model, int d_ff, int n_proj) {
          n_proj % 32 == 0;
 }
 
-extern "C" int rf_rowchain_fwd(const RfRowChain* chain, int M, void* stream) {
+extern "C" int rf_rowchain_fwd(const RfRowChain* chain, int M, float drop_p, const void* rng_state, void* stream) {
   RF_REQUIRE(chain && M > 0);
   const RfRowChain& c = *chain;
   RF_REQUIRE(rf_rowchain_supported(c.d_model, c.w1 ? c.d_ff : 0, c.wp ? c.n_proj : 0));
@@ -413,15 +465,22 @@ extern "C" int rf_rowchain_fwd(const RfRowChain* chain, int M, void* stream) {
   RF_REQUIRE(!c.wp || (c.proj && rc_al16(c.wp) && rc_al16(c.proj)));
   RF_REQUIRE((!c.xhat1 || (c.rstd1 && rc_al16(c.xhat1))) && (!c.xhat2 || (c.rstd2 && rc_al16(c.xhat2))) &&
              (!c.z || rc_al16(c.z)) && (!c.h || rc_al16(c.h)));
-  RowChainFwdP p{c, M};
+  RF_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state));
+  RowChainFwdP p{c, M, make_drop_cfg(rng_state, nullptr, 0, drop_p)};
   const hipStream_t st = static_cast<hipStream_t>(stream);
-  if (M <= 1024) RF_LAUNCH(rowchain_fwd_kernel<1>, dim3((M + 15) / 16), dim3(RC_NT), 0, st, p);
-  else RF_LAUNCH(rowchain_fwd_kernel<2>, dim3((M + 31) / 32), dim3(RC_NT), 0, st, p);
+  const bool drop = p.drop.state != nullptr;
+  if (M <= 1024) {
+    if (drop) RF_LAUNCH((rowchain_fwd_kernel<1, true>), dim3((M + 15) / 16), dim3(RC_NT), 0, st, p);
+    else RF_LAUNCH((rowchain_fwd_kernel<1, false>), dim3((M + 15) / 16), dim3(RC_NT), 0, st, p);
+  } else {
+    if (drop) RF_LAUNCH((rowchain_fwd_kernel<2, true>), dim3((M + 31) / 32), dim3(RC_NT), 0, st, p);
+    else RF_LAUNCH((rowchain_fwd_kernel<2, false>), dim3((M + 31) / 32), dim3(RC_NT), 0, st, p);
+  }
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
 
-extern "C" int rf_rowchain_bwd(const RfRowChainBwd* chain, int M, void* stream) {
+extern "C" int rf_rowchain_bwd(const RfRowChainBwd* chain, int M, float drop_p, const void* rng_state, void* stream) {
   RF_REQUIRE(chain && M > 0);
   const RfRowChainBwd& c = *chain;
   RF_REQUIRE(rf_rowchain_supported(c.d_model, c.w1 ? c.d_ff : 0, c.dproj ? c.n_proj : 0));
@@ -429,10 +488,18 @@ extern "C" int rf_rowchain_bwd(const RfRowChainBwd* chain, int M, void* stream) 
   RF_REQUIRE(c.wo && c.g1 && c.xhat1 && c.rstd1 && c.dpre1 && c.da && c.dg1 && c.db1 && rc_al16(c.dpre1) && rc_al16(c.da));
   RF_REQUIRE(!c.w1 || (c.w2 && c.g2 && c.xhat2 && c.rstd2 && c.zsrc && c.dpre2 && c.dz && c.dg2 && c.db2 && rc_al16(c.dpre2) &&
                        rc_al16(c.dz)));
-  RowChainBwdP p{c, M};
+  RF_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state));
+  RowChainBwdP p{c, M, make_drop_cfg(rng_state, nullptr, 0, drop_p)};
   const hipStream_t st = static_cast<hipStream_t>(stream);
-  if (M <= 1024) RF_LAUNCH(rowchain_bwd_kernel<1>, dim3((M + 15) / 16), dim3(RC_NT), 0, st, p);
-  else RF_LAUNCH(rowchain_bwd_kernel<2>, dim3((M + 31) / 32), dim3(RC_NT), 0, st, p);
+  const bool drop = p.drop.state != nullptr;
+  RF_REQUIRE(!drop || (c.dx && rc_al16(c.dx)));
+  if (M <= 1024) {
+    if (drop) RF_LAUNCH((rowchain_bwd_kernel<1, true>), dim3((M + 15) / 16), dim3(RC_NT), 0, st, p);
+    else RF_LAUNCH((rowchain_bwd_kernel<1, false>), dim3((M + 15) / 16), dim3(RC_NT), 0, st, p);
+  } else {
+    if (drop) RF_LAUNCH((rowchain_bwd_kernel<2, true>), dim3((M + 31) / 32), dim3(RC_NT), 0, st, p);
+    else RF_LAUNCH((rowchain_bwd_kernel<2, false>), dim3((M + 31) / 32), dim3(RC_NT), 0, st, p);
+  }
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

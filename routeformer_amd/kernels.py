@@ -1346,9 +1346,10 @@ class _RowChain(torch.autograd.Function):
     the engine's sinks (the caller checks that every one of them has a slot)."""
 
     @staticmethod
-    def forward(ctx, a, x, lin, norm1, ffn, proj, act, eps, save):
+    def forward(ctx, a, x, lin, norm1, ffn, proj, act, eps, save, drop=None):
         """lin = (Wo, bo); norm1 = (gamma, beta); ffn = None | (W1 (F, D[, 1]), b1, W2 (D, F[, 1]), b2, gamma, beta);
-        proj = None | (Wp (NP, D), bp, grad slot of Wp, grad slot of bp).  -> (x1 or y, proj or None)."""
+        proj = None | (Wp (NP, D), bp, grad slot of Wp, grad slot of bp); drop = None | (p, first dropout site: out-projection
+        output, then hidden activation and conv2 output).  -> (x1 or y, proj or None)."""
         D = a.shape[-1]
         M = a.numel() // D
         a2, x2 = a.reshape(M, D).contiguous(), x.reshape(M, D).contiguous()
@@ -1376,19 +1377,21 @@ class _RowChain(torch.autograd.Function):
         for name in ("xhat1", "rstd1", "z", "h", "xhat2", "rstd2"):
             setattr(c, name, ptr(sv.get(name)))
         c.d_model, c.d_ff, c.n_proj, c.act, c.eps = D, F_, NP, ACT[act], eps
+        drop_p, c.drop_site = (float(drop[0]), int(drop[1])) if drop is not None else (0.0, 0)
+        rng = ptr(RNG.state(dev)) if drop_p > 0.0 else None
         import ctypes
         ev = PROFILE.begin() if PROFILE.on else None
-        check(_hip.lib().rf_rowchain_fwd(ctypes.byref(c), M, _stream()), "rf_rowchain_fwd")
+        check(_hip.lib().rf_rowchain_fwd(ctypes.byref(c), M, drop_p, rng, _stream()), "rf_rowchain_fwd")
         if ev is not None:
             keep = (a2, x2, lin, norm1, ffn, proj, x1, y, pr, sv, c)
             PROFILE.end(f"rowchain_fwd_kernel<{1 if M <= 1024 else 2}>", ev, 2.0 * M * D * (D + 2 * F_ + NP),
                         4.0 * M * (D * (3 + (ffn is not None)) + NP + (len(sv) and (2 * D + 2 * F_))),
-                        replay=lambda cc=c, k=keep: _hip.lib().rf_rowchain_fwd(ctypes.byref(cc), M, _stream()))
+                        replay=lambda cc=c, k=keep: _hip.lib().rf_rowchain_fwd(ctypes.byref(cc), M, drop_p, rng, _stream()))
         out = y if ffn is not None else x1
         if save:
             ctx.sv, ctx.a2, ctx.x1, ctx.out = sv, a2, x1, out
             ctx.params = (lin, norm1, ffn, proj)
-            ctx.cfg = (M, D, F_, NP, act, a.shape, x.shape)
+            ctx.cfg = (M, D, F_, NP, act, a.shape, x.shape, drop_p, c.drop_site)
         return out.view(x.shape), (pr.view(*x.shape[:-1], NP) if pr is not None else None)
 
     @staticmethod
@@ -1396,7 +1399,7 @@ class _RowChain(torch.autograd.Function):
         import ctypes
         sv, a2, x1, out = ctx.sv, ctx.a2, ctx.x1, ctx.out
         lin, norm1, ffn, proj = ctx.params
-        M, D, F_, NP, act, ashape, xshape = ctx.cfg
+        M, D, F_, NP, act, ashape, xshape, drop_p, drop_site = ctx.cfg
         ctx.sv = None
         dev = a2.device
         f32 = dict(device=dev, dtype=torch.float32)
@@ -1414,8 +1417,12 @@ class _RowChain(torch.autograd.Function):
         c.wo, c.g1, c.xhat1, c.rstd1 = ptr(lin[0]), ptr(norm1[0]), ptr(sv["xhat1"]), ptr(sv["rstd1"])
         c.dpre1, c.da, c.dg1, c.db1 = ptr(dpre1), ptr(da), ptr(_slot(norm1[0])), ptr(_slot(norm1[1]))
         c.d_model, c.d_ff, c.n_proj, c.act = D, F_, (NP if dproj2 is not None else 0), ACT[act]
+        # with dropout the residual input's gradient (unmasked) and the out-projection's weight-gradient operand (masked) differ
+        dx = torch.empty(M, D, **f32) if drop_p > 0.0 else dpre1
+        c.dx, c.drop_site = (ptr(dx) if drop_p > 0.0 else None), drop_site
         ev = PROFILE.begin() if PROFILE.on else None
-        check(_hip.lib().rf_rowchain_bwd(ctypes.byref(c), M, _stream()), "rf_rowchain_bwd")
+        check(_hip.lib().rf_rowchain_bwd(ctypes.byref(c), M, drop_p, ptr(RNG.state(dev)) if drop_p > 0.0 else None, _stream()),
+              "rf_rowchain_bwd")
         if ev is not None:
             keep = (dproj2, dout2, sv, dpre1, da, dpre2, dz, c)
             PROFILE.end(f"rowchain_bwd_kernel<{1 if M <= 1024 else 2}>", ev, 2.0 * M * D * (D + 2 * F_ + NP),
@@ -1433,14 +1440,26 @@ class _RowChain(torch.autograd.Function):
             if _weight_grad(gy, xin, into=w_into, bias_into=b_into) is not True:
                 colsum(gy, into=b_into)
             _wrote(w_into, b_into)
-        return da.view(ashape), dpre1.view(xshape), None, None, None, None, None, None, None
+        return da.view(ashape), dx.view(xshape), None, None, None, None, None, None, None, None
 
 
-def rowchain(a, x, lin, norm1, ffn, proj, act: str, eps: float):
+def rowchain(a, x, lin, norm1, ffn, proj, act: str, eps: float, drop_p: float = 0.0):
     """See ``_RowChain``.  The caller has checked ``rowchain_supported`` and, when gradients are needed, that the sinks are
-    active and every parameter has a slot."""
+    active and every parameter has a slot.  ``drop_p`` > 0: nn.Dropout of the layer (train mode) -- one site for the
+    out-projection output, two more (hidden activation, conv2 output) with an FFN block, numbered in call order."""
     need_grad = torch.is_grad_enabled() and (a.requires_grad or x.requires_grad)
-    return _RowChain.apply(a, x, lin, norm1, ffn, proj, act, eps, need_grad)
+    drop = None
+    if drop_p > 0.0:
+        n_sites = 3 if ffn is not None else 1
+        site0 = RNG.site
+        RNG.site += n_sites
+        if RNG.record is not None:
+            D = a.shape[-1]
+            widths = (D, ffn[0].shape[0], D) if ffn is not None else (D,)
+            for k, cols in enumerate(widths):
+                RNG.record.append(RNG.materialise(site0 + k, tuple(a.shape[:-1]) + (cols,), drop_p, a.device))
+        drop = (drop_p, site0)
+    return _RowChain.apply(a, x, lin, norm1, ffn, proj, act, eps, need_grad, drop)
 
 
 class _TrajHead(torch.autograd.Function):

@@ -570,8 +570,8 @@ class Decoder(nn.Module):
                     and lay.conv1.weight.shape[0] == F_ and lay.act == l0.act and lay.conv1.bias is not None
                     and not sa.__dict__.get("output_attention") and not ca.__dict__.get("output_attention")):
                 return None
-            if self.training and (lay.p > 0.0 or ca.attn_dropout > 0.0):
-                return None  # (dropout sites inside the chain: not built; the layer-by-layer path draws them)
+            if self.training and (lay.p > 0.0 or ca.attn_dropout > 0.0) and (K.RNG.forced is not None or lay.p != l0.p):
+                return None  # injected masks (parity tests) go through the layer-by-layer path
         if not (K.rowchain_supported(D, F_, D) and K.rowchain_supported(D, F_, 3 * D)):
             return None
         need_grad = torch.is_grad_enabled() and (x.requires_grad or memory.requires_grad
@@ -604,16 +604,19 @@ class Decoder(nn.Module):
             # un-transposed output layout, no transpose copy
             ctx1 = K.attention(qkv, qkv, (0, D, 2 * D), (B, H, L, L, E), 2, index_sample=idx, n_top=n_top,
                                out_layout=1 if sa.mix else 0).view(B, L, D)
+            drop_p = lay.p if self.training else 0.0  # (sites in the layer-by-layer order: self out, cross probabilities,
+            #                                                  cross out, hidden activation, conv2 out)
             x1, q2 = K.rowchain(ctx1, x, (sa.out_projection.weight, sa.out_projection.bias), (lay.norm1.weight, lay.norm1.bias),
                                 None, (ca.query_projection.weight, ca.query_projection.bias,
                                        K._slot(ca.query_projection.weight), K._slot(ca.query_projection.bias)),
-                                lay.act, lay.norm1.eps)
+                                lay.act, lay.norm1.eps, drop_p)
             if pkc is not None:
                 kv = K.linear_packed(mem2, pkc["w"][D:], pkc["b"][D:], pkc["gw"][D:], pkc["gb"][D:])
             else:
                 kv = K.linear(mem2, torch.cat([ca.key_projection.weight, ca.value_projection.weight]),
                               torch.cat([ca.key_projection.bias, ca.value_projection.bias]))
-            ctx2 = K.attention(q2.reshape(B * L, D), kv, (0, 0, D), (B, H, L, S, E), 0).view(B, L, D)
+            ctx2 = K.attention(q2.reshape(B * L, D), kv, (0, 0, D), (B, H, L, S, E), 0,
+                               drop_p=ca.attn_dropout if self.training else 0.0).view(B, L, D)
             nxt = self.layers[i + 1].self_attention if i + 1 < len(self.layers) else None
             proj = None
             if nxt is not None:
@@ -625,7 +628,7 @@ class Decoder(nn.Module):
                             torch.cat([nxt.query_projection.bias, nxt.key_projection.bias, nxt.value_projection.bias]), None, None)
             ffn = (lay.conv1.weight, lay.conv1.bias, lay.conv2.weight, lay.conv2.bias, lay.norm3.weight, lay.norm3.bias)
             x, qkv = K.rowchain(ctx2, x1, (ca.out_projection.weight, ca.out_projection.bias), (lay.norm2.weight, lay.norm2.bias),
-                                ffn, proj, lay.act, lay.norm2.eps)
+                                ffn, proj, lay.act, lay.norm2.eps, drop_p)
         return x
 
     def forward(self, x, memory, first=None):

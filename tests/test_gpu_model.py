@@ -1108,12 +1108,15 @@ def test_fused_stack_dropout_vs_oracle_and_layerwise(B, L):
     assert fro_err(f["dx"], u["dx"]) < 0.1 and fro_err(f["grad"], u["grad"]) < 0.1, (fro_err(f["dx"], u["dx"]), fro_err(f["grad"], u["grad"]))
 
 
-@pytest.mark.parametrize("B,L,S,act", [(8, 40, 40, "gelu"), (3, 21, 40, "gelu"), (2, 70, 33, "relu")])
-def test_rowchain_decoder_vs_layerwise(B, L, S, act):
+@pytest.mark.parametrize("B,L,S,act,P", [(8, 40, 40, "gelu", 0.0), (3, 21, 40, "gelu", 0.0), (2, 70, 33, "relu", 0.0),
+                                         (8, 40, 40, "gelu", 0.2), (3, 33, 21, "relu", 0.1)])
+def test_rowchain_decoder_vs_layerwise(B, L, S, act, P):
     """The d_model = 64 PerceiveDecoder as attention launches + row-local chains (csrc/rowchain.hip: out-projection + residual
     + LayerNorm [+ FFN + LayerNorm] + the next projection in ONE launch, forward and backward) against the layer-by-layer
     kernels, bf16 matrix-core mode, same host draws and the layer-by-layer run's selections imposed: output, input gradients
-    (queries and memory) and the whole parameter-gradient buffer; and the chain path was really taken."""
+    (queries and memory) and the whole parameter-gradient buffer; and the chain path was really taken.  P > 0: train-mode
+    dropout INSIDE the chains (and on the cross-attention probabilities) -- the Philox masks the chain run drew are materialised
+    (``K.RNG.record``) and injected into the layer-by-layer run, so both apply the same masks at the same sites."""
     from conftest import fro_err
     from routeformer_amd import kernels as K
     from routeformer_amd.engine import GradReducer
@@ -1125,10 +1128,10 @@ def test_rowchain_decoder_vs_layerwise(B, L, S, act):
     out, calls = {}, []
     real = K._RowChain.apply
     try:
-        for chain in (False, True):
+        for chain in ((True, False) if P > 0 else (False, True)):  # (with dropout the chain run goes first: it draws the masks)
             K.ROWCHAIN = chain
             dec = _load(PerceiveDecoder(query_channels=128, value_channels=64, out_channels=64, out_len=L, n_heads=8, layers=2,
-                                        dropout=0.0, activation=act))
+                                        dropout=P, activation=act))
             dec.train()
             layers = [m for m in dec.modules() if hasattr(m, "packing_groups")]
             red = GradReducer(list(dec.parameters()), groups=[g_ for m in layers for g_ in m.packing_groups()])
@@ -1137,29 +1140,40 @@ def test_rowchain_decoder_vs_layerwise(B, L, S, act):
                 vw, vb = red.packed_view(gw), red.packed_view(gb)
                 m._packed = {"w": vw[0], "gw": vw[1], "b": vb[0], "gb": vb[1]}
             K.SINK.active = True
+            K.RNG.manual_seed(77)
+            K.RNG.begin_step(torch.device(DEV))
             red.zero()
             q, mem = q_cpu.to(DEV).requires_grad_(), m_cpu.to(DEV).requires_grad_()
             torch.manual_seed(11)
-            if chain:
-                K.TOPS.forced = [t_.clone() for t_ in out[False]["tops"]]
-                K._RowChain.apply = lambda *a: (calls.append(1), real(*a))[1]
-            else:
+            first = (not chain) if P == 0 else chain
+            if first:
                 K.TOPS.record = []
+                if P > 0:
+                    K.RNG.record = []
+            else:
+                K.TOPS.forced = [t_.clone() for t_ in out[not chain]["tops"]]
+                if P > 0:
+                    K.RNG.forced = [m.clone() for m in out[not chain]["masks"]]
+            if chain:
+                K._RowChain.apply = lambda *a: (calls.append(1), real(*a))[1]
             y = dec(mem, q)
             (y * w_cpu.to(DEV)).sum().backward()
             K.flush_weight_grads()
             torch.cuda.synchronize()
             out[chain] = dict(y=y.detach().cpu(), dq=q.grad.detach().cpu(), dm=mem.grad.detach().cpu(),
-                              grad=red.flat_grad.clone().cpu(), tops=K.TOPS.record, rng=torch.get_rng_state())
-            K.TOPS.record, K.TOPS.forced = None, None
+                              grad=red.flat_grad.clone().cpu(), tops=K.TOPS.record, masks=K.RNG.record, rng=torch.get_rng_state())
+            assert not K.TOPS.forced and not K.RNG.forced, "imposed selections / masks were not all consumed"
+            K.TOPS.record, K.TOPS.forced, K.RNG.record, K.RNG.forced = None, None, None, None
             K.SINK.active = False
     finally:
         K.ROWCHAIN = True
         K._RowChain.apply = real
         K.SINK.active = False
-        K.TOPS.record, K.TOPS.forced = None, None
+        K.TOPS.record, K.TOPS.forced, K.RNG.record, K.RNG.forced = None, None, None, None
     c, u = out[True], out[False]
     assert len(calls) == 4, "two chains per decoder layer expected"
+    if P > 0:  # 2 layers x (self out, cross probabilities, cross out, hidden, conv2 out)
+        assert len(c["masks"]) == 10 and abs(float(torch.stack([m.float().mean() for m in c["masks"]]).mean()) - (1 - P)) < 0.02
     assert torch.equal(c["rng"], u["rng"]), "host draws differ between the two paths"
     assert rel_err(c["y"], u["y"]) < 2e-2, rel_err(c["y"], u["y"])
     for k in ("dq", "dm", "grad"):
