@@ -78,15 +78,10 @@ __device__ __forceinline__ void rc_layer_norm(f32x4 (&v)[RT], float* __restrict_
 
 // LayerNorm backward (see stack_ln_bwd): in g = dy (rows >= L zero), out g = d pre-norm; dgamma / dbeta by atomics
 template <int RT>
-__device__ __forceinline__ void rc_ln_bwd(f32x4 (&g)[RT], const float* __restrict__ xhat_g, const float* __restrict__ rstd_g,
+__device__ __forceinline__ void rc_ln_bwd(f32x4 (&g)[RT], const f32x4 (&xh)[RT], const float* __restrict__ rstd_g,
                                           float gamma, float* __restrict__ dgam, float* __restrict__ dbet, int L,
                                           float2* __restrict__ part, float4* __restrict__ stat, int wave, int lane) {
   const int fr = lane & 15, fq = lane >> 4;
-  f32x4 xh[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xh[rt][r] = xhat_g[(long)min(rt * 16 + fq * 4 + r, L - 1) * RC_D];
   float dg = 0.f, db = 0.f;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -165,6 +160,17 @@ __global__ __launch_bounds__(RC_NT) void rowchain_fwd_kernel(const RowChainFwdP 
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) wfo[kk] = rc_wfrag(p.wo, RC_D, col, kk * 32 + fq * 8);
   const float bo = p.bo[col], g1 = p.g1[col], be1 = p.be1[col];
+  // conv1's fragments (this wave's column tiles wave, wave + 4, ...: at most 4) are requested now, long before their use
+  const int nct = p.w1 ? F / 16 : 0;
+  bf16x8 wf1[4][2];
+  float b1v[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int n = min(wave + it * RC_NW, max(nct - 1, 0)) * 16 + fr;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) wf1[it][kk] = p.w1 ? rc_wfrag(p.w1, RC_D, n, kk * 32 + fq * 8) : zero_frag();
+    b1v[it] = p.w1 ? p.b1[n] : 0.f;
+  }
   for (int i = tid; i < LP * (RC_D / 4); i += RC_NT) {
     const int row = i >> 4, c4 = (i & 15) * 4;
     const float4 v = *reinterpret_cast<const float4*>(p.a + (row0 + min(row, L - 1)) * RC_D + c4);
@@ -203,20 +209,19 @@ __global__ __launch_bounds__(RC_NT) void rowchain_fwd_kernel(const RowChainFwdP 
 
   // ---- FFN block: conv1 -> act -> conv2 + residual + LayerNorm ----
   if (p.w1) {
-#pragma unroll 1
-    for (int ct = wave; ct < F / 16; ct += RC_NW) {
-      const int n = ct * 16 + fr;
-      bf16x8 wf1[2];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) wf1[kk] = rc_wfrag(p.w1, RC_D, n, kk * 32 + fq * 8);
-      const float b1 = p.b1[n];
+    for (int it = 0; it < 4; ++it) {
+      const int ct = wave + it * RC_NW;
+      if (ct >= nct) break;
+      const int n = ct * 16 + fr;
+      const float b1 = b1v[it];
       f32x4 zz[RT], hh[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         zz[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
-          zz[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * RC_XP + kk * 32 + fq * 8), wf1[kk], zz[rt], 0, 0, 0);
+          zz[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * RC_XP + kk * 32 + fq * 8), wf1[it][kk], zz[rt], 0, 0, 0);
         f32x4 f = {1.f, 1.f, 1.f, 1.f};
         if constexpr (DROP) f = drop_factors(pp.drop, dkey, dstep, (uint32_t)(p.drop_site + 1), row0 + rt * 16, F, n, lane);
 #pragma unroll
@@ -230,16 +235,22 @@ __global__ __launch_bounds__(RC_NT) void rowchain_fwd_kernel(const RowChainFwdP 
       if (p.z) store_acc(zz, p.z, F, ct * 16);
       if (p.h) store_acc(hh, p.h, F, ct * 16);
     }
-    __syncthreads();  // hidden activation image complete
+    // conv2's fragments are requested before the barrier: one memory round trip, not one per k-step
+    const int nk = F / 32;  // <= 8
+    bf16x8 wf2[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) wf2[kk] = rc_wfrag(p.w2, F, col, min(kk, nk - 1) * 32 + fq * 8);
     const float b2 = p.b2[col], g2 = p.g2[col], be2 = p.be2[col];
+    __syncthreads();  // hidden activation image complete
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) v[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int kk = 0; kk < F / 32; ++kk) {
-      const bf16x8 wf2 = rc_wfrag(p.w2, F, col, kk * 32 + fq * 8);
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        v[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(hb + (rt * 16 + fr) * RC_HP + kk * 32 + fq * 8), wf2, v[rt], 0, 0, 0);
+    for (int kk = 0; kk < 8; ++kk) {
+      if (kk < nk) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          v[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(hb + (rt * 16 + fr) * RC_HP + kk * 32 + fq * 8), wf2[kk], v[rt], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -319,6 +330,31 @@ __global__ __launch_bounds__(RC_NT) void rowchain_bwd_kernel(const RowChainBwdP 
       for (int r = 0; r < 4; ++r) xb[(rt * 16 + fq * 4 + r) * RC_XP + col] = (__bf16)v[rt][r];
   };
 
+  // everything the later phases read from global memory is requested now (one round trip instead of one per phase):
+  // x-hat of both norms, conv2^T's fragments and the activation-gradient source of this wave's column tiles
+  const int nct = p.w1 ? F / 16 : 0;
+  f32x4 xh1[RT], xh2[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long at = (row0 + min(rt * 16 + fq * 4 + r, L - 1)) * RC_D + col;
+      xh1[rt][r] = p.xhat1[at];
+      xh2[rt][r] = p.w1 ? p.xhat2[at] : 0.f;
+    }
+  bf16x8 wf2t[4][2];
+  f32x4 zsv[4][RT];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int n = min(wave + it * RC_NW, max(nct - 1, 0)) * 16 + fr;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) wf2t[it][kk] = p.w1 ? rc_wfrag_t(p.w2, F, kk * 32 + fq * 8, n) : zero_frag();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zsv[it][rt][r] = p.w1 ? p.zsrc[(row0 + min(rt * 16 + fq * 4 + r, L - 1)) * F + n] : 0.f;
+  }
+
   // ---- gradient of the chain's output: what arrives from elsewhere + the projection's share ----
   f32x4 g[RT];
 #pragma unroll
@@ -338,13 +374,18 @@ __global__ __launch_bounds__(RC_NT) void rowchain_bwd_kernel(const RowChainBwdP 
       const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
       *reinterpret_cast<bf16x4*>(hb + row * RC_HP + c4) = o;
     }
-    __syncthreads();
-#pragma unroll 1
-    for (int kk = 0; kk < NP / 32; ++kk) {
-      const bf16x8 wf = rc_wfrag_t(p.wp, RC_D, kk * 32 + fq * 8, col);
+    const int nkp = NP / 32;  // <= 6
+    bf16x8 wfp[6];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        g[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(hb + (rt * 16 + fr) * RC_HP + kk * 32 + fq * 8), wf, g[rt], 0, 0, 0);
+    for (int kk = 0; kk < 6; ++kk) wfp[kk] = rc_wfrag_t(p.wp, RC_D, min(kk, nkp - 1) * 32 + fq * 8, col);  // (one round trip)
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) {
+      if (kk < nkp) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          g[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(hb + (rt * 16 + fr) * RC_HP + kk * 32 + fq * 8), wfp[kk], g[rt], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -355,7 +396,7 @@ __global__ __launch_bounds__(RC_NT) void rowchain_bwd_kernel(const RowChainBwdP 
   // ---- FFN block backward ----
   if (p.w1) {
     f32x4 res[RT];
-    rc_ln_bwd<RT>(g, p.xhat2 + row0 * RC_D + col, p.rstd2 + row0, p.g2[col], p.dg2 + col, p.db2 + col, L, part, stat, wave,
+    rc_ln_bwd<RT>(g, xh2, p.rstd2 + row0, p.g2[col], p.dg2 + col, p.db2 + col, L, part, stat, wave,
                   lane);  // (its first barrier also fences the d proj image reads)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -370,22 +411,21 @@ __global__ __launch_bounds__(RC_NT) void rowchain_bwd_kernel(const RowChainBwdP 
     store_acc(g, p.dpre2, RC_D, wave * 16);
     __syncthreads();  // d pre-norm-2 image complete
     // conv2^T + activation': dz
-#pragma unroll 1
-    for (int ct = wave; ct < F / 16; ct += RC_NW) {
-      const int n = ct * 16 + fr;
-      bf16x8 wf[2];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) wf[kk] = rc_wfrag_t(p.w2, F, kk * 32 + fq * 8, n);
+    for (int it = 0; it < 4; ++it) {
+      const int ct = wave + it * RC_NW;
+      if (ct >= nct) break;
+      const int n = ct * 16 + fr;
       f32x4 acc[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
-          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * RC_XP + kk * 32 + fq * 8), wf[kk], acc[rt], 0, 0, 0);
+          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(xb + (rt * 16 + fr) * RC_XP + kk * 32 + fq * 8), wf2t[it][kk], acc[rt], 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float zs = p.zsrc[(row0 + min(rt * 16 + fq * 4 + r, L - 1)) * F + n];
+          const float zs = zsv[it][rt][r];
           const float d = p.act == RF_ACT_GELU ? sl_gelu_grad(zs) : (p.act == RF_ACT_RELU ? (zs > 0.f ? 1.f : 0.f) : 1.f);
           acc[rt][r] *= d;
         }
@@ -399,16 +439,21 @@ __global__ __launch_bounds__(RC_NT) void rowchain_bwd_kernel(const RowChainBwdP 
       }
       store_acc(acc, p.dz, F, ct * 16);
     }
+    const int nk = F / 32;  // <= 8
+    bf16x8 wf1t[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) wf1t[kk] = rc_wfrag_t(p.w1, RC_D, min(kk, nk - 1) * 32 + fq * 8, col);  // (one round trip)
     __syncthreads();  // dz image complete
     // conv1^T + skip
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) g[rt] = res[rt];
-#pragma unroll 1
-    for (int kk = 0; kk < F / 32; ++kk) {
-      const bf16x8 wf = rc_wfrag_t(p.w1, RC_D, kk * 32 + fq * 8, col);
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        g[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(hb + (rt * 16 + fr) * RC_HP + kk * 32 + fq * 8), wf, g[rt], 0, 0, 0);
+    for (int kk = 0; kk < 8; ++kk) {
+      if (kk < nk) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          g[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ld_frag(hb + (rt * 16 + fr) * RC_HP + kk * 32 + fq * 8), wf1t[kk], g[rt], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -417,7 +462,7 @@ __global__ __launch_bounds__(RC_NT) void rowchain_bwd_kernel(const RowChainBwdP 
   }
 
   // ---- first block backward: LayerNorm, out-projection^T ----
-  rc_ln_bwd<RT>(g, p.xhat1 + row0 * RC_D + col, p.rstd1 + row0, p.g1[col], p.dg1 + col, p.db1 + col, L, part, stat, wave, lane);
+  rc_ln_bwd<RT>(g, xh1, p.rstd1 + row0, p.g1[col], p.dg1 + col, p.db1 + col, L, part, stat, wave, lane);
   if constexpr (DROP) {
     store_acc(g, p.dx, RC_D, wave * 16);  // the residual input sees the unmasked gradient
 #pragma unroll
