@@ -633,12 +633,17 @@ namespace {
 __device__ __forceinline__ float sl1(float d) { const float a = fabsf(d); return a < 1.f ? 0.5f * d * d : a - 0.5f; }
 __device__ __forceinline__ float sl1g(float d) { return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f); }
 
+constexpr int TH_NT = 1024;  // threads of the single workgroup (16 waves: the element loops are pure load latency)
+
 __device__ float block_sum(float v, float* red) {
   v = wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < TH_NT / 64; ++w) t += red[w];  // fixed order
+  return t;
 }
 
 // Both kernels are ONE workgroup on a few thousand elements -- pure latency, on the critical path between the forward and
@@ -647,24 +652,24 @@ __device__ float block_sum(float v, float* red) {
 // in a loop.
 constexpr int TH_MAXP = 256, TH_MAXROWS = 2048;  // horizon / B * P bounds of the LDS staging (else the direct path)
 
-__global__ __launch_bounds__(256) void traj_head_fwd_kernel(const float* __restrict__ out, const float* __restrict__ last,
+__global__ __launch_bounds__(TH_NT) void traj_head_fwd_kernel(const float* __restrict__ out, const float* __restrict__ last,
                                                             const float* __restrict__ tgt, const float* __restrict__ tvis,
                                                             float* __restrict__ pos, float* __restrict__ gpos,
                                                             float* __restrict__ scal, int B, int P, int C, int E,
                                                             float gamma, float ratio, int dense_on, float mstd,
                                                             float mmean) {
-  __shared__ float red[4];
+  __shared__ float red[TH_NT / 64];
   __shared__ float disc[TH_MAXP];
   __shared__ float mot[TH_MAXROWS * 2];
   const int tid = threadIdx.x;
   const bool staged = P <= TH_MAXP && B * P <= TH_MAXROWS;
   if (staged) {
-    for (int t = tid; t < P; t += 256) disc[t] = powf(gamma, (float)t);
-    for (int i = tid; i < B * P * 2; i += 256) mot[i] = out[(long)(i >> 1) * C + (i & 1)] * mstd + mmean;
+    for (int t = tid; t < P; t += TH_NT) disc[t] = powf(gamma, (float)t);
+    for (int i = tid; i < B * P * 2; i += TH_NT) mot[i] = out[(long)(i >> 1) * C + (i & 1)] * mstd + mmean;
     __syncthreads();
   }
   // positions: one thread per (b, coordinate), sequential cumsum over the horizon (P <= a few dozen)
-  for (int i = tid; i < B * 2; i += 256) {
+  for (int i = tid; i < B * 2; i += TH_NT) {
     const int b = i >> 1, c = i & 1;
     float run = last[b * 2 + c];
     for (int t = 0; t < P; ++t) {
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(256) void traj_head_fwd_kernel(const float* __restr
   }
   __syncthreads();
   float s_traj = 0.f, s_ade = 0.f, s_fde = 0.f;
-  for (int i = tid; i < B * P; i += 256) {
+  for (int i = tid; i < B * P; i += TH_NT) {
     const int b = i / P, t = i - b * P;
     const float w = staged ? disc[t] : powf(gamma, (float)t);
     const float px = staged ? mot[i * 2] : pos[i * 2], py = staged ? mot[i * 2 + 1] : pos[i * 2 + 1];
@@ -693,19 +698,19 @@ __global__ __launch_bounds__(256) void traj_head_fwd_kernel(const float* __restr
     // flat over the (b, t, e) elements, eight loads of each operand in flight per thread (this single workgroup sits
     // between the forward and the backward pass: a dependent load per row pass cost 15 us here)
     const int total = B * P * E;
-    for (int i0 = tid; i0 < total; i0 += 256 * 8) {
-      float o[8], tv[8];
-      int bt[8];
+    for (int i0 = tid; i0 < total; i0 += TH_NT * 4) {
+      float o[4], tv[4];
+      int bt[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int i = min(i0 + 256 * j, total - 1);
+      for (int j = 0; j < 4; ++j) {
+        const int i = min(i0 + TH_NT * j, total - 1);
         bt[j] = i / E;
         o[j] = out[(long)bt[j] * C + 2 + (i - bt[j] * E)];
         tv[j] = tvis[i];
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (i0 + 256 * j < total) {
+      for (int j = 0; j < 4; ++j) {
+        if (i0 + TH_NT * j < total) {
           const int t = bt[j] % P;
           s_dense += (staged ? disc[t] : powf(gamma, (float)t)) * sl1(o[j] - tv[j]);
         }
@@ -722,7 +727,7 @@ __global__ __launch_bounds__(256) void traj_head_fwd_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void traj_head_bwd_kernel(const float* __restrict__ out, const float* __restrict__ tvis,
+__global__ __launch_bounds__(TH_NT) void traj_head_bwd_kernel(const float* __restrict__ out, const float* __restrict__ tvis,
                                                             const float* __restrict__ gpos, const float* __restrict__ scal,
                                                             const float* __restrict__ gloss, float* __restrict__ dout,
                                                             int B, int P, int C, int E, float gamma, float mstd) {
@@ -733,12 +738,12 @@ __global__ __launch_bounds__(256) void traj_head_bwd_kernel(const float* __restr
   const float w = scal[5];
   const bool staged = P <= TH_MAXP && B * P <= TH_MAXROWS;
   if (staged) {
-    for (int t = tid; t < P; t += 256) disc[t] = powf(gamma, (float)t);
-    for (int i = tid; i < B * P * 2; i += 256) gp[i] = gpos[i];
+    for (int t = tid; t < P; t += TH_NT) disc[t] = powf(gamma, (float)t);
+    for (int i = tid; i < B * P * 2; i += TH_NT) gp[i] = gpos[i];
     __syncthreads();
   }
   // d traj / d motion[b,s,c] = mstd * sum_{t>=s} gpos[b,t,c] / (B*P*2)
-  for (int i = tid; i < B * 2; i += 256) {
+  for (int i = tid; i < B * 2; i += TH_NT) {
     const int b = i >> 1, c = i & 1;
     float run = 0.f;
     for (int t = P - 1; t >= 0; --t) {
@@ -749,19 +754,19 @@ __global__ __launch_bounds__(256) void traj_head_bwd_kernel(const float* __restr
   if (tvis) {
     const float k = g * w / (float)((long)B * P * E);
     const int total = B * P * E;
-    for (int i0 = tid; i0 < total; i0 += 256 * 8) {  // (see the forward kernel)
-      float o[8], tv[8];
-      int bt[8];
+    for (int i0 = tid; i0 < total; i0 += TH_NT * 4) {  // (see the forward kernel)
+      float o[4], tv[4];
+      int bt[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int i = min(i0 + 256 * j, total - 1);
+      for (int j = 0; j < 4; ++j) {
+        const int i = min(i0 + TH_NT * j, total - 1);
         bt[j] = i / E;
         o[j] = out[(long)bt[j] * C + 2 + (i - bt[j] * E)];
         tv[j] = tvis[i];
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int i = i0 + 256 * j;
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + TH_NT * j;
         if (i < total) {
           const int t = bt[j] % P;
           dout[(long)bt[j] * C + 2 + (i - bt[j] * E)] = k * (staged ? disc[t] : powf(gamma, (float)t)) * sl1g(o[j] - tv[j]);
@@ -779,7 +784,7 @@ extern "C" int rf_traj_head_fwd(const float* out, const float* last_gps, const f
                                 float motion_mean, void* stream) {
   RF_REQUIRE(out && last_gps && target_gps && positions && gpos && scalars && B > 0 && P > 0 && C >= 2);
   RF_REQUIRE(!target_vis || C >= 2 + E);
-  RF_LAUNCH(traj_head_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), out, last_gps,
+  RF_LAUNCH(traj_head_fwd_kernel, dim3(1), dim3(TH_NT), 0, static_cast<hipStream_t>(stream), out, last_gps,
                      target_gps, target_vis, positions, gpos, scalars, B, P, C, E, gamma, dense_ratio, dense_on,
                      motion_std, motion_mean);
   RF_CHECK_LAUNCH();
@@ -790,7 +795,7 @@ extern "C" int rf_traj_head_bwd(const float* out, const float* target_vis, const
                                 const float* grad_loss, float* dout, int B, int P, int C, int E, float gamma,
                                 float motion_std, void* stream) {
   RF_REQUIRE(out && gpos && scalars && dout && B > 0 && P > 0 && C >= 2);
-  RF_LAUNCH(traj_head_bwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), out, target_vis,
+  RF_LAUNCH(traj_head_bwd_kernel, dim3(1), dim3(TH_NT), 0, static_cast<hipStream_t>(stream), out, target_vis,
                      gpos, scalars, grad_loss, dout, B, P, C, E, gamma, motion_std);
   RF_CHECK_LAUNCH();
   return RF_OK;
