@@ -165,3 +165,40 @@ def test_fused_adamw_hyper_vector():
     assert len(h) == 10 and h[0] == 1.0 and h[1] == 2.5 and h[2] == 3e-4 and h[9] == 0.125
     assert abs(h[7] - (1 - 0.9 ** 7)) < 1e-12 and abs(h[8] - (1 - 0.999 ** 7) ** 0.5) < 1e-12
     assert opt.hyper(1.0, pending=False)[0] == 0.0
+
+
+def test_deferred_update_segments_and_pending_rows():
+    """Host side of the deferred optimizer update with skippable ranges (engine.GraphedTrainEngine._plan_segments /
+    _pending_rows): the flat buffers are cut at the GPS backbone's range (side stream) and at the gaze slots; a segment the
+    previous step skipped gets pending = 0, every other one the bias corrections of ITS OWN update count (torch.optim.AdamW
+    keeps state['step'] per parameter and advances it only for parameters that had a gradient)."""
+    from types import SimpleNamespace
+    from routeformer_amd.engine import FusedAdamW, GraphedTrainEngine
+    eng = GraphedTrainEngine.__new__(GraphedTrainEngine)
+    opt = FusedAdamW.__new__(FusedAdamW)
+    opt.betas, opt.eps, opt.wd, opt.max_norm, opt.param_groups, opt.t, opt._lag = (0.9, 0.999), 1e-8, 1e-4, 2.5, [{"lr": 1e-4}], 0, {}
+    eng.opt = opt
+    eng.reducer = SimpleNamespace(flat_param=torch.zeros(1000))
+    eng.model = SimpleNamespace(configs=SimpleNamespace(gaze_dropout=0.2), with_gaze=True)
+    eng._gps_range = (0, 600)
+    gaze = ((640, 704), (832, 896))
+    eng._prefix_ranges = lambda prefixes: gaze
+    segs = eng._plan_segments()
+    assert segs == [(0, 600, True), (600, 640, False), (640, 704, False), (704, 832, False), (832, 896, False), (896, 1000, False)]
+    eng._segments = segs
+    # step 1 keeps the gaze branch, steps 2 and 3 drop it, step 4 keeps it again
+    for skip in ((), gaze, gaze, ()):
+        opt.t += 1
+        opt._note_skipped(skip)
+        rows = eng._pending_rows(0.5, skip)
+        for (a, b, _), row in zip(segs, rows):
+            is_gaze = (a, b) in gaze
+            assert row[0] == (0.0 if (is_gaze and skip) else 1.0) and row[9] == 0.5
+            t_seg = opt.t - (opt._lag.get((a, b), 0) if is_gaze else 0)
+            assert abs(row[7] - (1 - 0.9 ** t_seg)) < 1e-12 and abs(row[8] - (1 - 0.999 ** t_seg) ** 0.5) < 1e-12
+    assert opt.t == 4 and opt._lag == {gaze[0]: 2, gaze[1]: 2}   # the gaze slots are at their 2nd update, the rest at the 4th
+    # without gaze dropout (or without a backbone range) the plan degenerates
+    eng.model.configs.gaze_dropout = 0.0
+    assert eng._plan_segments() == [(0, 600, True), (600, 1000, False)]
+    eng._gps_range = None
+    assert eng._plan_segments() == [(0, 1000, False)]
