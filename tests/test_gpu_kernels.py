@@ -888,6 +888,100 @@ def test_wgrad_grouped(prec, tol):
         assert rel_err(d[3], db) < 1e-4, sh
 
 
+@pytest.mark.parametrize("M,F_,NP,act", [(320, 256, 192, "gelu"), (320, 0, 64, "gelu"), (77, 256, 0, "relu"), (1300, 128, 64, "gelu")])
+def test_rowchain_kernels_vs_torch(M, F_, NP, act):
+    """rf_rowchain_fwd / _bwd through the C ABI against torch autograd (fp32, on bf16-rounded matmul operands -- the kernel's
+    arithmetic contract): a -> Wo + residual -> LayerNorm [-> conv1 -> act -> conv2 + residual -> LayerNorm] [-> projection];
+    outputs, every save, and in the backward da, the residual gradient, the weight-gradient operands and dgamma / dbeta."""
+    import ctypes
+    import torch.nn.functional as Fn
+    from routeformer_amd import _hip
+    from routeformer_amd._hip import ptr
+    D = 64
+    g = _g(41)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc)
+    a, x = rnd(M, D), rnd(M, D)
+    wo, bo, g1, be1 = rnd(D, D, sc=D ** -0.5), rnd(D, sc=0.1), 1 + rnd(D, sc=0.1), rnd(D, sc=0.1)
+    ffn = F_ > 0
+    w1, b1, w2, b2 = rnd(max(F_, 1), D, sc=D ** -0.5), rnd(max(F_, 1), sc=0.1), rnd(D, max(F_, 1), sc=max(F_, 1) ** -0.5), rnd(D, sc=0.1)
+    g2, be2 = 1 + rnd(D, sc=0.1), rnd(D, sc=0.1)
+    wp, bp = rnd(max(NP, 1), D, sc=D ** -0.5), rnd(max(NP, 1), sc=0.1)
+    dout, dproj = rnd(M, D), rnd(M, max(NP, 1))
+    # ---- torch reference (the matmul operands rounded to bf16 as the MFMAs see them) ----
+    at, xt = a.clone().requires_grad_(), x.clone().requires_grad_()
+    P = {k: v.clone().requires_grad_() for k, v in dict(wo=wo, bo=bo, g1=g1, be1=be1, w1=w1, b1=b1, w2=w2, b2=b2, g2=g2, be2=be2,
+                                                        wp=wp, bp=bp).items()}
+    bf = lambda t_: t_ + (_bf(t_.detach()) - t_.detach())  # straight-through bf16 rounding
+    pre1 = bf(at) @ bf(P["wo"]).T + P["bo"] + xt
+    x1 = Fn.layer_norm(pre1, (D,), P["g1"], P["be1"], 1e-5)
+    out = x1
+    if ffn:
+        z = bf(x1) @ bf(P["w1"]).T + P["b1"]
+        h = Fn.gelu(z) if act == "gelu" else torch.relu(z)
+        pre2 = bf(h) @ bf(P["w2"]).T + P["b2"] + x1
+        out = Fn.layer_norm(pre2, (D,), P["g2"], P["be2"], 1e-5)
+    loss = (out * dout).sum()
+    if NP:
+        proj = bf(out) @ bf(P["wp"]).T + P["bp"]
+        loss = loss + (proj * dproj).sum()
+    loss.backward()
+    # ---- kernels ----
+    dev = lambda t_: t_.detach().to(DEV).contiguous()
+    T = {k: dev(v) for k, v in dict(a=a, x=x, wo=wo, bo=bo, g1=g1, be1=be1, w1=w1, b1=b1, w2=w2, b2=b2, g2=g2, be2=be2, wp=wp, bp=bp,
+                                    dout=dout, dproj=dproj).items()}
+    O = {k: torch.empty(M, w, device=DEV) for k, w in dict(x1=D, y=D, proj=max(NP, 1), xhat1=D, xhat2=D, z=max(F_, 1), h=max(F_, 1)).items()}
+    O["rstd1"], O["rstd2"] = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    c = _hip.RowChain()
+    for k in ("a", "x", "wo", "bo", "g1", "be1"):
+        setattr(c, k, ptr(T[k]))
+    if ffn:
+        for k in ("w1", "b1", "w2", "b2", "g2", "be2"):
+            setattr(c, k, ptr(T[k]))
+        c.y, c.xhat2, c.rstd2, c.h = ptr(O["y"]), ptr(O["xhat2"]), ptr(O["rstd2"]), ptr(O["h"])
+        if act == "gelu":
+            c.z = ptr(O["z"])
+    if NP:
+        c.wp, c.bp, c.proj = ptr(T["wp"]), ptr(T["bp"]), ptr(O["proj"])
+    c.x1, c.xhat1, c.rstd1 = ptr(O["x1"]), ptr(O["xhat1"]), ptr(O["rstd1"])
+    c.d_model, c.d_ff, c.n_proj, c.act, c.eps = D, F_, NP, {"gelu": 2, "relu": 1}[act], 1e-5
+    st = torch.cuda.current_stream().cuda_stream
+    assert _hip.lib().rf_rowchain_supported(D, F_, NP)
+    assert _hip.lib().rf_rowchain_fwd(ctypes.byref(c), M, 0.0, None, st) == 0, _hip.lib().rf_last_error()
+    torch.cuda.synchronize()
+    assert rel_err(O["x1"].cpu(), x1.detach()) < 5e-3
+    if ffn:
+        assert rel_err(O["y"].cpu(), out.detach()) < 5e-3 and rel_err(O["h"].cpu(), h.detach()) < 5e-3
+        if act == "gelu":
+            assert rel_err(O["z"].cpu(), z.detach()) < 5e-3
+    if NP:
+        assert rel_err(O["proj"].cpu(), proj.detach()) < 5e-3
+    G = {k: torch.zeros(D, device=DEV) for k in ("dg1", "db1", "dg2", "db2")}
+    R = {k: torch.empty(M, w, device=DEV) for k, w in dict(dpre1=D, da=D, dpre2=D, dz=max(F_, 1)).items()}
+    b = _hip.RowChainBwd()
+    b.dyin = ptr(T["dout"])
+    if NP:
+        b.dproj, b.wp = ptr(T["dproj"]), ptr(T["wp"])
+    if ffn:
+        b.w1, b.w2, b.g2, b.xhat2, b.rstd2 = ptr(T["w1"]), ptr(T["w2"]), ptr(T["g2"]), ptr(O["xhat2"]), ptr(O["rstd2"])
+        b.zsrc = ptr(O["z"] if act == "gelu" else O["h"])
+        b.dpre2, b.dz, b.dg2, b.db2 = ptr(R["dpre2"]), ptr(R["dz"]), ptr(G["dg2"]), ptr(G["db2"])
+    b.wo, b.g1, b.xhat1, b.rstd1 = ptr(T["wo"]), ptr(T["g1"]), ptr(O["xhat1"]), ptr(O["rstd1"])
+    b.dpre1, b.da, b.dg1, b.db1 = ptr(R["dpre1"]), ptr(R["da"]), ptr(G["dg1"]), ptr(G["db1"])
+    b.d_model, b.d_ff, b.n_proj, b.act = D, F_, NP, c.act
+    assert _hip.lib().rf_rowchain_bwd(ctypes.byref(b), M, 0.0, None, st) == 0, _hip.lib().rf_last_error()
+    torch.cuda.synchronize()
+    tol = 2e-2  # bf16 gradient images
+    assert rel_err(R["da"].cpu(), at.grad) < tol and rel_err(R["dpre1"].cpu(), xt.grad) < tol
+    assert rel_err(G["dg1"].cpu(), P["g1"].grad) < tol and rel_err(G["db1"].cpu(), P["be1"].grad) < tol
+    # the weight-gradient operands: dW = dy^T x for the pairs the Python glue queues
+    assert rel_err(R["dpre1"].cpu().T @ a, P["wo"].grad) < tol
+    if ffn:
+        assert rel_err(G["dg2"].cpu(), P["g2"].grad) < tol and rel_err(G["db2"].cpu(), P["be2"].grad) < tol
+        assert rel_err(R["dpre2"].cpu().T @ O["h"].cpu(), P["w2"].grad) < tol
+        assert rel_err(R["dz"].cpu().T @ O["x1"].cpu(), P["w1"].grad) < tol
+        assert rel_err(R["dz"].cpu().sum(0), P["b1"].grad) < tol
+
+
 @pytest.mark.parametrize("ybf,xbf", [(True, True)])
 def test_wgrad_grouped_bf16_operands(ybf, xbf):
     """rf_wgrad_tr with operands that already lie in memory as bf16 (the fused encoder stacks' dy slabs / activation saves,
