@@ -163,6 +163,12 @@ class IndexSampler:
 SAMPLER = IndexSampler()
 
 
+def _tail(h, n: int):
+    """h[:, -n:, :] -- the tensor itself when that is all of it (the gaze encoder / decoder keep every position): a
+    full-range slice is still an autograd node whose backward is a zero-fill and a copy."""
+    return h if n >= h.shape[1] else h[:, -n:, :]
+
+
 def _dropout(x, p: float, training: bool):
     """nn.Dropout(p): device-side Philox mask, regenerated (not stored) in backward (kernels.dropout)."""
     return K.dropout(x, p, training)
@@ -523,13 +529,16 @@ class Encoder(nn.Module):
             lay.attention.__dict__["output_attention"] = bool(on)
         return self
 
-    def forward(self, x, idx_list=None, idx_group: int = 0):
-        x = self._forward(x, idx_list, idx_group)
+    def forward(self, x, idx_list=None, idx_group: int = 0, tail: Optional[int] = None):
+        """``tail``: the caller consumes only the last ``tail`` positions -- they are cut out BEFORE the final LayerNorm (a
+        row-wise op: same values; the camera-token encoder keeps 1 position of 65, so the norm and its backward run on 192 rows
+        instead of 12 480)."""
+        x = self._forward(x, idx_list, idx_group, tail)
         if self.__dict__.get("output_attention", False):
             self.__dict__["attentions"] = [lay.attention.__dict__.pop("attention_map") for lay in self.attn_layers]
         return x
 
-    def _forward(self, x, idx_list=None, idx_group: int = 0):
+    def _forward(self, x, idx_list=None, idx_group: int = 0, tail: Optional[int] = None):
         if self.conv_layers is not None:
             for attn, conv in zip(self.attn_layers, self.conv_layers):
                 x = conv(attn(x))
@@ -541,6 +550,8 @@ class Encoder(nn.Module):
             else:
                 for i, attn in enumerate(self.attn_layers):
                     x = attn(x, None if idx_list is None else idx_list[i], idx_group)
+        if tail is not None:
+            x = _tail(x, tail)
         if self.norm is not None:
             x = K.add_layer_norm(x, None, self.norm.weight, self.norm.bias)
         return x
@@ -677,9 +688,8 @@ class PerceiveEncoder(nn.Module):
         """``idx_list``: per layer a (G,L,k) int32 device tensor of pre-drawn key samples (several
         reference calls batched into one: rows [g*idx_group, (g+1)*idx_group) use table g)."""
         h = self.value_embedding(x_enc, residual=self.position_embedding(x_enc.shape[1])[0])
-        h = self.encoder(h, idx_list, idx_group)
-        # only the last pred_len tokens are consumed: project just those rows
-        y = K.linear(h[:, -self.pred_len:, :], self.projection.weight, self.projection.bias)
+        h = self.encoder(h, idx_list, idx_group, tail=self.pred_len)  # only the last pred_len tokens are consumed
+        y = K.linear(h, self.projection.weight, self.projection.bias)
         return (y, self.encoder.attentions) if self.output_attention else y
 
 
@@ -705,4 +715,4 @@ class PerceiveDecoder(nn.Module):
     def forward(self, x_enc, x_dec):
         h = self.value_embedding(x_dec, residual=self.position_embedding(x_dec.shape[1])[0])
         h = self.decoder(h, x_enc)
-        return K.linear(h[:, -self.pred_len:, :], self.projection.weight, self.projection.bias)
+        return K.linear(_tail(h, self.pred_len), self.projection.weight, self.projection.bias)

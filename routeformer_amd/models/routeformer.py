@@ -255,7 +255,9 @@ class Routeformer(nn.Module):
                     tokens = self.gaze_encoder(tokens)
                 else:
                     torch.cuda.current_stream().wait_stream(fork)
-                visual[-1] = self.gaze_video_decoder(gaze_video, tokens)[:, : gaze_video.shape[1]]
+                dec = self.gaze_video_decoder(gaze_video, tokens)
+                # (a full-range slice would still cost a zero-fill and a copy in the backward pass)
+                visual[-1] = dec if dec.shape[1] <= gaze_video.shape[1] else dec[:, : gaze_video.shape[1]]
         if self.with_video:
             embs = []
             if self.with_scene:
