@@ -271,10 +271,13 @@ int rf_assemble_streams_bwd(const float* dout, float* const* demb, int B, int T,
 int rf_traj_head_fwd(const float* out, const float* last_gps, const float* target_gps,
                      const float* target_vis, float* positions, float* gpos, float* scalars, int B, int P,
                      int C, int E, float gamma, float dense_ratio, int dense_on, float motion_std,
-                     float motion_mean, void* stream);
+                     float motion_mean, int64_t out_batch_stride, int64_t last_batch_stride, int64_t vis_batch_stride,
+                     void* stream);
+/* *_batch_stride (elements between batches; 0 = packed): `out` may be the last P rows of a longer decoder output, `last_gps`
+ * the last row of the input track, `target_vis` the first P rows of a longer feature sequence -- read in place. */
 int rf_traj_head_bwd(const float* out, const float* target_vis, const float* gpos, const float* scalars,
                      const float* grad_loss, float* dout, int B, int P, int C, int E, float gamma,
-                     float motion_std, void* stream);
+                     float motion_std, int64_t out_batch_stride, int64_t vis_batch_stride, void* stream);
 
 /* ---- attention ------------------------------------------------------------------------------
  * One workgroup per (batch, head).  q[(b*LQ+l)*q_ld + h*E + e] etc. (row pitches in floats).

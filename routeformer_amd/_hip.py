@@ -56,8 +56,8 @@ SIGNATURES = {
     "rf_rowblock_linear_nn": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _P, _L, _I, _I, _I, _P],
     "rf_assemble_streams_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "rf_assemble_streams_bwd": [_P, _P, _I, _I, _I, _I, _P],
-    "rf_traj_head_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _F, _F, _P],
-    "rf_traj_head_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P],
+    "rf_traj_head_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _F, _F, _L, _L, _L, _P],
+    "rf_traj_head_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _L, _L, _P],
     "rf_attn_fwd": [_P, _P, _P, _L, _L, _L, _P, _I, _P, _I, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "rf_attn_fwd_full_scores": [_I, _I, _I, _I, _I, _I, _I, _I],
     "rf_attn_bwd": [_P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _I,

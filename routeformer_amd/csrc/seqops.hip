@@ -657,7 +657,7 @@ __global__ __launch_bounds__(TH_NT) void traj_head_fwd_kernel(const float* __res
                                                             float* __restrict__ pos, float* __restrict__ gpos,
                                                             float* __restrict__ scal, int B, int P, int C, int E,
                                                             float gamma, float ratio, int dense_on, float mstd,
-                                                            float mmean) {
+                                                            float mmean, long out_bs, long last_bs, long tvis_bs) {
   __shared__ float red[TH_NT / 64];
   __shared__ float disc[TH_MAXP];
   __shared__ float mot[TH_MAXROWS * 2];
@@ -665,15 +665,15 @@ __global__ __launch_bounds__(TH_NT) void traj_head_fwd_kernel(const float* __res
   const bool staged = P <= TH_MAXP && B * P <= TH_MAXROWS;
   if (staged) {
     for (int t = tid; t < P; t += TH_NT) disc[t] = powf(gamma, (float)t);
-    for (int i = tid; i < B * P * 2; i += TH_NT) mot[i] = out[(long)(i >> 1) * C + (i & 1)] * mstd + mmean;
+    for (int i = tid; i < B * P * 2; i += TH_NT) mot[i] = out[(long)((i >> 1) / P) * out_bs + ((i >> 1) % P) * C + (i & 1)] * mstd + mmean;
     __syncthreads();
   }
   // positions: one thread per (b, coordinate), sequential cumsum over the horizon (P <= a few dozen)
   for (int i = tid; i < B * 2; i += TH_NT) {
     const int b = i >> 1, c = i & 1;
-    float run = last[b * 2 + c];
+    float run = last[(long)b * last_bs + c];
     for (int t = 0; t < P; ++t) {
-      run += staged ? mot[(b * P + t) * 2 + c] : out[((long)b * P + t) * C + c] * mstd + mmean;
+      run += staged ? mot[(b * P + t) * 2 + c] : out[(long)b * out_bs + t * C + c] * mstd + mmean;
       pos[((long)b * P + t) * 2 + c] = run;
       if (staged) mot[(b * P + t) * 2 + c] = run;  // keep the position: the loss loop below reads it from LDS
     }
@@ -705,8 +705,8 @@ __global__ __launch_bounds__(TH_NT) void traj_head_fwd_kernel(const float* __res
       for (int j = 0; j < 4; ++j) {
         const int i = min(i0 + TH_NT * j, total - 1);
         bt[j] = i / E;
-        o[j] = out[(long)bt[j] * C + 2 + (i - bt[j] * E)];
-        tv[j] = tvis[i];
+        o[j] = out[(long)(bt[j] / P) * out_bs + (bt[j] % P) * C + 2 + (i - bt[j] * E)];
+        tv[j] = tvis[(long)(bt[j] / P) * tvis_bs + (bt[j] % P) * E + (i - bt[j] * E)];
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -730,7 +730,8 @@ __global__ __launch_bounds__(TH_NT) void traj_head_fwd_kernel(const float* __res
 __global__ __launch_bounds__(TH_NT) void traj_head_bwd_kernel(const float* __restrict__ out, const float* __restrict__ tvis,
                                                             const float* __restrict__ gpos, const float* __restrict__ scal,
                                                             const float* __restrict__ gloss, float* __restrict__ dout,
-                                                            int B, int P, int C, int E, float gamma, float mstd) {
+                                                            int B, int P, int C, int E, float gamma, float mstd, long out_bs,
+                                                            long tvis_bs) {
   __shared__ float disc[TH_MAXP];
   __shared__ float gp[TH_MAXROWS * 2];
   const int tid = threadIdx.x;
@@ -761,8 +762,8 @@ __global__ __launch_bounds__(TH_NT) void traj_head_bwd_kernel(const float* __res
       for (int j = 0; j < 4; ++j) {
         const int i = min(i0 + TH_NT * j, total - 1);
         bt[j] = i / E;
-        o[j] = out[(long)bt[j] * C + 2 + (i - bt[j] * E)];
-        tv[j] = tvis[i];
+        o[j] = out[(long)(bt[j] / P) * out_bs + (bt[j] % P) * C + 2 + (i - bt[j] * E)];
+        tv[j] = tvis[(long)(bt[j] / P) * tvis_bs + (bt[j] % P) * E + (i - bt[j] * E)];
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -781,22 +782,31 @@ __global__ __launch_bounds__(TH_NT) void traj_head_bwd_kernel(const float* __res
 extern "C" int rf_traj_head_fwd(const float* out, const float* last_gps, const float* target_gps,
                                 const float* target_vis, float* positions, float* gpos, float* scalars, int B, int P,
                                 int C, int E, float gamma, float dense_ratio, int dense_on, float motion_std,
-                                float motion_mean, void* stream) {
+                                float motion_mean, int64_t out_batch_stride, int64_t last_batch_stride,
+                                int64_t vis_batch_stride, void* stream) {
   RF_REQUIRE(out && last_gps && target_gps && positions && gpos && scalars && B > 0 && P > 0 && C >= 2);
   RF_REQUIRE(!target_vis || C >= 2 + E);
+  // batch strides (elements; 0 = packed): the head reads the LAST P rows of the decoder output, the last input position and
+  // the first P rows of the target features where they lie -- no contiguous copies in front of this launch
+  const long obs = out_batch_stride > 0 ? out_batch_stride : (long)P * C, lbs = last_batch_stride > 0 ? last_batch_stride : 2;
+  const long vbs = vis_batch_stride > 0 ? vis_batch_stride : (long)P * E;
+  RF_REQUIRE(obs >= (long)P * C && lbs >= 2 && vbs >= (long)P * E);
   RF_LAUNCH(traj_head_fwd_kernel, dim3(1), dim3(TH_NT), 0, static_cast<hipStream_t>(stream), out, last_gps,
                      target_gps, target_vis, positions, gpos, scalars, B, P, C, E, gamma, dense_ratio, dense_on,
-                     motion_std, motion_mean);
+                     motion_std, motion_mean, obs, lbs, vbs);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
 
 extern "C" int rf_traj_head_bwd(const float* out, const float* target_vis, const float* gpos, const float* scalars,
                                 const float* grad_loss, float* dout, int B, int P, int C, int E, float gamma,
-                                float motion_std, void* stream) {
+                                float motion_std, int64_t out_batch_stride, int64_t vis_batch_stride, void* stream) {
   RF_REQUIRE(out && gpos && scalars && dout && B > 0 && P > 0 && C >= 2);
+  const long obs = out_batch_stride > 0 ? out_batch_stride : (long)P * C;
+  const long vbs = vis_batch_stride > 0 ? vis_batch_stride : (long)P * E;
+  RF_REQUIRE(obs >= (long)P * C && vbs >= (long)P * E);
   RF_LAUNCH(traj_head_bwd_kernel, dim3(1), dim3(TH_NT), 0, static_cast<hipStream_t>(stream), out, target_vis,
-                     gpos, scalars, grad_loss, dout, B, P, C, E, gamma, motion_std);
+                     gpos, scalars, grad_loss, dout, B, P, C, E, gamma, motion_std, obs, vbs);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

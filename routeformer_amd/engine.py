@@ -75,7 +75,7 @@ def train_step_losses(model, item, epoch: int = 0, trajectory_loss: Optional[Fut
             E = cfg.image_embedding_size
             g_t, g_d = tl.discount(), dl.discount()
             assert g_t == g_d, "fused head assumes one discount table for both losses (as in the reference driver)"
-            target_vis = target_vis[:, : raw.shape[1]].contiguous()
+            target_vis = target_vis[:, : raw.shape[1]]  # (read in place by the fused head: batch stride)
             loss, traj, dense, a_, f_, future_gps = K.traj_head(
                 raw, last_gps, target_gps, target_vis, g_t, cfg.dense_loss_ratio, epoch >= 10,
                 cfg.motion_std if cfg.normalize_motion else 1.0, cfg.motion_mean if cfg.normalize_motion else 0.0)
@@ -680,6 +680,14 @@ class TrainEngine:
         self._skip_cache[tuple(prefixes)] = tuple((a, b) for a, b in merged)
         return self._skip_cache[tuple(prefixes)]
 
+    def _loss_seed(self, loss):
+        """d loss / d loss = 1 as a persistent tensor (``backward()`` would fill a fresh one: a launch between the forward and
+        the backward pass, where nothing overlaps it)."""
+        seed = self.__dict__.get("_seed_one")
+        if seed is None or seed.device != loss.device or seed.dtype != loss.dtype or seed.shape != loss.shape:
+            seed = self._seed_one = torch.ones_like(loss)
+        return seed
+
     def _fwd_bwd(self, item, epoch, tokens_ready: bool = False):
         from routeformer_amd import kernels as K
         K.OVERLAP = self.overlap
@@ -690,7 +698,7 @@ class TrainEngine:
         try:
             self._begin_step_kernels()
             res = train_step_losses(self.model, item, epoch, self.tl, self.dl, tokens_ready=tokens_ready)
-            res["loss"].backward()
+            res["loss"].backward(gradient=self._loss_seed(res["loss"]))
             K.flush_weight_grads()  # queued dW / db launches, each on the stream its operands were produced on
             if self.overlap:
                 K.join_side_streams()

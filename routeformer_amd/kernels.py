@@ -1468,17 +1468,28 @@ class _TrajHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, out, last_gps, target_gps, target_vis, gamma, ratio, dense_on, mstd, mmean):
         _req(out, "traj_head.out")
-        out = out.contiguous()
         B, P, C = out.shape
         E = target_vis.shape[-1] if target_vis is not None else 0
-        last = last_gps.reshape(B, 2).to(torch.float32).contiguous()
+
+        def rows_in_place(t, width):  # (B, rows, width) with packed rows: only the batch stride is free (slices along time)
+            return t.dtype == torch.float32 and t.stride(2) == 1 and t.stride(1) == width
+        # the last P rows of the decoder output, the last input position and the first P rows of the target features are read
+        # where they lie (batch strides): three strided-copy launches less in front of the one launch that cannot overlap anything
+        if not rows_in_place(out, C):
+            out = out.contiguous()
+        last = last_gps.reshape(B, 1, 2) if last_gps.dim() != 3 else last_gps
+        if not rows_in_place(last, 2):
+            last = last.to(torch.float32).contiguous()
         tgt = target_gps.to(torch.float32).contiguous()
-        tv = target_vis.contiguous() if target_vis is not None else None
+        tv = target_vis
+        if tv is not None and not rows_in_place(tv, E):
+            tv = tv.contiguous()
         pos = torch.empty(B, P, 2, device=out.device, dtype=torch.float32)
         gpos = torch.empty(B, P, 2, device=out.device, dtype=torch.float32)
         scal = torch.empty(8, device=out.device, dtype=torch.float32)
+        obs, lbs, vbs = out.stride(0), last.stride(0), (tv.stride(0) if tv is not None else 0)
         check(_hip.lib().rf_traj_head_fwd(ptr(out), ptr(last), ptr(tgt), ptr(tv), ptr(pos), ptr(gpos), ptr(scal), B, P, C,
-                                          E, gamma, ratio, 1 if dense_on else 0, mstd, mmean, _stream()),
+                                          E, gamma, ratio, 1 if dense_on else 0, mstd, mmean, obs, lbs, vbs, _stream()),
               "rf_traj_head_fwd")
         ctx.save_for_backward(out, tv if tv is not None else out, gpos, scal)
         ctx.cfg = (B, P, C, E, gamma, mstd, tv is not None)
@@ -1492,10 +1503,12 @@ class _TrajHead(torch.autograd.Function):
         B, P, C, E, gamma, mstd, has_vis = ctx.cfg
         if g_traj is not None or g_dense is not None or g_ade is not None or g_fde is not None:
             raise NotImplementedError("traj_head: only the combined loss is differentiable")
-        dout = torch.zeros_like(out) if C > 2 + E else torch.empty_like(out)
+        alloc = torch.zeros if C > 2 + E else torch.empty
+        dout = alloc(B, P, C, device=out.device, dtype=torch.float32)
         gl = g_loss.reshape(1).contiguous() if g_loss is not None else None
         check(_hip.lib().rf_traj_head_bwd(ptr(out), ptr(tv) if has_vis else None, ptr(gpos), ptr(scal), ptr(gl), ptr(dout),
-                                          B, P, C, E, gamma, mstd, _stream()), "rf_traj_head_bwd")
+                                          B, P, C, E, gamma, mstd, out.stride(0), tv.stride(0) if has_vis else 0, _stream()),
+              "rf_traj_head_bwd")
         return dout, None, None, None, None, None, None, None, None
 
 
