@@ -1175,9 +1175,11 @@ def test_rowchain_decoder_vs_layerwise(B, L, S, act, P):
     if P > 0:  # 2 layers x (self out, cross probabilities, cross out, hidden, conv2 out)
         assert len(c["masks"]) == 10 and abs(float(torch.stack([m.float().mean() for m in c["masks"]]).mean()) - (1 - P)) < 0.02
     assert torch.equal(c["rng"], u["rng"]), "host draws differ between the two paths"
-    assert rel_err(c["y"], u["y"]) < 2e-2, rel_err(c["y"], u["y"])
+    errs = {"y": rel_err(c["y"], u["y"]), **{k: fro_err(c[k], u[k]) for k in ("dq", "dm", "grad")}}
+    print("rowchain vs layer-by-layer:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert errs["y"] < 1e-2, errs          # (observed: <= 2.5e-3 output, <= 3.4e-3 gradients)
     for k in ("dq", "dm", "grad"):
-        assert fro_err(c[k], u[k]) < 3e-2, (k, fro_err(c[k], u[k]))
+        assert errs[k] < 1.5e-2, errs
 
 
 @pytest.mark.parametrize("shape", [(6, 65, 8, "gelu", 0.0), (5, 40, 3, "gelu", 0.0), (3, 80, 2, "relu", 0.0),
