@@ -23,7 +23,11 @@ from routeformer_amd.losses import FutureDiscountedLoss
 from routeformer_amd.score import ade, fde
 
 
-WGRAD_SIDE = os.environ.get("RF_WGRAD_SIDE", "1") == "1"  # weight-gradient groups that fill up mid-backward on a side stream
+# Weight-gradient groups that fill up mid-backward on a side stream: -0.04 ms at C2, but OFF by default -- with it a pytest
+# session that ran the full-size engine tests and then the dropout-variant engine test died with a host segmentation fault inside
+# hipGraphLaunch (reproducible in that order only; every other order, and the bench, were fine; RF_WGRAD_SIDE=0 cured it).
+# One more fork inside an already many-branched capture is not worth that (cf. kernels.on_side_stream's note on nested forks).
+WGRAD_SIDE = os.environ.get("RF_WGRAD_SIDE", "0") == "1"
 
 
 def _capture_kw() -> dict:
