@@ -73,6 +73,18 @@ int rf_gemm_skinny(const float* A, int64_t lda_m, int64_t lda_k, const float* B,
                    int64_t ldr, int res_rows, int res_before_act, int act, float* preact, int64_t ldp,
                    const float* dact_src, int64_t ldd, int dact_mode, float* workspace, void* stream);
 
+/* The split-K slices' RAW products of rf_gemm / rf_gemm_skinny, left as slabs workspace[slice][M][N] (row pitch N): no
+ * epilogue and no slab-sum launch -- the consumer sums them (rf_layernorm_fwd_slabs: the out-projection / Conv1d(k=1) pair
+ * in front of every LayerNorm of the GPS backbone, layers/TransformerEncoderDecoder.py:44-53,104-118, is a product, a slab
+ * sum and a norm; the slab sum rides in the norm's loads).  Same kernels, slice boundaries and per-slice arithmetic as
+ * the full calls.  Slab counts: rf_gemm_split_count(K, splitk) for rf_gemm_partials (>= 1, the effective count after
+ * rf_gemm's own clamping of `splitk`), rf_gemm_skinny_split(...) for rf_gemm_skinny_partials (0: unsupported). */
+int rf_gemm_split_count(int K, int splitk);
+int rf_gemm_partials(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k, int64_t ldb_n,
+                     int M, int N, int K, int prec, int splitk, float* workspace, void* stream);
+int rf_gemm_skinny_partials(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k, int64_t ldb_n,
+                            int M, int N, int K, float* workspace, void* stream);
+
 /* out[n] (+)= sum_m X[m*ldx + n] (bias gradients; accumulate=1 adds into out, e.g. a slot of the flat
  * gradient buffer).  workspace: parts*N floats, parts = rf_colsum_parts(M,N). */
 int rf_colsum_parts(int M, int N);
@@ -166,6 +178,12 @@ int rf_fold3_circular_ld(const float* dcols, float* dx, int B, int L, int C, int
  * cross_modal_transformer.py:283-284,297,301,421. cols <= 1024. */
 int rf_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
                      float* y, float* xhat, float* rstd, int rows, int cols, float eps, void* stream);
+/* The same norm on s = (slabs[0] + slabs[1] + ... + slabs[splits-1]) (+ bias[col]) (+ residual), slabs =
+ * [splits][rows][cols] from rf_gemm_partials / rf_gemm_skinny_partials: summed in slab order, then the bias, then the
+ * residual -- bit-identical to rf_gemm (bias epilogue) followed by rf_layernorm_fwd(residual, product). */
+int rf_layernorm_fwd_slabs(const float* slabs, int splits, const float* bias, const float* residual,
+                           const float* gamma, const float* beta, float* y, float* xhat, float* rstd, int rows,
+                           int cols, float eps, void* stream);
 /* dx = d(loss)/d(s); dgamma/dbeta reduced deterministically through `workspace`
  * (rf_layernorm_bwd_parts(rows)*2*cols floats); accumulate=1 adds them into dgamma/dbeta. */
 int rf_layernorm_bwd_parts(int rows);

@@ -20,6 +20,9 @@ SIGNATURES = {
                 _I, _I, _I, _P, _I, _P, _P, _P],
     "rf_gemm_skinny_split": [_P, _L, _L, _P, _L, _L, _I, _I, _I],
     "rf_gemm_skinny": [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _P, _P, _L, _I, _I, _I, _P, _L, _P, _L, _I, _P, _P],
+    "rf_gemm_split_count": [_I, _I],
+    "rf_gemm_partials": [_P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _P, _P],
+    "rf_gemm_skinny_partials": [_P, _L, _L, _P, _L, _L, _I, _I, _I, _P, _P],
     "rf_colsum_parts": [_I, _I],
     "rf_colsum": [_P, _L, _I, _I, _P, _I, _P, _P],
     "rf_conv2d_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _I, _I, _P],
@@ -41,6 +44,7 @@ SIGNATURES = {
     "rf_unfold3_circular_ld": [_P, _P, _I, _I, _I, _I, _I, _P],
     "rf_fold3_circular_ld": [_P, _P, _I, _I, _I, _I, _I, _P],
     "rf_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "rf_layernorm_fwd_slabs": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "rf_layernorm_bwd_parts": [_I],
     "rf_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P],
     "rf_bn_stats": [_P, _P, _P, _I, _I, _P, _P, _P, _F, _P],

@@ -982,12 +982,28 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k,
-                       int64_t ldb_n, float* C, int64_t ldc, int M, int N, int K, const float* bias,
-                       const float* residual, int64_t ldr, int res_rows, int res_before_act, int act,
-                       float* preact, int64_t ldp, const float* dact_src, int64_t ldd, int dact_mode,
-                       int prec, int splitk, float* workspace, int atomic_accumulate, float* a_rowsum,
-                       uint32_t* tile_counters, void* stream) {
+namespace {
+// K range per split-K slice (a multiple of 64, which covers the k-step of both kernel generations) and the number of
+// slices that are not empty
+constexpr int GEMM_KQ = 64;
+inline int split_chunk(int K, int splitk, int* eff) {
+  const int ktiles = (K + GEMM_KQ - 1) / GEMM_KQ;
+  if (splitk > ktiles) splitk = ktiles;
+  if (splitk < 1) splitk = 1;
+  const int kchunk = ((ktiles + splitk - 1) / splitk) * GEMM_KQ;
+  *eff = (K + kchunk - 1) / kchunk;
+  return kchunk;
+}
+}  // namespace
+
+// `partials_only`: every slice (also a single one) leaves its raw product in workspace[slice][M][N]; no epilogue, no
+// slab sum -- the consumer sums the slabs (rf_layernorm_fwd_slabs)
+static int gemm_run(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k,
+                    int64_t ldb_n, float* C, int64_t ldc, int M, int N, int K, const float* bias,
+                    const float* residual, int64_t ldr, int res_rows, int res_before_act, int act,
+                    float* preact, int64_t ldp, const float* dact_src, int64_t ldd, int dact_mode,
+                    int prec, int splitk, float* workspace, int atomic_accumulate, float* a_rowsum,
+                    uint32_t* tile_counters, bool partials_only, void* stream) {
   RF_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0);
   RF_REQUIRE(prec == 0 || prec == 1);
   RF_REQUIRE(splitk >= 1 && (splitk == 1 || workspace != nullptr || atomic_accumulate));
@@ -1001,12 +1017,8 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
   p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = residual; p.ldr = ldr;
   p.res_rows = residual ? res_rows : 1; p.res_before_act = res_before_act; p.act = act;
   p.preact = preact; p.ldp = ldp; p.dsrc = dact_src; p.ldd = ldd; p.dact = dact_mode;
-  constexpr int KQ = 64;  // K-slice granularity (covers BK of both kernel generations)
-  const int ktiles = (K + KQ - 1) / KQ;
-  if (splitk > ktiles) splitk = ktiles;
-  p.kchunk = ((ktiles + splitk - 1) / splitk) * KQ;
-  splitk = (K + p.kchunk - 1) / p.kchunk;
-  p.ws = (splitk > 1 && !atomic_accumulate) ? workspace : nullptr;
+  p.kchunk = split_chunk(K, splitk, &splitk);
+  p.ws = ((splitk > 1 && !atomic_accumulate) || partials_only) ? workspace : nullptr;
   p.atomic = atomic_accumulate; p.a_rowsum = a_rowsum;
   p.tile_cnt = nullptr;
 
@@ -1044,7 +1056,7 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
     else dispatch_b<1, 2>(p, bm, splitk, st);
   }
   RF_CHECK_LAUNCH();
-  if (splitk > 1 && !atomic_accumulate && !in_kernel_reduce) {
+  if (splitk > 1 && !atomic_accumulate && !in_kernel_reduce && !partials_only) {
     const long total = (long)M * N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -1052,6 +1064,31 @@ extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float
     RF_CHECK_LAUNCH();
   }
   return RF_OK;
+}
+
+extern "C" int rf_gemm(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k,
+                       int64_t ldb_n, float* C, int64_t ldc, int M, int N, int K, const float* bias,
+                       const float* residual, int64_t ldr, int res_rows, int res_before_act, int act,
+                       float* preact, int64_t ldp, const float* dact_src, int64_t ldd, int dact_mode,
+                       int prec, int splitk, float* workspace, int atomic_accumulate, float* a_rowsum,
+                       uint32_t* tile_counters, void* stream) {
+  return gemm_run(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, bias, residual, ldr, res_rows, res_before_act, act,
+                  preact, ldp, dact_src, ldd, dact_mode, prec, splitk, workspace, atomic_accumulate, a_rowsum,
+                  tile_counters, false, stream);
+}
+
+extern "C" int rf_gemm_split_count(int K, int splitk) {
+  int eff = 1;
+  if (K > 0) (void)split_chunk(K, splitk, &eff);
+  return eff;
+}
+
+extern "C" int rf_gemm_partials(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k,
+                                int64_t ldb_n, int M, int N, int K, int prec, int splitk, float* workspace,
+                                void* stream) {
+  RF_REQUIRE(workspace && splitk >= 1);
+  return gemm_run(A, lda_m, lda_k, B, ldb_k, ldb_n, workspace, N, M, N, K, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0,
+                  nullptr, 0, 0, prec, splitk, workspace, 0, nullptr, nullptr, true, stream);
 }
 
 extern "C" int rf_conv2d_nhwc(const void* x_, const float* w, const float* bias, const void* residual_,

@@ -181,10 +181,11 @@ extern "C" int rf_gemm_skinny_split(const float* A, int64_t lda_m, int64_t lda_k
   return (K + SK_KSLICE - 1) / SK_KSLICE;
 }
 
-extern "C" int rf_gemm_skinny(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k, int64_t ldb_n,
-                              float* C, int64_t ldc, int M, int N, int K, const float* bias, const float* residual,
-                              int64_t ldr, int res_rows, int res_before_act, int act, float* preact, int64_t ldp,
-                              const float* dact_src, int64_t ldd, int dact_mode, float* workspace, void* stream) {
+static int skinny_run(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k, int64_t ldb_n,
+                      float* C, int64_t ldc, int M, int N, int K, const float* bias, const float* residual,
+                      int64_t ldr, int res_rows, int res_before_act, int act, float* preact, int64_t ldp,
+                      const float* dact_src, int64_t ldd, int dact_mode, float* workspace, bool partials_only,
+                      void* stream) {
   RF_REQUIRE(C);
   const int z = rf_gemm_skinny_split(A, lda_m, lda_k, B, ldb_k, ldb_n, M, N, K);
   if (z == 0) {
@@ -202,12 +203,12 @@ extern "C" int rf_gemm_skinny(const float* A, int64_t lda_m, int64_t lda_k, cons
   p.res_rows = residual ? res_rows : 1; p.res_before_act = res_before_act; p.act = act;
   p.preact = preact; p.ldp = ldp; p.dsrc = dact_src; p.ldd = ldd; p.dact = dact_mode;
   p.kslice = z == 1 ? ((K + 31) / 32) * 32 : SK_KSLICE;
-  p.ws = z > 1 ? workspace : nullptr;
+  p.ws = (z > 1 || partials_only) ? workspace : nullptr;
   const hipStream_t st = static_cast<hipStream_t>(stream);
   if (b0) sk_launch<0>(p, z, st);
   else sk_launch<1>(p, z, st);
   RF_CHECK_LAUNCH();
-  if (z > 1) {
+  if (z > 1 && !partials_only) {
     const long total = (long)M * N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -215,4 +216,20 @@ extern "C" int rf_gemm_skinny(const float* A, int64_t lda_m, int64_t lda_k, cons
     RF_CHECK_LAUNCH();
   }
   return RF_OK;
+}
+
+extern "C" int rf_gemm_skinny(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k, int64_t ldb_n,
+                              float* C, int64_t ldc, int M, int N, int K, const float* bias, const float* residual,
+                              int64_t ldr, int res_rows, int res_before_act, int act, float* preact, int64_t ldp,
+                              const float* dact_src, int64_t ldd, int dact_mode, float* workspace, void* stream) {
+  return skinny_run(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, bias, residual, ldr, res_rows, res_before_act, act,
+                    preact, ldp, dact_src, ldd, dact_mode, workspace, false, stream);
+}
+
+// The K slices' raw products, workspace[slice][M][N] with rf_gemm_skinny_split(...) slices: no epilogue, no slab sum.
+extern "C" int rf_gemm_skinny_partials(const float* A, int64_t lda_m, int64_t lda_k, const float* B, int64_t ldb_k,
+                                       int64_t ldb_n, int M, int N, int K, float* workspace, void* stream) {
+  RF_REQUIRE(workspace);
+  return skinny_run(A, lda_m, lda_k, B, ldb_k, ldb_n, workspace, N, M, N, K, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0,
+                    nullptr, 0, 0, workspace, true, stream);
 }

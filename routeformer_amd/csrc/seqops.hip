@@ -65,6 +65,111 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   if (rstd_out && lane == 0) rstd_out[row] = rstd;
 }
 
+// Wide rows (cols > 256: the GPS backbone's d_model = 832): ONE ROW PER WORKGROUP, the four waves take the 64-column
+// groups round-robin (wave w: groups w, w + 4, ...; NVW of them), the two row reductions meet in LDS.  A wave per row
+// walks 13 groups per lane, and M = 32 .. 560 rows are 8 .. 140 workgroups: pure load latency.  The input may be the
+// split-K slabs [splits][rows][cols] of the product that feeds the norm (rf_gemm_partials): they are summed here in slab
+// order, then the bias -- the arithmetic of the slab-sum launch this replaces, one launch less per site.
+template <int NVW, int SC, bool HAS_BIAS, bool HAS_RES>
+__global__ __launch_bounds__(256) void layernorm_row_kernel(const float* __restrict__ x, int splits,
+                                                            const float* __restrict__ bias, const float* __restrict__ res,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ xhat, float* __restrict__ rstd_out,
+                                                            int rows, int cols, float eps) {
+  __shared__ float red[2][LN_WAVES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x;
+  const long off = (long)row * cols, slab = (long)rows * cols;
+  int cc[NVW];
+  float v[NVW], gm[NVW], bt[NVW], bs[NVW], rs[NVW];
+  // every operand that does not depend on the slabs is requested first; nothing below branches around a load (a
+  // wave-uniform branch makes the compiler drain the memory counter at the join: one round trip per branch)
+#pragma unroll
+  for (int i = 0; i < NVW; ++i) {
+    cc[i] = min((wave + LN_WAVES * i) * 64 + lane, cols - 1);  // clamped, unconditional loads; masked below
+    gm[i] = gamma[cc[i]];
+    bt[i] = beta[cc[i]];
+    if constexpr (HAS_BIAS) bs[i] = bias[cc[i]];
+    if constexpr (HAS_RES) rs[i] = res[off + cc[i]];
+    v[i] = 0.f;
+  }
+  // SC slabs in flight per trip (clamped slab index, masked add: v + 0 = v), summed in ascending slab order
+  for (int s0 = 0; s0 < splits; s0 += SC) {
+    float t[SC][NVW];
+#pragma unroll
+    for (int u = 0; u < SC; ++u) {
+      const long so = (long)min(s0 + u, splits - 1) * slab + off;
+#pragma unroll
+      for (int i = 0; i < NVW; ++i) t[u][i] = x[so + cc[i]];
+    }
+#pragma unroll
+    for (int u = 0; u < SC; ++u) {
+      const bool in = s0 + u < splits;
+#pragma unroll
+      for (int i = 0; i < NVW; ++i) v[i] += in ? t[u][i] : 0.f;
+    }
+  }
+  float s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NVW; ++i) {
+    if constexpr (HAS_BIAS) v[i] += bs[i];
+    if constexpr (HAS_RES) v[i] += rs[i];
+    v[i] = ((wave + LN_WAVES * i) * 64 + lane < cols) ? v[i] : 0.f;
+    s1 += v[i];
+  }
+  s1 = wave_sum(s1);
+  if (lane == 0) red[0][wave] = s1;
+  __syncthreads();
+  const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NVW; ++i) {
+    const float d = ((wave + LN_WAVES * i) * 64 + lane < cols) ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  q = wave_sum(q);
+  if (lane == 0) red[1][wave] = q;
+  __syncthreads();
+  const float var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)cols;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < NVW; ++i) {
+    const int c = (wave + LN_WAVES * i) * 64 + lane;
+    if (c < cols) {
+      const float h = (v[i] - mean) * rstd;
+      if (xhat) xhat[off + c] = h;
+      y[off + c] = h * gm[i] + bt[i];
+    }
+  }
+  if (rstd_out && threadIdx.x == 0) rstd_out[row] = rstd;
+}
+
+constexpr int LN_ROW_MIN_COLS = 257;  // rows this wide (and every slab input) take layernorm_row_kernel
+
+template <int NVW, int SC>
+void launch_ln_row_nvw(const float* x, int splits, const float* bias, const float* res, const float* gamma,
+                       const float* beta, float* y, float* xhat, float* rstd, int rows, int cols, float eps,
+                       hipStream_t st) {
+#define RF_LN_ROW_GO(B_, R_) \
+  RF_LAUNCH((layernorm_row_kernel<NVW, SC, B_, R_>), dim3(rows), dim3(256), 0, st, x, splits, bias, res, gamma, beta, y, xhat, \
+            rstd, rows, cols, eps)
+  if (bias && res) RF_LN_ROW_GO(true, true);
+  else if (bias) RF_LN_ROW_GO(true, false);
+  else if (res) RF_LN_ROW_GO(false, true);
+  else RF_LN_ROW_GO(false, false);
+#undef RF_LN_ROW_GO
+}
+
+template <int SC>
+void launch_ln_row(const float* x, int splits, const float* bias, const float* res, const float* gamma,
+                   const float* beta, float* y, float* xhat, float* rstd, int rows, int cols, float eps, hipStream_t st) {
+  const int groups = (cols + 63) / 64;
+  if (groups <= LN_WAVES) launch_ln_row_nvw<1, SC>(x, splits, bias, res, gamma, beta, y, xhat, rstd, rows, cols, eps, st);
+  else if (groups <= 2 * LN_WAVES) launch_ln_row_nvw<2, SC>(x, splits, bias, res, gamma, beta, y, xhat, rstd, rows, cols, eps, st);
+  else launch_ln_row_nvw<4, SC>(x, splits, bias, res, gamma, beta, y, xhat, rstd, rows, cols, eps, st);
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                             const float* __restrict__ rstd,
@@ -481,8 +586,26 @@ inline int grid_for(long total, int block = 256, int cap = 4096) {
 extern "C" int rf_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
                                 float* y, float* xhat, float* rstd, int rows, int cols, float eps, void* stream) {
   RF_REQUIRE(x && gamma && beta && y && rows > 0 && cols > 0 && cols <= 64 * LN_MAXV);
+  if (cols >= LN_ROW_MIN_COLS) {
+    launch_ln_row<1>(x, 1, nullptr, residual, gamma, beta, y, xhat, rstd, rows, cols, eps, static_cast<hipStream_t>(stream));
+    RF_CHECK_LAUNCH();
+    return RF_OK;
+  }
   RF_LN_DISPATCH(layernorm_fwd_kernel, cols, dim3((rows + LN_WAVES - 1) / LN_WAVES), dim3(256), 0,
                  static_cast<hipStream_t>(stream), x, residual, gamma, beta, y, xhat, rstd, rows, cols, eps);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_layernorm_fwd_slabs(const float* slabs, int splits, const float* bias, const float* residual,
+                                      const float* gamma, const float* beta, float* y, float* xhat, float* rstd, int rows,
+                                      int cols, float eps, void* stream) {
+  RF_REQUIRE(slabs && splits >= 1 && gamma && beta && y && rows > 0 && cols > 0 && cols <= 64 * LN_MAXV);
+  // one slab is the plain norm's arithmetic: the same instantiation, so that the two entry points agree to the bit
+  if (splits == 1)
+    launch_ln_row<1>(slabs, 1, bias, residual, gamma, beta, y, xhat, rstd, rows, cols, eps, static_cast<hipStream_t>(stream));
+  else
+    launch_ln_row<4>(slabs, splits, bias, residual, gamma, beta, y, xhat, rstd, rows, cols, eps, static_cast<hipStream_t>(stream));
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

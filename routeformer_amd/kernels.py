@@ -387,6 +387,71 @@ def gemm(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, *, bias=None, residu
                     replay=lambda a=args, k=keep: _hip.lib().rf_gemm(*a, _stream()))
 
 
+# The GPS backbone's out-projection / Conv1d(k=1) pair in front of a LayerNorm is a split-K product, a slab-sum launch and the
+# norm: with RF_SLAB_LN (default on) the product leaves its raw slabs and the norm's loads sum them (rf_layernorm_fwd_slabs;
+# bit-identical arithmetic, one launch less per site)
+SLAB_LN = os.environ.get("RF_SLAB_LN", "1") != "0"
+
+
+def _partials_plan(a_ptr, lda: int, w, M: int, N: int, K: int):
+    """How ``gemm`` would run y = a w^T (a (M, K) with row pitch ``lda`` at ``a_ptr``, w (N, K) contiguous) if it needs a
+    slab-sum launch: ("skinny", slabs) / ("tiled", splitk, slabs), or None when the product finishes in its own launch
+    (or the slab path is off).  Same decisions as ``gemm``."""
+    if not SLAB_LN or IN_LAUNCH_SPLITK_REDUCE or N > 1024 or N <= 256 or not w.is_cuda:
+        return None  # (N <= 256: the plain norm is the wave-per-row kernel there, another reduction tree)
+    if SKINNY_GEMM and _PRECISION == 1 and M <= (SKINNY_MAX_M if K <= 1024 else SKINNY_MAX_M_DEEP):
+        z = _hip.lib().rf_gemm_skinny_split(a_ptr, lda, 1, ptr(w), 1, K, M, N, K)
+        if z > 0:
+            return ("skinny", z) if z > 1 else None
+    splitk = _auto_split(M, N, K)
+    if splitk <= 1:
+        return None
+    eff = _hip.lib().rf_gemm_split_count(K, splitk)
+    return ("tiled", splitk, eff) if eff > 1 else None
+
+
+def _gemm_partials(x2, w, M: int, N: int, K: int, plan):
+    """Launch the product of ``plan`` (see ``_partials_plan``) -> (slabs [splits, M, N], splits)."""
+    splits = plan[-1]
+    ws = torch.empty(splits * M * N, device=x2.device, dtype=torch.float32)
+    ev = PROFILE.begin() if PROFILE.on else None
+    if plan[0] == "skinny":
+        args = (ptr(x2), x2.stride(0), 1, ptr(w), 1, K, M, N, K, ptr(ws))
+        fn, name = _hip.lib().rf_gemm_skinny_partials, "rf_gemm_skinny_partials"
+        rtm = 1 if M <= 16 else (2 if M <= 32 else 4)
+        tag = f"gemm_skinny_kernel<{rtm}, {2 if (M > 64 and N >= 1024) else 1}, 0>"
+    else:
+        args = (ptr(x2), x2.stride(0), 1, ptr(w), 1, K, M, N, K, _PRECISION, plan[1], ptr(ws))
+        fn, name = _hip.lib().rf_gemm_partials, "rf_gemm_partials"
+        am = 0 if (x2.stride(0) % 4 == 0 and K % 4 == 0 and x2.data_ptr() % 16 == 0) else 2
+        bm = 0 if (K % 4 == 0 and w.data_ptr() % 16 == 0) else 2
+        tag = (f"gemm2_kernel<{_PRECISION}, {am}, {bm}, {3 if (M >= 4096 and N >= 64) else 0}>" if am == 0 and bm == 0
+               else f"gemm_kernel<{_PRECISION}, {am}, {bm}, 0>")
+    check(fn(*args, _stream()), name)
+    if ev is not None:
+        keep = (x2, w, ws)
+        PROFILE.end(tag, ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + splits * M * N),
+                    replay=lambda a=args, k=keep, f=fn: f(*a, _stream()))
+    return ws, splits
+
+
+def _ln_fwd_slabs(ws, splits, bias, r2, gamma, beta, M: int, N: int, eps: float, need_grad: bool):
+    """LayerNorm(sum of slabs + bias + r2) -> (y, xhat, rstd)."""
+    y = torch.empty(M, N, device=ws.device, dtype=torch.float32)
+    xhat = torch.empty_like(y) if need_grad else None
+    rstd = torch.empty(M, device=ws.device, dtype=torch.float32) if need_grad else None
+    ev = PROFILE.begin() if PROFILE.on else None
+    check(_hip.lib().rf_layernorm_fwd_slabs(ptr(ws), splits, ptr(bias), ptr(r2), ptr(gamma), ptr(beta), ptr(y), ptr(xhat),
+                                            ptr(rstd), M, N, eps, _stream()), "rf_layernorm_fwd_slabs")
+    if ev is not None:
+        PROFILE.end("layernorm_fwd_kernel", ev, (8.0 + splits) * M * N, 4.0 * M * N * (splits + 2 + (xhat is not None)))
+    return y, xhat, rstd
+
+
+class _Ctx:
+    """Stand-in for an autograd context when one Function's backward runs another's (attributes set by the caller)."""
+
+
 def colsum(X2d: torch.Tensor, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Column sums; ``into`` = slot of the flat gradient buffer to ACCUMULATE into (returns None then)."""
     M, N = X2d.shape
@@ -921,12 +986,51 @@ class _LinearAddLN(torch.autograd.Function):
         return da, dw, db, dpre.view(ctx.shapes[1]), dgam, dbet, None, None, None, None, None, None
 
 
+class _LinearAddLNSlabs(torch.autograd.Function):
+    """y = LayerNorm(res + a W^T + b) for a product that needs split-K (the GPS backbone's d_model = 832 out-projections):
+    the product leaves its slabs, the norm sums them -- ``add_layer_norm(res, linear(a, w, b))`` minus the slab-sum launch,
+    bit-identical forward; the backward IS that composition (LayerNorm backward, then ``_Linear.backward``)."""
+
+    @staticmethod
+    def forward(ctx, a, w, b, res, gamma, beta, eps, gw, gb, gg, gbeta, plan, need_grad=True):
+        _req(a, "linear_ln.a"); _req(w, "linear_ln.w")
+        K, N = a.shape[-1], w.shape[0]
+        a2 = a.reshape(-1, K)
+        r2 = res.reshape(-1, N).contiguous()
+        M = a2.shape[0]
+        ws, splits = _gemm_partials(a2, w, M, N, K, plan)
+        y, xhat, rstd = _ln_fwd_slabs(ws, splits, b, r2, gamma, beta, M, N, eps, need_grad)
+        if need_grad:
+            ctx.save_for_backward(a2, w, xhat, rstd, gamma)
+        ctx.sinks = (gw, gb, gg, gbeta)
+        ctx.has_bias = b is not None
+        ctx.shapes = (a.shape, res.shape)
+        return y.view(res.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a2, w, xhat, rstd, gamma = ctx.saved_tensors
+        gw, gb, gg, gbeta = ctx.sinks
+        M, N = xhat.shape
+        dpre, dgam, dbet = _ln_backward(dy.reshape(M, N).contiguous(), xhat, rstd, gamma, gg, gbeta)
+        lin = _Ctx()
+        lin.saved_tensors, lin.sinks, lin.has_bias, lin.xshape = (a2, w), (gw, gb), ctx.has_bias, ctx.shapes[0]
+        lin.needs_input_grad = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2], False)
+        da, dw, db = _Linear.backward(lin, dpre)[:3]
+        return da, dw, db, dpre.view(ctx.shapes[1]), dgam, dbet, None, None, None, None, None, None, None
+
+
 def linear_add_layer_norm(a, w, b, res, gamma, beta, eps: float = 1e-5):
     """LayerNorm(res + linear(a, w, b)); one launch when the row-block kernel applies."""
     a2 = a.reshape(-1, a.shape[-1])
     if b is not None and a2.stride(1) == 1 and _rowblock_ok(a2, w, w.shape[0], a.shape[-1], with_ln=True):
         return _LinearAddLN.apply(a, w, b, res, gamma, beta, eps, _slot(w), _slot(b), _slot(gamma), _slot(beta),
                                   torch.is_grad_enabled())
+    if a2.stride(1) == 1 and w.is_contiguous() and a.dtype == torch.float32 and res.shape[-1] == w.shape[0]:
+        plan = _partials_plan(ptr(a2), a2.stride(0), w, a2.shape[0], w.shape[0], a.shape[-1])
+        if plan is not None and res.numel() == a2.shape[0] * w.shape[0]:
+            return _LinearAddLNSlabs.apply(a, w, b, res, gamma, beta, eps, _slot(w), _slot(b), _slot(gamma), _slot(beta),
+                                           plan, torch.is_grad_enabled())
     return add_layer_norm(res, linear(a, w, b), gamma, beta, eps)
 
 
@@ -999,6 +1103,44 @@ class _FFNAddLN(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2, None, dgam, dbet, None, None, None, None, None, None, None, None
 
 
+class _FFNAddLNSlabs(torch.autograd.Function):
+    """y = LayerNorm(x + conv2(act(conv1 x))) where conv2 needs split-K (the GPS backbone's d_ff = 3328 -> 832): conv2
+    leaves its slabs and the norm sums them -- ``add_layer_norm(skip, ffn(x, fork=True))`` minus the slab-sum launch,
+    bit-identical forward; the backward IS that composition (LayerNorm backward, then ``_FFN.backward``)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act, gamma, beta, eps, g1, gb1, g2, gb2, gg, gbeta, plan, need_grad=True):
+        _req(x, "ffn_ln.x")
+        F, D = w1.shape[0], w1.shape[1]
+        w1, w2 = w1.reshape(F, D), w2.reshape(D, F)
+        x2 = x.reshape(-1, D)
+        M = x2.shape[0]
+        h = torch.empty(M, F, device=x.device, dtype=torch.float32)
+        z = torch.empty_like(h) if (act == "gelu" and need_grad) else None
+        gemm(x2, x2.stride(0), 1, w1, 1, D, h, F, M, F, D, bias=b1, act=ACT[act], preact=z, ldp=F)
+        ws, splits = _gemm_partials(h, w2, M, D, F, plan)
+        r2 = x2 if x2.is_contiguous() else x2.contiguous()
+        y, xhat, rstd = _ln_fwd_slabs(ws, splits, b2, r2, gamma, beta, M, D, eps, need_grad)
+        if need_grad:
+            ctx.save_for_backward(x2, w1, w2, h, z if z is not None else h, xhat, rstd, gamma)
+        ctx.sinks = (g1, gb1, g2, gb2, gg, gbeta)
+        ctx.act, ctx.xshape, ctx.wshapes = act, x.shape, (F, D)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, h, zsrc, xhat, rstd, gamma = ctx.saved_tensors
+        g1, gb1, g2, gb2, gg, gbeta = ctx.sinks
+        M, D = xhat.shape
+        dpre, dgam, dbet = _ln_backward(dy.reshape(M, D).contiguous(), xhat, rstd, gamma, gg, gbeta)
+        f = _Ctx()
+        f.saved_tensors, f.sinks, f.drop = (x2, w1, w2, h, zsrc), (g1, gb1, g2, gb2), None
+        f.act, f.xshape, f.wshapes, f.needs_input_grad = ctx.act, ctx.xshape, ctx.wshapes, (ctx.needs_input_grad[0],)
+        dpre_v = dpre.view(ctx.xshape)
+        dx, dw1, db1, dw2, db2 = _FFN.backward(f, dpre_v, dpre_v)[:5]  # the skip branch's gradient rides in the last dX epilogue
+        return dx, dw1, db1, dw2, db2, None, dgam, dbet, None, None, None, None, None, None, None, None, None
+
+
 def ffn_add_layer_norm(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str, gamma, beta, eps: float = 1e-5):
     """LayerNorm(x + ffn(x)); one launch when d_model = 128, d_ff = 256 in bf16 mode."""
     F, D = conv1_w.shape[0], conv1_w.shape[1]
@@ -1008,6 +1150,14 @@ def ffn_add_layer_norm(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str, gamma, b
         return _FFNAddLN.apply(x, conv1_w, conv1_b, conv2_w, conv2_b, act, gamma, beta, eps, _slot(conv1_w),
                                _slot(conv1_b), _slot(conv2_w), _slot(conv2_b), _slot(gamma), _slot(beta),
                                torch.is_grad_enabled())
+    if x.is_cuda and x.dtype == torch.float32 and conv1_w.is_contiguous() and conv2_w.is_contiguous():
+        M = x.numel() // D
+        # conv2's left operand is the hidden activation: a fresh contiguous (M, F) tensor, allocator-aligned like x itself
+        plan = _partials_plan(ptr(x) // 256 * 256, F, conv2_w.view(D, F), M, D, F) if x.is_contiguous() else None
+        if plan is not None:
+            return _FFNAddLNSlabs.apply(x, conv1_w, conv1_b, conv2_w, conv2_b, act, gamma, beta, eps, _slot(conv1_w),
+                                        _slot(conv1_b), _slot(conv2_w), _slot(conv2_b), _slot(gamma), _slot(beta), plan,
+                                        torch.is_grad_enabled())
     y, skip = ffn(x, conv1_w, conv1_b, conv2_w, conv2_b, act, fork=True)
     return add_layer_norm(skip, y, gamma, beta, eps)
 

@@ -1173,6 +1173,87 @@ def test_rowblock_layer_ops_match_unfused(M):
         assert rel_err(outs[True][1][k], outs[False][1][k]) < 5e-3, k
 
 
+@pytest.mark.parametrize("splits,rows,cols,with_bias,with_res", [(1, 5, 832, False, True), (3, 37, 832, True, True),
+                                                                 (8, 130, 128, True, False), (13, 9, 100, False, False),
+                                                                 (2, 33, 300, True, True), (5, 21, 1024, True, False)])
+def test_layernorm_fwd_slabs_vs_torch(splits, rows, cols, with_bias, with_res):
+    """rf_layernorm_fwd_slabs (C ABI): LayerNorm(sum of split-K slabs + bias + residual) against torch in double, and
+    bit-identical to rf_layernorm_fwd on the slab sum formed in the same order."""
+    from routeformer_amd import _hip
+    g = _g(splits * 100 + rows)
+    slabs = torch.randn(splits, rows, cols, generator=g)
+    bias = torch.randn(cols, generator=g) if with_bias else None
+    res = torch.randn(rows, cols, generator=g) if with_res else None
+    gam, bet = torch.rand(cols, generator=g) + 0.5, torch.randn(cols, generator=g)
+    sd, gd, bd = slabs.to(DEV), gam.to(DEV), bet.to(DEV)
+    biasd, resd = (None if bias is None else bias.to(DEV)), (None if res is None else res.to(DEV))
+    y, xhat, rstd = torch.empty(rows, cols, device=DEV), torch.empty(rows, cols, device=DEV), torch.empty(rows, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t_: None if t_ is None else t_.data_ptr()
+    rc = _hip.lib().rf_layernorm_fwd_slabs(p(sd), splits, p(biasd), p(resd), p(gd), p(bd), p(y), p(xhat), p(rstd), rows, cols,
+                                           1e-5, st)
+    assert rc == 0, _hip.lib().rf_last_error()
+    s64 = slabs.double().sum(0) + (0 if bias is None else bias.double()) + (0 if res is None else res.double())
+    want = F.layer_norm(s64, (cols,), gam.double(), bet.double(), 1e-5)
+    assert rel_err(y, want) < 1e-5
+    assert rel_err(rstd, 1.0 / torch.sqrt(s64.var(1, unbiased=False) + 1e-5)) < 1e-5
+    # the slab sum in the slab-sum launch's order (s0 + s1 + ..., then the bias), handed to the plain entry point
+    acc = sd[0].clone()
+    for i in range(1, splits):
+        acc += sd[i]
+    if biasd is not None:
+        acc += biasd
+    y2, xh2, rs2 = torch.empty_like(y), torch.empty_like(y), torch.empty_like(rstd)
+    rc = _hip.lib().rf_layernorm_fwd(p(acc), p(resd), p(gd), p(bd), p(y2), p(xh2), p(rs2), rows, cols, 1e-5, st)
+    assert rc == 0, _hip.lib().rf_last_error()
+    if cols > 256:  # wide rows: both entry points run the row-per-workgroup kernel -- the same reduction tree
+        assert torch.equal(y, y2) and torch.equal(xhat, xh2) and torch.equal(rstd, rs2)
+    else:
+        assert rel_err(y, y2) < 1e-6 and rel_err(xhat, xh2) < 1e-6 and rel_err(rstd, rs2) < 1e-6
+
+
+@pytest.mark.parametrize("M", [320, 560, 96, 40])
+@pytest.mark.parametrize("prec", ["bf16", "f32"])
+def test_slab_layernorm_layer_ops_match_unfused(M, prec):
+    """The GPS backbone's d_model = 832 layer tail (out-projection + residual + norm1, Conv1d pair + residual + norm2:
+    layers/TransformerEncoderDecoder.py:44-53) with the split-K slabs summed inside the norm (kernels.SLAB_LN) against the
+    product + slab-sum launch + norm path: the forward must be BIT-identical (same kernels, same summation order), and so
+    are the gradients (the backward is the same composition of launches)."""
+    from routeformer_amd import kernels as Kn
+    Kn.set_precision(prec)
+    g = _g(29)
+    D, Fd = 832, 3328
+    base = dict(a=torch.randn(M, D, generator=g), x=torch.randn(M, D, generator=g),
+                w=torch.randn(D, D, generator=g) / math.sqrt(D), b=torch.randn(D, generator=g) * 0.1,
+                w1=torch.randn(Fd, D, 1, generator=g) / math.sqrt(D), b1=torch.randn(Fd, generator=g) * 0.1,
+                w2=torch.randn(D, Fd, 1, generator=g) / math.sqrt(Fd), b2=torch.randn(D, generator=g) * 0.1,
+                g1=torch.rand(D, generator=g) + 0.5, be1=torch.randn(D, generator=g),
+                g2=torch.rand(D, generator=g) + 0.5, be2=torch.randn(D, generator=g))
+    dy = torch.randn(M, D, generator=g).to(DEV)
+    outs, saved = {}, Kn.SLAB_LN
+    try:
+        for fused in (True, False):
+            Kn.SLAB_LN = fused
+            t = {k: v.to(DEV).requires_grad_(True) for k, v in base.items()}
+            if fused:  # the conv pair's second product always needs slabs at these shapes: the fused path is what runs
+                assert Kn._partials_plan(t["x"].data_ptr(), Fd, t["w2"].view(D, Fd), M, D, Fd) is not None
+            u = Kn.linear_add_layer_norm(t["a"], t["w"], t["b"], t["x"], t["g1"], t["be1"])
+            y = Kn.ffn_add_layer_norm(u, t["w1"], t["b1"], t["w2"], t["b2"], "gelu", t["g2"], t["be2"])
+            if fused:
+                assert type(y.grad_fn).__name__.startswith("_FFNAddLNSlabs")
+            y.backward(dy)
+            with torch.no_grad():  # the no-grad form (eval): no saves
+                y0 = Kn.ffn_add_layer_norm(Kn.linear_add_layer_norm(t["a"], t["w"], t["b"], t["x"], t["g1"], t["be1"]),
+                                           t["w1"], t["b1"], t["w2"], t["b2"], "gelu", t["g2"], t["be2"])
+            outs[fused] = (y.detach(), {k: v.grad for k, v in t.items()}, y0)
+    finally:
+        Kn.SLAB_LN = saved
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert torch.equal(outs[True][2], outs[False][2]) and torch.equal(outs[True][2], outs[True][0])
+    for k in base:
+        assert rel_err(outs[True][1][k], outs[False][1][k]) < 1e-6, k
+
+
 @pytest.mark.parametrize("B,P,E,extra,normalize,dense_on", [(8, 30, 64, 0, False, True), (3, 7, 16, 5, True, True),
                                                               (4, 30, 64, 0, True, False), (1, 1, 4, 0, False, True)])
 def test_traj_head(B, P, E, extra, normalize, dense_on):
