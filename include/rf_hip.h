@@ -178,6 +178,12 @@ int rf_fold3_circular_ld(const float* dcols, float* dx, int B, int L, int C, int
  * cross_modal_transformer.py:283-284,297,301,421. cols <= 1024. */
 int rf_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
                      float* y, float* xhat, float* rstd, int rows, int cols, float eps, void* stream);
+/* The same with x a strided view: row r of x at x + (r / seg_rows) * seg_stride + (r % seg_rows) * row_stride (elements) --
+ * the consumed tail of a (B, L, C) activation (seg_rows = tail length, seg_stride = L * C, row_stride = C) or a row-pitched
+ * 2-D view (seg_rows = rows); residual and the outputs are contiguous (rows, cols). */
+int rf_layernorm_fwd_strided(const float* x, int seg_rows, int64_t seg_stride, int64_t row_stride, const float* residual,
+                             const float* gamma, const float* beta, float* y, float* xhat, float* rstd, int rows, int cols,
+                             float eps, void* stream);
 /* The same norm on s = (slabs[0] + slabs[1] + ... + slabs[splits-1]) (+ bias[col]) (+ residual), slabs =
  * [splits][rows][cols] from rf_gemm_partials / rf_gemm_skinny_partials: summed in slab order, then the bias, then the
  * residual -- bit-identical to rf_gemm (bias epilogue) followed by rf_layernorm_fwd(residual, product). */
@@ -585,6 +591,11 @@ int rf_timeline_scatter(const float* feats, const int64_t* idx, float* out, int6
 int rf_timeline_gather(const float* dout, const int64_t* idx, float* dfeats, int64_t N, int T, int F, int E, void* stream);
 int rf_smart_tail_fwd(const float* x, float* y, int B, int L, int P, int C, int smart, void* stream);
 int rf_smart_tail_bwd(const float* dy, const float* extra, float* dx, int B, int L, int P, int C, int smart, void* stream);
+/* dst (rows, ld) = [src (rows, cols) | zero columns]: the K-padded copy of a Conv1d(k=3) weight whose 3 c_in is not a
+ * multiple of 4 (the GPS token embedding, layers/Embedding.py:28-46 with c_in = 69: 207 -> 208 keeps the embedding GEMMs on
+ * the 16-B vector path), and the way back for its gradient: dst (rows, cols) (+)= src (rows, ld)[:, :cols]. */
+int rf_pad_cols(const float* src, float* dst, int rows, int cols, int ld, void* stream);
+int rf_unpad_cols(const float* src, float* dst, int rows, int cols, int ld, int accumulate, void* stream);
 
 /* ---- cross-resolution fusion of the conv trunk without intermediate maps (hrnetv2.py:250-271,453-498;
  * InverseForm.py:66-67; routeformer.py:478-487) ---------------------------------------------------------------

@@ -44,6 +44,7 @@ SIGNATURES = {
     "rf_unfold3_circular_ld": [_P, _P, _I, _I, _I, _I, _I, _P],
     "rf_fold3_circular_ld": [_P, _P, _I, _I, _I, _I, _I, _P],
     "rf_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "rf_layernorm_fwd_strided": [_P, _I, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "rf_layernorm_fwd_slabs": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "rf_layernorm_bwd_parts": [_I],
     "rf_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P],
@@ -108,6 +109,8 @@ SIGNATURES = {
     "rf_timeline_gather": [_P, _P, _P, _L, _I, _I, _I, _P],
     "rf_smart_tail_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "rf_smart_tail_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "rf_pad_cols": [_P, _P, _I, _I, _I, _P],
+    "rf_unpad_cols": [_P, _P, _I, _I, _I, _I, _P],
     "rf_fuse_upsample_sum": [_P, _I, _I, _P],
     "rf_concat_pool_tokens": [_P, _P, _P, _P, _I, _I, _P, _I, _P],
     "rf_comm_available": [],

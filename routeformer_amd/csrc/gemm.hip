@@ -244,18 +244,32 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
   }
 }
 
-__global__ void splitk_reduce_kernel(GemmP p, int splits) {
-  const long total = (long)p.M * p.N;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int m = (int)(i / p.N), n = (int)(i % p.N);
+// Sum of the split-K slabs + the epilogue.  One element per thread trip; four slabs in flight per trip (clamped slab
+// index, masked add -- the slabs are still summed in ascending order) and the epilogue's operands requested before the
+// slab loop through branch-free selects: the plain form (a runtime-count loop of load -> add, then one uniform branch
+// per optional operand) was a chain of splits + 3 dependent memory round trips for a 1-MB tensor.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int splits) {
+  const unsigned total = (unsigned)p.M * (unsigned)p.N;  // rf_gemm bounds M * N * splits below 2^31 for this path
+  const float* dummy = p.ws;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned m = i / (unsigned)p.N, n = i - m * (unsigned)p.N;
+    const float bv = *(p.bias ? p.bias + n : dummy);
+    const float rv = *(p.res ? p.res + (long)(m % (unsigned)p.res_rows) * p.ldr + n : dummy);
+    const float dv = *(p.dact ? p.dsrc + (long)m * p.ldd + n : dummy);
     float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += p.ws[(long)s * total + i];
-    if (p.bias) v += p.bias[n];
-    if (p.res && p.res_before_act) v += p.res[(long)(m % p.res_rows) * p.ldr + n];
+    for (int s0 = 0; s0 < splits; s0 += 4) {
+      float t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = p.ws[(size_t)min(s0 + u, splits - 1) * total + i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v += (s0 + u < splits) ? t[u] : 0.f;
+    }
+    if (p.bias) v += bv;
+    if (p.res && p.res_before_act) v += rv;
     if (p.preact) p.preact[(long)m * p.ldp + n] = v;
     v = apply_act(v, p.act);
-    if (p.dact) v *= act_grad(p.dsrc[(long)m * p.ldd + n], p.dact);
-    if (p.res && !p.res_before_act) v += p.res[(long)(m % p.res_rows) * p.ldr + n];
+    if (p.dact) v *= act_grad(dv, p.dact);
+    if (p.res && !p.res_before_act) v += rv;
     p.C[(long)m * p.ldc + n] = v;
   }
 }
@@ -1058,6 +1072,7 @@ static int gemm_run(const float* A, int64_t lda_m, int64_t lda_k, const float* B
   RF_CHECK_LAUNCH();
   if (splitk > 1 && !atomic_accumulate && !in_kernel_reduce && !partials_only) {
     const long total = (long)M * N;
+    RF_REQUIRE(total < (1L << 31));  // splitk_reduce_kernel indexes an element with 32 bits
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     RF_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, splitk);

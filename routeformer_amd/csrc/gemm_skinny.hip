@@ -137,12 +137,31 @@ __global__ __launch_bounds__(SK_NT) void gemm_skinny_kernel(const SkinnyP p) {
   }
 }
 
-__global__ void skinny_reduce_kernel(SkinnyP p, int splits) {
-  const long total = (long)p.M * p.N;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+// Slab sum + epilogue (K > 1024): as gemm.hip's splitk_reduce_kernel -- four slabs in flight per trip, summed in ascending
+// order, the epilogue's operands requested up front through branch-free selects.  M <= 640, N <= a few thousand: 32-bit.
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(SkinnyP p, int splits) {
+  const unsigned total = (unsigned)p.M * (unsigned)p.N;
+  const float* dummy = p.ws;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned m = i / (unsigned)p.N, n = i - m * (unsigned)p.N;
+    const float bv = *(p.bias ? p.bias + n : dummy);
+    const float rv = *(p.res ? p.res + (long)(m % (unsigned)p.res_rows) * p.ldr + n : dummy);
+    const float dv = *(p.dact ? p.dsrc + (long)m * p.ldd + n : dummy);
     float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += p.ws[(long)s * total + i];
-    sk_epilogue(p, (int)(i / p.N), (int)(i % p.N), v);
+    for (int s0 = 0; s0 < splits; s0 += 4) {
+      float t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = p.ws[(size_t)min(s0 + u, splits - 1) * total + i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v += (s0 + u < splits) ? t[u] : 0.f;
+    }
+    if (p.bias) v += bv;
+    if (p.res && p.res_before_act) v += rv;
+    if (p.preact) p.preact[(long)m * p.ldp + n] = v;
+    v = apply_act(v, p.act);
+    if (p.dact) v *= act_grad(dv, p.dact);
+    if (p.res && !p.res_before_act) v += rv;
+    p.C[(long)m * p.ldc + n] = v;
   }
 }
 

@@ -20,14 +20,18 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ xhat, float* __restrict__ rstd_out,
-                                                            int rows, int cols, float eps) {
+                                                            int rows, int cols, float eps, int seg_rows, long seg_stride,
+                                                            long row_stride) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * LN_WAVES + wave;
   if (row >= rows) return;
   const long off = (long)row * cols;
+  // x may be a strided view (the consumed tail of a (B, L, C) tensor, a row-pitched 2-D view): row -> (segment, row in it)
+  const int seg = row / seg_rows;
+  const long xoff = (long)seg * seg_stride + (long)(row - seg * seg_rows) * row_stride;
   float v[NV], gm[NV], bt[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = x[off + min(i * 64 + lane, cols - 1)];
+  for (int i = 0; i < NV; ++i) v[i] = x[xoff + min(i * 64 + lane, cols - 1)];
   if (res) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] += res[off + min(i * 64 + lane, cols - 1)];
@@ -76,11 +80,14 @@ __global__ __launch_bounds__(256) void layernorm_row_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ xhat, float* __restrict__ rstd_out,
-                                                            int rows, int cols, float eps) {
+                                                            int rows, int cols, float eps, int seg_rows, long seg_stride,
+                                                            long row_stride) {
   __shared__ float red[2][LN_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x;
   const long off = (long)row * cols, slab = (long)rows * cols;
+  const int seg = row / seg_rows;  // strided x (splits == 1 only): see layernorm_fwd_kernel
+  const long xoff = (long)seg * seg_stride + (long)(row - seg * seg_rows) * row_stride;
   int cc[NVW];
   float v[NVW], gm[NVW], bt[NVW], bs[NVW], rs[NVW];
   // every operand that does not depend on the slabs is requested first; nothing below branches around a load (a
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(256) void layernorm_row_kernel(const float* __restr
     float t[SC][NVW];
 #pragma unroll
     for (int u = 0; u < SC; ++u) {
-      const long so = (long)min(s0 + u, splits - 1) * slab + off;
+      const long so = (long)min(s0 + u, splits - 1) * slab + xoff;
 #pragma unroll
       for (int i = 0; i < NVW; ++i) t[u][i] = x[so + cc[i]];
     }
@@ -149,11 +156,11 @@ constexpr int LN_ROW_MIN_COLS = 257;  // rows this wide (and every slab input) t
 
 template <int NVW, int SC>
 void launch_ln_row_nvw(const float* x, int splits, const float* bias, const float* res, const float* gamma,
-                       const float* beta, float* y, float* xhat, float* rstd, int rows, int cols, float eps,
-                       hipStream_t st) {
+                       const float* beta, float* y, float* xhat, float* rstd, int rows, int cols, float eps, int seg_rows,
+                       long seg_stride, long row_stride, hipStream_t st) {
 #define RF_LN_ROW_GO(B_, R_) \
   RF_LAUNCH((layernorm_row_kernel<NVW, SC, B_, R_>), dim3(rows), dim3(256), 0, st, x, splits, bias, res, gamma, beta, y, xhat, \
-            rstd, rows, cols, eps)
+            rstd, rows, cols, eps, seg_rows, seg_stride, row_stride)
   if (bias && res) RF_LN_ROW_GO(true, true);
   else if (bias) RF_LN_ROW_GO(true, false);
   else if (res) RF_LN_ROW_GO(false, true);
@@ -163,11 +170,14 @@ void launch_ln_row_nvw(const float* x, int splits, const float* bias, const floa
 
 template <int SC>
 void launch_ln_row(const float* x, int splits, const float* bias, const float* res, const float* gamma,
-                   const float* beta, float* y, float* xhat, float* rstd, int rows, int cols, float eps, hipStream_t st) {
+                   const float* beta, float* y, float* xhat, float* rstd, int rows, int cols, float eps, int seg_rows,
+                   long seg_stride, long row_stride, hipStream_t st) {
   const int groups = (cols + 63) / 64;
-  if (groups <= LN_WAVES) launch_ln_row_nvw<1, SC>(x, splits, bias, res, gamma, beta, y, xhat, rstd, rows, cols, eps, st);
-  else if (groups <= 2 * LN_WAVES) launch_ln_row_nvw<2, SC>(x, splits, bias, res, gamma, beta, y, xhat, rstd, rows, cols, eps, st);
-  else launch_ln_row_nvw<4, SC>(x, splits, bias, res, gamma, beta, y, xhat, rstd, rows, cols, eps, st);
+#define RF_LN_ROW_ARGS x, splits, bias, res, gamma, beta, y, xhat, rstd, rows, cols, eps, seg_rows, seg_stride, row_stride, st
+  if (groups <= LN_WAVES) launch_ln_row_nvw<1, SC>(RF_LN_ROW_ARGS);
+  else if (groups <= 2 * LN_WAVES) launch_ln_row_nvw<2, SC>(RF_LN_ROW_ARGS);
+  else launch_ln_row_nvw<4, SC>(RF_LN_ROW_ARGS);
+#undef RF_LN_ROW_ARGS
 }
 
 template <int NV>
@@ -583,18 +593,27 @@ inline int grid_for(long total, int block = 256, int cap = 4096) {
 
 }  // namespace
 
-extern "C" int rf_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
-                                float* y, float* xhat, float* rstd, int rows, int cols, float eps, void* stream) {
-  RF_REQUIRE(x && gamma && beta && y && rows > 0 && cols > 0 && cols <= 64 * LN_MAXV);
+// x row r lives at x + (r / seg_rows) * seg_stride + (r % seg_rows) * row_stride (elements); everything else is contiguous
+extern "C" int rf_layernorm_fwd_strided(const float* x, int seg_rows, int64_t seg_stride, int64_t row_stride,
+                                        const float* residual, const float* gamma, const float* beta, float* y, float* xhat,
+                                        float* rstd, int rows, int cols, float eps, void* stream) {
+  RF_REQUIRE(x && gamma && beta && y && rows > 0 && cols > 0 && cols <= 64 * LN_MAXV && seg_rows > 0);
   if (cols >= LN_ROW_MIN_COLS) {
-    launch_ln_row<1>(x, 1, nullptr, residual, gamma, beta, y, xhat, rstd, rows, cols, eps, static_cast<hipStream_t>(stream));
+    launch_ln_row<1>(x, 1, nullptr, residual, gamma, beta, y, xhat, rstd, rows, cols, eps, seg_rows, (long)seg_stride,
+                     (long)row_stride, static_cast<hipStream_t>(stream));
     RF_CHECK_LAUNCH();
     return RF_OK;
   }
   RF_LN_DISPATCH(layernorm_fwd_kernel, cols, dim3((rows + LN_WAVES - 1) / LN_WAVES), dim3(256), 0,
-                 static_cast<hipStream_t>(stream), x, residual, gamma, beta, y, xhat, rstd, rows, cols, eps);
+                 static_cast<hipStream_t>(stream), x, residual, gamma, beta, y, xhat, rstd, rows, cols, eps, seg_rows,
+                 (long)seg_stride, (long)row_stride);
   RF_CHECK_LAUNCH();
   return RF_OK;
+}
+
+extern "C" int rf_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                                float* y, float* xhat, float* rstd, int rows, int cols, float eps, void* stream) {
+  return rf_layernorm_fwd_strided(x, rows > 0 ? rows : 1, 0, cols, residual, gamma, beta, y, xhat, rstd, rows, cols, eps, stream);
 }
 
 extern "C" int rf_layernorm_fwd_slabs(const float* slabs, int splits, const float* bias, const float* residual,
@@ -603,9 +622,11 @@ extern "C" int rf_layernorm_fwd_slabs(const float* slabs, int splits, const floa
   RF_REQUIRE(slabs && splits >= 1 && gamma && beta && y && rows > 0 && cols > 0 && cols <= 64 * LN_MAXV);
   // one slab is the plain norm's arithmetic: the same instantiation, so that the two entry points agree to the bit
   if (splits == 1)
-    launch_ln_row<1>(slabs, 1, bias, residual, gamma, beta, y, xhat, rstd, rows, cols, eps, static_cast<hipStream_t>(stream));
+    launch_ln_row<1>(slabs, 1, bias, residual, gamma, beta, y, xhat, rstd, rows, cols, eps, rows, 0, cols,
+                     static_cast<hipStream_t>(stream));
   else
-    launch_ln_row<4>(slabs, splits, bias, residual, gamma, beta, y, xhat, rstd, rows, cols, eps, static_cast<hipStream_t>(stream));
+    launch_ln_row<4>(slabs, splits, bias, residual, gamma, beta, y, xhat, rstd, rows, cols, eps, rows, 0, cols,
+                     static_cast<hipStream_t>(stream));
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

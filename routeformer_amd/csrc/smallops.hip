@@ -174,6 +174,27 @@ __global__ void smart_tail_bwd_kernel(const float* __restrict__ dy, const float*
   }
 }
 
+// dst (rows, ld) = [src (rows, cols) | zeros]: the K-padded copy of a weight whose row length is not a multiple of 4 (the GPS
+// token embedding's 3 x 69 = 207 -> 208: kernels.circular_conv3), and the way back for its gradient
+__global__ __launch_bounds__(256) void pad_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols,
+                                                       int ld) {
+  const unsigned total = (unsigned)rows * (unsigned)ld;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned r = i / (unsigned)ld, c = i - r * (unsigned)ld;
+    const float v = src[(size_t)r * cols + min(c, (unsigned)cols - 1)];  // clamped, unconditional load
+    dst[i] = c < (unsigned)cols ? v : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void unpad_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols,
+                                                         int ld, int accumulate) {
+  const unsigned total = (unsigned)rows * (unsigned)cols;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned r = i / (unsigned)cols, c = i - r * (unsigned)cols;
+    const float v = src[(size_t)r * ld + c];
+    dst[i] = accumulate ? dst[i] + v : v;
+  }
+}
+
 }  // namespace
 
 extern "C" int rf_median_windows(const float* x, float* y, int B, int T, int C, int target, void* stream) {
@@ -241,6 +262,23 @@ extern "C" int rf_smart_tail_bwd(const float* dy, const float* extra, float* dx,
   RF_REQUIRE(dy && dx && B > 0 && L > 0 && P >= 0 && C > 0);
   RF_LAUNCH(smart_tail_bwd_kernel, dim3(blocks_for((long)B * L * C)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, extra,
             dx, B, L, P, C, smart);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+
+extern "C" int rf_pad_cols(const float* src, float* dst, int rows, int cols, int ld, void* stream) {
+  RF_REQUIRE(src && dst && rows > 0 && cols > 0 && ld >= cols && (long)rows * ld < (1L << 31));
+  RF_LAUNCH(pad_cols_kernel, dim3(blocks_for((long)rows * ld)), dim3(256), 0, static_cast<hipStream_t>(stream), src, dst, rows,
+            cols, ld);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_unpad_cols(const float* src, float* dst, int rows, int cols, int ld, int accumulate, void* stream) {
+  RF_REQUIRE(src && dst && rows > 0 && cols > 0 && ld >= cols && (long)rows * ld < (1L << 31));
+  RF_LAUNCH(unpad_cols_kernel, dim3(blocks_for((long)rows * cols)), dim3(256), 0, static_cast<hipStream_t>(stream), src, dst,
+            rows, cols, ld, accumulate);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

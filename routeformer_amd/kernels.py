@@ -882,15 +882,21 @@ class _AddLayerNorm(torch.autograd.Function):
     def forward(ctx, x, residual, gamma, beta, eps, gg, gb, need_grad=True):
         _req(x, "layernorm.x")
         cols = x.shape[-1]
-        x2 = x.reshape(-1, cols).contiguous()
+        rows = x.numel() // cols
+        # a strided view (the consumed tail of a (B, L, C) activation, a row-pitched 2-D view) is read in place
+        if x.dim() == 3 and x.stride(2) == 1 and x.shape[0] * x.shape[1] == rows:
+            x2, seg = x, (x.shape[1], x.stride(0), x.stride(1))
+        elif x.dim() == 2 and x.stride(1) == 1:
+            x2, seg = x, (rows, 0, x.stride(0))
+        else:
+            x2, seg = x.reshape(-1, cols).contiguous(), (rows, 0, cols)
         r2 = residual.reshape(-1, cols).contiguous() if residual is not None else None
-        rows = x2.shape[0]
-        y = torch.empty_like(x2)
-        xhat = torch.empty_like(x2) if need_grad else None  # normalised input + 1/sigma: backward only
+        y = torch.empty(rows, cols, device=x.device, dtype=torch.float32)
+        xhat = torch.empty_like(y) if need_grad else None  # normalised input + 1/sigma: backward only
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if need_grad else None
         ev = PROFILE.begin() if PROFILE.on else None
-        check(_hip.lib().rf_layernorm_fwd(ptr(x2), ptr(r2), ptr(gamma), ptr(beta), ptr(y), ptr(xhat),
-                                          ptr(rstd), rows, cols, eps, _stream()), "rf_layernorm_fwd")
+        check(_hip.lib().rf_layernorm_fwd_strided(ptr(x2), seg[0], seg[1], seg[2], ptr(r2), ptr(gamma), ptr(beta), ptr(y),
+                                                  ptr(xhat), ptr(rstd), rows, cols, eps, _stream()), "rf_layernorm_fwd")
         if ev is not None:
             PROFILE.end("layernorm_fwd_kernel", ev, 8.0 * rows * cols, 4.0 * rows * cols * (4 if r2 is not None else 3))
         if need_grad:
@@ -1189,6 +1195,35 @@ class _Unfold3(torch.autograd.Function):
         return dx, None, None
 
 
+class _PadCols(torch.autograd.Function):
+    """(rows, cols) -> (rows, ld) with zero columns appended, one launch (was a zero-fill + a strided copy); the gradient goes
+    back in one launch too -- straight into the weight's slot of the flat gradient buffer when there is one (was a
+    slice copy + autograd's accumulation)."""
+
+    @staticmethod
+    def forward(ctx, w2, ld: int, gw):
+        _req(w2, "pad_cols.w")
+        w2 = w2.contiguous()
+        rows, cols = w2.shape
+        out = torch.empty(rows, ld, device=w2.device, dtype=torch.float32)
+        check(_hip.lib().rf_pad_cols(ptr(w2), ptr(out), rows, cols, ld, _stream()), "rf_pad_cols")
+        ctx.dims, ctx.gw = (rows, cols, ld), gw
+        return out
+
+    @staticmethod
+    def backward(ctx, dwp):
+        rows, cols, ld = ctx.dims
+        dwp = dwp.contiguous()
+        gw = ctx.gw
+        if gw is not None and gw.is_contiguous():
+            check(_hip.lib().rf_unpad_cols(ptr(dwp), ptr(gw), rows, cols, ld, 1, _stream()), "rf_unpad_cols")
+            _wrote(gw)
+            return None, None, None
+        dw = torch.empty(rows, cols, device=dwp.device, dtype=torch.float32)
+        check(_hip.lib().rf_unpad_cols(ptr(dwp), ptr(dw), rows, cols, ld, 0, _stream()), "rf_unpad_cols")
+        return dw, None, None
+
+
 def circular_conv3(x, weight, bias=None, pad: int = 1, residual=None):
     """Conv1d(k=3, padding_mode='circular') on channels-last sequences: weight (d, c, 3), used in place as
     a (d, 3c) matrix (the unfold emits columns in the weight's own (c, t) memory order).
@@ -1201,7 +1236,7 @@ def circular_conv3(x, weight, bias=None, pad: int = 1, residual=None):
         # slices its gradient back), all three GEMMs stay on the vector path.
         ld = (3 * c + 3) // 4 * 4
         cols = _Unfold3.apply(x, pad, ld)
-        wp = torch.nn.functional.pad(weight.reshape(d, 3 * c), (0, ld - 3 * c))
+        wp = _PadCols.apply(weight.reshape(d, 3 * c), ld, _slot(weight, (d, 3 * c)))
         return _Linear.apply(cols, wp, bias, residual, None, _slot(bias))
     cols = _Unfold3.apply(x, pad)
     return _Linear.apply(cols, weight.view(d, -1), bias, residual, _slot(weight, (d, weight.shape[1] * 3)),

@@ -1212,6 +1212,34 @@ def test_layernorm_fwd_slabs_vs_torch(splits, rows, cols, with_bias, with_res):
         assert rel_err(y, y2) < 1e-6 and rel_err(xhat, xh2) < 1e-6 and rel_err(rstd, rs2) < 1e-6
 
 
+@pytest.mark.parametrize("C", [128, 100, 832])
+def test_layernorm_strided_input(C):
+    """add_layer_norm on strided views (the consumed tail of a (B, L, C) activation, a row-pitched 2-D view) reads them in
+    place (rf_layernorm_fwd_strided): bit-identical to the norm of a contiguous copy, gradient included."""
+    from routeformer_amd import kernels as Kn
+    g = _g(C)
+    full = torch.randn(3, 11, C, generator=g).to(DEV)
+    gam, bet = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    res = torch.randn(3, 4, C, generator=g).to(DEV)
+    for view, r in ((lambda t_: t_[:, -4:, :], res), (lambda t_: t_[:, 2:3, :], None),
+                    (lambda t_: t_.reshape(33, C)[:, :].as_strided((16, C), (2 * C, 1)), None)):
+        outs = []
+        for contiguous in (False, True):
+            src = full.clone().requires_grad_(True)
+            x = view(src)
+            assert not x.is_contiguous() or x.numel() == C * 3
+            if contiguous:
+                x = x.contiguous()
+            rr = None if r is None else r.reshape(x.shape)
+            y = Kn.add_layer_norm(x, rr, gam, bet)
+            y.backward(torch.ones_like(y) * 0.5 + y.detach())
+            outs.append((y.detach(), src.grad))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        want = F.layer_norm(view(full).double() + (0 if r is None else r.reshape(view(full).shape).double()), (C,),
+                            gam.double(), bet.double(), 1e-5)
+        assert rel_err(outs[0][0], want.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("M", [320, 560, 96, 40])
 @pytest.mark.parametrize("prec", ["bf16", "f32"])
 def test_slab_layernorm_layer_ops_match_unfused(M, prec):
@@ -1561,6 +1589,24 @@ def test_token_cache_semantics():
     foreign.bind(0x7654321)
     with pytest.raises(ValueError, match="fingerprint mismatch"):
         foreign.load_state_dict(ns.state_dict())
+
+
+def test_pad_cols_roundtrip_and_gradient():
+    """rf_pad_cols / rf_unpad_cols (the K-padded copy of the GPS token-embedding weight, 207 -> 208 columns) against
+    F.pad and its gradient; the slot-accumulating form adds into a buffer.  Bit-exact."""
+    from routeformer_amd import _hip, kernels as Kn
+    g = _g(43)
+    w = torch.randn(832, 69, 3, generator=g)
+    wd = w.to(DEV).requires_grad_(True)
+    wp = Kn._PadCols.apply(wd.reshape(832, 207), 208, None)
+    assert torch.equal(wp.detach().cpu(), F.pad(w.reshape(832, 207), (0, 1)))
+    dwp = torch.randn(832, 208, generator=g)
+    wp.backward(dwp.to(DEV))
+    assert torch.equal(wd.grad.cpu(), dwp[:, :207].reshape(832, 69, 3))
+    slot = torch.ones(832, 207, device=DEV)
+    rc = _hip.lib().rf_unpad_cols(dwp.to(DEV).data_ptr(), slot.data_ptr(), 832, 207, 208, 1, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _hip.lib().rf_last_error()
+    assert torch.equal(slot.cpu(), 1.0 + dwp[:, :207])
 
 
 def test_gather_frames():
