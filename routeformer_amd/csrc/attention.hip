@@ -145,6 +145,16 @@ __device__ __forceinline__ void load_qkv_trips(float* Qs, float* Ks, float* Vs, 
     rk[u] = *reinterpret_cast<const float4*>(kb + (long)lk * p.k_ld + e);
     rv[u] = *reinterpret_cast<const float4*>(vb + (long)lk * p.v_ld + e);
   }
+  // Pin every loaded register HERE.  Without it the compiler sinks each load into the guarded store that consumes it
+  // (legal, the pointers are restrict) and the prologue becomes a chain of load -> wait -> ds_write blocks, with one
+  // slice staged through scratch: five dependent memory round trips at TRIPS = 2 (7.2 k of the 26 k cycles of a
+  // GPS-backbone attention launch, tools/attn_phase_probe.py) instead of one.
+#pragma unroll
+  for (int u = 0; u < TRIPS; ++u) {
+    if constexpr (HAS_Q) asm volatile("" : "+v"(rq[u].x), "+v"(rq[u].y), "+v"(rq[u].z), "+v"(rq[u].w));
+    asm volatile("" : "+v"(rk[u].x), "+v"(rk[u].y), "+v"(rk[u].z), "+v"(rk[u].w));
+    asm volatile("" : "+v"(rv[u].x), "+v"(rv[u].y), "+v"(rv[u].z), "+v"(rv[u].w));
+  }
 #pragma unroll
   for (int u = 0; u < TRIPS; ++u) {
     const int i = tid + u * nt, l = ls[u], e = es[u];
@@ -270,27 +280,82 @@ __device__ __forceinline__ void mm_tiles(int TI, int TJ, int KS, int lane, int w
 __device__ __forceinline__ int rows_per_trip() { return (blockDim.x >> 6) * 4; }
 __device__ __forceinline__ int row_of(int trip_base) { return trip_base + (threadIdx.x >> 6) * 4 + ((threadIdx.x & 63) >> 4); }
 
+// One row by its 16 lanes: row[s] = softmax over s < kmax of (row[s] * scale), zeros up to ldw.  Up to 64 columns the row
+// stays in registers for all three passes (one LDS read and one write per element instead of three and two); wider rows
+// are read in chunks of four elements per lane (clamped index, masked use).  Same ascending-s order of the sum as the
+// plain loops.  Measured with tools/attn_phase_probe.py: 2 371 -> 1 637 cycles at L = 40, 5 236 -> 4 437 at L = 160.
+// (These kernels are VALU-issue bound -- 16 waves of a lone workgroup share the CU's four SIMDs at 4 cycles per wave64
+//  instruction -- so what pays is FEWER instructions: chunking the MFMA k-loops, the ranking and the sparsity measure the
+//  same way issued their LDS reads together but added clamps and selects, and measured no faster or slower; not kept.)
+__device__ __forceinline__ void softmax_row16(float* row, int kmax, int ldw, float scale, bool live) {
+  const int l16 = threadIdx.x & 15;
+  if (ldw <= 64) {
+    float r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = row[min(l16 + 16 * u, ldw - 1)];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mx = (l16 + 16 * u < kmax) ? fmaxf(mx, r[u]) : mx;
+    mx = row16_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float e_ = __expf((r[u] - mx) * scale);
+      r[u] = (l16 + 16 * u < kmax) ? e_ : 0.f;
+      if (l16 + 16 * u < kmax) sum += e_;
+    }
+    sum = row16_sum(sum);
+    const float inv = 1.f / sum;
+    if (live) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (l16 + 16 * u < ldw) row[l16 + 16 * u] = r[u] * inv;
+    }
+    return;
+  }
+  float mx = -INFINITY;
+  for (int s0 = l16; s0 < kmax; s0 += 64) {
+    float r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = row[min(s0 + 16 * u, ldw - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mx = (s0 + 16 * u < kmax) ? fmaxf(mx, r[u]) : mx;
+  }
+  mx = row16_max(mx);
+  float sum = 0.f;
+  for (int s0 = l16; s0 < kmax; s0 += 64) {
+    float r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = row[min(s0 + 16 * u, ldw - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (s0 + 16 * u < kmax) {
+        const float e_ = __expf((r[u] - mx) * scale);
+        row[s0 + 16 * u] = e_;
+        sum += e_;
+      }
+  }
+  sum = row16_sum(sum);
+  const float inv = 1.f / sum;
+  if (live)
+    for (int s0 = l16; s0 < ldw; s0 += 64) {
+      float r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = row[min(s0 + 16 * u, ldw - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + 16 * u < ldw) row[s0 + 16 * u] = (s0 + 16 * u < kmax) ? r[u] * inv : 0.f;
+    }
+}
+
 __device__ __forceinline__ void softmax_rows(float* S, int n_rows, int LK, const int* top_list, int masked, int ld = 0) {
   if (ld == 0) ld = LK;
-  const int l16 = threadIdx.x & 15;
   for (int base = 0; base < n_rows; base += rows_per_trip()) {
     const int si = row_of(base);
     const bool live = si < n_rows;
     float* row = S + (long)(live ? si : 0) * ld;
     const int kmax = live ? (masked ? top_list[si] + 1 : LK) : 0;
-    float mx = -INFINITY;
-    for (int s = l16; s < kmax; s += 16) mx = fmaxf(mx, row[s]);
-    mx = row16_max(mx);
-    float sum = 0.f;
-    for (int s = l16; s < kmax; s += 16) {
-      const float e_ = __expf(row[s] - mx);
-      row[s] = e_;
-      sum += e_;
-    }
-    sum = row16_sum(sum);
-    const float inv = 1.f / sum;
-    if (live)
-      for (int s = l16; s < ld; s += 16) row[s] = s < kmax ? row[s] * inv : 0.f;
+    softmax_row16(row, kmax, ld, 1.0f, live);
   }
 }
 
@@ -403,28 +468,12 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
     }
     RF_MARK(5);
     RF_MARK(6);
-    {
-      const int l16 = tid & 15;
-      for (int base_ = 0; base_ < n_sel; base_ += rows_per_trip()) {
-        const int si = row_of(base_);
-        const bool live = si < n_sel;
-        const int q = live ? top_list[si] : 0;
-        float* row = S + q * LKP;
-        const int kmax = live ? (p.mode == 2 ? q + 1 : LK) : 0;
-        float mx = -INFINITY;
-        for (int s_ = l16; s_ < kmax; s_ += 16) mx = fmaxf(mx, row[s_]);
-        mx = row16_max(mx);
-        float sum = 0.f;
-        for (int s_ = l16; s_ < kmax; s_ += 16) {
-          const float e_ = __expf((row[s_] - mx) * p.scale);  // scale > 0: the row maximum is the same
-          row[s_] = e_;
-          sum += e_;
-        }
-        sum = row16_sum(sum);
-        const float inv = 1.f / sum;
-        if (live)
-          for (int s_ = l16; s_ < LKP; s_ += 16) row[s_] = s_ < kmax ? row[s_] * inv : 0.f;
-      }
+    for (int base_ = 0; base_ < n_sel; base_ += rows_per_trip()) {
+      const int si = row_of(base_);
+      const bool live = si < n_sel;
+      const int q = live ? top_list[si] : 0;
+      // scale > 0: the row maximum is the same before and after scaling
+      softmax_row16(S + q * LKP, live ? (p.mode == 2 ? q + 1 : LK) : 0, LKP, p.scale, live);
     }
     __syncthreads();
     RF_MARK(7);
@@ -679,6 +728,29 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
     // attention-probability dropout: ctx = (P * keep / (1-p)) V, so dP arrives masked and dV needs the masked P
     const unsigned long long e0 = (unsigned long long)((((long)b * p.H + h) * LQ + top_list[live ? si : 0]) * LK);
     float dot = 0.f;
+    if (!gen.on() && LKP <= 64) {
+      // the row pair stays in registers (four elements per lane, clamped reads): each element read once instead of twice;
+      // same ascending-s order of the dot product
+      float pr[4], ds[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s_ = min(l16 + 16 * u, LKP - 1);
+        pr[u] = Pr[s_];
+        ds[u] = dSr[s_];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (live && l16 + 16 * u < LK) dot += pr[u] * ds[u];
+      dot = row16_sum(dot);
+      if (live) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int s_ = l16 + 16 * u;
+          if (s_ < LKP) dSr[s_] = s_ < LK ? pr[u] * (ds[u] - dot) * p.scale : 0.f;
+        }
+      }
+      continue;
+    }
     if (live) {
       if (gen.on())
         for (int s_ = l16; s_ < LK; s_ += 16) dSr[s_] *= gen.factor(e0 + s_);
