@@ -9,6 +9,8 @@
 //   4. other rows:     ctx[q] = mean_s V[s]  (unmasked)   |   cumsum_{s<=q} V[s]  (masked)
 // Sequence lengths here are tiny, so the kernels are latency-bound by design;
 // rows are spread over lanes and reductions use wave shuffles.
+#include <cstdlib>
+
 #include "common.h"
 #include "philox.h"
 
@@ -16,8 +18,15 @@ namespace {
 
 // Threads per workgroup are chosen at launch (threads_for): these kernels are chains of short barrier-
 // separated phases, so when a launch has fewer (batch, head) problems than CUs (the Informer / gaze /
-// fusion layers: 64 workgroups) each problem gets 16 waves instead of 4 to shorten every phase.
-inline int threads_for(int problems) { return problems <= 128 ? 1024 : (problems <= 512 ? 512 : 256); }
+// fusion layers: 64 workgroups) each problem gets 8 waves instead of 4 to shorten every phase (16 until round 3).
+inline int threads_for(int problems) {
+  // RF_ATTN_SMALL_THREADS: threads of a launch with <= 128 problems (measurement switch).  8 waves since round 3: with the
+  // whole-score-matrix form limited to 64 KB (below) the C2 step takes 5.40-5.41 ms against 5.44-5.45 with 16 waves and a
+  // 160-KB limit, four alternating pairs on one box (gpurun_out/r6m); 4 waves: 5.67 (r6i)
+  static const int small = [] { const char* e = getenv("RF_ATTN_SMALL_THREADS"); const int v = e ? atoi(e) : 512;
+                                return (v == 256 || v == 512 || v == 1024) ? v : 512; }();
+  return problems <= 128 ? small : (problems <= 512 ? 512 : 256);
+}
 
 struct AttnP {
   const float *q, *k, *v;
@@ -953,7 +962,12 @@ extern "C" int rf_attn_fwd_full_scores(int B, int H, int LQ, int LK, int E, int 
   const size_t full = fwd_lds(LQ, LK, E, n_top, sample_k, true, true);
   // a workgroup alone on its CU (<= 128 problems) may use the whole LDS; a chip-filling launch must keep four
   // workgroups per CU resident (at 48 KB -- three per CU -- the frame-encoder launch went from 53 to 75 us)
-  return full <= (threads_for(B * H) == 1024 ? 160 * 1024 : 32 * 1024);
+  // RF_ATTN_FULLS_KB: the LDS budget (KB) of the whole-score-matrix form in a launch of <= 128 problems (measurement switch).
+  // 64 KB keeps it for the GPS encoder (L 40, E 104: as many scores either way) and drops it for the fusion encoder
+  // (L 160: 25 600 scores formed for 9 600 needed) and the GPS decoder (L 70)
+  static const size_t small_kb = [] { const char* e = getenv("RF_ATTN_FULLS_KB"); const int v = e ? atoi(e) : 64;
+                                      return (size_t)(v < 0 ? 0 : (v > 160 ? 160 : v)); }();
+  return full <= (B * H <= 128 ? small_kb * 1024 : (size_t)32 * 1024);
 }
 
 #ifdef RF_ATTN_TIMING

@@ -325,8 +325,12 @@ def _auto_split(M: int, N: int, K: int) -> int:
     tiles = tm * -(-N // 64)
     if tiles >= 256 or K < 256:
         return 1
-    want = -(-512 // tiles) if K >= 1024 else 256 // tiles
+    want = -(-_SPLIT_WG_DEEP // tiles) if K >= 1024 else _SPLIT_WG // tiles
     return max(1, min(16, K // 128, want))
+
+
+_SPLIT_WG = int(os.environ.get("RF_SPLIT_WG", "256"))            # workgroups a shallow (K < 1024) product is split towards
+_SPLIT_WG_DEEP = int(os.environ.get("RF_SPLIT_WG_DEEP", "512"))  # ... and a deep one
 
 
 # Skinny GEMM (csrc/gemm_skinny.hip) for the small-M linear layers of the GPS backbone: RF_SKINNY=0 turns it off,
