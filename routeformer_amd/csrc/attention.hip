@@ -22,7 +22,8 @@ namespace {
 inline int threads_for(int problems) {
   // RF_ATTN_SMALL_THREADS: threads of a launch with <= 128 problems (measurement switch).  8 waves since round 3: with the
   // whole-score-matrix form limited to 64 KB (below) the C2 step takes 5.40-5.41 ms against 5.44-5.45 with 16 waves and a
-  // 160-KB limit, four alternating pairs on one box (gpurun_out/r6m); 4 waves: 5.67 (r6i)
+  // 160-KB limit, four alternating pairs on one box (gpurun_out/r6m); most of that is the form, 8 vs 16 waves alone is
+  // 0.00-0.03 ms (r6j, r6k, r6w2); 4 waves: 5.67 (r6i)
   static const int small = [] { const char* e = getenv("RF_ATTN_SMALL_THREADS"); const int v = e ? atoi(e) : 512;
                                 return (v == 256 || v == 512 || v == 1024) ? v : 512; }();
   return problems <= 128 ? small : (problems <= 512 ? 512 : 256);
@@ -963,8 +964,11 @@ extern "C" int rf_attn_fwd_full_scores(int B, int H, int LQ, int LK, int E, int 
   // a workgroup alone on its CU (<= 128 problems) may use the whole LDS; a chip-filling launch must keep four
   // workgroups per CU resident (at 48 KB -- three per CU -- the frame-encoder launch went from 53 to 75 us)
   // RF_ATTN_FULLS_KB: the LDS budget (KB) of the whole-score-matrix form in a launch of <= 128 problems (measurement switch).
-  // 64 KB keeps it for the GPS encoder (L 40, E 104: as many scores either way) and drops it for the fusion encoder
-  // (L 160: 25 600 scores formed for 9 600 needed) and the GPS decoder (L 70)
+  // At 64 KB none of the C2 step's 64-problem shapes takes it any more -- the fusion encoder (L 160, E 16: 25 600 scores formed
+  // for 9 600 needed), the GPS decoder (L 70, E 104) and the GPS encoder (L 40, E 104: 68.9 KB) -- smaller heads still do.
+  // A launch ALONE is faster in that form (13.4 vs 15.9 us at L 40, 20.1 vs 22.2 at L 160, tools/attn_phase_probe.py); the
+  // replayed step, where these launches run next to the side-stream branches, is faster without it (5.40 vs 5.44 ms, four
+  // alternating pairs, gpurun_out/r6m; 64 vs 72 KB, i.e. with / without the GPS encoder's: no difference, r6w)
   static const size_t small_kb = [] { const char* e = getenv("RF_ATTN_FULLS_KB"); const int v = e ? atoi(e) : 64;
                                       return (size_t)(v < 0 ? 0 : (v > 160 ? 160 : v)); }();
   return full <= (B * H <= 128 ? small_kb * 1024 : (size_t)32 * 1024);
