@@ -15,6 +15,8 @@
 // Weight orientations: BMODE 0 = k contiguous (forward: y = x W^T), BMODE 1 = n contiguous (dX = dY W: the contraction
 // index is W's row, 8 strided 4-B loads per fragment, each instruction still 4 x 64-B segments).
 // bf16-input MFMA with fp32 accumulation: the same rounding as gemm.hip's PREC = 1 path (sum order differs).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -173,7 +175,9 @@ struct SkShape { int rtm, tn; };
 inline SkShape sk_shape(int M, int N) {
   SkShape s;
   s.rtm = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
-  s.tn = (M > 64 && N >= 1024) ? 2 : 1;
+  // RF_SKINNY_TN2_MIN_N: output width from which a workgroup takes two 16-column tiles (measurement switch)
+  static const int tn2_min_n = [] { const char* e = getenv("RF_SKINNY_TN2_MIN_N"); return e ? atoi(e) : 1024; }();
+  s.tn = (M > 64 && N >= tn2_min_n) ? 2 : 1;
   return s;
 }
 
