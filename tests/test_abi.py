@@ -72,3 +72,29 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/librf_hip.so")
     with pytest.raises(_hip.HipLibraryError):
         _hip.lib()
+
+
+def test_split_counts_without_gpu():
+    """The pure slab-count helpers of the split-K products (no launch): ``rf_gemm_split_count`` is rf_gemm's own clamping
+    of ``splitk`` (64-wide K granules, no empty slice), ``rf_gemm_skinny_split`` the skinny kernel's K slices of 1 024 --
+    what a caller sizes the slab workspace of ``rf_gemm_partials`` / ``rf_gemm_skinny_partials`` with."""
+    from routeformer_amd import _hip
+    lib = _hip.lib()
+
+    def mirror(K, s):
+        ktiles = -(-K // 64)
+        s = max(1, min(s, ktiles))
+        kchunk = -(-ktiles // s) * 64
+        return -(-K // kchunk)
+
+    for K in (1, 63, 64, 100, 128, 207, 208, 832, 2496, 3328, 4097):
+        for s in (1, 2, 3, 5, 8, 13, 16, 64):
+            got = lib.rf_gemm_split_count(K, s)
+            assert got == mirror(K, s) and 1 <= got <= s, (K, s, got)
+    assert lib.rf_gemm_split_count(3328, 16) == 13 and lib.rf_gemm_split_count(832, 3) == 3
+    # skinny: only layouts are inspected, never the pointers' contents (any aligned non-null address will do)
+    a = ctypes.c_void_p(0x1000)
+    assert lib.rf_gemm_skinny_split(a, 832, 1, a, 1, 832, 40, 832, 832) == 1
+    assert lib.rf_gemm_skinny_split(a, 3328, 1, a, 1, 3328, 40, 832, 3328) == 4
+    assert lib.rf_gemm_skinny_split(a, 3328, 1, a, 1, 3328, 700, 832, 3328) == 0   # M > 640: the tiled kernel
+    assert lib.rf_gemm_skinny_split(None, 832, 1, a, 1, 832, 40, 832, 832) == 0
