@@ -23,11 +23,11 @@ from routeformer_amd.losses import FutureDiscountedLoss
 from routeformer_amd.score import ade, fde
 
 
-# Weight-gradient groups that fill up mid-backward on a side stream: -0.04 ms at C2, but OFF by default -- with it a pytest
-# session that ran the full-size engine tests and then the dropout-variant engine test died with a host segmentation fault inside
-# hipGraphLaunch (reproducible in that order only; every other order, and the bench, were fine; RF_WGRAD_SIDE=0 cured it).
-# One more fork inside an already many-branched capture is not worth that (cf. kernels.on_side_stream's note on nested forks).
+# Weight-gradient groups that fill up mid-backward go to a side stream (-0.04 .. -0.09 ms at C2).
 WGRAD_SIDE = os.environ.get("RF_WGRAD_SIDE", "0") == "1"
+# "engine" (default): every engine owns its side streams, fork bookkeeping and weight-gradient queue; "global": the round-3
+# process-wide set (kept for the crash bisect of DESIGN section 5b only)
+SIDE_SCOPE = os.environ.get("RF_SIDE_SCOPE", "engine")
 
 
 def _capture_kw() -> dict:
@@ -57,8 +57,7 @@ def train_step_losses(model, item, epoch: int = 0, trajectory_loss: Optional[Fut
             # frozen conv trunk: one pass over the history AND target frames (336 images at B=8)
             model.prefetch_video_tokens([item["train"], item["target"]])
         if overlap:  # fork point: the target-side pass must not wait for the input forward
-            side = K.side_stream("target")
-            side.wait_stream(torch.cuda.current_stream())
+            side = K.fork_side_stream("target")
         fused = (K.OVERLAP and target_gps.is_cuda and hasattr(model, "forward_raw") and model.training
                  and not cfg.autoregressive and tl.loss_function == "smooth_l1" and dl.loss_function == "smooth_l1"
                  and item["train"]["gps"].dtype == torch.float32)
@@ -590,6 +589,12 @@ class TrainEngine:
         self.overlap = overlap  # independent sub-graphs of the step on separate HIP streams
         # weight gradients queued during backward and flushed as grouped launches (kernels._WgradQueue)
         self.group_wgrad = __import__("os").environ.get("RF_GROUP_WGRAD", "1") != "0"
+        from routeformer_amd import kernels as K
+        # side streams, open-fork bookkeeping and the deferred weight-gradient queue belong to THIS engine: nothing of
+        # another engine's capture (streams, queued operands, "slot written" notes) can reach into this one's
+        self._streams = K.SideStreams() if SIDE_SCOPE == "engine" else K.STREAMS
+        self._wgrad = K._WgradQueue() if SIDE_SCOPE == "engine" else K.WGRAD
+        self._saved_scope = None
         cfg = model.configs
         layers = [m for m in model.modules() if hasattr(m, "packing_groups")]
         groups = [g for m in layers for g in m.packing_groups()]
@@ -692,8 +697,20 @@ class TrainEngine:
             seed = self._seed_one = torch.ones_like(loss)
         return seed
 
+    def _scope_in(self):
+        from routeformer_amd import kernels as K
+        self._saved_scope = (K.STREAMS, K.WGRAD)
+        K.STREAMS, K.WGRAD = self._streams, self._wgrad
+
+    def _scope_out(self):
+        from routeformer_amd import kernels as K
+        if self._saved_scope is not None:
+            K.STREAMS, K.WGRAD = self._saved_scope
+            self._saved_scope = None
+
     def _fwd_bwd(self, item, epoch, tokens_ready: bool = False):
         from routeformer_amd import kernels as K
+        self._scope_in()
         K.OVERLAP = self.overlap
         K.SINK.active = True  # kernels accumulate parameter gradients straight into the flat buffer
         K.SINK.on_write = None
@@ -709,6 +726,7 @@ class TrainEngine:
         finally:
             K.SINK.active, K.SINK.on_write, K.OVERLAP, K.WGRAD.active = False, None, False, False
             K.WGRAD.side_early = False
+            self._scope_out()
             self.model.__dict__.pop("_before_gps_backbone", None)
         return res
 
@@ -717,6 +735,7 @@ class TrainEngine:
     #    The all-reduce of the backbone's buckets then runs underneath stage 2. ---------------------------------
     def _enter(self):
         from routeformer_amd import kernels as K
+        self._scope_in()
         K.OVERLAP = self.overlap
         K.SINK.active = True
         K.SINK.on_write = None
@@ -725,6 +744,7 @@ class TrainEngine:
     def _leave(self):
         from routeformer_amd import kernels as K
         K.SINK.active, K.SINK.on_write, K.OVERLAP, K.WGRAD.active = False, None, False, False
+        self._scope_out()
         self.model.__dict__.pop("_before_gps_backbone", None)
 
     def _stage1(self, item, epoch, tokens_ready: bool = False):
@@ -739,6 +759,8 @@ class TrainEngine:
         if cut is None or not cut.requires_grad:  # GPS-only model: nothing upstream of the backbone
             res["loss"].backward()
             K.flush_weight_grads()
+            if self.overlap:
+                K.join_side_streams()
             return res, None
         # gradients of the cut AND of the backbone parameters that autograd itself accumulates (the few that no
         # kernel writes through a sink, e.g. the time-feature embedding): they would otherwise be skipped
@@ -748,14 +770,18 @@ class TrainEngine:
             if g is not None:
                 p.grad.add_(g)
         K.flush_weight_grads()
+        forked = {}
         if self.overlap:
-            K.join_side_streams()  # (the backbone's own side branch: stage 1 may be the end of a captured graph)
-        return res, (cut, grads[0])
+            forked = K.STREAMS.join()  # (the backbone's own side branch: stage 1 may be the end of a captured graph)
+        return res, (cut, grads[0], forked)
 
     def _stage2(self, carry):
         from routeformer_amd import kernels as K
         if carry is not None:
-            cut, dcut = carry
+            cut, dcut, forked = carry
+            # the rest of backward runs on the streams stage 1 forked (autograd replays each node on its forward's stream)
+            # and writes gradient sinks there: the final join has to cover them again
+            K.STREAMS.forked.update(forked)
             cut.backward(dcut)
             K.flush_weight_grads()
         if self.overlap:
@@ -884,8 +910,7 @@ class GraphedTrainEngine(TrainEngine):
         # the 16-us pack kernel ran for as long as the update did -- kernel trace, profiles/r03/overlap_experiments.txt)
         self._repack_fused()
         if use_side:
-            side = K.side_stream("update")
-            side.wait_stream(cur)
+            side = K.fork_side_stream("update", origin=cur)
             with torch.cuda.stream(side):
                 run([x for x in seg if x[1][2]])
             self.model.__dict__["_before_gps_backbone"] = lambda: torch.cuda.current_stream().wait_stream(side)
@@ -1115,7 +1140,7 @@ class GraphedTrainEngine(TrainEngine):
         # gaze dropout, routeformer.py:301,405-410): depth-first over the outcomes, each variant run once eagerly
         # with its decisions imposed (decisions beyond the imposed prefix default to "keep")
         plans, unused, stack = [], [], [[]]
-        side = torch.cuda.Stream()
+        side = torch.cuda.Stream() if K.STREAM_PLAIN else self._streams.get("warmup")
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             while stack:
@@ -1148,7 +1173,7 @@ class GraphedTrainEngine(TrainEngine):
             n = sum(v.shape[0] * idx.numel() for v, idx in clips)
             self._tok_cur = torch.empty(n, 65, 240, device=dev, dtype=torch.float32)
             self._tok_next = torch.empty_like(self._tok_cur)
-            self._tstream = torch.cuda.Stream()
+            self._tstream = torch.cuda.Stream() if K.STREAM_PLAIN else self._streams.get("trunk")
             self._alloc_clip_stage(item)
             self._stage_clips(item)
             self._trunk_graph().replay()
@@ -1184,6 +1209,11 @@ class GraphedTrainEngine(TrainEngine):
         now = SAMPLER._variant
         SAMPLER.select_static(variant)  # the captured pass takes this variant's decisions and key-sample slots
         g = torch.cuda.CUDAGraph()
+        dot = os.environ.get("RF_GRAPH_DOT")  # diagnosis: keep the hipGraph_t and print it (hipGraphDebugDotPrint)
+        if dot:
+            g.enable_debug_mode()
+        if os.environ.get("RF_ENGINE_DEBUG"):
+            print(f"[engine {id(self):x}] capture variant {variant} lookahead {la} split {self.split}", file=__import__("sys").stderr, flush=True)
         if not self.split:
             with torch.cuda.graph(g, **_capture_kw()):
                 cur = torch.cuda.current_stream()
@@ -1223,6 +1253,9 @@ class GraphedTrainEngine(TrainEngine):
         self.model.clear_video_tokens()
         SAMPLER.select_static(now)
         self._graphs[key] = (g, out)
+        if dot and not isinstance(g, tuple):
+            os.makedirs(dot, exist_ok=True)
+            g.debug_dump(os.path.join(dot, f"graph_{id(self):x}_v{variant}_la{int(la)}.dot"))
         return g, out
 
     def _multi_copy(self, pairs):
@@ -1330,6 +1363,9 @@ class GraphedTrainEngine(TrainEngine):
         self.reducer.begin_step()  # the replay does not run the Python bookkeeping of zero()
         if self.defer_update:
             self._set_hyper()  # scalars of the update this replay starts with (or "nothing pending")
+        if os.environ.get("RF_ENGINE_DEBUG"):
+            print(f"[engine {id(self):x}] replay variant {variant} lookahead {isinstance(g, tuple) or (g is self._graphs.get((True, variant), (None,))[0])}",
+                  file=__import__("sys").stderr, flush=True)
         if isinstance(g, tuple):
             g[0].replay()
             # 95 % of the gradient bytes (the GPS backbone's) are final here: reduce them underneath stage 2

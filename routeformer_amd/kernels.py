@@ -39,60 +39,110 @@ def _stream():
 # HIP streams lets the otherwise idle CUs overlap them.  Off by default (strict reference call order for
 # the test hooks); the training engine switches it on.  Host-RNG draw order is unaffected.
 OVERLAP = False
-OVERLAP_MASK = int(__import__("os").environ.get("RF_OVERLAP", "11"))  # bit0 target pass, bit1 gaze encoder, bit2 wgrad (no gain measured), bit3 decoder self-attention block beside the encoder
-_SIDE_STREAMS = {}
+OVERLAP_MASK = int(os.environ.get("RF_OVERLAP", "11"))  # bit0 target pass, bit1 gaze encoder, bit3 decoder self-attention block beside the encoder
+
+
+def _distinct_stream(taken):
+    """A torch stream whose HIP handle differs from every handle in ``taken`` and from the current stream.
+    ``torch.cuda.Stream()`` hands out a pool of 32 handles round-robin: in a long-lived process (a test session that
+    builds a dozen engines) a "new" stream can BE the capture stream or another side stream -- a fork onto it then
+    serialises silently, and ``on_side_stream`` reports the main stream as a side stream."""
+    cur = torch.cuda.current_stream().cuda_stream
+    for _ in range(64):
+        st = torch.cuda.Stream()
+        if st.cuda_stream != cur and st.cuda_stream not in taken:
+            return st
+    raise RuntimeError("no distinct HIP stream left in torch's stream pool")
+
+
+class SideStreams:
+    """The side streams of ONE owner (a training engine; the module-level default serves direct calls from tests and
+    tools) plus the bookkeeping of an open fork: which of them were forked since the last join, and the tensors their
+    kernels read (kept referenced until the join: no early reuse by the caching allocator).
+
+    Engine-scoped on purpose (round 4).  The round-3 form was one process-global dict whose join waited on EVERY
+    stream ever created -- including streams no fork of the current capture had touched (another engine's "update" /
+    "wgrad" stream, the "gaze" stream in a variant that dropped the gaze branch).  Inside a stream capture such a wait
+    records an event on a stream that is NOT capturing and makes the capturing stream wait on it; DESIGN section 5b
+    has what that does to a HIP graph on ROCm 7.0's runtime."""
+
+    def __init__(self):
+        self.streams = {}   # (key, device) -> torch.cuda.Stream
+        self.forked = {}    # HIP handle -> stream, forked since the last join
+        self.keepalive = []
+
+    def handles(self):
+        return {st.cuda_stream for st in self.streams.values()}
+
+    def get(self, key: str):
+        dev = torch.cuda.current_device()
+        st = self.streams.get((key, dev))
+        if st is None:
+            taken = self.handles()
+            cap = getattr(torch.cuda.graph, "default_capture_stream", None)
+            if cap is not None:
+                taken.add(cap.cuda_stream)
+            st = self.streams[(key, dev)] = torch.cuda.Stream() if STREAM_PLAIN else _distinct_stream(taken)
+        return st
+
+    def fork(self, key: str, origin=None, keep=None):
+        """Stream ``key`` made to wait for everything queued on ``origin`` (default: the current stream); the join
+        that ends the step (or the stage) waits for it."""
+        st = self.get(key)
+        st.wait_stream(origin if origin is not None else torch.cuda.current_stream())
+        self.forked[st.cuda_stream] = st
+        if keep is not None:
+            self.keepalive.append(keep)
+        return st
+
+    def contains(self, stream) -> bool:
+        h = stream.cuda_stream
+        return any(st.cuda_stream == h for st in self.streams.values())
+
+    def join(self, into=None):
+        """``into`` (default: the current stream) waits for every stream forked since the last join -- and for no other.
+        Inside a stream capture only streams that are themselves capturing are waited for: a forked stream that is not
+        (the second graph of the split step inherits the first one's fork set, and autograd pulls only some of those
+        streams into it) holds no work of this capture.  Returns the joined fork set (handle -> stream)."""
+        cur = into if into is not None else torch.cuda.current_stream()
+        todo = {st.cuda_stream: st for st in self.streams.values()} if JOIN_ALL else dict(self.forked)
+        capturing = (not JOIN_ALL) and _is_capturing(cur)
+        for h, st in todo.items():
+            if h != cur.cuda_stream and (not capturing or _is_capturing(st)):
+                cur.wait_stream(st)
+        self.forked.clear()
+        self.keepalive.clear()
+        return todo
+
+
+def _is_capturing(stream) -> bool:
+    with torch.cuda.stream(stream):
+        return torch.cuda.is_current_stream_capturing()
+
+
+JOIN_ALL = os.environ.get("RF_JOIN_ALL", "0") == "1"  # round-3 behaviour, for the crash bisect only
+STREAM_PLAIN = os.environ.get("RF_STREAM_PLAIN", "0") == "1"  # likewise: streams straight from torch's round-robin pool
+STREAMS = SideStreams()
 
 
 def side_stream(key: str):
-    dev = torch.cuda.current_device()
-    st = _SIDE_STREAMS.get((key, dev))
-    if st is None:
-        st = _SIDE_STREAMS[(key, dev)] = torch.cuda.Stream()
-    return st
+    return STREAMS.get(key)
+
+
+def fork_side_stream(key: str, origin=None, keep=None):
+    return STREAMS.fork(key, origin, keep)
 
 
 def on_side_stream() -> bool:
-    """True when the current stream is itself one of the side streams (no nested forks: a fork from a
-    forked stream crashes hipStreamEndCapture on ROCm 7.2)."""
-    cur = torch.cuda.current_stream()
-    return any(cur == st for st in _SIDE_STREAMS.values())
-
-
-_KEEPALIVE = []  # tensors read by side-stream kernels: kept referenced until the join (no early reuse)
+    """True when the current stream is itself one of the side streams: no nested forks (a stream forked from a forked
+    stream is not ended by hipStreamEndCapture on ROCm 7.0 -- DESIGN section 5b)."""
+    return STREAMS.contains(torch.cuda.current_stream())
 
 
 def join_side_streams():
-    """Make the current stream wait for everything queued on the side streams.  Needed after backward:
-    gradient sinks written by side-stream kernels bypass autograd's own leaf-stream synchronisation."""
-    cur = torch.cuda.current_stream()
-    dev = torch.cuda.current_device()
-    for (_, d), st in _SIDE_STREAMS.items():
-        if d == dev:
-            cur.wait_stream(st)
-    _KEEPALIVE.clear()
-
-
-class _WgradStream:
-    """Weight / bias gradients only feed the optimizer, not the backward chain: with gradient sinks active
-    they are launched on a side stream so the dX chain (the critical path) is not serialised behind them."""
-
-    def __init__(self, *tensors):
-        self.st = None
-        if OVERLAP and (OVERLAP_MASK & 4) and SINK.active and not on_side_stream():
-            self.st = side_stream("wgrad")
-            self.st.wait_stream(torch.cuda.current_stream())
-            _KEEPALIVE.append(tensors)
-            self.ctx = torch.cuda.stream(self.st)
-
-    def __enter__(self):
-        if self.st is not None:
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.st is not None:
-            self.ctx.__exit__(*exc)
-        return False
+    """Make the current stream wait for everything queued on the side streams forked since the last join.  Needed after
+    backward: gradient sinks written by side-stream kernels bypass autograd's own leaf-stream synchronisation."""
+    STREAMS.join()
 
 
 class _Profiler:
@@ -520,11 +570,13 @@ class _WgradQueue:
         self.queues = {}     # stream handle -> (torch stream, [items])
         self.pending = set() # data_ptr of slots with a queued (not yet launched) write
         self.written = set() # data_ptr of slots already written by a grouped launch this step
+        self.side_slots = set()  # ... of those, the ones a group on the "wgrad" side stream wrote (not yet joined)
 
     def begin_step(self):
         """Gradient slots were just zeroed: the first (and, per launch, only) writer of a slot may use plain
         stores instead of atomics (``RfWgradEntry.exclusive``)."""
         self.written.clear()
+        self.side_slots.clear()
 
     def push(self, dy2, x2, into, bias_into, M, N, K, splits):
         st = torch.cuda.current_stream()
@@ -545,11 +597,18 @@ class _WgradQueue:
         runs underneath the rest of the backward instead of in front of it."""
         if not q:
             return
-        if side and OVERLAP and not on_side_stream():
-            sd = side_stream("wgrad")
-            sd.wait_stream(st)
-            _KEEPALIVE.append(list(q))
-            st = sd
+        slots = {p_ for it in q for p_ in (it[2].data_ptr(), None if it[3] is None else it[3].data_ptr())}
+        if side and OVERLAP and not STREAMS.contains(st):
+            st = fork_side_stream("wgrad", origin=st, keep=list(q))
+            self.side_slots |= slots
+        else:
+            if self.side_slots & slots:
+                # a slot the side-stream group wrote (plain exclusive stores) gets another contribution here: order the
+                # two launches (ADVICE r3: they were unordered until the final join -- a race on dW)
+                st.wait_stream(STREAMS.get("wgrad"))
+                self.side_slots.clear()
+            if STREAMS.contains(st):
+                STREAMS.forked[st.cuda_stream] = st  # work queued behind autograd's own leaf-stream sync: the join waits for it
         n = len(q)
         arr = (_hip.WgradEntry * n)()
         uses = {}
@@ -745,14 +804,13 @@ class _Linear(torch.autograd.Function):
         if dy2.stride(1) != 1 or dy2.stride(0) != dy2.shape[1]:
             dy2 = dy2.contiguous()
         dx = dw = db = dres = None
-        with _WgradStream(dy2, x2):
-            fused_bias = False
-            if gw is not None:
-                fused_bias = _weight_grad(dy2, x2, into=gw, bias_into=gb if ctx.has_bias else None) is True
-            elif ctx.needs_input_grad[1]:
-                dw = _weight_grad(dy2, x2)
-            if ctx.has_bias and not fused_bias and (gb is not None or ctx.needs_input_grad[2]):
-                db = colsum(dy2, into=gb)
+        fused_bias = False
+        if gw is not None:
+            fused_bias = _weight_grad(dy2, x2, into=gw, bias_into=gb if ctx.has_bias else None) is True
+        elif ctx.needs_input_grad[1]:
+            dw = _weight_grad(dy2, x2)
+        if ctx.has_bias and not fused_bias and (gb is not None or ctx.needs_input_grad[2]):
+            db = colsum(dy2, into=gb)
         if ctx.needs_input_grad[0]:
             ds2 = None
             if dskip is not None:
@@ -832,15 +890,13 @@ class _FFN(torch.autograd.Function):
             _drop_launch(dy2, dyd, drop[0], *drop[2])
             dy2 = dyd
         # dZ = (dY W2) * act'(Z)   (relu: mask from H > 0; gelu: from the saved pre-activation)
-        with _WgradStream(dy2, h):
-            dw2 = _weight_grad(dy2, h, into=None if g2 is None else g2.view(D, F), bias_into=gb2)
-            db2 = None if dw2 is True else colsum(dy2, into=gb2)
+        dw2 = _weight_grad(dy2, h, into=None if g2 is None else g2.view(D, F), bias_into=gb2)
+        db2 = None if dw2 is True else colsum(dy2, into=gb2)
         dz = _input_grad(dy2, w2, dact_src=zsrc, ldd=zsrc.stride(0), dact=ACT[ctx.act])
         if drop is not None:  # hidden dropout sits between the activation and conv2: dZ = (dH * keep/(1-p)) * act'(Z)
             _drop_launch(dz, dz, drop[0], *drop[1])
-        with _WgradStream(dz, x2):
-            dw1 = _weight_grad(dz, x2, into=None if g1 is None else g1.view(F, D), bias_into=gb1)
-            db1 = None if dw1 is True else colsum(dz, into=gb1)
+        dw1 = _weight_grad(dz, x2, into=None if g1 is None else g1.view(F, D), bias_into=gb1)
+        db1 = None if dw1 is True else colsum(dz, into=gb1)
         if dw1 is True or dw1 is False:
             dw1 = None
         if dw2 is True or dw2 is False:

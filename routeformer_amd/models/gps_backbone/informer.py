@@ -49,8 +49,7 @@ class Informer(nn.Module):
             # the decoder's embedding and the self-attention block of its first layer do not depend on the encoder:
             # they run on a side stream that forks HERE (before the encoder), although the host issues them after the
             # encoder -- the reference's draw order (encoder layers, then decoder) is untouched
-            fork = K.side_stream("decoder")
-            fork.wait_stream(torch.cuda.current_stream())
+            fork = K.fork_side_stream("decoder")
         memory = self.encoder(self.enc_embedding(x))
         if fork is not None:
             with torch.cuda.stream(fork):

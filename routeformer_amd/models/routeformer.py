@@ -237,8 +237,7 @@ class Routeformer(nn.Module):
             if use_gaze and K.OVERLAP and (K.OVERLAP_MASK & 2) and motion.is_cuda and not K.on_side_stream():
                 # the gaze-token encoder depends only on the gaze track: run it on a side stream while the
                 # main stream encodes the video frames (its host draws still come after the frame draws)
-                fork = K.side_stream("gaze")
-                fork.wait_stream(torch.cuda.current_stream())
+                fork = K.fork_side_stream("gaze")
                 swap = (len(jobs) * len(self.frame_encoder.encoder.attn_layers), len(self.gaze_encoder.encoder.attn_layers))
                 K.TOPS.swap_blocks(*swap, before=True)  # test hooks: imposed selections arrive in the reference's order
                 with torch.cuda.stream(fork):

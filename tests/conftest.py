@@ -17,6 +17,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """RF_SEGV_BT=1: native backtrace on a host SIGSEGV (tools/probes/segv_bt.c), installed after pytest's faulthandler."""
+    if os.environ.get("RF_SEGV_BT") == "1":
+        import ctypes
+        lib = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "libsegv_bt.so"))
+        assert lib.rf_segv_bt_install() == 0
+
+
 def pytest_collection_modifyitems(config, items):
     if torch.cuda.is_available():
         return

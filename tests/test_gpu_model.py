@@ -323,7 +323,14 @@ def test_model_eval_forward_bf16(name):
     assert free < 5e-2
 
 
-@pytest.mark.parametrize("name", ["c1_default", "c1_recursive", "c1_noise", "c2_small", "c4_small", "c2_paper"])
+# (norm / sum tolerance, full-tensor tolerance, names with their own full-tensor tolerance, that tolerance)
+_QK0 = ("gps_backbone.encoder.attn_layers.0.attention.query_projection.weight",
+        "gps_backbone.encoder.attn_layers.0.attention.key_projection.weight")
+TRAIN_TOL = {"c2_paper": (1.5e-2, 3e-2, (), 0.0), "c1_paper": (5e-3, 2e-3, (), 0.0), "c5_small": (1.5e-2, 2e-4, _QK0, 3e-2)}
+
+
+@pytest.mark.parametrize("name", ["c1_default", "c1_recursive", "c1_noise", "c2_small", "c4_small", "c2_paper", "c5_small",
+                                  "c1_paper"])
 def test_model_train_step_golden(name):
     """The train-step recipe (loss, ADE, FDE, gradients) vs the reference, epochs 0 and 10, with the
     oracle's top-u selections imposed (train-mode oracle run with the same seed)."""
@@ -368,8 +375,13 @@ def test_model_train_step_golden(name):
         # layer that sits on a tie: perturbing the trunk tokens by 5e-7 (the fused vs the unfused concat + pool kernels,
         # tools/dbg_fuse_determinism.py) moves a handful of gradients from <= 3e-4 to 0.7-1.7e-2 of their largest element,
         # deterministically run to run.  Bound 3e-2 there: still far below a sign / permutation error (O(1)).
-        _check_grads(G, key, dict(model.named_parameters()), 1.5e-2 if name == "c2_paper" else 5e-3, oracle_grads=ograds,
-                     tol_full=3e-2 if name == "c2_paper" else 2e-4)
+        # c5_small (round 4: fusion length 320, gaze length 80, decoder length 105 -- the row-tiled stack's shapes): its
+        # first Informer layer has the same nearly-uniform softmax rows (80 keys); the reference and the oracle differ by
+        # 3.7e-3 on those two weights' norms (tests/test_oracle_golden.py), every other parameter is held to 2e-4.
+        # c1_paper (round 4: the d_model-832 backbone alone, B = 4, 10 -> 15 steps).
+        tol, tol_full, loose, tol_loose = TRAIN_TOL.get(name, (5e-3, 2e-4, (), 0.0))
+        _check_grads(G, key, dict(model.named_parameters()), tol, oracle_grads=ograds, tol_full=tol_full, loose=loose,
+                     tol_loose=tol_loose)
 
 
 def _grad_agreement(named_params, oracle_grads):
@@ -387,7 +399,7 @@ def _grad_agreement(named_params, oracle_grads):
     return rows
 
 
-@pytest.mark.parametrize("name", ["c2_small", "c4_small", "c2_paper"])
+@pytest.mark.parametrize("name", ["c2_small", "c4_small", "c2_paper", "c5_small"])
 def test_model_train_step_bf16(name):
     """The arithmetic mode bench.py times -- bf16 matrix-core operands, fused encoder stacks forward AND backward,
     gradient sinks, grouped weight gradients (``TrainEngine._fwd_bwd``) -- against the reference's train step
@@ -1037,13 +1049,16 @@ def test_token_cache_in_model_and_engine():
     assert all(abs(a - b) < 5e-4 * max(1.0, abs(a)) for a, b in zip(losses["eager"], losses["graph_cached"])), losses
 
 
-@pytest.mark.parametrize("B,L", [(6, 65), (3, 160), (2, 97)])
+@pytest.mark.parametrize("B,L", [(6, 65), (3, 160), (2, 97), (2, 320), (1, 97)])
 def test_fused_stack_dropout_vs_oracle_and_layerwise(B, L):
-    """(L = 65: the one-workgroup-per-sequence stack; L = 160 / 97: the row-tiled stack, csrc/enclayer.hip.)
-    Dropout INSIDE the fused encoder stack (train mode, p = 0.2): the Philox masks the kernel drew are materialised
-    (``K.RNG.record``) and handed to the CPU oracle -- outputs must agree (bf16 tolerance, the oracle's selections
-    imposed); and the backward (layer-by-layer kernels regenerating the same masks from (seed, step, site)) must agree
-    with the layer-by-layer forward + backward run on the same masks and selections."""
+    """(L = 65: the one-workgroup-per-sequence stack; L = 160 / 97 / 320: the row-tiled stack, csrc/enclayer.hip --
+    cross_modal_transformer.py:288-301 x layers.)
+    Dropout INSIDE the fused encoder stack (train mode, p = 0.2), forward AND backward against the CPU oracle's autograd:
+    a first free run materialises the Philox masks the kernels draw (``K.RNG.record``; they depend on (seed, step, site,
+    element) only) and the host draws; the oracle runs on those masks and draws, with autograd; the fused stack then runs
+    again with the oracle's top-u selections imposed and its output, input gradient and EVERY parameter gradient are held
+    to the oracle's (bf16 operand rounding is the only difference); finally the layer-by-layer kernels run on the same
+    masks and selections (fused-vs-layerwise, as before)."""
     from conftest import fro_err
     from routeformer_amd import kernels as K, synthetic
     from routeformer_amd.engine import GradReducer
@@ -1053,10 +1068,10 @@ def test_fused_stack_dropout_vs_oracle_and_layerwise(B, L):
     g = torch.Generator().manual_seed(3)
     x_cpu = torch.randn(B, L, 240, generator=g)
     w_cpu = torch.randn(B, 1, 64, generator=g)
-    out = {}
+    out, orc = {}, {}
     try:
-        for fused in (True, False):
-            K.SEQSTACK = fused
+        for mode in ("fused_free", "fused", "layerwise"):
+            K.SEQSTACK = mode != "layerwise"
             enc = _load(PerceiveEncoder(in_channels=240, out_channels=64, out_len=1, n_heads=8, layers=3, d_ff=256, dropout=P))
             enc.train()
             # gradient sinks + packed QKV views (what TrainEngine sets up): the fused path needs them for its backward
@@ -1073,37 +1088,62 @@ def test_fused_stack_dropout_vs_oracle_and_layerwise(B, L):
             eng.reducer.zero()
             x = x_cpu.to(DEV).requires_grad_()
             torch.manual_seed(11)
-            if fused:
+            if mode == "fused_free":
                 K.RNG.record, K.TOPS.record = [], []
                 SAMPLER.log = []
             else:
-                K.RNG.forced = [m.clone() for m in out[True]["masks"]]
-                K.TOPS.forced = [t_.clone() for t_ in out[True]["tops"]]
+                if mode == "layerwise":
+                    K.RNG.forced = [m.clone() for m in out["fused_free"]["masks"]]
+                K.TOPS.forced = [t_.clone() for t_ in orc["tops"]]
             y = enc(x)
             (y * w_cpu.to(DEV)).sum().backward()
             K.flush_weight_grads()
             torch.cuda.synchronize()
-            out[fused] = dict(y=y.detach().cpu(), dx=x.grad.detach().cpu(), grad=eng.reducer.flat_grad.clone().cpu(),
-                              masks=K.RNG.record, tops=K.TOPS.record, draws=SAMPLER.log,
-                              sd={k: v.detach().cpu().clone() for k, v in enc.state_dict().items()})
+            assert mode == "fused_free" or not K.TOPS.forced
+            out[mode] = dict(y=y.detach().cpu(), dx=x.grad.detach().cpu(), grad=eng.reducer.flat_grad.clone().cpu(),
+                             pgrad={n: p_.grad.detach().cpu().clone() for n, p_ in enc.named_parameters()},
+                             masks=K.RNG.record, tops=K.TOPS.record, draws=SAMPLER.log,
+                             sd={k: v.detach().cpu().clone() for k, v in enc.state_dict().items()})
             K.RNG.record, K.RNG.forced, K.TOPS.record, K.TOPS.forced, SAMPLER.log = None, None, None, None, None
             K.SINK.active = False
+            if mode == "fused_free":
+                f = out[mode]
+                assert len(f["masks"]) == 9
+                assert abs(float(torch.stack([m.float().mean() for m in f["masks"]]).mean()) - (1 - P)) < 0.01
+                # the CPU oracle on the same masks (it drops the hidden activation in its (B, d_ff, L) layout) and draws
+                sd = {"m." + k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(".pe")) for k, v in f["sd"].items()}
+                masks = [m.cpu() if (i % 3) != 1 else m.cpu().transpose(1, 2) for i, m in enumerate(f["masks"])]
+                src = O.IndexSource([d.clone() for d in f["draws"]])
+                x_o = x_cpu.clone().requires_grad_()
+                y_o = O.perceive_encoder(sd, "m", x_o, 8, 1, src, dropout=P, drop=O.DropoutSource(masks))
+                (y_o * w_cpu).sum().backward()
+                orc = dict(y=y_o.detach(), dx=x_o.grad.detach(), tops=src.tops,
+                           pgrad={k[2:]: v.grad.detach() for k, v in sd.items() if v.requires_grad and v.grad is not None})
+                flips = sum(int((a.cpu().long() != b).any(-1).sum()) for a, b in zip(f["tops"], src.tops))
+                print(f"fused dropout (B {B}, L {L}): free-running selections differing from the oracle's: {flips} of "
+                      f"{sum(t_.shape[0] * t_.shape[1] for t_ in src.tops)} (b, h) problems; free rel err {rel_err(f['y'], y_o):.2e}")
     finally:
         K.SEQSTACK = True
         K.SINK.active = False
         K.RNG.record, K.RNG.forced, K.TOPS.record, K.TOPS.forced, SAMPLER.log = None, None, None, None, None
-    f, u = out[True], out[False]
-    assert len(f["masks"]) == 9 and abs(float(torch.stack([m.float().mean() for m in f["masks"]]).mean()) - (1 - P)) < 0.01
-    # vs the CPU oracle with the same masks (the oracle drops the hidden activation in its (B, d_ff, L) layout)
-    sd = {"m." + k: v for k, v in f["sd"].items()}
-    masks = [m.cpu() if (i % 3) != 1 else m.cpu().transpose(1, 2) for i, m in enumerate(f["masks"])]
-    src = O.IndexSource([d.clone() for d in f["draws"]])
-    y_o = O.perceive_encoder(sd, "m", x_cpu, 8, 1, src, dropout=P, drop=O.DropoutSource(masks))
-    same_sel = all(torch.equal(a.cpu().long(), b) for a, b in zip(f["tops"], src.tops))
-    print(f"fused dropout: selections equal to the oracle's: {same_sel}; rel err {rel_err(f['y'], y_o):.2e}")
-    if same_sel:
-        assert rel_err(f["y"], y_o) < 3e-2
-    # vs the layer-by-layer path on the same masks and selections
+    f, u = out["fused"], out["layerwise"]
+    # (1) fused forward + backward vs the oracle's autograd, same masks, draws and selections
+    e_y, e_dx = rel_err(f["y"], orc["y"]), fro_err(f["dx"], orc["dx"])
+    rows = sorted(((fro_err(f["pgrad"][n], go), n) for n, go in orc["pgrad"].items()
+                   if float(go.norm()) > 1e-3 * max(float(g_.norm()) for g_ in orc["pgrad"].values())), reverse=True)
+    flat_o = torch.cat([orc["pgrad"][n].double().reshape(-1) for n in sorted(orc["pgrad"])])
+    flat_f = torch.cat([f["pgrad"][n].double().reshape(-1) for n in sorted(orc["pgrad"])])
+    whole = float(flat_f @ flat_o / (flat_f.norm() * flat_o.norm()))
+    print(f"fused dropout (B {B}, L {L}) vs oracle autograd: y rel err {e_y:.2e}, dx fro err {e_dx:.2e}, whole-gradient cosine "
+          f"{whole:.5f}, worst parameter gradients (fro): " + ", ".join(f"{n} {e:.2e}" for e, n in rows[:5]))
+    # bounds: bf16 operand rounding through 3 layers (observed: y <= 5e-3, dx <= 2e-2, parameters <= 4e-2 except the
+    # cancellation-dominated query / key projections, which are reported above and bounded through the whole gradient)
+    assert e_y < TOL_BF16 and e_dx < 5e-2, (e_y, e_dx)
+    assert whole > 0.995, whole
+    soft = lambda n: ".query_projection." in n or ".key_projection." in n  # noqa: E731
+    hard = [(e, n) for e, n in rows if not soft(n)]
+    assert hard[0][0] < 8e-2, hard[:5]
+    # (2) vs the layer-by-layer path on the same masks and selections
     assert rel_err(f["y"], u["y"]) < 3e-2
     assert fro_err(f["dx"], u["dx"]) < 0.1 and fro_err(f["grad"], u["grad"]) < 0.1, (fro_err(f["dx"], u["dx"]), fro_err(f["grad"], u["grad"]))
 

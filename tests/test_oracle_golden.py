@@ -171,7 +171,7 @@ def test_model_eval_forward(name):
         assert rel_err(vis, G["eval.future_vis"]) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["c1_default", "c1_recursive", "c1_noise", "c2_small", "c4_small"])
+@pytest.mark.parametrize("name", ["c1_default", "c1_recursive", "c1_noise", "c2_small", "c4_small", "c5_small", "c1_paper"])
 def test_model_train_step(name):
     model, cfg, sd, c = build_product_model(name)
     G = golden(name)
@@ -196,12 +196,21 @@ def test_model_train_step(name):
         # the oracle's autograd gradients are the element-wise gradient reference of the GPU tests: pinned here by the
         # reference's recorded L2 norm AND sum of every parameter gradient
         floor = 1e-3 * float(G[key + ".grad_stats"][:, 0].max())
+        # two cases added in round 4 need two documented allowances: (i) c5_small's first Informer layer has nearly uniform
+        # softmax rows (L = 80 keys): dS = P (dP - sum P dP) cancels 3-4 digits, so dW_q / dW_k carry ~4e-3 relative
+        # summation-order noise between the reference's kernels and the oracle's (same effect as c2_paper's);
+        # (ii) c1_paper's 832 x 832 weights: |sum| <= sqrt(numel) * norm, so the sum is compared on that scale (as the GPU
+        # tests do) instead of the norm's
+        ill = (".attn_layers.0.attention.query_projection.weight", ".attn_layers.0.attention.key_projection.weight")
+        wide = name in ("c5_small", "c1_paper")
         for n, (nrm, total) in zip((str(s) for s in G[key + ".grad_names"]), G[key + ".grad_stats"]):
             g = sdg[n].grad
             got = 0.0 if g is None else float(g.double().norm())
-            assert abs(got - nrm) <= 5e-4 * max(1e-3, nrm), (name, key, n, got, nrm)
+            tol_n = 5e-3 if (name == "c5_small" and n.startswith("gps_backbone.encoder") and n.endswith(ill)) else 5e-4
+            assert abs(got - nrm) <= tol_n * max(1e-3, nrm), (name, key, n, got, nrm)
             got_sum = 0.0 if g is None else float(g.double().sum())
-            assert abs(got_sum - total) <= 1e-3 * max(floor, nrm), (name, key, n, got_sum, total)
+            scale = max(1.0, float(np.sqrt(sdg[n].numel())) / 8) if wide else 1.0
+            assert abs(got_sum - total) <= 2 * tol_n * max(floor, nrm) * scale, (name, key, n, got_sum, total)
 
 
 # ------------------------------------------------------------------------------------------------
