@@ -23,11 +23,45 @@ from routeformer_amd.losses import FutureDiscountedLoss
 from routeformer_amd.score import ade, fde
 
 
-# Weight-gradient groups that fill up mid-backward go to a side stream (-0.04 .. -0.09 ms at C2).
-WGRAD_SIDE = os.environ.get("RF_WGRAD_SIDE", "0") == "1"
-# "engine" (default): every engine owns its side streams, fork bookkeeping and weight-gradient queue; "global": the round-3
-# process-wide set (kept for the crash bisect of DESIGN section 5b only)
-SIDE_SCOPE = os.environ.get("RF_SIDE_SCOPE", "engine")
+# Weight-gradient groups that fill up mid-backward go to a side stream (-0.04 .. -0.09 ms at C2).  Round 3 switched this
+# off after a host crash inside hipGraphLaunch that only showed with it; the cause was elsewhere (graph execs destroyed
+# under PyTorch's HIP runtime, see _new_graph below) -- the extra branch merely changed which freed object the launch hit.
+WGRAD_SIDE = os.environ.get("RF_WGRAD_SIDE", "1") == "1"
+
+
+# ---- captured graphs are never destroyed ------------------------------------------------------------------------
+# The HIP runtime PyTorch 2.10+rocm7.0 ships (libamdhip64 7.0.2, the one this process runs on whatever /opt/rocm holds)
+# leaves OTHER graph execs with dangling parallel-stream pointers when a multi-branch hipGraphExec is destroyed: a later
+# hipGraphLaunch -- of a new exec or of one that was alive all along -- walks freed hip::Stream objects (GraphExec::Run ->
+# Graph::UpdateStreams, fault at libamdhip64.so+0xaee41) and segfaults once the allocator has reused them.  Stand-alone
+# repro without PyTorch: tools/probes/graph_width_probe.hip (crashes within tens of rounds under that runtime as soon as
+# older execs are destroyed, never when none is, never under ROCm 7.2's runtime); this was round 3's "host segmentation
+# fault inside hipGraphLaunch" (DESIGN section 5b).  So: every torch.cuda.CUDAGraph this engine creates gets one reference
+# that is never given back (no destructor, not even at interpreter exit), and what a dropped graph held of the engine's
+# memory pool is handed back by hand (``_retire``).
+_KEPT_GRAPHS: list = []
+
+
+def _new_graph() -> "torch.cuda.CUDAGraph":
+    import ctypes
+    g = torch.cuda.CUDAGraph()
+    _KEPT_GRAPHS.append(g)
+    ctypes.pythonapi.Py_IncRef(ctypes.py_object(g))
+    return g
+
+
+def _retire(g, device) -> None:
+    """The engine drops graph ``g`` (re-capture after a recipe change, engine teardown): the exec stays alive (see above),
+    its use count on the memory pool is released so that the pool's blocks return to the allocator once every graph that
+    shared the pool has been retired.  A retired graph must never be replayed again."""
+    for one in (g if isinstance(g, tuple) else (g,)):
+        if one is None or getattr(one, "_rf_retired", False):
+            continue
+        one._rf_retired = True
+        try:
+            torch._C._cuda_releasePool(device.index if device.index is not None else torch.cuda.current_device(), one.pool())
+        except Exception:  # (a graph whose capture never began has no pool)
+            pass
 
 
 def _capture_kw() -> dict:
@@ -592,8 +626,8 @@ class TrainEngine:
         from routeformer_amd import kernels as K
         # side streams, open-fork bookkeeping and the deferred weight-gradient queue belong to THIS engine: nothing of
         # another engine's capture (streams, queued operands, "slot written" notes) can reach into this one's
-        self._streams = K.SideStreams() if SIDE_SCOPE == "engine" else K.STREAMS
-        self._wgrad = K._WgradQueue() if SIDE_SCOPE == "engine" else K.WGRAD
+        self._streams = K.SideStreams()
+        self._wgrad = K._WgradQueue()
         self._saved_scope = None
         cfg = model.configs
         layers = [m for m in model.modules() if hasattr(m, "packing_groups")]
@@ -838,6 +872,8 @@ class GraphedTrainEngine(TrainEngine):
         self._static_item = None
         self._out = None
         self._trunk_g = None
+        self._graphs = {}
+        self._pool = None
         self._ready_id = None
         self._ready_checked = None
         self._cached_ids = {}     # batch id -> (cache slots, content keys) of its frames
@@ -1096,13 +1132,31 @@ class GraphedTrainEngine(TrainEngine):
                 warnings.warn("TokenCache is full: batches that do not fit keep running the conv trunk every step")
             self._uncached_ids.add(iid)
 
+    def _drop_graphs(self, keep_trunk: bool = False):
+        """Forget the captured graphs (never destroyed: ``_retire``)."""
+        dev = self.reducer.flat_param.device
+        for g, _ in self.__dict__.get("_graphs", {}).values():
+            _retire(g, dev)
+        self._graphs = {}
+        self.graph = self._out = None
+        if not keep_trunk:
+            _retire(self._trunk_g, dev)
+            self._trunk_g = None
+
+    def __del__(self):
+        try:
+            if self.reducer.flat_param.is_cuda:
+                self._drop_graphs()
+        except Exception:
+            pass
+
     def _trunk_graph(self):
         """Graph of one trunk pass over the staged frames into ``self._tok_next`` (cold start / no look-ahead)."""
         if self._trunk_g is None:
             self._encode(self._staged(), out=self._tok_next)  # warm (weight folding, caches)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, **_capture_kw()):
+            g = _new_graph()
+            with torch.cuda.graph(g, pool=self._pool, **_capture_kw()):
                 self._encode(self._staged(), out=self._tok_next)
             self._trunk_g = g
         return self._trunk_g
@@ -1135,12 +1189,20 @@ class GraphedTrainEngine(TrainEngine):
         # they are kept by reference; otherwise the captured trunk reads them and they are copied like gps / gaze.
         self._static_item = {part: {n: (v if (v.dim() == 5 and self._pipelined) else v.clone()) for n, v in item[part].items()}
                              for part in ("train", "target")}
-        self._trunk_g = None
+        self._drop_graphs()
+        # ONE memory pool for every graph of this engine (trunk, all decision variants, both stages of the split step):
+        # they replay one at a time and each is self-contained (static inputs and persistent buffers live outside the
+        # pool, a variant's outputs stay allocated), so their intermediates may share memory -- 12 variants cost the
+        # memory of one, and a re-capture after a recipe change reuses what the retired graphs gave back
+        self._pool = torch.cuda.graph_pool_handle()
         # plan: which host draws does one step make?  One plan per variant of the host dropout decisions (view /
         # gaze dropout, routeformer.py:301,405-410): depth-first over the outcomes, each variant run once eagerly
         # with its decisions imposed (decisions beyond the imposed prefix default to "keep")
         plans, unused, stack = [], [], [[]]
-        side = torch.cuda.Stream() if K.STREAM_PLAIN else self._streams.get("warmup")
+        side = self._streams.get("warmup")
+        cap_ = getattr(torch.cuda.graph, "default_capture_stream", None)
+        K.debug_line(f"[engine {id(self):x}] warmup stream {side.cuda_stream:x}, current {torch.cuda.current_stream().cuda_stream:x}, "
+                     f"capture stream {cap_.cuda_stream if cap_ is not None else 0:x}")
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             while stack:
@@ -1173,7 +1235,8 @@ class GraphedTrainEngine(TrainEngine):
             n = sum(v.shape[0] * idx.numel() for v, idx in clips)
             self._tok_cur = torch.empty(n, 65, 240, device=dev, dtype=torch.float32)
             self._tok_next = torch.empty_like(self._tok_cur)
-            self._tstream = torch.cuda.Stream() if K.STREAM_PLAIN else self._streams.get("trunk")
+            self._tstream = self._streams.get("trunk")
+            K.debug_line(f"[engine {id(self):x}] trunk stream {self._tstream.cuda_stream:x}")
             self._alloc_clip_stage(item)
             self._stage_clips(item)
             self._trunk_graph().replay()
@@ -1182,7 +1245,6 @@ class GraphedTrainEngine(TrainEngine):
             torch.cuda.synchronize()
         self._epoch = epoch
         self._recipe = self._recipe_for(epoch)
-        self._graphs = {}
         self.graph, self._out = self._main_graph(False, 0)
         self._ready_id = None
         return self
@@ -1208,14 +1270,14 @@ class GraphedTrainEngine(TrainEngine):
         from routeformer_amd.models.blocks import SAMPLER
         now = SAMPLER._variant
         SAMPLER.select_static(variant)  # the captured pass takes this variant's decisions and key-sample slots
-        g = torch.cuda.CUDAGraph()
+        g = _new_graph()
         dot = os.environ.get("RF_GRAPH_DOT")  # diagnosis: keep the hipGraph_t and print it (hipGraphDebugDotPrint)
         if dot:
             g.enable_debug_mode()
-        if os.environ.get("RF_ENGINE_DEBUG"):
-            print(f"[engine {id(self):x}] capture variant {variant} lookahead {la} split {self.split}", file=__import__("sys").stderr, flush=True)
+        from routeformer_amd import kernels as K
+        K.debug_line(f"[engine {id(self):x}] capture variant {variant} lookahead {la} split {self.split}")
         if not self.split:
-            with torch.cuda.graph(g, **_capture_kw()):
+            with torch.cuda.graph(g, pool=self._pool, **_capture_kw()):
                 cur = torch.cuda.current_stream()
 
                 if la:
@@ -1232,10 +1294,10 @@ class GraphedTrainEngine(TrainEngine):
         else:
             # two graphs over one memory pool, replayed back to back: the host can start the all-reduce of the GPS
             # backbone's gradient buckets between them (see step())
-            g2 = torch.cuda.CUDAGraph()
+            g2 = _new_graph()
             self._enter()
             try:
-                with torch.cuda.graph(g, **_capture_kw()):
+                with torch.cuda.graph(g, pool=self._pool, **_capture_kw()):
                     cur = torch.cuda.current_stream()
                     if la:
                         self._tstream.wait_stream(cur)
@@ -1244,7 +1306,7 @@ class GraphedTrainEngine(TrainEngine):
                     out, carry = self._stage1(self._static_item, self._epoch, tokens_ready=self._pipelined)
                     if la:
                         cur.wait_stream(self._tstream)
-                with torch.cuda.graph(g2, pool=g.pool(), **_capture_kw()):
+                with torch.cuda.graph(g2, pool=self._pool, **_capture_kw()):
                     self._stage2(carry)
             finally:
                 self._leave()
@@ -1310,7 +1372,7 @@ class GraphedTrainEngine(TrainEngine):
             # dense-loss switch (epoch 10) or a new discount (a key of ``discount_factor``): the loss arithmetic in
             # the captured graphs is stale -- capture the main graphs again on the same static buffers
             torch.cuda.synchronize()
-            self._graphs.clear()
+            self._drop_graphs(keep_trunk=True)
             self._epoch, self._recipe = epoch, recipe
             self.graph, self._out = self._main_graph(False, 0)
         # host side of the step first: the reference's draws in its order (key samples, view / gaze dropout decisions)
@@ -1364,8 +1426,9 @@ class GraphedTrainEngine(TrainEngine):
         if self.defer_update:
             self._set_hyper()  # scalars of the update this replay starts with (or "nothing pending")
         if os.environ.get("RF_ENGINE_DEBUG"):
-            print(f"[engine {id(self):x}] replay variant {variant} lookahead {isinstance(g, tuple) or (g is self._graphs.get((True, variant), (None,))[0])}",
-                  file=__import__("sys").stderr, flush=True)
+            from routeformer_amd import kernels as K
+            K.debug_line(f"[engine {id(self):x}] replay variant {variant} lookahead "
+                         f"{isinstance(g, tuple) or (g is self._graphs.get((True, variant), (None,))[0])}")
         if isinstance(g, tuple):
             g[0].replay()
             # 95 % of the gradient bytes (the GPS backbone's) are final here: reduce them underneath stage 2

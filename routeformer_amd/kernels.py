@@ -34,6 +34,19 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def debug_line(msg: str):
+    """RF_ENGINE_DEBUG=1: one line to RF_DEBUG_FILE (appended, unbuffered -- survives a crash and pytest's capture) or stderr."""
+    if os.environ.get("RF_ENGINE_DEBUG"):
+        path = os.environ.get("RF_DEBUG_FILE")
+        if path:
+            fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
+            os.write(fd, (msg + "\n").encode())
+            os.close(fd)
+        else:
+            import sys
+            print(msg, file=sys.stderr, flush=True)
+
+
 # Independent sub-graphs of one step (the gaze-token encoder vs the video frame encoders; the target-side
 # feature pass vs the input forward) are latency-bound chains of small kernels: running them on separate
 # HIP streams lets the otherwise idle CUs overlap them.  Off by default (strict reference call order for
@@ -62,9 +75,10 @@ class SideStreams:
 
     Engine-scoped on purpose (round 4).  The round-3 form was one process-global dict whose join waited on EVERY
     stream ever created -- including streams no fork of the current capture had touched (another engine's "update" /
-    "wgrad" stream, the "gaze" stream in a variant that dropped the gaze branch).  Inside a stream capture such a wait
-    records an event on a stream that is NOT capturing and makes the capturing stream wait on it; DESIGN section 5b
-    has what that does to a HIP graph on ROCm 7.0's runtime."""
+    "wgrad" stream, the "gaze" stream in a variant that dropped the gaze branch): inside a stream capture that records an
+    event on a stream that is NOT capturing and makes the capturing stream wait on it.  The runtime tolerates it
+    (tools/probes/capture_probe.hip, mode bit 2), but it ties every capture to the history of the process; a join now
+    names exactly the streams its own forks opened."""
 
     def __init__(self):
         self.streams = {}   # (key, device) -> torch.cuda.Stream
@@ -82,7 +96,8 @@ class SideStreams:
             cap = getattr(torch.cuda.graph, "default_capture_stream", None)
             if cap is not None:
                 taken.add(cap.cuda_stream)
-            st = self.streams[(key, dev)] = torch.cuda.Stream() if STREAM_PLAIN else _distinct_stream(taken)
+            st = self.streams[(key, dev)] = _distinct_stream(taken)
+            debug_line(f"[streams {id(self):x}] {key} -> {st.cuda_stream:x} (current {torch.cuda.current_stream().cuda_stream:x})")
         return st
 
     def fork(self, key: str, origin=None, keep=None):
@@ -105,8 +120,8 @@ class SideStreams:
         (the second graph of the split step inherits the first one's fork set, and autograd pulls only some of those
         streams into it) holds no work of this capture.  Returns the joined fork set (handle -> stream)."""
         cur = into if into is not None else torch.cuda.current_stream()
-        todo = {st.cuda_stream: st for st in self.streams.values()} if JOIN_ALL else dict(self.forked)
-        capturing = (not JOIN_ALL) and _is_capturing(cur)
+        todo = dict(self.forked)
+        capturing = _is_capturing(cur)
         for h, st in todo.items():
             if h != cur.cuda_stream and (not capturing or _is_capturing(st)):
                 cur.wait_stream(st)
@@ -120,8 +135,6 @@ def _is_capturing(stream) -> bool:
         return torch.cuda.is_current_stream_capturing()
 
 
-JOIN_ALL = os.environ.get("RF_JOIN_ALL", "0") == "1"  # round-3 behaviour, for the crash bisect only
-STREAM_PLAIN = os.environ.get("RF_STREAM_PLAIN", "0") == "1"  # likewise: streams straight from torch's round-robin pool
 STREAMS = SideStreams()
 
 
@@ -134,8 +147,10 @@ def fork_side_stream(key: str, origin=None, keep=None):
 
 
 def on_side_stream() -> bool:
-    """True when the current stream is itself one of the side streams: no nested forks (a stream forked from a forked
-    stream is not ended by hipStreamEndCapture on ROCm 7.0 -- DESIGN section 5b)."""
+    """True when the current stream is itself one of the side streams: the fork sites do not nest.  (Round 1 blamed a
+    crash on nested forks; tools/probes/capture_probe.hip mode bit 4 captures and replays them without trouble -- that
+    crash was most likely the destroyed-graph defect of DESIGN section 5b.  The sites stay un-nested because a branch of
+    a branch has nothing left to overlap with.)"""
     return STREAMS.contains(torch.cuda.current_stream())
 
 

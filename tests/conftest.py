@@ -22,7 +22,18 @@ def pytest_sessionstart(session):
     if os.environ.get("RF_SEGV_BT") == "1":
         import ctypes
         lib = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "libsegv_bt.so"))
-        assert lib.rf_segv_bt_install() == 0
+        path = os.environ.get("RF_SEGV_FILE")
+        fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644) if path else -1
+        assert lib.rf_segv_bt_install(fd) == 0
+    if os.environ.get("RF_GC") == "off":  # crash bisect: is the cyclic collector's timing part of it?
+        import gc
+        gc.disable()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        print(f"\n[gpu memory] peak reserved {torch.cuda.max_memory_reserved() / 2**30:.1f} GiB, reserved at exit "
+              f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -13,6 +13,8 @@
 #include <unistd.h>
 #include <fcntl.h>
 
+static int out_fd = 2;
+
 static void dump_maps(void) {
     int fd = open("/proc/self/maps", O_RDONLY);
     if (fd < 0) return;
@@ -22,15 +24,15 @@ static void dump_maps(void) {
     close(fd);
     buf[tot] = 0;
     const char* hdr = "---- executable mappings ----\n";
-    write(2, hdr, strlen(hdr));
+    write(out_fd, hdr, strlen(hdr));
     char* line = buf;
     while (line && *line) {
         char* nl = strchr(line, '\n');
         if (nl) *nl = 0;
         if (strstr(line, " r-xp ") && (strstr(line, "hip") || strstr(line, "hsa") || strstr(line, "torch") || strstr(line, "c10") ||
                                         strstr(line, "librf") || strstr(line, "libc.so"))) {
-            write(2, line, strlen(line));
-            write(2, "\n", 1);
+            write(out_fd, line, strlen(line));
+            write(out_fd, "\n", 1);
         }
         line = nl ? nl + 1 : NULL;
     }
@@ -40,16 +42,18 @@ static void handler(int sig, siginfo_t* info, void* uctx) {
     (void)uctx;
     char msg[128];
     int n = snprintf(msg, sizeof msg, "\n==== segv_bt: signal %d, fault address %p ====\n", sig, info ? info->si_addr : NULL);
-    write(2, msg, n);
+    write(out_fd, msg, n);
     void* frames[96];
     int depth = backtrace(frames, 96);
-    backtrace_symbols_fd(frames, depth, 2);
+    backtrace_symbols_fd(frames, depth, out_fd);
     dump_maps();
     signal(sig, SIG_DFL);
     raise(sig);
 }
 
-int rf_segv_bt_install(void) {
+/* fd < 0: stderr.  (pytest captures fd 2 into a temporary file that dies with the process.) */
+int rf_segv_bt_install(int fd) {
+    if (fd >= 0) out_fd = fd;
     struct sigaction sa;
     memset(&sa, 0, sizeof sa);
     sa.sa_sigaction = handler;
