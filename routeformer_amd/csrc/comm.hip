@@ -50,6 +50,10 @@ Api& api() {
   return a;
 }
 
+// ONE `ready` / `done` event pair per communicator is enough only because every collective of a communicator goes out
+// on its ONE communication stream: collectives are totally ordered there, so `done` -- re-recorded after each of them --
+// always marks the last one, and waiting on it covers all earlier ones; `ready` is consumed (hipStreamWaitEvent) before the
+// next record overwrites it.  A second communication stream would need its own pair.
 struct Comm {
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;   // the communication stream
@@ -91,15 +95,11 @@ extern "C" int rf_comm_unique_id(void* id_out_128_bytes) {
   return RF_OK;
 }
 
-extern "C" int rf_comm_init(void** comm_out, const void* id_128_bytes, int rank, int world) {
-  RF_REQUIRE(comm_out && id_128_bytes && world >= 1 && rank >= 0 && rank < world);
-  if (!api().ok) {
-    rf_g_last_error = "rf_comm: RCCL (librccl.so) could not be resolved";
-    return RF_EUNSUPPORTED;
-  }
-  Comm* c = new Comm();
-  c->rank = rank;
-  c->world = world;
+extern "C" int rf_comm_destroy(void* comm);
+
+namespace {
+// rf_comm_init's body: every failure path leaves through the caller, which frees whatever was already created
+int comm_init_body(Comm* c, const void* id_128_bytes, int rank, int world) {
   RF_HIP_TRY(hipGetDevice(&c->device));
   ncclUniqueId id;
   std::memcpy(&id, id_128_bytes, sizeof(id));
@@ -109,6 +109,27 @@ extern "C" int rf_comm_init(void** comm_out, const void* id_128_bytes, int rank,
   RF_HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));  // highest priority: never queued behind compute
   RF_HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
   RF_HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+  return RF_OK;
+}
+}  // namespace
+
+extern "C" int rf_comm_init(void** comm_out, const void* id_128_bytes, int rank, int world) {
+  RF_REQUIRE(comm_out && id_128_bytes && world >= 1 && rank >= 0 && rank < world);
+  if (!api().ok) {
+    rf_g_last_error = "rf_comm: RCCL (librccl.so) could not be resolved";
+    return RF_EUNSUPPORTED;
+  }
+  Comm* c = new Comm();
+  c->rank = rank;
+  c->world = world;
+  int rc = comm_init_body(c, id_128_bytes, rank, world);
+  if (rc != RF_OK) {  //  nothing of a failed init survives: communicator, stream, events, the struct
+    const char* why = rf_g_last_error;
+    (void)rf_comm_destroy(c);
+    rf_g_last_error = why;
+    *comm_out = nullptr;
+    return rc;
+  }
   *comm_out = c;
   return RF_OK;
 }

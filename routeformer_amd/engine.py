@@ -492,6 +492,65 @@ class GradReducer:
             dist.broadcast(self.flat_param, src=src, group=self.group)
 
 
+class LagMap:
+    """Skipped-update count per element of the flat buffers, piecewise constant: ``cuts[i] <= x < cuts[i + 1]`` has count
+    ``vals[i]`` (the last piece runs to the end).  torch.optim.AdamW keeps ``state['step']`` per parameter and advances it
+    only when the parameter has a gradient; a range skipped by one step (a dropped gaze branch) and another range skipped
+    by another step may overlap, and their counts then ADD on the overlap (the former per-range dict took the
+    maximum over enclosing ranges, right only while a single skip set exists)."""
+
+    def __init__(self, cuts=(0,), vals=(0,)):
+        self.cuts, self.vals = list(cuts), list(vals)
+
+    def _split(self, x: int) -> int:
+        import bisect
+        i = bisect.bisect_right(self.cuts, x) - 1
+        if i < 0:
+            self.cuts.insert(0, x)
+            self.vals.insert(0, 0)
+            return 0
+        if self.cuts[i] != x:
+            self.cuts.insert(i + 1, x)
+            self.vals.insert(i + 1, self.vals[i])
+            return i + 1
+        return i
+
+    def add(self, lo: int, hi: int, n: int = 1):
+        if hi <= lo:
+            return
+        i, j = self._split(int(lo)), self._split(int(hi))
+        for k in range(i, j):
+            self.vals[k] += n
+
+    def inner_cuts(self, lo: int, hi: int):
+        return [c for c in self.cuts if lo < c < hi]
+
+    def lag(self, a: int, b: int) -> int:
+        """The count of [a, b), which must lie inside one piece (the callers cut at ``inner_cuts`` first)."""
+        import bisect
+        i = bisect.bisect_right(self.cuts, a) - 1
+        v = self.vals[i] if i >= 0 else 0
+        j = bisect.bisect_left(self.cuts, b) - 1
+        if any(self.vals[k] != v for k in range(max(i, 0), j + 1)):
+            raise ValueError(f"[{a}, {b}) spans ranges with different update counts: cut the segment plan there")
+        return v
+
+    def as_dict(self):
+        """{(lo, hi): count} of the pieces with a non-zero count (neighbours with equal counts merged)."""
+        out, n = {}, len(self.cuts)
+        k = 0
+        while k < n:
+            if self.vals[k] == 0 or k == n - 1:
+                k += 1
+                continue
+            e = k
+            while e + 1 < n - 1 and self.vals[e + 1] == self.vals[k]:
+                e += 1
+            out[(self.cuts[k], self.cuts[e + 1])] = self.vals[k]
+            k = e + 1
+        return out
+
+
 class FusedAdamW:
     """AdamW + global-norm clipping over flat buffers; two kernel launches per step."""
 
@@ -506,7 +565,20 @@ class FusedAdamW:
         self.betas, self.eps, self.wd, self.max_norm = betas, eps, weight_decay, max_grad_norm
         self.param_groups = [{"lr": lr}]  # what an LR scheduler drives (optimizers.LinearWarmupCosineAnnealingLR)
         self.t = 0
-        self._lag = {}  # (lo, hi) of a skippable range -> number of steps it was skipped (per-parameter step counters)
+        self._lag = LagMap()  # per element: how many of the ``t`` updates skipped it (per-parameter step counters)
+
+    def state_dict(self) -> dict:
+        """Moments, update count AND the per-range skipped-update counts (a resumed run must not restart the
+        bias corrections of a range that sat out some steps)."""
+        return {"t": self.t, "m": self.m, "v": self.v, "lag_cuts": list(self._lag.cuts), "lag_vals": list(self._lag.vals),
+                "lr": self.lr}
+
+    def load_state_dict(self, sd: dict):
+        self.t = int(sd["t"])
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self._lag = LagMap(sd["lag_cuts"], sd["lag_vals"])
+        self.lr = float(sd["lr"])
 
     @property
     def lr(self) -> float:
@@ -554,19 +626,17 @@ class FusedAdamW:
         in an EARLIER step: torch.optim.AdamW keeps ``state['step']`` per parameter and advances it only when the
         parameter has a gradient (full_comparison.py:694-702 + routeformer.py:299-310: a dropped gaze branch leaves
         ``.grad`` None), so the bias corrections of such a range use its own update count ``t - lag``."""
-        cuts = sorted(set([lo, hi] + [x for r in list(skip) + list(self._lag) for x in r if lo < x < hi]))
+        cuts = sorted(set([lo, hi] + [x for r in skip for x in r if lo < x < hi] + self._lag.inner_cuts(lo, hi)))
         out = []
         for a, b in zip(cuts[:-1], cuts[1:]):
             if any(x <= a and b <= y for x, y in skip):
                 continue
-            lag = max([n for (x, y), n in self._lag.items() if x <= a and b <= y] + [0])
-            out.append((a, b, self.t - lag))
+            out.append((a, b, self.t - self._lag.lag(a, b)))
         return out
 
     def _note_skipped(self, skip):
         for r in skip:
-            r = (int(r[0]), int(r[1]))
-            self._lag[r] = self._lag.get(r, 0) + 1
+            self._lag.add(int(r[0]), int(r[1]))
 
     def step_sharded(self, reducer: "GradReducer", grad_scale: float, skip=()):
         """Modes "direct" / "direct_bf16": this rank holds the rank-summed gradients of ITS chunk of every region; it
@@ -974,7 +1044,7 @@ class GraphedTrainEngine(TrainEngine):
         opt, rows = self.opt, []
         for a, b, _ in self._segments:
             skipped = any(x <= a and b <= y for x, y in skip)
-            lag = max([k for (x, y), k in opt._lag.items() if x <= a and b <= y] + [0])
+            lag = opt._lag.lag(a, b)
             rows.append(opt.hyper(scale, pending=not skipped, t=opt.t - lag))
         return rows
 
@@ -1068,7 +1138,9 @@ class GraphedTrainEngine(TrainEngine):
 
     @staticmethod
     def _clip_ptrs(item):
-        return tuple(v.data_ptr() for part in ("train", "target") for v in item[part].values() if v.dim() == 5)
+        # addresses AND version counters: a loader that refills fixed staging buffers in place keeps the addresses; the
+        # in-place write bumps ``_version`` -- a changed version forces the device-side content hash again
+        return tuple((v.data_ptr(), v._version) for part in ("train", "target") for v in item[part].values() if v.dim() == 5)
 
     def _check_id_content(self, item) -> bool:
         """Device-side check that the frames of ``item`` are the ones remembered under its id (no host synchronisation;

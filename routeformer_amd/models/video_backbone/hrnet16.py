@@ -169,7 +169,7 @@ class HRNet16Backbone(VideoBackboneModule):
         arithmetic mode): cache keys are namespaced with it, as the reference's torchcache keys on the module hash."""
         import hashlib
         key = (tuple(p._version for p in self._Backbone.parameters()), tuple(b._version for b in self._Backbone.buffers()),
-               id(next(self._Backbone.parameters())))
+               id(next(self._Backbone.parameters())), self._weights_epoch())
         hit = self.__dict__.get("_fingerprint")
         if hit is None or hit[0] != key:
             h = hashlib.blake2b(digest_size=8)
@@ -189,9 +189,19 @@ class HRNet16Backbone(VideoBackboneModule):
             cache.bind(self.fingerprint())  # (re-attach the cache after loading other weights into the trunk)
         self.__dict__["_token_cache_obj"] = cache
 
+    def _weights_epoch(self) -> int:
+        """Part of the cache keys below.  The fused optimizer kernels rewrite parameters through raw pointers and never
+        bump ``_version`` (the engine counts those writes in ``kernels.WEIGHTS_EPOCH``): as soon as a trunk parameter is
+        trainable or lives in an engine's flat buffer (``train_backbone=True``, InverseForm.py:72-78 -- not built yet), the
+        folded weights and the token-cache namespace must follow that counter too.  Frozen trunk: constant 0,
+        so an optimizer step elsewhere does not invalidate anything."""
+        from routeformer_amd import kernels as K
+        live = any(p.requires_grad or hasattr(p, "_rf_grad") for p in self._Backbone.parameters())
+        return K.WEIGHTS_EPOCH if live else 0
+
     def _prepare(self, device):
         key = (str(device), tuple(p._version for p in self._Backbone.parameters()),
-               tuple(b._version for b in self._Backbone.buffers()), id(next(self._Backbone.parameters())))
+               tuple(b._version for b in self._Backbone.buffers()), id(next(self._Backbone.parameters())), self._weights_epoch())
         if self._folded is not None and self._folded_key == key:
             return self._folded
         sd = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in self._Backbone.state_dict().items()}

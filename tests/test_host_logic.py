@@ -173,10 +173,10 @@ def test_deferred_update_segments_and_pending_rows():
     previous step skipped gets pending = 0, every other one the bias corrections of ITS OWN update count (torch.optim.AdamW
     keeps state['step'] per parameter and advances it only for parameters that had a gradient)."""
     from types import SimpleNamespace
-    from routeformer_amd.engine import FusedAdamW, GraphedTrainEngine
+    from routeformer_amd.engine import FusedAdamW, GraphedTrainEngine, LagMap
     eng = GraphedTrainEngine.__new__(GraphedTrainEngine)
     opt = FusedAdamW.__new__(FusedAdamW)
-    opt.betas, opt.eps, opt.wd, opt.max_norm, opt.param_groups, opt.t, opt._lag = (0.9, 0.999), 1e-8, 1e-4, 2.5, [{"lr": 1e-4}], 0, {}
+    opt.betas, opt.eps, opt.wd, opt.max_norm, opt.param_groups, opt.t, opt._lag = (0.9, 0.999), 1e-8, 1e-4, 2.5, [{"lr": 1e-4}], 0, LagMap()
     eng.opt = opt
     eng.reducer = SimpleNamespace(flat_param=torch.zeros(1000))
     eng.model = SimpleNamespace(configs=SimpleNamespace(gaze_dropout=0.2), with_gaze=True)
@@ -194,9 +194,18 @@ def test_deferred_update_segments_and_pending_rows():
         for (a, b, _), row in zip(segs, rows):
             is_gaze = (a, b) in gaze
             assert row[0] == (0.0 if (is_gaze and skip) else 1.0) and row[9] == 0.5
-            t_seg = opt.t - (opt._lag.get((a, b), 0) if is_gaze else 0)
+            t_seg = opt.t - (opt._lag.lag(a, b) if is_gaze else 0)
             assert abs(row[7] - (1 - 0.9 ** t_seg)) < 1e-12 and abs(row[8] - (1 - 0.999 ** t_seg) ** 0.5) < 1e-12
-    assert opt.t == 4 and opt._lag == {gaze[0]: 2, gaze[1]: 2}   # the gaze slots are at their 2nd update, the rest at the 4th
+    assert opt.t == 4 and opt._lag.as_dict() == {gaze[0]: 2, gaze[1]: 2}   # the gaze slots are at their 2nd update, the rest at the 4th
+    # overlapping skip sets ADD on the overlap: [640, 704) skipped twice above, now [600, 704) once more
+    opt._note_skipped(((600, 704),))
+    assert opt._lag.as_dict() == {(600, 640): 1, (640, 704): 3, (832, 896): 2}
+    opt.t += 1
+    assert [(a, b, t) for a, b, t in opt._segments(590, 720, ())] == [(590, 600, 5), (600, 640, 4), (640, 704, 2), (704, 720, 5)]
+    with pytest.raises(ValueError):
+        opt._lag.lag(620, 660)
+    back = LagMap(list(opt._lag.cuts), list(opt._lag.vals))   # what state_dict() / load_state_dict() carry
+    assert back.as_dict() == opt._lag.as_dict()
     # without gaze dropout (or without a backbone range) the plan degenerates
     eng.model.configs.gaze_dropout = 0.0
     assert eng._plan_segments() == [(0, 600, True), (600, 1000, False)]
