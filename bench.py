@@ -404,6 +404,25 @@ def main():
     for k in ("ade", "fde"):
         assert torch.isfinite(res[k]).all().item(), f"{k} is not finite"
     rccl_ranks = dist.get_world_size() if multi else 1
+    # a line for N GPUs is only printed when N ranks actually took part in the RCCL exchange.  The gloo
+    # rehearsal of tests/test_gpu_dp.py (RF_DIST_BACKEND=gloo: two ranks sharing one GPU) says so in the line ("rehearsal").
+    ranks_on_devices = 1
+    if world > 1:
+        devs = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(devs, torch.tensor([local], dtype=torch.int64, device=device))
+        ranks_on_devices = len({int(d) for d in devs})
+    rehearsal_line = world > 1 and (backend != "nccl" or ranks_on_devices != world)
+    if world > 1 and rccl_ranks != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {world} but the process group has {rccl_ranks} ranks: no line printed", file=sys.stderr)
+        dist.destroy_process_group()
+        sys.exit(3)
+    if rehearsal_line and os.environ.get("RF_DIST_BACKEND") is None:
+        if rank == 0:
+            print(f"bench.py: --gpus {world} ranks share {ranks_on_devices} device(s) (backend {backend}): not a {world}-GPU "
+                  f"measurement, no line printed (set RF_DIST_BACKEND explicitly for a rehearsal)", file=sys.stderr)
+        dist.destroy_process_group()
+        sys.exit(3)
     # more than "finite": the timed model must treat the samples of its batch independently (eval forward of sample
     # 0 inside the batch == the same sample alone, same seed; fp32 mode, bound 1e-3 = north_star's fp32 tolerance)
     indep = batch_independence(model, item, args.precision)
@@ -506,7 +525,9 @@ def main():
                        "step": "fwd + target-feature fwd + losses + bwd + grad all-reduce + clip + AdamW",
                        "launch": ("hipGraph replay of fwd+bwd" + (" (+ the previous step's clip/AdamW at its head)" if defer else ""))
                        if use_graph else "eager launches"},
-            "loss": float(res["loss"].detach()), "rccl_ranks": rccl_ranks, "batch_independence_rel": indep["f32"], "batch_independence_rel_timed_mode": indep[args.precision],
+            "loss": float(res["loss"].detach()), "rccl_ranks": rccl_ranks,
+            **({"rehearsal": f"{world} ranks over {backend} on {ranks_on_devices} device(s): NOT a {world}-GPU measurement"}
+               if rehearsal_line else {}), "batch_independence_rel": indep["f32"], "batch_independence_rel_timed_mode": indep[args.precision],
             "roofline": roof, "roofline_top": top or None, "roofline_fused_encoder_stack": fused or None,
         }
         if multi:

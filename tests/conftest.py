@@ -62,14 +62,19 @@ def t(a):
     return torch.from_numpy(np.asarray(a))
 
 
-def build_product_model(case_name, device="cpu"):
-    """The product model with the fixture's synthetic weights; returns (model, cfg, state_dict, case)."""
+def build_product_model(case_name, device="cpu", rf=None, gps=None):
+    """The product model with the fixture's synthetic weights; returns (model, cfg, state_dict, case).
+    ``rf`` / ``gps``: overrides of the case's RouteformerConfig / GPSBackboneConfig keywords (e.g. the dropouts)."""
     from routeformer_amd import presets, synthetic
     from routeformer_amd.models import Routeformer, RouteformerConfig
     from routeformer_amd.models.gps_backbone import GPSBackboneConfig, Informer
     from routeformer_amd.models.video_backbone import HRNet16Backbone, VideoBackboneConfig
 
     c = presets.case(case_name)
+    if rf:
+        c["rf"] = dict(c["rf"], **rf)
+    if gps:
+        c["gps"] = dict(c["gps"], **gps)
     _, cfg = presets.build_configs(c, GPSBackboneConfig, RouteformerConfig, VideoBackboneConfig)
     model = Routeformer(cfg, gps_backbone=Informer, video_backbone=HRNet16Backbone if cfg.with_video else None)
     sd = synthetic.synth_state_dict(model.state_dict(), WSEED)

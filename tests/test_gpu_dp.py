@@ -74,3 +74,20 @@ def test_rccl_rehearsal_process_group_and_rf_comm():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
     assert "rf_comm unit (one rank): values + stream ordering -> OK" in r.stdout
     assert r.stdout.count("-> OK") == 5 and "MISMATCH" not in r.stdout
+
+
+def test_rccl_rehearsal_dropout_variants_through_split_step():
+    """the paper run's dropouts (six host-decision variants, captured on first use) through the N > 1 form of
+    the step -- every variant as TWO graphs over the engine's memory pool with the GPS backbone's all-reduce issued between
+    the two replays -- over a one-rank RCCL communicator on the one GPU, both transports.  The rehearsed run must reproduce
+    the plain graph-replayed run (same host seed, same mask seed), and several variants must actually have been replayed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29657", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_rehearsal.py"), "c2_small", "10", "--dropout", "--verdict",
+                        "--comm=pg", "--comm=rf"], env=env, capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
+    assert r.stdout.count("-> OK") == 4 and "MISMATCH" not in r.stdout
+    import re
+    seen = [eval(m) for m in re.findall(r"split \(two-graph\) step: (\[[0-9, ]*\])", r.stdout)]
+    assert len(seen) == 2 and all(len(v) >= 3 for v in seen), seen

@@ -21,7 +21,10 @@ import torch
 import torch.distributed as dist
 
 
-def run(mode: str, preset: str, rehearse: bool, steps: int = 4):
+DROPOUTS = dict(rf=dict(feature_dropout=0.1, view_dropout=0.6, gaze_dropout=0.2), gps=dict(dropout=0.1))  # (tests' _dropout_case)
+
+
+def run(mode: str, preset: str, rehearse: bool, steps: int = 4, dropout: bool = False):
     from conftest import build_product_model
     from routeformer_amd import kernels as K, synthetic
     from routeformer_amd.engine import GraphedTrainEngine, TrainEngine
@@ -30,19 +33,24 @@ def run(mode: str, preset: str, rehearse: bool, steps: int = 4):
     os.environ["RF_REHEARSE_COLLECTIVES"] = "1" if rehearse else "0"
     os.environ.pop("RF_SPLIT_BWD", None)
     K.set_precision("bf16")
-    model, cfg, sd, c = build_product_model(preset, "cuda:0")
+    model, cfg, sd, c = build_product_model(preset, "cuda:0", **(DROPOUTS if dropout else {}))
     model.train()
+    if dropout:
+        K.RNG.manual_seed(11)  # device-side mask generator: both runs draw the same masks
 
     def batch(step):
         item = synthetic.synth_item(c["B"], c["T"], c["P"], 100 + step, c["H"], c["W"], streams=c["streams"],
                                     gaze=c["gaze"])
         return {k: {n: v.cuda() for n, v in d.items()} for k, d in item.items()}
 
-    eng = TrainEngine(model, lr=1e-3) if mode == "eager" else GraphedTrainEngine(model, lr=1e-3)
+    lr = 1e-4 if dropout else 1e-3
+    eng = TrainEngine(model, lr=lr) if mode == "eager" else GraphedTrainEngine(model, lr=lr)
     assert eng.reducer.exchange == rehearse
     if mode != "eager":
         eng.capture(batch(0), epoch=10)
         assert isinstance(eng.graph, tuple) == rehearse, "rehearsal must take the two-graph (split backward) path"
+        if dropout:
+            assert SAMPLER.n_variants == 6, SAMPLER.n_variants  # view: keep | drop left | drop right, x gaze: keep | drop
     torch.manual_seed(1234)
     items = [batch(s) for s in range(steps)]
     torch.cuda.synchronize()
@@ -51,6 +59,11 @@ def run(mode: str, preset: str, rehearse: bool, steps: int = 4):
         eng.step(it, epoch=10)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    if dropout and mode != "eager":
+        # the decision variants are captured on first use, EACH as two graphs over the engine's pool with the backbone's
+        # all-reduce between the two replays (GraphedTrainEngine._main_graph, split form)
+        run.variants = sorted({k[1] for k in eng._graphs})
+        assert all(isinstance(g, tuple) == rehearse for g, _ in eng._graphs.values())
     return eng.reducer.flat_param.detach().clone(), ms
 
 
@@ -103,8 +116,11 @@ def main():
                 continue
             os.environ["RF_DP_MODE"] = dp_mode
             for mode in ("eager", "graph"):
-                ref, ms_ref = run(mode, preset, rehearse=False, steps=steps)
-                got, ms = run(mode, preset, rehearse=True, steps=steps)
+                drop = "--dropout" in sys.argv
+                ref, ms_ref = run(mode, preset, rehearse=False, steps=steps, dropout=drop)
+                got, ms = run(mode, preset, rehearse=True, steps=steps, dropout=drop)
+                if drop and mode == "graph":
+                    print(f"dropout variants replayed through the split (two-graph) step: {run.variants}", flush=True)
                 if got.numel() != ref.numel():  # direct modes pad their regions: compare what both hold
                     same, dmax, dmean = True, float("nan"), float("nan")
                 else:
@@ -112,11 +128,11 @@ def main():
                     dmax, dmean = float(d.max()), float(d.mean())
                     # fp32 atomics in the weight gradients are not bit-stable, and Adam at lr 1e-3 amplifies the noise step
                     # by step (chaotic after ~5 updates): the equality verdict is for short runs, long runs are timing runs
-                    same = bool(dmax < 5e-3 and dmean < 5e-4) if steps <= 4 else True
+                    same = bool(dmax < 5e-3 and dmean < 5e-4) if (steps <= 4 or "--verdict" in sys.argv) else True
                 ok &= same
                 print(f"comm={comm:2s} dp={dp_mode:11s} {mode:6s}: plain {ms_ref:7.2f} ms/step | with RCCL exchange {ms:7.2f} "
                       f"ms/step ({(ms / ms_ref - 1) * 100:+.1f} %) | parameter diff max {dmax:.2e} mean {dmean:.2e} -> "
-                      f"{('OK' if same else 'MISMATCH') if steps <= 4 else 'timing run (no equality verdict)'}", flush=True)
+                      f"{('OK' if same else 'MISMATCH') if (steps <= 4 or '--verdict' in sys.argv) else 'timing run (no equality verdict)'}", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
 
