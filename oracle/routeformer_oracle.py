@@ -33,6 +33,32 @@ def _tap(name: str, x):
 # ---------------------------------------------------------------------------------------------
 # host-RNG index source (ProbSparse key sampling)
 # ---------------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------
+# Arithmetic model of the reference's OWN training precision on a GPU (measurement aid, bench.py ade_vs_cpu_ref)
+# ---------------------------------------------------------------------------------------------
+# experiments/full_comparison.py:48 sets torch.set_float32_matmul_precision("medium"): fp32 matmuls (nn.Linear, matmul /
+# bmm / einsum: every projection and all three attention products) may round their operands to bfloat16; PyTorch's cuDNN
+# default (torch.backends.cudnn.allow_tf32 = True) lets the convolutions (token embeddings, the Conv1d(k=1) feed-forward
+# pairs, the distilling convolution, the conv trunk) run on TF32 operands (10 mantissa bits).  Accumulation stays fp32.
+# ARITH = None: exact fp32 (the oracle proper; every parity test).  ARITH = "medium": operands rounded as above, so that
+# the rate at which the REFERENCE's precision mode flips ProbSparse selections can be put next to the product's bf16 mode.
+ARITH: Optional[str] = None
+
+
+def _mm(t):
+    """Operand of a matmul-class op under ARITH."""
+    return t.to(torch.bfloat16).to(torch.float32) if ARITH == "medium" else t
+
+
+def _cv(t):
+    """Operand of a convolution under ARITH: TF32 = fp32 with the mantissa rounded to 10 bits (round to nearest even)."""
+    if ARITH != "medium":
+        return t
+    i = t.contiguous().view(torch.int32)
+    i = (i + 0xFFF + ((i >> 13) & 1)) & ~0x1FFF
+    return i.view(torch.float32)
+
+
 class IndexSource:
     """Supplies ``index_sample`` tensors in call order.
 
@@ -51,6 +77,9 @@ class IndexSource:
         # difference of such dot products, so their rounding error is what can flip a selection).
         self.tops: List[torch.Tensor] = []
         self.margins: List[torch.Tensor] = []
+        # measurement aid: ``forced`` = selections imposed on the calls in order (teacher forcing; the call's own selection
+        # still goes to ``tops``), so that an ARITH = "medium" run can be counted for flips on the fp32 run's trajectory
+        self.forced: Optional[List[torch.Tensor]] = None
 
     def randint(self, high: int, size) -> torch.Tensor:
         if self.replay is not None:
@@ -111,12 +140,12 @@ def full_attention(q, k, v, scale=None, masked: bool = False, dropout: float = 0
     branch of the GPS copy (layers/SelfAttentionFamily.py:9-17,53-57).  (B,L,H,E) in/out."""
     E = q.shape[-1]
     scale = scale or 1.0 / math.sqrt(E)
-    s = torch.einsum("blhe,bshe->bhls", q, k)
+    s = torch.einsum("blhe,bshe->bhls", _mm(q), _mm(k))
     if masked:
         L = q.shape[1]
         s = s.masked_fill(torch.triu(torch.ones(L, s.shape[-1], dtype=torch.bool), diagonal=1), float("-inf"))
     a = _drop(torch.softmax(scale * s, dim=-1), dropout, drop)  # (:63) on the (B,H,L,S) probabilities
-    return torch.einsum("bhls,bshd->blhd", a, v).contiguous()
+    return torch.einsum("bhls,bshd->blhd", _mm(a), _mm(v)).contiguous()
 
 
 def prob_attention(q, k, v, index_sample, factor: int, masked: bool, scale=None,
@@ -132,16 +161,19 @@ def prob_attention(q, k, v, index_sample, factor: int, masked: bool, scale=None,
     assert tuple(index_sample.shape) == (L_Q, sample_k)
     # sampled scores Q[q] . K[index_sample[q, j]]  (:94-97)
     K_s = K[:, :, index_sample, :]  # (B,H,L_Q,k,D)
-    qk_s = torch.einsum("bhqd,bhqjd->bhqj", Q, K_s)
+    qk_s = torch.einsum("bhqd,bhqjd->bhqj", _mm(Q), _mm(K_s))  # (a matmul in the reference: :96)
     M = qk_s.max(-1).values - qk_s.sum(-1) / L_K  # sparsity measure (:100)
     top = M.topk(n_top, sorted=False).indices  # (B,H,u)  (:101)
-    if trace is not None:
+    if trace is not None and trace.forced is not None:
+        own, top = top, trace.forced.pop(0).long()
+        trace.tops.append(own.sort(dim=-1).values)
+    elif trace is not None:
         trace.tops.append(top.sort(dim=-1).values)
         srt = M.detach().sort(dim=-1, descending=True).values
         gap = (srt[..., n_top - 1] - srt[..., n_top]) if n_top < L_Q else torch.full(srt.shape[:-1], float("inf"))
         trace.margins.append(gap / qk_s.detach().abs().amax(dim=(-1, -2)).clamp_min(1e-12))
     Q_red = torch.gather(Q, 2, top.unsqueeze(-1).expand(-1, -1, -1, D))
-    scores = torch.matmul(Q_red, K.transpose(-2, -1)) * (scale or 1.0 / math.sqrt(D))  # (:107,158-160)
+    scores = torch.matmul(_mm(Q_red), _mm(K).transpose(-2, -1)) * (scale or 1.0 / math.sqrt(D))  # (:107,158-160)
     if masked:  # ProbMask: key s visible to selected query i iff s <= top[i]  (:22-29)
         assert L_Q == L_K
         key_pos = torch.arange(L_K).view(1, 1, 1, L_K)
@@ -150,14 +182,14 @@ def prob_attention(q, k, v, index_sample, factor: int, masked: bool, scale=None,
     else:
         ctx = V.mean(dim=-2, keepdim=True).expand(B, H, L_Q, V.shape[-1]).clone()  # (:113-116)
     attn = torch.softmax(scores, dim=-1)
-    upd = torch.matmul(attn, V)
+    upd = torch.matmul(_mm(attn), _mm(V))
     ctx = ctx.scatter(2, top.unsqueeze(-1).expand(-1, -1, -1, V.shape[-1]), upd)  # (:131-133)
     out = ctx.contiguous() if gps_variant else ctx.transpose(1, 2).contiguous()
     return (out, top) if return_top else out
 
 
 def _linear(sd: SD, p: str, x):
-    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+    return F.linear(_mm(x), _mm(sd[p + ".weight"]), sd.get(p + ".bias"))
 
 
 def attention_layer(sd: SD, p: str, xq, xk, xv, n_heads: int, kind: str, idx: IndexSource,
@@ -196,9 +228,9 @@ def _ffn(sd: SD, p: str, x, activation: str, dropout: float = 0.0, drop: Optiona
     """dropout(Conv1d(k=1)(dropout(act(Conv1d(k=1)(x))))) on (B,L,C) -- cross_modal_transformer.py:298-299: the
     first dropout acts on the (B, d_ff, L) Conv1d layout, the second after the transpose back."""
     w1, w2 = sd[p + ".conv1.weight"].squeeze(-1), sd[p + ".conv2.weight"].squeeze(-1)
-    y = _act(activation)(F.linear(x, w1, sd[p + ".conv1.bias"]))
+    y = _act(activation)(F.linear(_cv(x), _cv(w1), sd[p + ".conv1.bias"]))  # (Conv1d(k=1) in the reference: a convolution)
     y = _drop(y.transpose(-1, 1), dropout, drop).transpose(-1, 1)
-    return _drop(F.linear(y, w2, sd[p + ".conv2.bias"]), dropout, drop)
+    return _drop(F.linear(_cv(y), _cv(w2), sd[p + ".conv2.bias"]), dropout, drop)
 
 
 def encoder_layer(sd: SD, p: str, x, n_heads, idx, factor, activation, gps_variant, kind: str = "prob",
@@ -239,7 +271,7 @@ def circular_conv3(x, weight, bias=None, padding: int = 1):
     pos = torch.arange(-padding, L + padding) % L  # circularly padded source positions
     xp = x[:, pos, :]  # (B, L+2p, C)
     taps = [xp[:, t: t + L + 2 * padding - 2, :] for t in range(3)]
-    y = sum(torch.matmul(taps[t], weight[:, :, t].t()) for t in range(3))
+    y = sum(torch.matmul(_cv(taps[t]), _cv(weight[:, :, t]).t()) for t in range(3))
     return y if bias is None else y + bias
 
 
@@ -282,7 +314,7 @@ def data_embedding(sd: SD, p: str, x, dropout: float = 0.0, drop: Optional[Dropo
     B, L, _ = x.shape
     mark = torch.arange(L, dtype=torch.float32).view(1, L, 1).expand(B, L, 1)
     return _drop(circular_conv3(x, sd[p + ".value_embedding.tokenConv.weight"])
-                 + F.linear(mark, sd[p + ".temporal_embedding.embed.weight"])
+                 + F.linear(_mm(mark), _mm(sd[p + ".temporal_embedding.embed.weight"]))
                  + sd[p + ".position_embedding.pe"][:, :L], dropout, drop)
 
 
@@ -410,7 +442,7 @@ def warmup_cosine_lr(base_lr: float, epochs: int, warmup_epochs: int, max_epochs
 # ---------------------------------------------------------------------------------------------
 def _conv_bn(sd: SD, conv: str, bn: Optional[str], x, stride=1, relu=False):
     w = sd[conv + ".weight"]
-    y = F.conv2d(x, w, None, stride=stride, padding=(w.shape[-1] - 1) // 2 if w.shape[-1] == 3 else 0)
+    y = F.conv2d(_cv(x), _cv(w), None, stride=stride, padding=(w.shape[-1] - 1) // 2 if w.shape[-1] == 3 else 0)
     if bn is not None:  # eval-mode BatchNorm2d (frozen, InverseForm.py:69-71)
         y = F.batch_norm(y, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"],
                          sd[bn + ".bias"], False, 0.1, 1e-5)
