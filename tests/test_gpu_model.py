@@ -315,12 +315,22 @@ def test_model_eval_forward_bf16(name):
     with torch.no_grad():
         out = model(_to_dev(item["train"]))
     free = rel_err(out[0] if isinstance(out, tuple) else out, G["eval.future_gps"])
-    print(f"[{name}] bf16 free-running rel err {free:.2e}")
-    # free-running: the selections leave the oracle's path (bench.py ade_vs_cpu_ref: 40 % of the teacher-forced selections
-    # differ in bf16 mode -- 13 % already in the first layer of the frame encoder, whose input is the bf16 conv trunk's --
-    # against 5e-5 in fp32 mode); a different-but-valid set of active queries moves a trajectory by up to 2.7e-2 over
-    # 32 bench samples (median 5e-3, 2/3 within 1e-2: profiles/r03/bench_n1_*.json).  Bound = 2 x the observed maximum.
-    assert free < 5e-2
+    # the same quantity for the REFERENCE's own GPU training precision (oracle.ARITH = "medium": bf16-rounded matmul
+    # operands per torch.set_float32_matmul_precision("medium"), full_comparison.py:48, TF32 convolutions) on this case
+    try:
+        O.ARITH = "medium"
+        (pos_m, _), _ = _oracle_eval(cfg, sd, item["train"], draws(G, "eval."))
+    finally:
+        O.ARITH = None
+    free_ref = rel_err(pos_m, G["eval.future_gps"])
+    print(f"[{name}] bf16 free-running rel err {free:.2e}; the fp32 oracle in the reference's 'medium' precision: {free_ref:.2e}")
+    # free-running: the selections leave the fp32 path.  Measured in round 4 (bench.py ade_vs_cpu_ref, 16 samples x 2 seeds,
+    # profiles/r04/bench_n1_default_20_medium_leg.json): the product's bf16 mode flips 42 % of the teacher-forced selections
+    # (12.7 % in the first frame-encoder layer) and ends at median 3.1e-3 / p90 9.0e-3 / max 2.1e-2 of the trajectory
+    # scale; the CPU oracle run in the reference's own GPU precision mode flips 34 % (10.9 %) and ends at 5.3e-3 / 1.1e-2 /
+    # 2.0e-2 -- the product sits inside what the reference's training arithmetic does to itself.  Bound = 1.5 x the larger of
+    # the two observed maxima (was 5e-2).
+    assert free < 3e-2
 
 
 # (norm / sum tolerance, full-tensor tolerance, names with their own full-tensor tolerance, that tolerance)
