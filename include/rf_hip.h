@@ -190,6 +190,18 @@ int rf_layernorm_fwd_strided(const float* x, int seg_rows, int64_t seg_stride, i
 int rf_layernorm_fwd_slabs(const float* slabs, int splits, const float* bias, const float* residual,
                            const float* gamma, const float* beta, float* y, float* xhat, float* rstd, int rows,
                            int cols, float eps, void* stream);
+/* rf_layernorm_fwd_slabs whose output is written straight in the im2col layout of the distilling convolution that
+ * consumes it (Conv1d k = 3, circular padding 2, layers/TransformerEncoderDecoder.py:12-18): rows = B * L sequences rows,
+ * cols_out[b][r][3 c + t] = y[b][(r + t - 2) mod L][c] for r in [0, L + 2) -- what rf_unfold3_circular(pad = 2) would
+ * produce from y; the unfold launch between the norm and the product is gone (round 4).  cols >= 257. */
+int rf_layernorm_fwd_slabs_unfold(const float* slabs, int splits, const float* bias, const float* residual,
+                                  const float* gamma, const float* beta, float* cols_out, float* xhat, float* rstd,
+                                  int rows, int cols, int L, float eps, void* stream);
+/* rf_layernorm_bwd whose incoming gradient is that of the im2col image above, dcols[b][L + 2][3 cols]: the fold
+ * (rf_fold3_circular, pad = 2) happens on load. */
+int rf_layernorm_bwd_fold(const float* dcols, const float* xhat, const float* rstd, const float* gamma, float* dx,
+                          float* dgamma, float* dbeta, int accumulate, float* workspace, int rows, int cols, int L,
+                          void* stream);
 /* dx = d(loss)/d(s); dgamma/dbeta reduced deterministically through `workspace`
  * (rf_layernorm_bwd_parts(rows)*2*cols floats); accumulate=1 adds them into dgamma/dbeta. */
 int rf_layernorm_bwd_parts(int rows);

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void layernorm_row_kernel(const float* __restr
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ xhat, float* __restrict__ rstd_out,
                                                             int rows, int cols, float eps, int seg_rows, long seg_stride,
-                                                            long row_stride) {
+                                                            long row_stride, int unf_L) {
   __shared__ float red[2][LN_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x;
@@ -140,6 +140,32 @@ __global__ __launch_bounds__(256) void layernorm_row_kernel(const float* __restr
   __syncthreads();
   const float var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)cols;
   const float rstd = 1.0f / sqrtf(var + eps);
+  if (unf_L > 0) {
+    // The consumer is the distilling convolution (Conv1d k = 3, circular padding 2: layers/TransformerEncoderDecoder.py:12-18):
+    // y is written straight in its im2col layout  cols[b][r][3 c + t] = y[b][(r + t - 2) mod L][c],  r in [0, L + 2)
+    // (the layout rf_unfold3_circular(pad = 2) produces: the unfold launch between the norm and the product is gone).
+    // Source row l feeds r = l + 2 - t, plus the wrapped copies r -+ L that fall inside [0, L + 2).
+    const int L = unf_L, b = row / L, l = row - b * L, Lout = L + 2;
+    float* cb = y + (long)b * Lout * 3 * cols;
+#pragma unroll
+    for (int i = 0; i < NVW; ++i) {
+      const int c = (wave + LN_WAVES * i) * 64 + lane;
+      if (c < cols) {
+        const float h = (v[i] - mean) * rstd;
+        if (xhat) xhat[off + c] = h;
+        const float o = h * gm[i] + bt[i];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int r = l + 2 - t;
+          cb[(long)r * 3 * cols + 3 * c + t] = o;
+          if (r - L >= 0) cb[(long)(r - L) * 3 * cols + 3 * c + t] = o;
+          if (r + L < Lout) cb[(long)(r + L) * 3 * cols + 3 * c + t] = o;
+        }
+      }
+    }
+    if (rstd_out && threadIdx.x == 0) rstd_out[row] = rstd;
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NVW; ++i) {
     const int c = (wave + LN_WAVES * i) * 64 + lane;
@@ -157,10 +183,10 @@ constexpr int LN_ROW_MIN_COLS = 257;  // rows this wide (and every slab input) t
 template <int NVW, int SC>
 void launch_ln_row_nvw(const float* x, int splits, const float* bias, const float* res, const float* gamma,
                        const float* beta, float* y, float* xhat, float* rstd, int rows, int cols, float eps, int seg_rows,
-                       long seg_stride, long row_stride, hipStream_t st) {
+                       long seg_stride, long row_stride, hipStream_t st, int unf_L = 0) {
 #define RF_LN_ROW_GO(B_, R_) \
   RF_LAUNCH((layernorm_row_kernel<NVW, SC, B_, R_>), dim3(rows), dim3(256), 0, st, x, splits, bias, res, gamma, beta, y, xhat, \
-            rstd, rows, cols, eps, seg_rows, seg_stride, row_stride)
+            rstd, rows, cols, eps, seg_rows, seg_stride, row_stride, unf_L)
   if (bias && res) RF_LN_ROW_GO(true, true);
   else if (bias) RF_LN_ROW_GO(true, false);
   else if (res) RF_LN_ROW_GO(false, true);
@@ -171,9 +197,9 @@ void launch_ln_row_nvw(const float* x, int splits, const float* bias, const floa
 template <int SC>
 void launch_ln_row(const float* x, int splits, const float* bias, const float* res, const float* gamma,
                    const float* beta, float* y, float* xhat, float* rstd, int rows, int cols, float eps, int seg_rows,
-                   long seg_stride, long row_stride, hipStream_t st) {
+                   long seg_stride, long row_stride, hipStream_t st, int unf_L = 0) {
   const int groups = (cols + 63) / 64;
-#define RF_LN_ROW_ARGS x, splits, bias, res, gamma, beta, y, xhat, rstd, rows, cols, eps, seg_rows, seg_stride, row_stride, st
+#define RF_LN_ROW_ARGS x, splits, bias, res, gamma, beta, y, xhat, rstd, rows, cols, eps, seg_rows, seg_stride, row_stride, st, unf_L
   if (groups <= LN_WAVES) launch_ln_row_nvw<1, SC>(RF_LN_ROW_ARGS);
   else if (groups <= 2 * LN_WAVES) launch_ln_row_nvw<2, SC>(RF_LN_ROW_ARGS);
   else launch_ln_row_nvw<4, SC>(RF_LN_ROW_ARGS);
@@ -185,7 +211,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
                                                             float* __restrict__ ws, int rows, int cols,
-                                                            float* __restrict__ agamma, float* __restrict__ abeta) {
+                                                            float* __restrict__ agamma, float* __restrict__ abeta, int fold_L) {
   __shared__ float red[2][LN_WAVES][NV * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dg[NV], db[NV], gm[NV];
@@ -197,11 +223,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
     const long off = (long)row * cols;
     float g[NV], h[NV];
+    if (fold_L > 0) {
+      // dy arrives as the gradient of the im2col image the forward wrote (layernorm_row_kernel, unf_L): the fold --
+      // rf_fold3_circular(pad = 2) -- happens on load: dy[b][l][c] = sum over (r, t) with (r + t - 2) mod L == l
+      const int L = fold_L, b = row / L, l = row - b * L, Lout = L + 2;
+      const float* cb = dy + (long)b * Lout * 3 * cols;
+      // per tap: the row r0 = l + 2 - t always contributes; at most ONE wrapped copy (r0 - L or r0 + L) lies inside
+      // [0, L + 2) -- loads are unconditional (a missing copy re-reads r0 with weight 0: no branch around a load)
+      long ro[3], rw[3];
+      float ww[3];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int cc = min(i * 64 + lane, cols - 1);  // clamped, unconditional; masked below
-      g[i] = dy[off + cc];
-      h[i] = xhat[off + cc];
+      for (int t = 0; t < 3; ++t) {
+        const int r0 = l + 2 - t;
+        const int rwrap = r0 - L >= 0 ? r0 - L : (r0 + L < Lout ? r0 + L : -1);
+        ro[t] = (long)r0 * 3 * cols + t;
+        rw[t] = (long)(rwrap >= 0 ? rwrap : r0) * 3 * cols + t;
+        ww[t] = rwrap >= 0 ? 1.f : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int cc = min(i * 64 + lane, cols - 1);
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a += cb[ro[t] + 3 * cc] + ww[t] * cb[rw[t] + 3 * cc];
+        g[i] = a;
+        h[i] = xhat[off + cc];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int cc = min(i * 64 + lane, cols - 1);  // clamped, unconditional; masked below
+        g[i] = dy[off + cc];
+        h[i] = xhat[off + cc];
+      }
     }
     const float r = rstd[row];
     float s1 = 0.f, s2 = 0.f;
@@ -631,15 +685,47 @@ extern "C" int rf_layernorm_fwd_slabs(const float* slabs, int splits, const floa
   return RF_OK;
 }
 
+extern "C" int rf_layernorm_fwd_slabs_unfold(const float* slabs, int splits, const float* bias, const float* residual,
+                                             const float* gamma, const float* beta, float* cols_out, float* xhat, float* rstd,
+                                             int rows, int cols, int L, float eps, void* stream) {
+  RF_REQUIRE(slabs && splits >= 1 && gamma && beta && cols_out && rows > 0 && cols >= LN_ROW_MIN_COLS && cols <= 64 * LN_MAXV);
+  RF_REQUIRE(L >= 2 && rows % L == 0);
+  if (splits == 1)
+    launch_ln_row<1>(slabs, 1, bias, residual, gamma, beta, cols_out, xhat, rstd, rows, cols, eps, rows, 0, cols,
+                     static_cast<hipStream_t>(stream), L);
+  else
+    launch_ln_row<4>(slabs, splits, bias, residual, gamma, beta, cols_out, xhat, rstd, rows, cols, eps, rows, 0, cols,
+                     static_cast<hipStream_t>(stream), L);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
 extern "C" int rf_layernorm_bwd_parts(int rows) {
   // enough workgroups to cover all 256 CUs a few times over; each writes one (dgamma, dbeta) partial row
   const int blocks = (rows + 4 * LN_WAVES - 1) / (4 * LN_WAVES);
   return blocks > 768 ? 768 : (blocks < 1 ? 1 : blocks);
 }
 
+static int layernorm_bwd_run(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,
+                             float* dgamma, float* dbeta, int accumulate, float* workspace, int rows, int cols, int fold_L,
+                             void* stream);
+
 extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,
                                 float* dgamma, float* dbeta, int accumulate, float* workspace, int rows, int cols,
                                 void* stream) {
+  return layernorm_bwd_run(dy, xhat, rstd, gamma, dx, dgamma, dbeta, accumulate, workspace, rows, cols, 0, stream);
+}
+
+extern "C" int rf_layernorm_bwd_fold(const float* dcols, const float* xhat, const float* rstd, const float* gamma, float* dx,
+                                     float* dgamma, float* dbeta, int accumulate, float* workspace, int rows, int cols, int L,
+                                     void* stream) {
+  RF_REQUIRE(L >= 2 && rows % L == 0);
+  return layernorm_bwd_run(dcols, xhat, rstd, gamma, dx, dgamma, dbeta, accumulate, workspace, rows, cols, L, stream);
+}
+
+static int layernorm_bwd_run(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,
+                             float* dgamma, float* dbeta, int accumulate, float* workspace, int rows, int cols, int fold_L,
+                             void* stream) {
   RF_REQUIRE(dy && xhat && rstd && gamma && dx && dgamma && dbeta && (workspace || accumulate == 2));
   RF_REQUIRE(rows > 0 && cols > 0 && cols <= 64 * LN_MAXV);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -649,13 +735,13 @@ extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float*
     int blocks = (rows + LN_WAVES - 1) / LN_WAVES;
     blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);  // (128 .. 1 024 measured: no difference)
     RF_LN_DISPATCH(layernorm_bwd_kernel, cols, dim3(blocks), dim3(256), 0, st, dy, xhat, rstd, gamma, dx,
-                   static_cast<float*>(nullptr), rows, cols, dgamma, dbeta);
+                   static_cast<float*>(nullptr), rows, cols, dgamma, dbeta, fold_L);
     RF_CHECK_LAUNCH();
     return RF_OK;
   }
   const int parts = rf_layernorm_bwd_parts(rows);
   RF_LN_DISPATCH(layernorm_bwd_kernel, cols, dim3(parts), dim3(256), 0, st, dy, xhat, rstd, gamma, dx, workspace, rows,
-                 cols, static_cast<float*>(nullptr), static_cast<float*>(nullptr));
+                 cols, static_cast<float*>(nullptr), static_cast<float*>(nullptr), fold_L);
   RF_CHECK_LAUNCH();
   RF_LAUNCH(ln_param_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, workspace, parts, cols,
                      dgamma, dbeta, accumulate);

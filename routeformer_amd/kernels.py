@@ -504,14 +504,21 @@ def _gemm_partials(x2, w, M: int, N: int, K: int, plan):
     return ws, splits
 
 
-def _ln_fwd_slabs(ws, splits, bias, r2, gamma, beta, M: int, N: int, eps: float, need_grad: bool):
-    """LayerNorm(sum of slabs + bias + r2) -> (y, xhat, rstd)."""
-    y = torch.empty(M, N, device=ws.device, dtype=torch.float32)
-    xhat = torch.empty_like(y) if need_grad else None
+def _ln_fwd_slabs(ws, splits, bias, r2, gamma, beta, M: int, N: int, eps: float, need_grad: bool, unfold_L: int = 0):
+    """LayerNorm(sum of slabs + bias + r2) -> (y, xhat, rstd).  ``unfold_L`` = L > 0: y comes out as the (B, L + 2, 3 N)
+    im2col image of the distilling convolution that consumes it (rf_layernorm_fwd_slabs_unfold)."""
+    xhat = torch.empty(M, N, device=ws.device, dtype=torch.float32) if need_grad else None
     rstd = torch.empty(M, device=ws.device, dtype=torch.float32) if need_grad else None
     ev = PROFILE.begin() if PROFILE.on else None
-    check(_hip.lib().rf_layernorm_fwd_slabs(ptr(ws), splits, ptr(bias), ptr(r2), ptr(gamma), ptr(beta), ptr(y), ptr(xhat),
-                                            ptr(rstd), M, N, eps, _stream()), "rf_layernorm_fwd_slabs")
+    if unfold_L:
+        y = torch.empty(M // unfold_L, unfold_L + 2, 3 * N, device=ws.device, dtype=torch.float32)
+        check(_hip.lib().rf_layernorm_fwd_slabs_unfold(ptr(ws), splits, ptr(bias), ptr(r2), ptr(gamma), ptr(beta), ptr(y),
+                                                       ptr(xhat), ptr(rstd), M, N, unfold_L, eps, _stream()),
+              "rf_layernorm_fwd_slabs_unfold")
+    else:
+        y = torch.empty(M, N, device=ws.device, dtype=torch.float32)
+        check(_hip.lib().rf_layernorm_fwd_slabs(ptr(ws), splits, ptr(bias), ptr(r2), ptr(gamma), ptr(beta), ptr(y), ptr(xhat),
+                                                ptr(rstd), M, N, eps, _stream()), "rf_layernorm_fwd_slabs")
     if ev is not None:
         PROFILE.end("layernorm_fwd_kernel", ev, (8.0 + splits) * M * N, 4.0 * M * N * (splits + 2 + (xhat is not None)))
     return y, xhat, rstd
@@ -991,9 +998,10 @@ class _AddLayerNorm(torch.autograd.Function):
         return dx, (dx if ctx.has_res else None), dg, db, None, None, None, None
 
 
-def _ln_backward(dy2, xhat, rstd, gamma, gg, gb):
+def _ln_backward(dy2, xhat, rstd, gamma, gg, gb, fold_L: int = 0):
     """LayerNorm backward on saved (xhat, rstd): -> (d pre-norm input, dgamma, dbeta); with sinks the
-    parameter gradients are accumulated there and returned as None."""
+    parameter gradients are accumulated there and returned as None.  ``fold_L`` = L > 0: ``dy2`` is the gradient of the
+    (B, L + 2, 3 cols) im2col image the forward wrote (``_ln_fwd_slabs(unfold_L=L)``); the fold happens on load."""
     rows, cols = xhat.shape
     dx = torch.empty_like(xhat)
     sink = gg is not None and gb is not None
@@ -1005,9 +1013,14 @@ def _ln_backward(dy2, xhat, rstd, gamma, gg, gb):
         parts = _hip.lib().rf_layernorm_bwd_parts(rows)
         ws = torch.empty(parts * 2 * cols, device=dy2.device, dtype=torch.float32)
     ev = PROFILE.begin() if PROFILE.on else None
-    check(_hip.lib().rf_layernorm_bwd(ptr(dy2), ptr(xhat), ptr(rstd), ptr(gamma), ptr(dx), ptr(dg), ptr(db),
-                                      2 if atomic else (1 if sink else 0), ptr(ws), rows, cols, _stream()),
-          "rf_layernorm_bwd")
+    if fold_L:
+        check(_hip.lib().rf_layernorm_bwd_fold(ptr(dy2), ptr(xhat), ptr(rstd), ptr(gamma), ptr(dx), ptr(dg), ptr(db),
+                                               2 if atomic else (1 if sink else 0), ptr(ws), rows, cols, fold_L, _stream()),
+              "rf_layernorm_bwd_fold")
+    else:
+        check(_hip.lib().rf_layernorm_bwd(ptr(dy2), ptr(xhat), ptr(rstd), ptr(gamma), ptr(dx), ptr(dg), ptr(db),
+                                          2 if atomic else (1 if sink else 0), ptr(ws), rows, cols, _stream()),
+              "rf_layernorm_bwd")
     if ev is not None:
         PROFILE.end("layernorm_bwd_kernel(+ln_param_reduce)", ev, 12.0 * rows * cols, 4.0 * rows * cols * 3)
     if sink:
@@ -1190,7 +1203,10 @@ class _FFNAddLNSlabs(torch.autograd.Function):
     bit-identical forward; the backward IS that composition (LayerNorm backward, then ``_FFN.backward``)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, act, gamma, beta, eps, g1, gb1, g2, gb2, gg, gbeta, plan, need_grad=True):
+    def forward(ctx, x, w1, b1, w2, b2, act, gamma, beta, eps, g1, gb1, g2, gb2, gg, gbeta, plan, need_grad=True,
+                unfold_L: int = 0):
+        """``unfold_L`` = L: the output is the (B, L + 2, 3 D) im2col image of the distilling convolution that follows
+        (``circular_conv3(pad=2)`` without its unfold launch; the backward folds on load)."""
         _req(x, "ffn_ln.x")
         F, D = w1.shape[0], w1.shape[1]
         w1, w2 = w1.reshape(F, D), w2.reshape(D, F)
@@ -1201,30 +1217,49 @@ class _FFNAddLNSlabs(torch.autograd.Function):
         gemm(x2, x2.stride(0), 1, w1, 1, D, h, F, M, F, D, bias=b1, act=ACT[act], preact=z, ldp=F)
         ws, splits = _gemm_partials(h, w2, M, D, F, plan)
         r2 = x2 if x2.is_contiguous() else x2.contiguous()
-        y, xhat, rstd = _ln_fwd_slabs(ws, splits, b2, r2, gamma, beta, M, D, eps, need_grad)
+        y, xhat, rstd = _ln_fwd_slabs(ws, splits, b2, r2, gamma, beta, M, D, eps, need_grad, unfold_L)
         if need_grad:
             ctx.save_for_backward(x2, w1, w2, h, z if z is not None else h, xhat, rstd, gamma)
         ctx.sinks = (g1, gb1, g2, gb2, gg, gbeta)
-        ctx.act, ctx.xshape, ctx.wshapes = act, x.shape, (F, D)
-        return y.view(x.shape)
+        ctx.act, ctx.xshape, ctx.wshapes, ctx.unfold_L = act, x.shape, (F, D), unfold_L
+        return y if unfold_L else y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
         x2, w1, w2, h, zsrc, xhat, rstd, gamma = ctx.saved_tensors
         g1, gb1, g2, gb2, gg, gbeta = ctx.sinks
         M, D = xhat.shape
-        dpre, dgam, dbet = _ln_backward(dy.reshape(M, D).contiguous(), xhat, rstd, gamma, gg, gbeta)
+        if ctx.unfold_L:
+            dpre, dgam, dbet = _ln_backward(dy.contiguous(), xhat, rstd, gamma, gg, gbeta, fold_L=ctx.unfold_L)
+        else:
+            dpre, dgam, dbet = _ln_backward(dy.reshape(M, D).contiguous(), xhat, rstd, gamma, gg, gbeta)
         f = _Ctx()
         f.saved_tensors, f.sinks, f.drop = (x2, w1, w2, h, zsrc), (g1, gb1, g2, gb2), None
         f.act, f.xshape, f.wshapes, f.needs_input_grad = ctx.act, ctx.xshape, ctx.wshapes, (ctx.needs_input_grad[0],)
         dpre_v = dpre.view(ctx.xshape)
         dx, dw1, db1, dw2, db2 = _FFN.backward(f, dpre_v, dpre_v)[:5]  # the skip branch's gradient rides in the last dX epilogue
-        return dx, dw1, db1, dw2, db2, None, dgam, dbet, None, None, None, None, None, None, None, None, None
+        return dx, dw1, db1, dw2, db2, None, dgam, dbet, None, None, None, None, None, None, None, None, None, None
 
 
-def ffn_add_layer_norm(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str, gamma, beta, eps: float = 1e-5):
-    """LayerNorm(x + ffn(x)); one launch when d_model = 128, d_ff = 256 in bf16 mode."""
+UNFOLD_IN_NORM = os.environ.get("RF_UNFOLD_IN_NORM", "1") != "0"  # measurement switch
+
+
+def ffn_add_layer_norm(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str, gamma, beta, eps: float = 1e-5, unfold: bool = False):
+    """LayerNorm(x + ffn(x)); one launch when d_model = 128, d_ff = 256 in bf16 mode.
+    ``unfold``: the caller is followed by a distilling convolution (circular k = 3, padding 2) and can take the output as
+    its im2col image: -> (tensor, True) when the slab-summing norm wrote that image, else (plain output, False)."""
     F, D = conv1_w.shape[0], conv1_w.shape[1]
+    if unfold:
+        if (UNFOLD_IN_NORM and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous() and D > 256
+                and (3 * D) % 4 == 0 and conv1_w.is_contiguous() and conv2_w.is_contiguous() and x.shape[1] >= 2):
+            M = x.numel() // D
+            plan = _partials_plan(ptr(x) // 256 * 256, F, conv2_w.view(D, F), M, D, F)
+            if plan is not None:
+                y = _FFNAddLNSlabs.apply(x, conv1_w, conv1_b, conv2_w, conv2_b, act, gamma, beta, eps, _slot(conv1_w),
+                                         _slot(conv1_b), _slot(conv2_w), _slot(conv2_b), _slot(gamma), _slot(beta), plan,
+                                         torch.is_grad_enabled(), x.shape[1])
+                return y, True
+        return ffn_add_layer_norm(x, conv1_w, conv1_b, conv2_w, conv2_b, act, gamma, beta, eps), False
     if (ROWBLOCK and _PRECISION == 1 and D == 128 and F == 256 and x.is_cuda and conv1_b is not None
             and conv2_b is not None and conv1_w.is_contiguous() and conv2_w.is_contiguous()
             and conv1_w.data_ptr() % 16 == 0 and conv2_w.data_ptr() % 16 == 0):
@@ -1297,6 +1332,12 @@ class _PadCols(torch.autograd.Function):
         dw = torch.empty(rows, cols, device=dwp.device, dtype=torch.float32)
         check(_hip.lib().rf_unpad_cols(ptr(dwp), ptr(dw), rows, cols, ld, 0, _stream()), "rf_unpad_cols")
         return dw, None, None
+
+
+def circular_conv3_unfolded(cols, weight, bias=None):
+    """The product of ``circular_conv3(pad=2)`` on an im2col image that already exists (ffn_add_layer_norm(unfold=True))."""
+    d = weight.shape[0]
+    return _Linear.apply(cols, weight.view(d, -1), bias, None, _slot(weight, (d, weight.shape[1] * 3)), _slot(bias))
 
 
 def circular_conv3(x, weight, bias=None, pad: int = 1, residual=None):

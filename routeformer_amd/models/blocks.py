@@ -340,22 +340,25 @@ class EncoderLayer(nn.Module):
         self.p = dropout
         self.act = "relu" if activation == "relu" else "gelu"
 
-    def _ffn_norm(self, x, norm):
-        """LayerNorm(x + dropout(conv2(dropout(act(conv1 x))))) -- cross_modal_transformer.py:297-301."""
+    def _ffn_norm(self, x, norm, unfold: bool = False):
+        """LayerNorm(x + dropout(conv2(dropout(act(conv1 x))))) -- cross_modal_transformer.py:297-301.
+        ``unfold``: -> (output, is it the im2col image of the distilling convolution that follows)."""
         if self.p > 0.0 and self.training:  # dropout sites between the products: the unfused FFN + fused add-norm
             y, skip = K.ffn(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.act,
                             fork=True, drop_p=self.p)
-            return K.add_layer_norm(skip, y, norm.weight, norm.bias, norm.eps)
+            y = K.add_layer_norm(skip, y, norm.weight, norm.bias, norm.eps)
+            return (y, False) if unfold else y
         return K.ffn_add_layer_norm(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.act,
-                                    norm.weight, norm.bias, norm.eps)
+                                    norm.weight, norm.bias, norm.eps, **({"unfold": True} if unfold else {}))
 
-    def forward(self, x, idx=None, idx_group: int = 0):
+    def forward(self, x, idx=None, idx_group: int = 0, unfold: bool = False):
+        """``unfold`` (the Informer encoder's distilling layers, Encoder._forward): see ``_ffn_norm``."""
         if self.p > 0.0 and self.training:
             x = K.add_layer_norm(x, _dropout(self.attention(x, idx=idx, idx_group=idx_group), self.p, self.training),
                                  self.norm1.weight, self.norm1.bias)
         else:
             x = self.attention(x, idx=idx, idx_group=idx_group, norm=self.norm1)
-        return self._ffn_norm(x, self.norm2)
+        return self._ffn_norm(x, self.norm2, unfold)
 
 
 class DecoderLayer(nn.Module):
@@ -401,8 +404,13 @@ class DistilConv(nn.Module):
         self.downConv = nn.Conv1d(c, c, kernel_size=3, padding=2, padding_mode="circular")
         self.norm = nn.BatchNorm1d(c)
 
-    def forward(self, x):
-        z = K.circular_conv3(x, self.downConv.weight, self.downConv.bias, pad=2)
+    def forward(self, x, unfolded: bool = False):
+        """``unfolded``: ``x`` is already the (B, L + 2, 3 C) im2col image (written by the norm in front, kernels.
+        ffn_add_layer_norm(unfold=True))."""
+        if unfolded:
+            z = K.circular_conv3_unfolded(x, self.downConv.weight, self.downConv.bias)
+        else:
+            z = K.circular_conv3(x, self.downConv.weight, self.downConv.bias, pad=2)
         n = self.norm
         return K.bn_elu_pool(z, n.weight, n.bias, n.running_mean, n.running_var, n.num_batches_tracked,
                              training=self.training, momentum=n.momentum, eps=n.eps)
@@ -541,7 +549,10 @@ class Encoder(nn.Module):
     def _forward(self, x, idx_list=None, idx_group: int = 0, tail: Optional[int] = None):
         if self.conv_layers is not None:
             for attn, conv in zip(self.attn_layers, self.conv_layers):
-                x = conv(attn(x))
+                if isinstance(attn, EncoderLayer) and isinstance(conv, DistilConv) and not attn.attention.__dict__.get("output_attention"):
+                    x = conv(*attn(x, unfold=True))  # the layer's last norm writes the convolution's im2col image itself
+                else:
+                    x = conv(attn(x))
             x = self.attn_layers[-1](x)
         else:
             y = None if self.__dict__.get("output_attention", False) else self._fused_forward(x, idx_list, idx_group)

@@ -1284,6 +1284,46 @@ def test_slab_layernorm_layer_ops_match_unfused(M, prec):
         assert rel_err(outs[True][1][k], outs[False][1][k]) < 1e-6, k
 
 
+@pytest.mark.parametrize("B,L,prec", [(8, 40, "bf16"), (8, 21, "bf16"), (3, 7, "f32"), (2, 2, "bf16"), (4, 5, "bf16")])
+def test_norm_writes_distil_im2col_image(B, L, prec):
+    """Round 4: the last norm of an Informer encoder layer writes its output straight as the im2col image of the distilling
+    convolution that follows (Conv1d k = 3, circular padding 2, layers/TransformerEncoderDecoder.py:12-18;
+    rf_layernorm_fwd_slabs_unfold), and its backward folds the image's gradient on load (rf_layernorm_bwd_fold) -- the
+    unfold / fold launches between norm and product are gone.  Against the unfused composition (norm, then
+    circular_conv3(pad=2)): the image is BIT-identical to rf_unfold3_circular of the norm's output, the convolution's
+    output too, gradients agree to summation order."""
+    from routeformer_amd import kernels as Kn
+    Kn.set_precision(prec)
+    g = _g(31)
+    D, Fd = 832, 3328
+    base = dict(x=torch.randn(B, L, D, generator=g), w1=torch.randn(Fd, D, 1, generator=g) / math.sqrt(D),
+                b1=torch.randn(Fd, generator=g) * 0.1, w2=torch.randn(D, Fd, 1, generator=g) / math.sqrt(Fd),
+                b2=torch.randn(D, generator=g) * 0.1, g2=torch.rand(D, generator=g) + 0.5, be2=torch.randn(D, generator=g),
+                wc=torch.randn(D, D, 3, generator=g) / math.sqrt(3 * D), bc=torch.randn(D, generator=g) * 0.1)
+    dz = torch.randn(B, L + 2, D, generator=g).to(DEV)
+    outs = {}
+    for fused in (True, False):
+        t = {k: v.to(DEV).requires_grad_(True) for k, v in base.items()}
+        if fused:
+            y, is_image = Kn.ffn_add_layer_norm(t["x"], t["w1"], t["b1"], t["w2"], t["b2"], "relu", t["g2"], t["be2"], unfold=True)
+            assert is_image and tuple(y.shape) == (B, L + 2, 3 * D)
+            z = Kn.circular_conv3_unfolded(y, t["wc"], t["bc"])
+        else:
+            y = Kn.ffn_add_layer_norm(t["x"], t["w1"], t["b1"], t["w2"], t["b2"], "relu", t["g2"], t["be2"])
+            z = Kn.circular_conv3(y, t["wc"], t["bc"], pad=2)
+        z.backward(dz)
+        outs[fused] = (y.detach(), z.detach(), {k: v.grad for k, v in t.items()})
+    image = torch.empty(B, L + 2, 3 * D, device=DEV)
+    from routeformer_amd import _hip
+    src = outs[False][0].contiguous()
+    _hip.check(_hip.lib().rf_unfold3_circular(src.data_ptr(), image.data_ptr(), B, L, D, 2, torch.cuda.current_stream().cuda_stream), "rf_unfold3_circular")
+    torch.cuda.synchronize()
+    assert torch.equal(outs[True][0], image)
+    assert torch.equal(outs[True][1], outs[False][1])
+    for k in base:  # (bf16 mode: the fold's fp32 summation order moves a few bf16 operand roundings of the weight-gradient products)
+        assert rel_err(outs[True][2][k], outs[False][2][k]) < (1e-4 if prec == "bf16" else 2e-6), k
+
+
 @pytest.mark.parametrize("B,P,E,extra,normalize,dense_on", [(8, 30, 64, 0, False, True), (3, 7, 16, 5, True, True),
                                                               (4, 30, 64, 0, True, False), (1, 1, 4, 0, False, True)])
 def test_traj_head(B, P, E, extra, normalize, dense_on):
