@@ -31,6 +31,10 @@ SIGNATURES = {
     "rf_conv3x3_pack_bf16": [_P, _P, _I, _I, _P],
     "rf_conv3x3_group_bf16": [_P, _I, _I, _P],
     "rf_conv3x3_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "rf_conv3x3s2_bf16_supported": [_I, _I, _I],
+    "rf_conv3x3s2_packed_elems": [_I, _I],
+    "rf_conv3x3s2_pack_bf16": [_P, _P, _I, _I, _P],
+    "rf_conv3x3s2_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "rf_pointwise_bf16_supported": [_I, _I],
     "rf_pointwise_packed_elems": [_I, _I],
     "rf_pointwise_pack_bf16": [_P, _P, _I, _I, _P],
@@ -224,6 +228,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = c_int
         handle.rf_conv3x3_packed_elems.restype = c_int64
+        handle.rf_conv3x3s2_packed_elems.restype = c_int64
         handle.rf_pointwise_packed_elems.restype = c_int64
         handle.rf_seqlayer_pack_bytes.restype = c_int64
         handle.rf_seqlayer_bwd_pack_bytes.restype = c_int64

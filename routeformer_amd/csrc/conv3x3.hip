@@ -209,6 +209,217 @@ __device__ __forceinline__ void conv3x3_body(const AT* __restrict__ x, const __b
   CV_MARK(4);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 / STRIDE 2 / pad 1 (round 4): the two stem convolutions of the trunk (hrnetv2.py:292-293,434-440: 4 -> 64 and
+// 64 -> 64 channels, 3 % + 14 % of the trunk's FLOPs, 20 % of its time as K = 36-padded-to-64 implicit GEMMs with
+// per-element index arithmetic).  Same raster-window idea: output raster index m = (n Ho + ho) Wo + wo has its
+// stencil centre at INPUT raster index c(m) = 2 (m / Wo) W + 2 (m % Wo)  (H = 2 Ho, W = 2 Wo: image n's rows follow
+// image n - 1's, so the formula holds across images), and the input rows that the 16 * RT * 4 consecutive outputs of a
+// workgroup touch -- from the row above the first output's centre row to the row below the last one's -- are ONE
+// contiguous span of memory, staged once with 16-B loads.  A fragments are ds_reads at c(m) - s0 + tap offset.
+// CIN = 64: k-steps / packed weights exactly as the stride-1 kernel's (rf_conv3x3_pack_bf16).  CIN = 4 (the 3 + 1
+// channels rf_stem_conv0 writes): a k-step is 8 taps x 4 channels, a lane's 8 k-values are two taps (two 8-B reads),
+// two k-steps (tap 8 + seven zero taps in the second); weights packed by rf_conv3x3s2_pack_bf16.
+template <int CIN, int COUT, int RT>
+__device__ __forceinline__ void conv3x3s2_body(const __bf16* __restrict__ x, const __bf16* __restrict__ wt,
+                                               const float* __restrict__ bias, __bf16* __restrict__ y, int total_out,
+                                               long total_in, int H, int W, int relu, int tile) {
+  constexpr int TILE_ = 64 * RT;                     // output pixels per workgroup
+  constexpr int LDC = CIN == 4 ? 4 : CIN + 8;        // LDS pixel pitch (bf16)
+  constexpr int KSTEPS = CIN == 4 ? 2 : 9 * (CIN / 32);
+  constexpr int NTL = COUT / 16;
+  __bf16* win = rf_conv_win;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int Wo = W >> 1, Ho = H >> 1;
+  const long m0 = (long)tile * TILE_;
+  const long mlast = min(m0 + TILE_ - 1, (long)total_out - 1);
+  const long s0 = 2 * (m0 / Wo) * W - W;             // first pixel of the row above the first centre row (may be < 0)
+  const int span = (int)(2 * (mlast / Wo) * W + 2 * W - s0);  // ... through the end of the row below the last centre row
+
+  // ---- stage the window: a plain copy of `span` pixels x CIN channels (16-B loads, four in flight per thread) ----
+  {
+    constexpr int U = 4;
+    const long e0 = s0 * CIN;                        // first element (multiple of 8: W is even)
+    const int nvec = span * CIN / 8;
+    for (int base = 0; base < nvec; base += NT * U) {
+      float4 raw[U];
+      int at[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + tid + u * NT;
+        const long g = e0 + (long)i * 8;
+        at[u] = i < nvec ? (CIN == 4 ? i * 8 : (i / (CIN / 8)) * LDC + (i % (CIN / 8)) * 8) : -1;
+        raw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nvec && g >= 0 && g + 8 <= total_in * CIN) raw[u] = *reinterpret_cast<const float4*>(x + g);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (at[u] >= 0) *reinterpret_cast<float4*>(win + at[u]) = raw[u];
+    }
+  }
+
+  // ---- this lane's output pixels (one per MFMA row tile), their window-relative centres and border masks ----
+  int pl[RT];
+  unsigned vmask[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) {
+    const long m = m0 + wave * (16 * RT) + i * 16 + fr;
+    unsigned msk = 0;
+    int c = W + 1;
+    if (m < total_out) {
+      const int wo = (int)(m % Wo);
+      const long r = m / Wo;
+      const int ho = (int)(r % Ho);
+      c = (int)(2 * r * W + 2 * wo - s0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int hi = 2 * ho + t / 3 - 1, wi = 2 * wo + t % 3 - 1;
+        if (hi >= 0 && hi < H && wi >= 0 && wi < W) msk |= 1u << t;
+      }
+    }
+    pl[i] = c;
+    vmask[i] = msk;
+  }
+
+  f32x4 acc[RT][NTL];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto ldb = [&](int s, int j) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(wt + ((long)(s * NTL + j) * 64 + lane) * 8);
+  };
+  constexpr int PF = KSTEPS < 4 ? KSTEPS : 4;
+  bf16x8 bq[PF][NTL];
+#pragma unroll
+  for (int d = 0; d < PF; ++d)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) bq[d][j] = ldb(d, j);
+  __syncthreads();  // window staged
+
+#pragma unroll 1
+  for (int sb = 0; sb < KSTEPS; sb += PF) {
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+      const int s = sb + d;
+      if (s < KSTEPS) {
+        bf16x8 a[RT];
+        if constexpr (CIN == 4) {
+          const int t0 = 8 * s + 2 * fq, t1 = t0 + 1;  // this lane's two taps (>= 9: zero)
+          const int o0 = t0 < 9 ? (t0 / 3 - 1) * W + (t0 % 3 - 1) : 0, o1 = t1 < 9 ? (t1 / 3 - 1) * W + (t1 % 3 - 1) : 0;
+#pragma unroll
+          for (int i = 0; i < RT; ++i) {
+            const bool k0 = t0 < 9 && ((vmask[i] >> t0) & 1u), k1 = t1 < 9 && ((vmask[i] >> t1) & 1u);
+            bf16x4 lo = *reinterpret_cast<const bf16x4*>(win + (pl[i] + (k0 ? o0 : 0)) * LDC);
+            bf16x4 hi = *reinterpret_cast<const bf16x4*>(win + (pl[i] + (k1 ? o1 : 0)) * LDC);
+            if (!k0) lo = bf16x4{0, 0, 0, 0};
+            if (!k1) hi = bf16x4{0, 0, 0, 0};
+            a[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        } else {
+          const int tap = s / (CIN / 32), c0 = (s % (CIN / 32)) * 32 + fq * 8;
+          const int toff = (tap / 3 - 1) * W + (tap % 3 - 1);
+#pragma unroll
+          for (int i = 0; i < RT; ++i) {
+            const bool ok = (vmask[i] >> tap) & 1u;
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(win + (pl[i] + (ok ? toff : 0)) * LDC + c0);
+            if (!ok) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            a[i] = v;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < NTL; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[d][j], acc[i][j], 0, 0, 0);
+        if (s + PF < KSTEPS) {
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) bq[d][j] = ldb(s + PF, j);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: as the stride-1 kernel's (fp32 patch per wave in the dead window, 8 channels per lane) ----
+  constexpr int SP = COUT + 4;
+  float* patch = reinterpret_cast<float*>(win) + wave * 16 * SP;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RT; ++i) {
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) patch[(fq * 4 + r) * SP + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    constexpr int VPP = COUT / 8;
+    for (int v = lane; v < 16 * VPP; v += 64) {
+      const int px = v / VPP, c = (v % VPP) * 8;
+      const long m = m0 + wave * (16 * RT) + i * 16 + px;
+      if (m < total_out) {
+        float4 lo = *reinterpret_cast<const float4*>(patch + px * SP + c);
+        float4 hi = *reinterpret_cast<const float4*>(patch + px * SP + c + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + c), b1 = *reinterpret_cast<const float4*>(bias + c + 4);
+        lo.x += b0.x; lo.y += b0.y; lo.z += b0.z; lo.w += b0.w;
+        hi.x += b1.x; hi.y += b1.y; hi.z += b1.z; hi.w += b1.w;
+        if (relu) {
+          lo.x = fmaxf(lo.x, 0.f); lo.y = fmaxf(lo.y, 0.f); lo.z = fmaxf(lo.z, 0.f); lo.w = fmaxf(lo.w, 0.f);
+          hi.x = fmaxf(hi.x, 0.f); hi.y = fmaxf(hi.y, 0.f); hi.z = fmaxf(hi.z, 0.f); hi.w = fmaxf(hi.w, 0.f);
+        }
+        act_st4(y + m * COUT + c, lo);
+        act_st4(y + m * COUT + c + 4, hi);
+      }
+    }
+    if (i + 1 < RT) __syncthreads();
+  }
+}
+
+template <int CIN, int COUT, int RT>
+__global__ __launch_bounds__(NT) void conv3x3s2_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ wt,
+                                                        const float* __restrict__ bias, __bf16* __restrict__ y,
+                                                        int total_out, long total_in, int H, int W, int relu) {
+  conv3x3s2_body<CIN, COUT, RT>(x, wt, bias, y, total_out, total_in, H, W, relu, (int)blockIdx.x);
+}
+
+// LDS bytes of a stride-2 workgroup: the widest span (an output tile that starts at the end of a row) or the epilogue patches
+static size_t s2_lds(int cin, int cout, int rt, int W) {
+  const int Wo = W / 2, tile = 64 * rt, ldc = cin == 4 ? 4 : cin + 8;
+  const int rows = (tile - 1 + Wo - 1) / Wo + 1;            // output rows a tile can touch
+  size_t lds = (size_t)(2 * (rows - 1) * W + 3 * W) * ldc * sizeof(__bf16) + 64;  // row above + centre rows + row below
+  const size_t patches = (size_t)(NT / 64) * 16 * (cout + 4) * sizeof(float);
+  return lds < patches ? patches : lds;
+}
+
+template <int CIN, int COUT, int RT>
+int launch_s2(const void* x, const void* wt, const float* bias, void* y, long total_out, long total_in, int H, int W, int relu,
+              hipStream_t st) {
+  const size_t lds = s2_lds(CIN, COUT, RT, W);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_kernel<CIN, COUT, RT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int blocks = (int)((total_out + 64 * RT - 1) / (64 * RT));
+  RF_LAUNCH((conv3x3s2_kernel<CIN, COUT, RT>), dim3(blocks), dim3(NT), lds, st, static_cast<const __bf16*>(x),
+            static_cast<const __bf16*>(wt), bias, static_cast<__bf16*>(y), (int)total_out, total_in, H, W, relu);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+// CIN = 4 packing: out[((s*NTL + j)*64 + lane)*8 + e] = w[j*16 + (lane&15)][tap = 8 s + 2 (lane>>4) + (e>>2)][e & 3]
+__global__ void pack_weights_c4_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int cout) {
+  const int ntl = cout / 16;
+  const long total = (long)2 * ntl * 64 * 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const int sj = (int)(i >> 9), j = sj % ntl, s = sj / ntl;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int tap = 8 * s + 2 * fq + (e >> 2), c = e & 3;
+    out[i] = (__bf16)(tap < 9 ? w[((long)(j * 16 + fr) * 9 + tap) * 4 + c] : 0.f);
+  }
+}
+
 template <int CIN, int COUT, typename AT>
 __global__ __launch_bounds__(NT) void conv3x3_kernel(const AT* __restrict__ x, const __bf16* __restrict__ wt,
                                                       const float* __restrict__ bias,
@@ -344,6 +555,41 @@ extern "C" int rf_conv3x3_group_bf16(const RfConvEntry* entries, int count, int 
   else RF_LAUNCH(conv3x3_group_kernel<float>, dim3(blocks), dim3(NT), lds, st, g);
   RF_CHECK_LAUNCH();
   return RF_OK;
+}
+
+extern "C" int rf_conv3x3s2_bf16_supported(int cin, int cout, int W) {
+  if (!((cin == 4 || cin == 64) && cout == 64) || W < 4 || (W & 1)) return 0;
+  return s2_lds(cin, cout, 2, W) <= 160 * 1024 || s2_lds(cin, cout, 1, W) <= 160 * 1024;
+}
+
+extern "C" int64_t rf_conv3x3s2_packed_elems(int cin, int cout) {
+  if (cin == 4 && cout == 64) return (int64_t)2 * (cout / 16) * 64 * 8;
+  if (cin == 64 && cout == 64) return rf_conv3x3_packed_elems(64, 64);
+  return 0;
+}
+
+extern "C" int rf_conv3x3s2_pack_bf16(const float* w, void* w_packed, int cin, int cout, void* stream) {
+  RF_REQUIRE(w && w_packed && rf_conv3x3s2_packed_elems(cin, cout) > 0);
+  if (cin == 64) return rf_conv3x3_pack_bf16(w, w_packed, cin, cout, stream);
+  const long total = rf_conv3x3s2_packed_elems(cin, cout);
+  RF_LAUNCH(pack_weights_c4_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+            static_cast<__bf16*>(w_packed), cout);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_conv3x3s2_bf16(const void* x, const void* w_bf16, const float* bias, void* y, int N, int H, int W, int cin,
+                                 int cout, int relu, void* stream) {
+  RF_REQUIRE(x && w_bf16 && bias && y && N > 0 && H >= 2 && W >= 4 && !(H & 1) && !(W & 1));
+  RF_REQUIRE(rf_conv3x3s2_bf16_supported(cin, cout, W));
+  const long total_in = (long)N * H * W, total_out = total_in / 4;
+  RF_REQUIRE(total_in < (1L << 31));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool big = s2_lds(cin, cout, 2, W) <= 80 * 1024 || s2_lds(cin, cout, 1, W) > 160 * 1024;  // 128-pixel tiles while two workgroups still fit a CU
+  if (cin == 4) return big ? launch_s2<4, 64, 2>(x, w_bf16, bias, y, total_out, total_in, H, W, relu, st)
+                           : launch_s2<4, 64, 1>(x, w_bf16, bias, y, total_out, total_in, H, W, relu, st);
+  return big ? launch_s2<64, 64, 2>(x, w_bf16, bias, y, total_out, total_in, H, W, relu, st)
+             : launch_s2<64, 64, 1>(x, w_bf16, bias, y, total_out, total_in, H, W, relu, st);
 }
 
 extern "C" int rf_conv3x3_bf16_supported(int cin, int cout) {

@@ -99,6 +99,19 @@ def pack_conv3x3_weights(w_khwc: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_conv3x3s2_weights(w_khwc: torch.Tensor) -> torch.Tensor:
+    """(cout, 3, 3, cin) fp32 device tensor -> the bf16 fragment-order buffer rf_conv3x3s2_bf16 consumes (the two stem
+    convolutions: cin 4 / 64, cout 64)."""
+    cout, _, _, cin = w_khwc.shape
+    out = torch.empty(int(_hip.lib().rf_conv3x3s2_packed_elems(cin, cout)), device=w_khwc.device, dtype=torch.bfloat16)
+    w = w_khwc.contiguous().float()
+    check(_hip.lib().rf_conv3x3s2_pack_bf16(ptr(w), ptr(out), cin, cout, K._stream()), "rf_conv3x3s2_pack_bf16")
+    return out
+
+
+STEM_S2 = _os.environ.get("RF_STEM_S2", "1") != "0"  # measurement switch: the stride-2 raster-window kernel for the stem pair
+
+
 def pack_pointwise_weights(w: torch.Tensor) -> torch.Tensor:
     """(cout, cin) fp32 device tensor -> the bf16 fragment-order buffer rf_pointwise_bf16 keeps in registers."""
     cout, cin = w.shape
@@ -222,7 +235,9 @@ class HRNet16Backbone(VideoBackboneModule):
                 wk = torch.zeros(cout, k, k, cin_p, device=device, dtype=torch.float32)
                 wk[..., :cin] = w.permute(0, 2, 3, 1)
                 wb = None  # bf16 copy in MFMA fragment order for the raster-window 3x3 kernel
-                if k == 3 and bias is not None and _hip.lib().rf_conv3x3_bf16_supported(cin_p, cout):
+                if conv in ("conv1", "conv2") and k == 3 and bias is not None and _hip.lib().rf_conv3x3s2_packed_elems(cin_p, cout) > 0:
+                    wb = pack_conv3x3s2_weights(wk)  # the stem pair: stride 2 (rf_conv3x3s2_bf16)
+                elif k == 3 and bias is not None and _hip.lib().rf_conv3x3_bf16_supported(cin_p, cout):
                     wb = pack_conv3x3_weights(wk)
                 elif k == 1 and bias is not None and _hip.lib().rf_pointwise_bf16_supported(cin_p, cout):
                     wb = pack_pointwise_weights(wk.view(cout, cin_p))  # streaming 1x1 kernel (bf16 maps)
@@ -251,9 +266,13 @@ class HRNet16Backbone(VideoBackboneModule):
         act = self._act_code(x)
         assert residual is None or residual.dtype == x.dtype
         ev = K.PROFILE.begin() if K.PROFILE.on else None
-        fast = wb is not None and k == 3 and stride == 1 and K._PRECISION == 1
+        fast = wb is not None and k == 3 and stride == 1 and K._PRECISION == 1 and unit not in ("conv1", "conv2")
         pw = wb is not None and k == 1 and stride == 1 and K._PRECISION == 1 and act == 1
-        if pw:  # 1x1 over bf16 maps: streaming GEMM, weights in registers
+        s2 = (STEM_S2 and wb is not None and unit in ("conv1", "conv2") and k == 3 and stride == 2 and K._PRECISION == 1 and act == 1
+              and residual is None and H % 2 == 0 and Wd % 2 == 0 and _hip.lib().rf_conv3x3s2_bf16_supported(cin, cout, Wd))
+        if s2:  # the stem pair on bf16 maps: stride-2 raster window, no im2col index arithmetic
+            fn, cargs = _hip.lib().rf_conv3x3s2_bf16, (ptr(x), ptr(wb), ptr(b), ptr(y), N, H, Wd, cin, cout, 1 if relu else 0)
+        elif pw:  # 1x1 over bf16 maps: streaming GEMM, weights in registers
             fn, cargs = _hip.lib().rf_pointwise_bf16, (ptr(x), ptr(wb), ptr(b), ptr(residual), ptr(y), N * H * Wd, cin, cout,
                                                        1 if relu else 0)
         elif fast:  # 3x3/s1 on the bf16 matrix cores straight out of an LDS raster window
@@ -265,7 +284,7 @@ class HRNet16Backbone(VideoBackboneModule):
         check(fn(*cargs, K._stream()), "trunk convolution")
         if ev is not None:  # algorithmic work: one read of x / w (/ residual), one write of y
             M = N * Ho * Wo
-            tag = f"pointwise_kernel<{cin}, {cout}>" if pw else \
+            tag = f"conv3x3s2_kernel<{cin}, {cout}>" if s2 else f"pointwise_kernel<{cin}, {cout}>" if pw else \
                 f"conv3x3_kernel<{cin}, {cout}, {'__bf16' if act else 'float'}>" if fast else \
                 f"gemm2_kernel<{K._PRECISION}, 3, 0, {1 if cout <= 16 else (2 if cout <= 32 else 0)}>"
             es = x.element_size()
