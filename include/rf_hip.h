@@ -126,14 +126,16 @@ typedef struct RfConvEntry {
 int rf_conv3x3_group_bf16(const RfConvEntry* entries, int count, int act_dtype, void* stream);
 int rf_conv3x3_bf16(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,
                     int act_dtype, int N, int H, int W, int cin, int cout, int relu, void* stream);
-/* 3x3 / stride 2 / pad 1 on bf16 NHWC maps (round 4): the trunk's two stem convolutions (hrnetv2.py:292-293,434-440),
- * (cin, cout) = (4, 64) -- the 3 + 1 channels rf_stem_conv0 writes -- and (64, 64); H, W even.  Weights: [cout][3][3][cin]
- * fp32 (BatchNorm folded) -> rf_conv3x3s2_pack_bf16 (rf_conv3x3s2_packed_elems bf16 elements).  No residual. */
+/* 3x3 / stride 2 / pad 1 on bf16 NHWC maps (round 4): the trunk's two stem convolutions (hrnetv2.py:292-293,434-440: cin 4 -- the
+ * 3 + 1 channels rf_stem_conv0 writes -- and 64 -> 64) and the stride-2 chains of the cross-resolution fuse layers and transitions
+ * (hrnetv2.py:148-200,337-370: cin in {16, 32, 64} -> cout in {16, 32, 64, 128}, cout >= cin); H, W even.  Weights: [cout][3][3][cin]
+ * fp32 (BatchNorm folded) -> rf_conv3x3s2_pack_bf16 (rf_conv3x3s2_packed_elems bf16 elements).  y = relu?(conv + bias [+ residual]),
+ * residual = a bf16 map of y's shape or NULL. */
 int rf_conv3x3s2_bf16_supported(int cin, int cout, int W);
 int64_t rf_conv3x3s2_packed_elems(int cin, int cout);
 int rf_conv3x3s2_pack_bf16(const float* w, void* w_packed, int cin, int cout, void* stream);
-int rf_conv3x3s2_bf16(const void* x, const void* w_bf16, const float* bias, void* y, int N, int H, int W, int cin,
-                      int cout, int relu, void* stream);
+int rf_conv3x3s2_bf16(const void* x, const void* w_bf16, const float* bias, const void* residual, void* y, int N, int H, int W,
+                      int cin, int cout, int relu, void* stream);
 
 /* 1x1 convolution over bf16 maps as a streaming GEMM with the layer's weights held in registers (the Bottleneck
  * stage, hrnetv2.py:79-99): y[M,cout] = relu?(x[M,cin] W^T + bias (+ residual[M,cout])), x / residual / y bf16,

@@ -34,7 +34,7 @@ SIGNATURES = {
     "rf_conv3x3s2_bf16_supported": [_I, _I, _I],
     "rf_conv3x3s2_packed_elems": [_I, _I],
     "rf_conv3x3s2_pack_bf16": [_P, _P, _I, _I, _P],
-    "rf_conv3x3s2_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "rf_conv3x3s2_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "rf_pointwise_bf16_supported": [_I, _I],
     "rf_pointwise_packed_elems": [_I, _I],
     "rf_pointwise_pack_bf16": [_P, _P, _I, _I, _P],

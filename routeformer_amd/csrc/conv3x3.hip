@@ -222,11 +222,12 @@ __device__ __forceinline__ void conv3x3_body(const AT* __restrict__ x, const __b
 // two k-steps (tap 8 + seven zero taps in the second); weights packed by rf_conv3x3s2_pack_bf16.
 template <int CIN, int COUT, int RT>
 __device__ __forceinline__ void conv3x3s2_body(const __bf16* __restrict__ x, const __bf16* __restrict__ wt,
-                                               const float* __restrict__ bias, __bf16* __restrict__ y, int total_out,
+                                               const float* __restrict__ bias, const __bf16* __restrict__ residual,
+                                               __bf16* __restrict__ y, int total_out,
                                                long total_in, int H, int W, int relu, int tile) {
   constexpr int TILE_ = 64 * RT;                     // output pixels per workgroup
   constexpr int LDC = CIN == 4 ? 4 : CIN + 8;        // LDS pixel pitch (bf16)
-  constexpr int KSTEPS = CIN == 4 ? 2 : 9 * (CIN / 32);
+  constexpr int KSTEPS = CIN == 4 ? 2 : (CIN == 16 ? 5 : 9 * (CIN / 32));
   constexpr int NTL = COUT / 16;
   __bf16* win = rf_conv_win;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -318,11 +319,13 @@ __device__ __forceinline__ void conv3x3s2_body(const __bf16* __restrict__ x, con
             a[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           }
         } else {
-          const int tap = s / (CIN / 32), c0 = (s % (CIN / 32)) * 32 + fq * 8;
-          const int toff = (tap / 3 - 1) * W + (tap % 3 - 1);
+          int tap, c0;  // (CIN = 16: a k-step is both 8-channel halves of two taps, the tenth tap is zero -- as in the stride-1 kernel)
+          if constexpr (CIN == 16) { tap = 2 * s + (fq >> 1); c0 = (fq & 1) * 8; }
+          else { tap = s / (CIN / 32); c0 = (s % (CIN / 32)) * 32 + fq * 8; }
+          const int toff = tap < 9 ? (tap / 3 - 1) * W + (tap % 3 - 1) : 0;
 #pragma unroll
           for (int i = 0; i < RT; ++i) {
-            const bool ok = (vmask[i] >> tap) & 1u;
+            const bool ok = tap < 9 && ((vmask[i] >> tap) & 1u);
             bf16x8 v = *reinterpret_cast<const bf16x8*>(win + (pl[i] + (ok ? toff : 0)) * LDC + c0);
             if (!ok) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             a[i] = v;
@@ -362,6 +365,11 @@ __device__ __forceinline__ void conv3x3s2_body(const __bf16* __restrict__ x, con
         const float4 b0 = *reinterpret_cast<const float4*>(bias + c), b1 = *reinterpret_cast<const float4*>(bias + c + 4);
         lo.x += b0.x; lo.y += b0.y; lo.z += b0.z; lo.w += b0.w;
         hi.x += b1.x; hi.y += b1.y; hi.z += b1.z; hi.w += b1.w;
+        if (residual) {
+          const float4 r0 = act_ld4(residual + m * COUT + c), r1 = act_ld4(residual + m * COUT + c + 4);
+          lo.x += r0.x; lo.y += r0.y; lo.z += r0.z; lo.w += r0.w;
+          hi.x += r1.x; hi.y += r1.y; hi.z += r1.z; hi.w += r1.w;
+        }
         if (relu) {
           lo.x = fmaxf(lo.x, 0.f); lo.y = fmaxf(lo.y, 0.f); lo.z = fmaxf(lo.z, 0.f); lo.w = fmaxf(lo.w, 0.f);
           hi.x = fmaxf(hi.x, 0.f); hi.y = fmaxf(hi.y, 0.f); hi.z = fmaxf(hi.z, 0.f); hi.w = fmaxf(hi.w, 0.f);
@@ -376,9 +384,10 @@ __device__ __forceinline__ void conv3x3s2_body(const __bf16* __restrict__ x, con
 
 template <int CIN, int COUT, int RT>
 __global__ __launch_bounds__(NT) void conv3x3s2_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ wt,
-                                                        const float* __restrict__ bias, __bf16* __restrict__ y,
-                                                        int total_out, long total_in, int H, int W, int relu) {
-  conv3x3s2_body<CIN, COUT, RT>(x, wt, bias, y, total_out, total_in, H, W, relu, (int)blockIdx.x);
+                                                        const float* __restrict__ bias, const __bf16* __restrict__ residual,
+                                                        __bf16* __restrict__ y, int total_out, long total_in, int H, int W,
+                                                        int relu) {
+  conv3x3s2_body<CIN, COUT, RT>(x, wt, bias, residual, y, total_out, total_in, H, W, relu, (int)blockIdx.x);
 }
 
 // LDS bytes of a stride-2 workgroup: the widest span (an output tile that starts at the end of a row) or the epilogue patches
@@ -391,8 +400,8 @@ static size_t s2_lds(int cin, int cout, int rt, int W) {
 }
 
 template <int CIN, int COUT, int RT>
-int launch_s2(const void* x, const void* wt, const float* bias, void* y, long total_out, long total_in, int H, int W, int relu,
-              hipStream_t st) {
+int launch_s2(const void* x, const void* wt, const float* bias, const void* residual, void* y, long total_out, long total_in,
+              int H, int W, int relu, hipStream_t st) {
   const size_t lds = s2_lds(CIN, COUT, RT, W);
   static bool attr = false;
   if (!attr) {
@@ -402,7 +411,8 @@ int launch_s2(const void* x, const void* wt, const float* bias, void* y, long to
   }
   const int blocks = (int)((total_out + 64 * RT - 1) / (64 * RT));
   RF_LAUNCH((conv3x3s2_kernel<CIN, COUT, RT>), dim3(blocks), dim3(NT), lds, st, static_cast<const __bf16*>(x),
-            static_cast<const __bf16*>(wt), bias, static_cast<__bf16*>(y), (int)total_out, total_in, H, W, relu);
+            static_cast<const __bf16*>(wt), bias, static_cast<const __bf16*>(residual), static_cast<__bf16*>(y), (int)total_out,
+            total_in, H, W, relu);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
@@ -557,39 +567,54 @@ extern "C" int rf_conv3x3_group_bf16(const RfConvEntry* entries, int count, int 
   return RF_OK;
 }
 
+static bool s2_combo(int cin, int cout) {
+  if (cin == 4) return cout == 64;
+  return (cin == 16 || cin == 32 || cin == 64) && (cout == 16 || cout == 32 || cout == 64 || cout == 128) && cout >= cin;
+}
+
 extern "C" int rf_conv3x3s2_bf16_supported(int cin, int cout, int W) {
-  if (!((cin == 4 || cin == 64) && cout == 64) || W < 4 || (W & 1)) return 0;
+  if (!s2_combo(cin, cout) || W < 4 || (W & 1)) return 0;
   return s2_lds(cin, cout, 2, W) <= 160 * 1024 || s2_lds(cin, cout, 1, W) <= 160 * 1024;
 }
 
 extern "C" int64_t rf_conv3x3s2_packed_elems(int cin, int cout) {
-  if (cin == 4 && cout == 64) return (int64_t)2 * (cout / 16) * 64 * 8;
-  if (cin == 64 && cout == 64) return rf_conv3x3_packed_elems(64, 64);
-  return 0;
+  if (!s2_combo(cin, cout)) return 0;
+  return (int64_t)(cin == 4 ? 2 : (cin == 16 ? 5 : 9 * (cin / 32))) * (cout / 16) * 64 * 8;
 }
 
 extern "C" int rf_conv3x3s2_pack_bf16(const float* w, void* w_packed, int cin, int cout, void* stream) {
   RF_REQUIRE(w && w_packed && rf_conv3x3s2_packed_elems(cin, cout) > 0);
-  if (cin == 64) return rf_conv3x3_pack_bf16(w, w_packed, cin, cout, stream);
   const long total = rf_conv3x3s2_packed_elems(cin, cout);
-  RF_LAUNCH(pack_weights_c4_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w,
-            static_cast<__bf16*>(w_packed), cout);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (cin == 4)
+    RF_LAUNCH(pack_weights_c4_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, w, static_cast<__bf16*>(w_packed), cout);
+  else  // the stride-1 kernel's fragment order (k-steps depend on cin only)
+    RF_LAUNCH(pack_weights_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, w, static_cast<__bf16*>(w_packed), cin, cout);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
 
-extern "C" int rf_conv3x3s2_bf16(const void* x, const void* w_bf16, const float* bias, void* y, int N, int H, int W, int cin,
-                                 int cout, int relu, void* stream) {
+template <int CIN, int COUT>
+static int launch_s2_rt(bool big, const void* x, const void* w, const float* bias, const void* res, void* y, long to, long ti, int H,
+                        int W, int relu, hipStream_t st) {
+  return big ? launch_s2<CIN, COUT, 2>(x, w, bias, res, y, to, ti, H, W, relu, st)
+             : launch_s2<CIN, COUT, 1>(x, w, bias, res, y, to, ti, H, W, relu, st);
+}
+
+extern "C" int rf_conv3x3s2_bf16(const void* x, const void* w_bf16, const float* bias, const void* residual, void* y, int N, int H,
+                                 int W, int cin, int cout, int relu, void* stream) {
   RF_REQUIRE(x && w_bf16 && bias && y && N > 0 && H >= 2 && W >= 4 && !(H & 1) && !(W & 1));
   RF_REQUIRE(rf_conv3x3s2_bf16_supported(cin, cout, W));
-  const long total_in = (long)N * H * W, total_out = total_in / 4;
-  RF_REQUIRE(total_in < (1L << 31));
+  const long ti = (long)N * H * W, to = ti / 4;
+  RF_REQUIRE(ti < (1L << 31));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool big = s2_lds(cin, cout, 2, W) <= 80 * 1024 || s2_lds(cin, cout, 1, W) > 160 * 1024;  // 128-pixel tiles while two workgroups still fit a CU
-  if (cin == 4) return big ? launch_s2<4, 64, 2>(x, w_bf16, bias, y, total_out, total_in, H, W, relu, st)
-                           : launch_s2<4, 64, 1>(x, w_bf16, bias, y, total_out, total_in, H, W, relu, st);
-  return big ? launch_s2<64, 64, 2>(x, w_bf16, bias, y, total_out, total_in, H, W, relu, st)
-             : launch_s2<64, 64, 1>(x, w_bf16, bias, y, total_out, total_in, H, W, relu, st);
+  // 128-pixel tiles while two workgroups still fit a CU (or when the 64-pixel window does not fit at all)
+  const bool big = s2_lds(cin, cout, 2, W) <= 80 * 1024 || s2_lds(cin, cout, 1, W) > 160 * 1024;
+#define RF_S2_GO(CI, CO) if (cin == CI && cout == CO) return launch_s2_rt<CI, CO>(big, x, w_bf16, bias, residual, y, to, ti, H, W, relu, st)
+  RF_S2_GO(4, 64); RF_S2_GO(16, 16); RF_S2_GO(16, 32); RF_S2_GO(16, 64); RF_S2_GO(16, 128); RF_S2_GO(32, 32); RF_S2_GO(32, 64);
+  RF_S2_GO(32, 128); RF_S2_GO(64, 64); RF_S2_GO(64, 128);
+#undef RF_S2_GO
+  return RF_EUNSUPPORTED;
 }
 
 extern "C" int rf_conv3x3_bf16_supported(int cin, int cout) {

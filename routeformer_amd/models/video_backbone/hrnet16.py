@@ -109,7 +109,8 @@ def pack_conv3x3s2_weights(w_khwc: torch.Tensor) -> torch.Tensor:
     return out
 
 
-STEM_S2 = _os.environ.get("RF_STEM_S2", "1") != "0"  # measurement switch: the stride-2 raster-window kernel for the stem pair
+STEM_S2 = _os.environ.get("RF_STEM_S2", "1") != "0"  # measurement switches: the stride-2 raster-window kernel for the stem pair ...
+CONV_S2 = _os.environ.get("RF_CONV_S2", "1") != "0"  # ... and for every stride-2 3x3 convolution it supports
 
 
 def pack_pointwise_weights(w: torch.Tensor) -> torch.Tensor:
@@ -235,10 +236,10 @@ class HRNet16Backbone(VideoBackboneModule):
                 wk = torch.zeros(cout, k, k, cin_p, device=device, dtype=torch.float32)
                 wk[..., :cin] = w.permute(0, 2, 3, 1)
                 wb = None  # bf16 copy in MFMA fragment order for the raster-window 3x3 kernel
-                if conv in ("conv1", "conv2") and k == 3 and bias is not None and _hip.lib().rf_conv3x3s2_packed_elems(cin_p, cout) > 0:
-                    wb = pack_conv3x3s2_weights(wk)  # the stem pair: stride 2 (rf_conv3x3s2_bf16)
-                elif k == 3 and bias is not None and _hip.lib().rf_conv3x3_bf16_supported(cin_p, cout):
-                    wb = pack_conv3x3_weights(wk)
+                if k == 3 and bias is not None and _hip.lib().rf_conv3x3_bf16_supported(cin_p, cout) and conv not in ("conv1", "conv2"):
+                    wb = pack_conv3x3_weights(wk)  # (the stride-2 kernel reads the same fragment order for these shapes)
+                elif k == 3 and bias is not None and _hip.lib().rf_conv3x3s2_packed_elems(cin_p, cout) > 0:
+                    wb = pack_conv3x3s2_weights(wk)  # stride-2 only shapes: the stem pair, the fuse layers' / transitions' chains
                 elif k == 1 and bias is not None and _hip.lib().rf_pointwise_bf16_supported(cin_p, cout):
                     wb = pack_pointwise_weights(wk.view(cout, cin_p))  # streaming 1x1 kernel (bf16 maps)
                 folded[conv] = (wk.contiguous(), bias, cin_p, cout, k, wb)
@@ -266,12 +267,14 @@ class HRNet16Backbone(VideoBackboneModule):
         act = self._act_code(x)
         assert residual is None or residual.dtype == x.dtype
         ev = K.PROFILE.begin() if K.PROFILE.on else None
-        fast = wb is not None and k == 3 and stride == 1 and K._PRECISION == 1 and unit not in ("conv1", "conv2")
+        fast = (wb is not None and k == 3 and stride == 1 and K._PRECISION == 1 and _hip.lib().rf_conv3x3_bf16_supported(cin, cout))
         pw = wb is not None and k == 1 and stride == 1 and K._PRECISION == 1 and act == 1
-        s2 = (STEM_S2 and wb is not None and unit in ("conv1", "conv2") and k == 3 and stride == 2 and K._PRECISION == 1 and act == 1
-              and residual is None and H % 2 == 0 and Wd % 2 == 0 and _hip.lib().rf_conv3x3s2_bf16_supported(cin, cout, Wd))
-        if s2:  # the stem pair on bf16 maps: stride-2 raster window, no im2col index arithmetic
-            fn, cargs = _hip.lib().rf_conv3x3s2_bf16, (ptr(x), ptr(wb), ptr(b), ptr(y), N, H, Wd, cin, cout, 1 if relu else 0)
+        s2 = (CONV_S2 and wb is not None and k == 3 and stride == 2 and K._PRECISION == 1 and act == 1
+              and (STEM_S2 if unit in ("conv1", "conv2") else True)
+              and H % 2 == 0 and Wd % 2 == 0 and _hip.lib().rf_conv3x3s2_bf16_supported(cin, cout, Wd))
+        if s2:  # stride-2 raster window on bf16 maps (the stem pair, fuse-layer / transition chains): no im2col index arithmetic
+            fn, cargs = _hip.lib().rf_conv3x3s2_bf16, (ptr(x), ptr(wb), ptr(b), ptr(residual), ptr(y), N, H, Wd, cin, cout,
+                                                       1 if relu else 0)
         elif pw:  # 1x1 over bf16 maps: streaming GEMM, weights in registers
             fn, cargs = _hip.lib().rf_pointwise_bf16, (ptr(x), ptr(wb), ptr(b), ptr(residual), ptr(y), N * H * Wd, cin, cout,
                                                        1 if relu else 0)

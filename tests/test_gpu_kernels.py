@@ -794,28 +794,34 @@ def test_hrnet16_golden(prec, tol):
         assert rel_err(y, G[tag + ".y"]) < tol, tag
 
 
-@pytest.mark.parametrize("cin,N,H,W", [(4, 3, 28, 28), (4, 2, 112, 112), (4, 1, 30, 44), (64, 3, 28, 28), (64, 2, 56, 56),
-                                       (64, 1, 18, 112), (64, 5, 6, 4)])
-def test_conv3x3_stride2_stem_kernel(cin, N, H, W):
-    """rf_conv3x3s2_bf16 (round 4: the trunk's two stem convolutions, 3x3 / stride 2 / pad 1 on bf16 NHWC maps, 4 -> 64 and
-    64 -> 64 channels; hrnetv2.py:292-293,434-440) against torch's conv2d on the same bf16-rounded operands: tiles that
-    straddle rows and images, borders, both tile sizes."""
+@pytest.mark.parametrize("cin,cout,N,H,W,res", [(4, 64, 3, 28, 28, False), (4, 64, 2, 112, 112, False), (4, 64, 1, 30, 44, False),
+                                                (64, 64, 3, 28, 28, False), (64, 64, 2, 56, 56, False), (64, 64, 1, 18, 112, False),
+                                                (64, 64, 5, 6, 4, True), (16, 16, 3, 28, 28, True), (16, 32, 2, 28, 28, False),
+                                                (16, 64, 2, 14, 28, True), (16, 128, 1, 56, 56, True), (32, 32, 3, 14, 14, True),
+                                                (32, 64, 3, 14, 14, False), (32, 128, 2, 28, 28, True), (64, 128, 2, 14, 14, True),
+                                                (16, 16, 2, 112, 112, False)])
+def test_conv3x3_stride2_kernel(cin, cout, N, H, W, res):
+    """rf_conv3x3s2_bf16 (round 4: 3x3 / stride 2 / pad 1 on bf16 NHWC maps -- the trunk's two stem convolutions, hrnetv2.py:
+    292-293,434-440, and the stride-2 chains of its fuse layers / transitions, :148-200) against torch's conv2d on the same
+    bf16-rounded operands: tiles that straddle rows and images, borders, both tile sizes, with and without the residual."""
     from routeformer_amd import _hip
     from routeformer_amd.models.video_backbone.hrnet16 import pack_conv3x3s2_weights
     g = _g(41)
-    cout = 64
     assert _hip.lib().rf_conv3x3s2_bf16_supported(cin, cout, W) == 1
     x = torch.randn(N, H, W, cin, generator=g).bfloat16()
     if cin == 4:
         x[..., 3] = 0  # (the stem's zero fourth channel)
     w = (torch.randn(cout, 3, 3, cin, generator=g) / math.sqrt(9 * cin)).bfloat16().float()
     b = torch.randn(cout, generator=g) * 0.2
-    ref = F.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, stride=2, padding=1)).permute(0, 2, 3, 1)
+    r = torch.randn(N, H // 2, W // 2, cout, generator=g).bfloat16() if res else None
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, stride=2, padding=1).permute(0, 2, 3, 1)
+    ref = F.relu(ref + r.float()) if res else F.relu(ref)
     xd, bd = x.to(DEV), b.to(DEV)
+    rd = r.to(DEV) if res else None
     wp = pack_conv3x3s2_weights(w.to(DEV))
     y = torch.full((N, H // 2, W // 2, cout), float("nan"), device=DEV, dtype=torch.bfloat16)
-    _hip.check(_hip.lib().rf_conv3x3s2_bf16(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), N, H, W, cin, cout, 1,
-                                            torch.cuda.current_stream().cuda_stream), "rf_conv3x3s2_bf16")
+    _hip.check(_hip.lib().rf_conv3x3s2_bf16(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), rd.data_ptr() if res else None, y.data_ptr(),
+                                            N, H, W, cin, cout, 1, torch.cuda.current_stream().cuda_stream), "rf_conv3x3s2_bf16")
     torch.cuda.synchronize()
     assert torch.isfinite(y.float()).all()
     assert rel_err(y.float(), ref) < 8e-3, rel_err(y.float(), ref)   # bf16 output rounding: 2^-9 of the largest value
