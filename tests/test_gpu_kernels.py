@@ -1353,8 +1353,11 @@ def test_norm_writes_distil_im2col_image(B, L, prec):
     torch.cuda.synchronize()
     assert torch.equal(outs[True][0], image)
     assert torch.equal(outs[True][1], outs[False][1])
-    for k in base:  # (bf16 mode: the fold's fp32 summation order moves a few bf16 operand roundings of the weight-gradient products)
-        assert rel_err(outs[True][2][k], outs[False][2][k]) < (1e-4 if prec == "bf16" else 2e-6), k
+    # bf16 mode: the fold adds its (up to six) terms in another order than rf_fold3_circular; where that moves the fp32 sum by an
+    # ulp across a bf16 rounding boundary, one operand of the weight-gradient products changes by 2^-9 -- with M = 4 rows
+    # (B = 2, L = 2) that is up to 1e-3 of a gradient element (observed 7e-4); fp32 mode has no such amplifier
+    for k in base:
+        assert rel_err(outs[True][2][k], outs[False][2][k]) < (2e-3 if prec == "bf16" else 2e-6), k
 
 
 @pytest.mark.parametrize("B,P,E,extra,normalize,dense_on", [(8, 30, 64, 0, False, True), (3, 7, 16, 5, True, True),
