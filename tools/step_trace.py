@@ -1,6 +1,7 @@
 """Timeline of ONE replayed step from a rocprofv3 kernel trace (csv):  python tools/step_trace.py <kernel_trace.csv> [which]
 Prints start offset (us), duration (us), gap to the previous kernel on the same queue, queue, workgroups, kernel --
-steps are delimited by the `sumsq_kernel` launch that opens each deferred update (`which` = -2: the last complete step).
+steps are delimited by the `sumsq_kernel` launch that opens each deferred update (`which`: index of the delimiter; default: the
+last step whose launch count is the most common one -- the tail of a bench run holds a shorter last step and the final flush).
 NOTE: the profiler serialises side-stream branches more than the un-profiled replay does: read durations and
 the order of the chain from this, not branch start times."""
 import csv
@@ -17,7 +18,7 @@ def short(n):
 
 def main():
     path = sys.argv[1]
-    which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
+    which = int(sys.argv[2]) if len(sys.argv) > 2 else None
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
@@ -27,6 +28,11 @@ def main():
                          grid // max(wg, 1)))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if r[3].startswith("sumsq_kernel")]
+    if which is None:
+        from collections import Counter
+        lens = [b - a for a, b in zip(marks[:-1], marks[1:])]
+        common = Counter(lens).most_common(1)[0][0]
+        which = max(i for i, n in enumerate(lens) if n == common) - len(marks)
     lo, hi = marks[which], marks[which + 1] if which + 1 < 0 or which + 1 < len(marks) else len(rows)
     step = rows[lo:hi]
     t0 = step[0][0]
