@@ -36,7 +36,7 @@ struct SeqStackP {
   int32_t* top;                 // (layers, B, 8, n_top): written (read when force_top); may be null without save
   float* y;                     // (layers, B*L, 128): layer outputs
   float *qkv, *ctx, *xhat1, *rstd1, *x1, *z, *h, *xhat2, *rstd2;  // training saves (layers, B*L, width)
-  int bf16_saves;  // ctx, x1 and (with z) h are bf16 slabs (RfSeqStack.flags & 1)
+  int bf16_saves;  // RfSeqStack.flags: bit 0 = ctx, x1 and (with z) h are bf16 slabs; bit 1 = qkv is a bf16 slab
   __bf16* xin;     // optional bf16 (layers, B*L, 128): every layer's input image
   int B, L, F, n_layers, act, sample_k, n_top, idx_group, force_top, save;
   int split;  // 1: q / k projection and sparsity-measure scores in split-bf16 (default); 0: plain bf16 (RF_SEQ_SPLIT=0, A/B only)
@@ -179,7 +179,10 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
     {
       constexpr int LO_BYTES = 2 * LP * SL_E * 2;
       static_assert(LO_BYTES + TB * 4 <= 6656, "q / k low halves + one staged tile must fit the wave scratch");
-      float* qkv_g = SAVE ? p.qkv + lrow * (3 * SL_D) + wave * 16 : nullptr;
+      // (element offsets from the slab base: the slab is fp32 or, RfSeqStack.flags bit 1, bf16)
+      void* qkv_g = nullptr;
+      if (SAVE) qkv_g = (p.bf16_saves & 2) ? static_cast<void*>(reinterpret_cast<__bf16*>(p.qkv) + lrow * (3 * SL_D) + wave * 16)
+                                           : static_cast<void*>(p.qkv + lrow * (3 * SL_D) + wave * 16);
       __bf16* ql = reinterpret_cast<__bf16*>(scr);
       __bf16* kl = ql + LP * SL_E;
       float* st1 = reinterpret_cast<float*>(scr + LO_BYTES);  // one staged 16 x 16 tile (pitch 20)
@@ -233,8 +236,8 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
             for (int r = 0; r < 4; ++r) st1[(fq * 4 + r) * 20 + fr] = acc[pt][r];
             wave_sync_lds();
             if (rt * 16 + srow < L)
-              *reinterpret_cast<float4*>(qkv_g + (rt * 16 + srow) * (3 * SL_D) + pt * SL_D + sc4) =
-                  *reinterpret_cast<const float4*>(st1 + srow * 20 + sc4);
+              store_qkv4(qkv_g, (long)(rt * 16 + srow) * (3 * SL_D) + pt * SL_D + sc4,
+                         *reinterpret_cast<const float4*>(st1 + srow * 20 + sc4), p.bf16_saves & 2);
             wave_sync_lds();
           }
         }
@@ -262,8 +265,8 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
           for (int r = 0; r < 4; ++r) st1[(fq * 4 + r) * 20 + fr] = acc[r];
           wave_sync_lds();
           if (rt * 16 + srow < L)
-            *reinterpret_cast<float4*>(qkv_g + (rt * 16 + srow) * (3 * SL_D) + 2 * SL_D + sc4) =
-                *reinterpret_cast<const float4*>(st1 + srow * 20 + sc4);
+            store_qkv4(qkv_g, (long)(rt * 16 + srow) * (3 * SL_D) + 2 * SL_D + sc4,
+                       *reinterpret_cast<const float4*>(st1 + srow * 20 + sc4), p.bf16_saves & 2);
           wave_sync_lds();
         }
       }
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
         }
       }
       if (SAVE)  // the context as the out-projection (and its weight gradient) consumes it: the bf16 image (widened, or as it is)
-        save_image_as(xb, SL_XP, SL_D, p.ctx, lrow * SL_D, L, tid, p.bf16_saves != 0);
+        save_image_as(xb, SL_XP, SL_D, p.ctx, lrow * SL_D, L, tid, (p.bf16_saves & 1) != 0);
       stack_layer_norm<RT>(v, SAVE ? p.rstd1 + lrow : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the ctx reads)
       if (SAVE) {  // x-hat of norm1: RT staged tiles, one sync pair
         float* xh_g = p.xhat1 + lrow * SL_D + wave * 16;
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
           xres[rt][r] = y1;
           xb[(rt * 16 + fq * 4 + r) * SL_XP + col] = (__bf16)y1;
         }
-      if (SAVE && !p.bf16_saves) {  // (bf16 saves: the x1 IMAGE is copied out once it is complete, below)
+      if (SAVE && !(p.bf16_saves & 1)) {  // (bf16 saves: the x1 IMAGE is copied out once it is complete, below)
         float* x1_g = p.x1 + lrow * SL_D + wave * 16;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -529,9 +532,9 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
     SL_MARK(10);
 
     SL_LOCAL();
-    if (SAVE && p.bf16_saves) save_image_bf16(xb, SL_XP, SL_D, reinterpret_cast<__bf16*>(p.x1) + lrow * SL_D, L, tid);
+    if (SAVE && (p.bf16_saves & 1)) save_image_bf16(xb, SL_XP, SL_D, reinterpret_cast<__bf16*>(p.x1) + lrow * SL_D, L, tid);
     // ================= phase 4: conv1 + activation (wave = column tiles wave, wave + 8) =================
-    const bool h_img = SAVE && p.bf16_saves && p.z;  // h leaves as the bf16 image it is for conv2 (z stays fp32: GELU' reads it)
+    const bool h_img = SAVE && (p.bf16_saves & 1) && p.z;  // h leaves as the bf16 image it is for conv2 (z stays fp32: GELU' reads it)
     {
       float* z_g = (SAVE && p.z) ? p.z + lrow * F : nullptr;
       float* h_g = (SAVE && !h_img) ? p.h + lrow * F : nullptr;
@@ -636,9 +639,11 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
           for (int r = 0; r < 4; ++r) v[rt][r] += b2 + xres[rt][r];
       }
       stack_layer_norm<RT>(v, SAVE ? p.rstd2 + lrow : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the hb / xb reads)
-      // without saves only the last layer's output is needed: it goes to slab 0
-      const bool store_y = SAVE || li == p.n_layers - 1;
-      float* y_g = p.y + (SAVE ? lrow : (long)b * L) * SL_D + wave * 16;
+      // without saves only the last layer's output is needed: it goes to slab 0.  With saves AND the bf16 input images
+      // (p.xin: what the weight gradients read) the intermediate outputs have no reader either
+      const bool all_y = SAVE && !p.xin;
+      const bool store_y = all_y || li == p.n_layers - 1;
+      float* y_g = p.y + (all_y ? lrow : (long)b * L) * SL_D + wave * 16;
       if (SAVE) {
         float* xh_g = p.xhat2 + lrow * SL_D + wave * 16;
 #pragma unroll
@@ -814,7 +819,7 @@ extern "C" int rf_seqlayer_fwd(const RfSeqStack* st_, const float* x, int B, int
   p.idx_stride = s.idx_stride > 0 ? s.idx_stride : (long)L * sample_k;
   p.top = s.top; p.y = s.y;
   p.qkv = s.qkv; p.ctx = s.ctx; p.xhat1 = s.xhat1; p.rstd1 = s.rstd1; p.x1 = s.x1; p.z = s.z; p.h = s.h;
-  p.xhat2 = s.xhat2; p.rstd2 = s.rstd2; p.bf16_saves = (save && (s.flags & 1)) ? 1 : 0;
+  p.xhat2 = s.xhat2; p.rstd2 = s.rstd2; p.bf16_saves = save ? (s.flags & 3) : 0;
   p.xin = save ? static_cast<__bf16*>(s.xin) : nullptr;
   RF_REQUIRE(!p.xin || al16(p.xin));
   p.B = B; p.L = L; p.F = d_ff; p.n_layers = s.n_layers; p.act = act; p.sample_k = sample_k; p.n_top = n_top;

@@ -37,6 +37,7 @@ struct SeqStackBwdP {
   float* db2[RF_SEQLAYER_MAX_LAYERS];
   int B, L, F, n_layers, act, n_top;
   int bf16_grads;  // dpre2 / dz / dpre1 / dqkv are bf16 slabs (RfSeqStackBwd.flags & 1)
+  int qkv_bf16;    // the saved q | k | v slab is bf16 (RfSeqStackBwd.flags & 2)
   float scale;
   DropCfg drop;   // the forward's nn.Dropout masks are regenerated from (seed, step, site, element); state == null: off
   int drop_site0; // layer i: sites drop_site0 + 3 i + {0: attention output, 1: hidden activation, 2: conv2 output}
@@ -247,7 +248,10 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
       }
     }
     // the attention phase needs only wave-private LDS until it writes the dq image, which aliases xb / hb
-    const float* qkv_g = p.qkv + lrow * (3 * SL_D);
+    // q | k | v as the forward saved them: an fp32 slab or (RfSeqStackBwd.flags bit 1) a bf16 slab -- the same bf16 operands
+    const int qbf = p.qkv_bf16;
+    const void* qkv_g = qbf ? static_cast<const void*>(reinterpret_cast<const __bf16*>(p.qkv) + lrow * (3 * SL_D))
+                            : static_cast<const void*>(p.qkv + lrow * (3 * SL_D));
     {
       const int32_t* top_g = p.top + (((long)li * p.B + b) * SL_H + wave) * u;
       if (lane < 32) top_l[lane] = top_g[min(lane, u - 1)];
@@ -297,8 +301,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
 #pragma unroll
       for (int ct = 0; ct < RT; ++ct) {
         if (fq < 2) {
-          const float* kp = qkv_g + (long)min(ct * 16 + fr, L - 1) * (3 * SL_D) + SL_D + wave * 16 + fq * 8;
-          kb[ct] = pack8(*reinterpret_cast<const float4*>(kp), *reinterpret_cast<const float4*>(kp + 4));
+          kb[ct] = ld_qkv8(qkv_g, (long)min(ct * 16 + fr, L - 1) * (3 * SL_D) + SL_D + wave * 16 + fq * 8, qbf);
         } else {
           kb[ct] = zero_frag();
         }
@@ -307,8 +310,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
       for (int t2 = 0; t2 < 2; ++t2) {
         bf16x8 qa = zero_frag();
         if (fq < 2) {
-          const float* qp = qkv_g + (long)top_l[t2 * 16 + fr] * (3 * SL_D) + wave * 16 + fq * 8;
-          qa = pack8(*reinterpret_cast<const float4*>(qp), *reinterpret_cast<const float4*>(qp + 4));
+          qa = ld_qkv8(qkv_g, (long)top_l[t2 * 16 + fr] * (3 * SL_D) + wave * 16 + fq * 8, qbf);
         }
         float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
@@ -353,8 +355,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
 #pragma unroll
       for (int ct = 0; ct < RT; ++ct) {
         if (fq < 2) {
-          const float* vp = qkv_g + (long)min(ct * 16 + fr, L - 1) * (3 * SL_D) + 2 * SL_D + wave * 16 + fq * 8;
-          vb[ct] = pack8(*reinterpret_cast<const float4*>(vp), *reinterpret_cast<const float4*>(vp + 4));
+          vb[ct] = ld_qkv8(qkv_g, (long)min(ct * 16 + fr, L - 1) * (3 * SL_D) + 2 * SL_D + wave * 16 + fq * 8, qbf);
         } else {
           vb[ct] = zero_frag();
         }
@@ -425,12 +426,12 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
           *reinterpret_cast<bf16x4*>(buf + (ct * 16 + fr) * TP + t2 * 16 + fq * 4) = v4;
         }
       const int4 ta = *reinterpret_cast<const int4*>(top_l + fq * 8), tb = *reinterpret_cast<const int4*>(top_l + fq * 8 + 4);
-      const float* qc = qkv_g + wave * 16 + fr;  // B[k = selected i][col = e]: q[top[i]][e]
+      const long qc = wave * 16 + fr;  // B[k = selected i][col = e]: q[top[i]][e]
       bf16x8 qtb;
-      qtb[0] = (__bf16)qc[(long)ta.x * (3 * SL_D)]; qtb[1] = (__bf16)qc[(long)ta.y * (3 * SL_D)];
-      qtb[2] = (__bf16)qc[(long)ta.z * (3 * SL_D)]; qtb[3] = (__bf16)qc[(long)ta.w * (3 * SL_D)];
-      qtb[4] = (__bf16)qc[(long)tb.x * (3 * SL_D)]; qtb[5] = (__bf16)qc[(long)tb.y * (3 * SL_D)];
-      qtb[6] = (__bf16)qc[(long)tb.z * (3 * SL_D)]; qtb[7] = (__bf16)qc[(long)tb.w * (3 * SL_D)];
+      qtb[0] = ld_qkv1(qkv_g, qc + (long)ta.x * (3 * SL_D), qbf); qtb[1] = ld_qkv1(qkv_g, qc + (long)ta.y * (3 * SL_D), qbf);
+      qtb[2] = ld_qkv1(qkv_g, qc + (long)ta.z * (3 * SL_D), qbf); qtb[3] = ld_qkv1(qkv_g, qc + (long)ta.w * (3 * SL_D), qbf);
+      qtb[4] = ld_qkv1(qkv_g, qc + (long)tb.x * (3 * SL_D), qbf); qtb[5] = ld_qkv1(qkv_g, qc + (long)tb.y * (3 * SL_D), qbf);
+      qtb[6] = ld_qkv1(qkv_g, qc + (long)tb.z * (3 * SL_D), qbf); qtb[7] = ld_qkv1(qkv_g, qc + (long)tb.w * (3 * SL_D), qbf);
       wave_sync_lds();
 #pragma unroll
       for (int kt = 0; kt < RT; ++kt) {
@@ -457,12 +458,12 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
       if constexpr (KS32 > LP) {
         for (int i = lane; i < 32 * (KS32 - LP); i += 64) buf[(i / (KS32 - LP)) * DTP + LP + i % (KS32 - LP)] = (__bf16)0.f;
       }
-      const float* kc = qkv_g + SL_D + wave * 16 + fr;  // B[k = key][col = e]: k[key][e]
+      const long kc = SL_D + wave * 16 + fr;  // B[k = key][col = e]: k[key][e]
       bf16x8 ktb[KSTEPS];
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ktb[ks][j] = (__bf16)kc[(long)min(ks * 32 + fq * 8 + j, L - 1) * (3 * SL_D)];
+        for (int j = 0; j < 8; ++j) ktb[ks][j] = ld_qkv1(qkv_g, kc + (long)min(ks * 32 + fq * 8 + j, L - 1) * (3 * SL_D), qbf);
       // q part of the dq image: zeros, then the selected rows
       {
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -567,6 +568,7 @@ extern "C" int rf_seqlayer_bwd(const RfSeqStackBwd* st_, const float* dy, float*
   }
   p.B = B; p.L = L; p.F = d_ff; p.n_layers = s.n_layers; p.act = act; p.n_top = n_top; p.scale = scale;
   p.bf16_grads = s.flags & 1;
+  p.qkv_bf16 = (s.flags & 2) ? 1 : 0;
   RF_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state));
   p.drop = make_drop_cfg(rng_state, nullptr, 0, drop_p);
   p.drop_site0 = drop_site0;

@@ -80,6 +80,27 @@ __device__ __forceinline__ f32x4 drop_factors(const DropCfg& d, uint2 key, uint3
 }
 
 
+// q | k | v save slab (fp32, or bf16: what the backward's matrix cores consume either way): four consecutive elements
+__device__ __forceinline__ void store_qkv4(void* base, long off, const float4& v, int bf) {
+  if (bf) {
+    const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + off) = o;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + off) = v;
+  }
+}
+
+__device__ __forceinline__ bf16x8 ld_qkv8(const void* base, long off, int bf) {  // eight consecutive elements as bf16
+  if (bf) return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(base) + off);
+  const float* f = reinterpret_cast<const float*>(base) + off;
+  const float4 a = *reinterpret_cast<const float4*>(f), b = *reinterpret_cast<const float4*>(f + 4);
+  bf16x8 o = {(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+  return o;
+}
+__device__ __forceinline__ __bf16 ld_qkv1(const void* base, long off, int bf) {
+  return bf ? reinterpret_cast<const __bf16*>(base)[off] : (__bf16)reinterpret_cast<const float*>(base)[off];
+}
+
 // byte offsets inside a layer's packed blob
 struct PackOff { long wqkv, wo, w1, w2, vec, lo, total; };
 __host__ __device__ inline PackOff pack_offsets(int F) {

@@ -27,6 +27,13 @@ from routeformer_amd.score import ade, fde
 # off after a host crash inside hipGraphLaunch that only showed with it; the cause was elsewhere (graph execs destroyed
 # under PyTorch's HIP runtime, see _new_graph below) -- the extra branch merely changed which freed object the launch hit.
 WGRAD_SIDE = os.environ.get("RF_WGRAD_SIDE", "1") == "1"
+# Deferred update, one process: RF_EARLY_SUMSQ=1 sums the GPS backbone's share of the clip norm mid-backward on a side stream
+# (TrainEngine._backward_gps_first) instead of in the whole-buffer pass at the head of the next step (68 us of HBM time in
+# front of the encoders' update).  Measured neutral to slightly slower (5.35 vs 5.39 ms over four alternating pairs, 5.41 vs
+# 5.49 with the backbone's weight gradients flushed at its input): the sum contends with the backward chain for the time it
+# saves at the head.  Off by default; kept as a measurement switch (tests run it explicitly).
+EARLY_SUMSQ = os.environ.get("RF_EARLY_SUMSQ", "0") == "1"
+EARLY_SUMSQ_FLUSH = os.environ.get("RF_EARLY_SUMSQ_FLUSH", "0") == "1"  # flush the backbone's queued weight gradients at its input
 
 
 # ---- captured graphs are never destroyed ------------------------------------------------------------------------
@@ -562,6 +569,7 @@ class FusedAdamW:
         from routeformer_amd import _hip
         self.parts = int(_hip.lib().rf_sumsq_parts(flat_param.numel()))
         self.sumsq = torch.zeros(self.parts, device=flat_param.device, dtype=torch.float32)  # per-workgroup partials
+        self._ss_plan = None  # split_sumsq: [(lo, hi, first partial, early)]
         self.betas, self.eps, self.wd, self.max_norm = betas, eps, weight_decay, max_grad_norm
         self.param_groups = [{"lr": lr}]  # what an LR scheduler drives (optimizers.LinearWarmupCosineAnnealingLR)
         self.t = 0
@@ -595,9 +603,32 @@ class FusedAdamW:
         return [1.0 if pending else 0.0, self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                 1.0 - self.betas[0] ** t, (1.0 - self.betas[1] ** t) ** 0.5, grad_scale]
 
-    def launch_sumsq(self):
+    def split_sumsq(self, lo: int, hi: int):
+        """The partial sums of squares of the clip norm in up to three launches -- [0, lo), [lo, hi), [hi, n) -- each into its
+        own run of ``self.sumsq``: the middle range ("early": the GPS backbone, 95 % of the bytes) can then be summed as soon
+        as its gradients are complete, underneath the rest of the backward pass, and only the small remainder ("late") sits
+        in front of the update.  The update kernel adds ALL partials in one fixed order, whichever launch wrote them."""
+        from routeformer_amd import _hip
+        n, o, plan = self.p.numel(), 0, []
+        for a, b, early in ((0, lo, False), (lo, hi, True), (hi, n, False)):
+            if b > a:
+                k = int(_hip.lib().rf_sumsq_parts(b - a))
+                plan.append((a, b, o, early))
+                o += k
+        self._ss_plan, self.parts = plan, o
+        self.sumsq = torch.zeros(o, device=self.p.device, dtype=torch.float32)
+
+    def launch_sumsq(self, which: str = "all"):
+        """``which``: "all", or with ``split_sumsq`` in force "early" / "late" (see there)."""
         from routeformer_amd import _hip, kernels as K
-        _hip.check(_hip.lib().rf_sumsq(self.g.data_ptr(), self.p.numel(), self.sumsq.data_ptr(), K._stream()), "rf_sumsq")
+        if self._ss_plan is None:
+            assert which == "all"
+            _hip.check(_hip.lib().rf_sumsq(self.g.data_ptr(), self.p.numel(), self.sumsq.data_ptr(), K._stream()), "rf_sumsq")
+            return
+        for a, b, o, early in self._ss_plan:
+            if which == "all" or (which == "early") == early:
+                _hip.check(_hip.lib().rf_sumsq(self.g.data_ptr() + 4 * a, b - a, self.sumsq.data_ptr() + 4 * o, K._stream()),
+                           "rf_sumsq")
 
     def launch_update_dev(self, lo: int, hi: int, hyper_dev: torch.Tensor, max_blocks: int = 0):
         """AdamW over the slice [lo, hi) of the flat buffers on the current stream, scalars from ``hyper_dev``
@@ -673,7 +704,7 @@ class FusedAdamW:
         self.t += 1
         self._note_skipped(skip)
         n = self.p.numel()
-        _hip.check(_hip.lib().rf_sumsq(self.g.data_ptr(), n, self.sumsq.data_ptr(), K._stream()), "rf_sumsq")
+        self.launch_sumsq()
         for a, b, t in self._segments(0, n, skip):
             o = 4 * a
             _hip.check(_hip.lib().rf_adamw_clip(self.p.data_ptr() + o, self.g.data_ptr() + o, self.m.data_ptr() + o,
@@ -699,6 +730,7 @@ class TrainEngine:
         self._streams = K.SideStreams()
         self._wgrad = K._WgradQueue()
         self._saved_scope = None
+        self._early_sumsq = False  # (GraphedTrainEngine with a deferred update: see _backward_gps_first)
         cfg = model.configs
         layers = [m for m in model.modules() if hasattr(m, "packing_groups")]
         groups = [g for m in layers for g in m.packing_groups()]
@@ -822,8 +854,16 @@ class TrainEngine:
         K.WGRAD.side_early = self.overlap and WGRAD_SIDE  # (single-graph / eager path only: no collective waits on these)
         try:
             self._begin_step_kernels()
-            res = train_step_losses(self.model, item, epoch, self.tl, self.dl, tokens_ready=tokens_ready)
-            res["loss"].backward(gradient=self._loss_seed(res["loss"]))
+            self.model._keep_gps_input = self._early_sumsq
+            try:
+                res = train_step_losses(self.model, item, epoch, self.tl, self.dl, tokens_ready=tokens_ready)
+            finally:
+                self.model._keep_gps_input = False
+            cut = self.model.__dict__.pop("_gps_input", None)
+            if self._early_sumsq:
+                self._backward_gps_first(res["loss"], cut)
+            else:
+                res["loss"].backward(gradient=self._loss_seed(res["loss"]))
             K.flush_weight_grads()  # queued dW / db launches, each on the stream its operands were produced on
             if self.overlap:
                 K.join_side_streams()
@@ -833,6 +873,52 @@ class TrainEngine:
             self._scope_out()
             self.model.__dict__.pop("_before_gps_backbone", None)
         return res
+
+    def _backward_gps_first(self, loss, cut):
+        """Backward pass with the clip norm's big term taken early (single process, deferred update): the GPS backbone --
+        95 % of the trainable bytes, differentiated FIRST -- down to its input ``cut``, its queued weight gradients flushed
+        (side stream), then the sum of squares of ITS range of the gradient buffer on that side stream, underneath the rest
+        of the backward pass.  The next step's update then waits for a sum over the remaining 5 % only (``FusedAdamW.
+        split_sumsq``; the whole-buffer pass was 68 us of HBM time at the head of every step, in front of the camera /
+        gaze / fusion encoders' update)."""
+        from routeformer_amd import kernels as K
+        seed = self._loss_seed(loss)
+        if cut is None or not cut.requires_grad:  # GPS-only model: nothing upstream of the backbone
+            loss.backward(gradient=seed)
+            K.flush_weight_grads()
+            self.opt.launch_sumsq("early")
+            return
+        bp = self.__dict__.get("_gps_params")
+        if bp is None:
+            bp = self._gps_params = [p for n, p in self.model.named_parameters() if n.startswith("gps_backbone.") and p.requires_grad]
+        grads = torch.autograd.grad(loss, [cut] + bp, grad_outputs=seed, allow_unused=True)
+        for p, g in zip(bp, grads[1:]):  # (the few backbone parameters no kernel writes through a sink)
+            if g is not None:
+                p.grad.add_(g)
+        cur = torch.cuda.current_stream()
+
+        def early(st):  # st: the stream the last of the backbone's weight-gradient groups was launched on
+            if self.overlap and st.cuda_stream == cur.cuda_stream:
+                st = K.fork_side_stream("wgrad", origin=st)
+            # the backbone's gradient sinks were written on the main stream and on every branch of this step: order the sum
+            # behind all of them (a replayed graph starts a node as soon as its captured dependencies allow)
+            if st.cuda_stream != cur.cuda_stream:
+                st.wait_stream(cur)
+            for other in list(K.STREAMS.forked.values()):
+                if other.cuda_stream != st.cuda_stream:
+                    st.wait_stream(other)
+            with torch.cuda.stream(st):
+                self.opt.launch_sumsq("early")
+
+        if EARLY_SUMSQ_FLUSH:
+            K.WGRAD.flush(side=K.WGRAD.side_early)
+        slots = self.__dict__.get("_gps_slots")
+        if slots is None:
+            slots = self._gps_slots = {p._rf_grad.data_ptr() for p in bp if getattr(p, "_rf_grad", None) is not None}
+        K.WGRAD.when_launched(slots, early)
+        cut.backward(grads[0])
+        if K.WGRAD._watch is not None:  # (still queued: the final flush launches them -- and calls ``early``)
+            K.flush_weight_grads()
 
     # -- the same step in two stages (GraphedTrainEngine with N > 1): stage 1 = forward + the backward of the
     #    GPS backbone, which owns 95 % of the trainable bytes and is differentiated FIRST; stage 2 = the rest.
@@ -865,6 +951,8 @@ class TrainEngine:
             K.flush_weight_grads()
             if self.overlap:
                 K.join_side_streams()
+            if self._early_sumsq:
+                self.opt.launch_sumsq("early")
             return res, None
         # gradients of the cut AND of the backbone parameters that autograd itself accumulates (the few that no
         # kernel writes through a sink, e.g. the time-feature embedding): they would otherwise be skipped
@@ -877,6 +965,8 @@ class TrainEngine:
         forked = {}
         if self.overlap:
             forked = K.STREAMS.join()  # (the backbone's own side branch: stage 1 may be the end of a captured graph)
+        if self._early_sumsq:  # (one process rehearsing the two-graph step: the backbone's gradients are complete here)
+            self.opt.launch_sumsq("early")
         return res, (cut, grads[0], forked)
 
     def _stage2(self, carry):
@@ -992,7 +1082,7 @@ class GraphedTrainEngine(TrainEngine):
             self.reducer.zero()
             return
         r, opt = self.reducer, self.opt
-        opt.launch_sumsq()
+        opt.launch_sumsq("late" if self._early_sumsq else "all")  # ("early" = the backbone's range: _backward_gps_first)
         use_side = self._gps_range is not None and self.overlap and __import__("os").environ.get("RF_DEFER_SIDE", "1") != "0"
         cur = torch.cuda.current_stream()
 
@@ -1252,6 +1342,10 @@ class GraphedTrainEngine(TrainEngine):
             from routeformer_amd._hip import lib as _lib  # noqa: F401  (fail loudly without the extension)
             self._gps_range = self._backbone_range()
             self._segments = self._plan_segments()
+            self._early_sumsq = (EARLY_SUMSQ and self._gps_range is not None and self.overlap and not self.reducer.exchange
+                                 and not self.reducer.sharded)
+            if self._early_sumsq:
+                self.opt.split_sumsq(*self._gps_range)
             # one row of scalars per segment; all zero = "nothing pending" during the warm-up passes
             self._hyper = torch.zeros(len(self._segments), 16, device=dev, dtype=torch.float32)
             self._hyper_pinned = torch.zeros(len(self._segments), 16, dtype=torch.float32).pin_memory()

@@ -593,12 +593,22 @@ class _WgradQueue:
         self.pending = set() # data_ptr of slots with a queued (not yet launched) write
         self.written = set() # data_ptr of slots already written by a grouped launch this step
         self.side_slots = set()  # ... of those, the ones a group on the "wgrad" side stream wrote (not yet joined)
+        self._watch = None       # (slot data_ptrs, callback(stream)): see when_launched
 
     def begin_step(self):
         """Gradient slots were just zeroed: the first (and, per launch, only) writer of a slot may use plain
         stores instead of atomics (``RfWgradEntry.exclusive``)."""
         self.written.clear()
         self.side_slots.clear()
+        self._watch = None
+
+    def when_launched(self, slots, callback):
+        """Call ``callback(stream)`` once no queued write to any of ``slots`` (data_ptrs) is outstanding: now, on the
+        current stream, or from the flush that launches the last of them, on that group's stream."""
+        if not (self.pending & slots):
+            callback(torch.cuda.current_stream())
+        else:
+            self._watch = (slots, callback)
 
     def push(self, dy2, x2, into, bias_into, M, N, K, splits):
         st = torch.cuda.current_stream()
@@ -676,6 +686,9 @@ class _WgradQueue:
                     SINK.on_write(into)
                     if bias_into is not None:
                         SINK.on_write(bias_into)
+            if self._watch is not None and not (self.pending & self._watch[0]):
+                cb, self._watch = self._watch[1], None
+                cb(st)
         q.clear()
 
     def flush(self, side=False):
@@ -2179,7 +2192,7 @@ def _seqstack_bwd_launch(dy2, sv, wpack, stride, ln_slots, B, L, F_, act, n_top,
     dx = torch.empty(M, 128, **f32)
     st = _hip.SeqStackBwd()
     st.wpack, st.wpack_stride, st.n_layers = wpack.data_ptr(), stride, n
-    st.flags = 1 if BF16_SAVES else 0
+    st.flags = (1 if BF16_SAVES else 0) | (2 if sv["qkv"].dtype == torch.bfloat16 else 0)
     for name in ("qkv", "xhat1", "rstd1", "xhat2", "rstd2", "top"):
         setattr(st, name, ptr(sv[name]))
     st.zsrc = ptr(sv["z"] if "z" in sv else sv["h"])
@@ -2213,6 +2226,7 @@ def seqstack_pack_bytes(d_ff: int) -> int:
 # in those GEMMs, rounded the same way) and half the bytes (PMC): 645 -> 569 MB moved by the camera-token stack's forward,
 # 732 -> 553 MB by its backward, 355 -> 281 MB per weight-gradient launch.
 BF16_SAVES = os.environ.get("RF_BF16_SAVES", "1") != "0"
+BF16_QKV = os.environ.get("RF_BF16_QKV", "1") != "0"  # ... and the saved q | k | v (measurement switch)
 
 
 def _seqstack_launch(x2, wpack, stride, idx_list, idx_group, B, L, F_, act, sample_k, n_top, save, forced_tops, eps,
@@ -2222,18 +2236,20 @@ def _seqstack_launch(x2, wpack, stride, idx_list, idx_group, B, L, F_, act, samp
     n = len(idx_list)
     dev, M = x2.device, B * L
     f32 = dict(device=dev, dtype=torch.float32)
-    sv = {"y": torch.empty(n if save else 1, M, 128, **f32)}
+    half = save and BF16_SAVES
+    # every layer's output only when a backward reads them as the next layer's input: with bf16 saves that is the `xin` image
+    sv = {"y": torch.empty(n if (save and not half) else 1, M, 128, **f32)}
     force = forced_tops is not None
     if save or force:
         sv["top"] = (torch.stack([t.to(device=dev, dtype=torch.int32) for t in forced_tops]).contiguous() if force
                      else torch.empty(n, B, 8, n_top, device=dev, dtype=torch.int32))
-    half = save and BF16_SAVES
     if save:
         # ctx, x1 and (GELU: z is there for the activation gradient) h are read again by the weight-gradient GEMMs only,
         # as bf16 MFMA operands -- BF16_SAVES keeps them as the bf16 images the kernel holds anyway
         bf = dict(device=dev, dtype=torch.bfloat16)
+        # q | k | v: the backward's matrix cores consume them rounded to bf16 whatever the slab holds (lossless as well)
         for name, width in (("qkv", 384), ("ctx", 128), ("xhat1", 128), ("x1", 128), ("xhat2", 128), ("h", F_)):
-            as_bf = half and (name in ("ctx", "x1") or (name == "h" and act == "gelu"))
+            as_bf = half and (name in ("ctx", "x1") or (name == "qkv" and BF16_QKV) or (name == "h" and act == "gelu"))
             sv[name] = torch.empty(n, M, width, **(bf if as_bf else f32))
         if act == "gelu":
             sv["z"] = torch.empty(n, M, F_, **f32)
@@ -2243,7 +2259,7 @@ def _seqstack_launch(x2, wpack, stride, idx_list, idx_group, B, L, F_, act, samp
         sv["rstd2"] = torch.empty(n, M, **f32)
     st = _hip.SeqStack()
     st.wpack, st.wpack_stride, st.n_layers = wpack.data_ptr(), stride, n
-    st.flags = 1 if half else 0
+    st.flags = (3 if BF16_QKV else 1) if half else 0  # bit 0: ctx / x1 / h, bit 1: q | k | v are bf16 slabs
     idx_stride = 0
     for i, t in enumerate(idx_list):
         assert t.dim() == 3 and t.dtype == torch.int32 and t.stride(2) == 1 and t.stride(1) == t.shape[2], "key-sample table"
@@ -2356,7 +2372,7 @@ def _stack_backward_layerwise(sv, stack, x2, dy2, B, L, F_, n_top, drop_p, site0
 
         for li in reversed(range(len(stack.layers))):
             lay = stack.layers[li]
-            x_in = x2 if li == 0 else sv["y"][li - 1]
+            x_in = x2 if li == 0 else (sv["xin"][li] if "xin" in sv else sv["y"][li - 1])  # (its weight gradient's operand)
             w1, w2 = lay.conv1.weight.reshape(F_, D), lay.conv2.weight.reshape(D, F_)
             zsrc = sv["z"][li] if "z" in sv else sv["h"][li]
             # ---- norm2 + conv pair (as _FFNAddLN.backward) ----

@@ -505,7 +505,8 @@ def test_graphed_step_matches_eager():
     from routeformer_amd.engine import GraphedTrainEngine, TrainEngine
     from routeformer_amd.models.blocks import SAMPLER
     results = {}
-    for mode in ("eager", "graph", "graph_nolookahead", "graph_deferred", "graph_deferred_split"):
+    from routeformer_amd import engine as E
+    for mode in ("eager", "graph", "graph_nolookahead", "graph_deferred", "graph_deferred_split", "graph_deferred_early"):
         model, cfg, sd, c = build_product_model("c2_small", DEV)
         items = []
         for seed in (11, 12):
@@ -517,17 +518,32 @@ def test_graphed_step_matches_eager():
             # deferred: clip + AdamW of step k replayed at the start of step k+1 (backbone share on a side stream)
             eng = GraphedTrainEngine(model, lr=1e-3, defer_update=mode.startswith("graph_deferred"))
             eng.split = mode.endswith("_split")  # two-graph step (the N > 1 form)
-            eng.capture(items[0], epoch=10)
+            was = E.EARLY_SUMSQ  # "_early": the backbone's share of the clip norm summed mid-backward (measurement switch)
+            E.EARLY_SUMSQ = mode.endswith("_early")
+            try:
+                eng.capture(items[0], epoch=10)
+            finally:
+                E.EARLY_SUMSQ = was
+            assert eng._early_sumsq == mode.endswith("_early")
         torch.manual_seed(99)
         SAMPLER.log = []
         losses = []
         for i in range(4):
-            nxt = items[(i + 1) % 2] if mode in ("graph", "graph_deferred") else None
+            nxt = items[(i + 1) % 2] if mode in ("graph", "graph_deferred", "graph_deferred_early") else None
             losses.append(float(eng.step(items[i % 2], epoch=10, next_item=nxt)["loss"]))
         torch.cuda.synchronize()
         grads = eng.reducer.flat_grad.clone()
         if mode.startswith("graph_deferred"):
             assert eng._pending is not None
+            # the clip norm's early partial sums (the GPS backbone's range, summed mid-backward on a side stream:
+            # engine._backward_gps_first) cover every gradient of that range -- none was still queued when they were taken
+            for a, b, o, early in (eng.opt._ss_plan if eng._early_sumsq else ()):
+                if early:
+                    from routeformer_amd import _hip
+                    k = int(_hip.lib().rf_sumsq_parts(b - a))
+                    got = float(eng.opt.sumsq[o:o + k].double().sum())
+                    want = float(grads[a:b].double().pow(2).sum())
+                    assert want > 0 and abs(got - want) < 1e-5 * want, (mode, got, want)
             eng.flush()  # the last step's update is still pending
             torch.cuda.synchronize()
             assert eng._pending is None and eng.opt.t == 4
@@ -537,7 +553,7 @@ def test_graphed_step_matches_eager():
         SAMPLER.drop_static()
     le, pe, de, re_, ge = results["eager"]
     assert abs(le[0] - le[1]) > 1e-6, "the two batches should differ"
-    for mode in ("graph", "graph_nolookahead", "graph_deferred", "graph_deferred_split"):
+    for mode in ("graph", "graph_nolookahead", "graph_deferred", "graph_deferred_split", "graph_deferred_early"):
         lg, pg, dg, rg, gg = results[mode]
         assert len(de) == len(dg) and all(torch.equal(a, b) for a, b in zip(de, dg)), mode
         assert torch.equal(re_, rg), "host RNG state diverged between eager and graph mode"
@@ -913,10 +929,16 @@ def test_graphed_engine_with_dropouts_matches_eager():
         it = synthetic.synth_item(c["B"], c["T"], c["P"], seed, c["H"], c["W"], streams=c["streams"], gaze=c["gaze"])
         items.append({"train": _to_dev(it["train"]), "target": _to_dev(it["target"]), "id": seed})
     runs = {}
+    from routeformer_amd import engine as E
     for mode in ("eager", "graph", "graph_deferred"):
         model, sd = _dropout_model(cfg)
-        eng = (TrainEngine(model, lr=1e-4) if mode == "eager" else
-               GraphedTrainEngine(model, lr=1e-4, defer_update=mode == "graph_deferred").capture(items[0], epoch=10))
+        was = E.EARLY_SUMSQ  # the deferred run also takes the clip norm's big term mid-backward (measurement switch, off by default)
+        E.EARLY_SUMSQ = mode == "graph_deferred"
+        try:
+            eng = (TrainEngine(model, lr=1e-4) if mode == "eager" else
+                   GraphedTrainEngine(model, lr=1e-4, defer_update=mode == "graph_deferred").capture(items[0], epoch=10))
+        finally:
+            E.EARLY_SUMSQ = was
         if mode != "eager":
             assert SAMPLER.n_variants == 6  # view: keep | drop left | drop right, x gaze: keep | drop
         if mode == "graph_deferred":  # the update is launched per segment: backbone | gaze slots | the rest
@@ -932,6 +954,15 @@ def test_graphed_engine_with_dropouts_matches_eager():
             decisions.append(tuple(model.__dict__.get("_unused_prefixes", ())) if mode == "eager"
                              else tuple(eng._variant_unused[SAMPLER._variant]))
             gaze_moved.append(bool((gaze_w.detach() != before).any()))
+            if mode == "graph_deferred":  # the clip norm's early partial sums saw every gradient of the backbone's range
+                from routeformer_amd import _hip
+                assert eng._early_sumsq
+                for a, b, o, early in eng.opt._ss_plan:
+                    if early:
+                        k = int(_hip.lib().rf_sumsq_parts(b - a))
+                        got = float(eng.opt.sumsq[o:o + k].double().sum())
+                        want = float(eng.reducer.flat_grad[a:b].double().pow(2).sum())
+                        assert want > 0 and abs(got - want) < 1e-5 * want, (i, got, want)
         torch.cuda.synchronize()
         if mode == "graph_deferred":
             before = gaze_w.detach().clone()

@@ -27,7 +27,17 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), short(r["Kernel_Name"]),
                          grid // max(wg, 1)))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if r[3].startswith("sumsq_kernel")]
+    # a step opens with the sum of squares in front of the update (with the early partial sum of the GPS backbone's range --
+    # engine.EARLY_SUMSQ -- there are more sumsq launches per step: the opening one is followed by the update kernel)
+    def opens(i):
+        if not rows[i][3].startswith("sumsq_kernel"):
+            return False
+        prev = [r[3] for r in rows[max(0, i - 200):i] if r[2] == rows[i][2]]
+        if prev and prev[-1].startswith("sumsq_kernel"):
+            return False
+        nxt = [r[3] for r in rows[i + 1:i + 200] if r[2] == rows[i][2] and not r[3].startswith("sumsq_kernel")]  # same queue
+        return bool(nxt) and nxt[0].startswith("adamw_clip")
+    marks = [i for i in range(len(rows)) if opens(i)]
     if which is None:
         from collections import Counter
         lens = [b - a for a, b in zip(marks[:-1], marks[1:])]
