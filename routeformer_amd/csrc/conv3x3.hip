@@ -35,17 +35,37 @@ extern "C" void* rf_conv_timing_address() {
 namespace {
 
 constexpr int NT = 256;
+#ifndef RF_CONV_U
+#define RF_CONV_U 4
+#endif
+constexpr int CONV_U = RF_CONV_U;  // 16-B loads a thread keeps in flight while it stages a channel slice
 constexpr int TILE = 128;  // output pixels per workgroup (4 waves x 2 MFMA row tiles)
+
+// How many k-steps the weight fragments run ahead of the MFMAs (register ring).  A fragment comes from L2, ~1 us away under
+// load; with a distance of 4 the 256 -> 16 transition's loop ran at ~400 cycles per k-step (tools/conv_phase_probe.py: 2 MFMAs
+// of 32 cycles each per step, the rest is waiting for weights).  Few column tiles = few registers per step: fetch deeper
+// (one / two column tiles: up to 24 fragments = 96 VGPRs in flight, whole slices at once when they fit; with four or more
+// column tiles a step already holds 8+ MFMAs and the deeper ring only cost occupancy: 99 -> 108 us for layer1's 64 -> 64).
+constexpr int pf_depth(int ksteps, int ntl) {
+  const int want = ntl <= 2 ? 24 / ntl : 4;
+  return ksteps < want ? ksteps : want;
+}
 
 extern __shared__ __attribute__((aligned(16))) __bf16 rf_conv_win[];
 
 // One 128-pixel tile (`tile`) of one convolution; all threads of the workgroup take the same path.
-template <int CIN, int COUT, typename AT>
+// CH < CIN (the 256 -> 16 transition): the window is staged CH input channels at a time and the accumulators carry over --
+// the whole 256-channel window of a 56-wide map is 128 KB of LDS (ONE four-wave workgroup per CU staging 124 KB for 144
+// MFMAs per wave: 433 us for 405 MB at C5, 1 TB/s); a 64-channel slice is 35 KB, four workgroups per CU overlap each
+// other's staging.  The packed weights are the same (k-step = tap x 32-channel group).
+template <int CIN, int COUT, typename AT, int CH = CIN>
 __device__ __forceinline__ void conv3x3_body(const AT* __restrict__ x, const __bf16* __restrict__ wt,
                                              const float* __restrict__ bias, const AT* __restrict__ residual,
                                              AT* __restrict__ y, int total, int H, int W, int relu, int tile) {
-  constexpr int LDC = CIN + 8;                       // LDS pixel pitch (bf16): odd multiple of 16 B
-  constexpr int KSTEPS = (CIN == 16) ? 5 : 9 * (CIN / 32);
+  static_assert(CIN % CH == 0 && (CH == CIN || CH % 32 == 0), "channel slices are whole 32-channel k-groups");
+  constexpr int LDC = CH + 8;                        // LDS pixel pitch (bf16): odd multiple of 16 B
+  constexpr int NCH = CIN / CH;                      // channel slices
+  constexpr int KSTEPS = (CIN == 16) ? 5 : 9 * (CH / 32);  // k-steps per slice
   constexpr int NTL = COUT / 16;                     // MFMA column tiles
   __bf16* win = rf_conv_win;
 
@@ -56,11 +76,11 @@ __device__ __forceinline__ void conv3x3_body(const AT* __restrict__ x, const __b
   const long s0 = m0 - W - 1;                        // raster index of window pixel 0
 
   CV_MARK(0);
-  // ---- stage the input window (contiguous in memory) ----
+  // ---- stage (a channel slice of) the input window (contiguous pixels in memory) ----
   // 16-B loads (8 bf16 / 4 fp32 channels), four per thread in flight before the first LDS store: the plain
   // load -> store loop paid one memory round trip per iteration (49 of them for the 256-channel window)
-  {
-    constexpr int VEC = sizeof(AT) == 2 ? 8 : 4, VPP = CIN / VEC, U = 4;
+  auto stage = [&](int ch) {
+    constexpr int VEC = sizeof(AT) == 2 ? 8 : 4, VPP = CH / VEC, U = NCH > 1 ? CONV_U : 4;  // (slices: fewer, deeper batches)
     const int nvec = span * VPP;
     for (int base = 0; base < nvec; base += NT * U) {
       float4 raw[U];
@@ -72,7 +92,7 @@ __device__ __forceinline__ void conv3x3_body(const AT* __restrict__ x, const __b
         const long g = s0 + px;
         at[u] = i < nvec ? px * LDC + c : -1;
         raw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < nvec && g >= 0 && g < total) raw[u] = *reinterpret_cast<const float4*>(x + g * CIN + c);
+        if (i < nvec && g >= 0 && g < total) raw[u] = *reinterpret_cast<const float4*>(x + g * CIN + ch * CH + c);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -85,7 +105,8 @@ __device__ __forceinline__ void conv3x3_body(const AT* __restrict__ x, const __b
         }
       }
     }
-  }
+  };
+  stage(0);
 
   // ---- this lane's two output pixels (one per MFMA row tile) and their border masks ----
   int pl[2];          // window-relative index of the centre pixel
@@ -124,42 +145,54 @@ __device__ __forceinline__ void conv3x3_body(const AT* __restrict__ x, const __b
   // Weight fragments run PF k-steps ahead of the MFMAs in a register ring: every step's fragments come from L2
   // (~1 us away when little else is in flight) and the small maps (4x4, 7x7: a few dozen workgroups, one per CU)
   // have nothing else to hide that behind -- with a distance of one the loop ran at one memory round trip per step.
-  constexpr int PF = KSTEPS < 4 ? KSTEPS : 4;
+  constexpr int PF = pf_depth(KSTEPS, NTL);
+  // k-step s of channel slice ch in the packed order (tap-major over ALL 32-channel groups of CIN)
+  auto gstep = [&](int s, int ch) -> int {
+    if constexpr (NCH == 1) return s;
+    else return (s / (CH / 32)) * (CIN / 32) + ch * (CH / 32) + s % (CH / 32);
+  };
   bf16x8 bq[PF][NTL];
+#pragma unroll 1
+  for (int ch = 0; ch < NCH; ++ch) {
+    if (ch > 0) {
+      __syncthreads();  // every wave is done reading the previous slice
+      stage(ch);
+    }
 #pragma unroll
-  for (int d = 0; d < PF; ++d)
+    for (int d = 0; d < PF; ++d)
 #pragma unroll
-    for (int j = 0; j < NTL; ++j) bq[d][j] = ldb(d, j);
-  CV_MARK(1);
-  __syncthreads();  // window staged
-  CV_MARK(2);
+      for (int j = 0; j < NTL; ++j) bq[d][j] = ldb(gstep(d, ch), j);
+    CV_MARK(1);
+    __syncthreads();  // window staged
+    CV_MARK(2);
 
 #pragma unroll 1
-  for (int s0 = 0; s0 < KSTEPS; s0 += PF) {
+    for (int s0 = 0; s0 < KSTEPS; s0 += PF) {
 #pragma unroll
-    for (int d = 0; d < PF; ++d) {
-      const int s = s0 + d;
-      if (s < KSTEPS) {
-        int tap, c0;
-        if constexpr (CIN == 16) { tap = 2 * s + (fq >> 1); c0 = (fq & 1) * 8; }
-        else { tap = s / (CIN / 32); c0 = (s % (CIN / 32)) * 32 + fq * 8; }
-        const int toff = (tap < 9) ? (tap / 3 - 1) * W + (tap % 3 - 1) : 0;
-        bf16x8 a[2];
+      for (int d = 0; d < PF; ++d) {
+        const int s = s0 + d;
+        if (s < KSTEPS) {
+          int tap, c0;
+          if constexpr (CIN == 16) { tap = 2 * s + (fq >> 1); c0 = (fq & 1) * 8; }
+          else { tap = s / (CH / 32); c0 = (s % (CH / 32)) * 32 + fq * 8; }
+          const int toff = (tap < 9) ? (tap / 3 - 1) * W + (tap % 3 - 1) : 0;
+          bf16x8 a[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const bool ok = tap < 9 && ((vmask[i] >> tap) & 1u);
-          bf16x8 v = *reinterpret_cast<const bf16x8*>(win + (pl[i] + (ok ? toff : 0)) * LDC + c0);
-          if (!ok) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-          a[i] = v;
-        }
+          for (int i = 0; i < 2; ++i) {
+            const bool ok = tap < 9 && ((vmask[i] >> tap) & 1u);
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(win + (pl[i] + (ok ? toff : 0)) * LDC + c0);
+            if (!ok) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            a[i] = v;
+          }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < NTL; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[d][j], acc[i][j], 0, 0, 0);
-        if (s + PF < KSTEPS) {
+            for (int j = 0; j < NTL; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[d][j], acc[i][j], 0, 0, 0);
+          if (s + PF < KSTEPS) {
 #pragma unroll
-          for (int j = 0; j < NTL; ++j) bq[d][j] = ldb(s + PF, j);
+            for (int j = 0; j < NTL; ++j) bq[d][j] = ldb(gstep(s + PF, ch), j);
+          }
         }
       }
     }
@@ -220,37 +253,57 @@ __device__ __forceinline__ void conv3x3_body(const AT* __restrict__ x, const __b
 // CIN = 64: k-steps / packed weights exactly as the stride-1 kernel's (rf_conv3x3_pack_bf16).  CIN = 4 (the 3 + 1
 // channels rf_stem_conv0 writes): a k-step is 8 taps x 4 channels, a lane's 8 k-values are two taps (two 8-B reads),
 // two k-steps (tap 8 + seven zero taps in the second); weights packed by rf_conv3x3s2_pack_bf16.
-template <int CIN, int COUT, int RT>
+// CIN >= 64: the window is staged one 32-channel slice at a time (S2Slice), the accumulators carry over -- as the
+// stride-1 kernel's 256-channel case: the 64-channel window of the second stem convolution is 80 KB at W = 112 (one
+// workgroup per CU: 395 us for 506 MB at C5), a 32-channel slice 45 KB.
+template <int CIN> struct S2Slice { static constexpr int DEFAULT = 32; };
+
+// output pixels a stride-2 workgroup of capacity `cap` (64 or 128) takes: whole output rows when a row fits
+__host__ __device__ inline int s2_tile_px(int cap, int Wo) { return Wo <= cap ? (cap / Wo) * Wo : cap; }
+
+template <int CIN, int COUT, int RT, int CH>
 __device__ __forceinline__ void conv3x3s2_body(const __bf16* __restrict__ x, const __bf16* __restrict__ wt,
                                                const float* __restrict__ bias, const __bf16* __restrict__ residual,
                                                __bf16* __restrict__ y, int total_out,
                                                long total_in, int H, int W, int relu, int tile) {
   constexpr int TILE_ = 64 * RT;                     // output pixels per workgroup
-  constexpr int LDC = CIN == 4 ? 4 : CIN + 8;        // LDS pixel pitch (bf16)
-  constexpr int KSTEPS = CIN == 4 ? 2 : (CIN == 16 ? 5 : 9 * (CIN / 32));
+  constexpr int NCH = CIN / CH;
+  constexpr int LDC = CIN == 4 ? 4 : CH + 8;         // LDS pixel pitch (bf16)
+  constexpr int KSTEPS = CIN == 4 ? 2 : (CIN == 16 ? 5 : 9 * (CH / 32));  // per slice
   constexpr int NTL = COUT / 16;
   __bf16* win = rf_conv_win;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int Wo = W >> 1, Ho = H >> 1;
-  const long m0 = (long)tile * TILE_;
-  const long mlast = min(m0 + TILE_ - 1, (long)total_out - 1);
+  // Output rows no wider than the tile: a workgroup takes WHOLE rows (tile_px = the largest multiple of Wo that fits) -- its
+  // window is then 2 rows + 3 input rows instead of the up to two more an unaligned tile drags in (Wo = 28, 64 outputs:
+  // 504 staged pixels unaligned, 280 for 56 aligned outputs), at the price of a few idle rows in the last MFMA tile.
+  const int tile_px = s2_tile_px(TILE_, Wo);
+  const long m0 = (long)tile * tile_px;
+  const long mend = min(m0 + tile_px, (long)total_out);  // one past this workgroup's last output
+  const long mlast = mend - 1;
   const long s0 = 2 * (m0 / Wo) * W - W;             // first pixel of the row above the first centre row (may be < 0)
   const int span = (int)(2 * (mlast / Wo) * W + 2 * W - s0);  // ... through the end of the row below the last centre row
 
-  // ---- stage the window: a plain copy of `span` pixels x CIN channels (16-B loads, four in flight per thread) ----
-  {
-    constexpr int U = 4;
-    const long e0 = s0 * CIN;                        // first element (multiple of 8: W is even)
-    const int nvec = span * CIN / 8;
+  // ---- stage the window: a plain copy of `span` pixels x (a slice of) the channels (16-B loads, four in flight per thread) ----
+  auto stage = [&](int ch) {
+    constexpr int U = NCH > 1 ? CONV_U : 4;
+    const int nvec = span * CH / 8;
     for (int base = 0; base < nvec; base += NT * U) {
       float4 raw[U];
       int at[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int i = base + tid + u * NT;
-        const long g = e0 + (long)i * 8;
-        at[u] = i < nvec ? (CIN == 4 ? i * 8 : (i / (CIN / 8)) * LDC + (i % (CIN / 8)) * 8) : -1;
+        long g;  // first element of this 16-B group in the map
+        if constexpr (CIN == 4) {
+          g = s0 * CIN + (long)i * 8;                // (two pixels per group; s0 * 4 is a multiple of 8: W is even)
+          at[u] = i < nvec ? i * 8 : -1;
+        } else {
+          const int px = i / (CH / 8), c = (i % (CH / 8)) * 8;
+          g = (s0 + px) * CIN + ch * CH + c;
+          at[u] = i < nvec ? px * LDC + c : -1;
+        }
         raw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < nvec && g >= 0 && g + 8 <= total_in * CIN) raw[u] = *reinterpret_cast<const float4*>(x + g);
       }
@@ -258,7 +311,8 @@ __device__ __forceinline__ void conv3x3s2_body(const __bf16* __restrict__ x, con
       for (int u = 0; u < U; ++u)
         if (at[u] >= 0) *reinterpret_cast<float4*>(win + at[u]) = raw[u];
     }
-  }
+  };
+  stage(0);
 
   // ---- this lane's output pixels (one per MFMA row tile), their window-relative centres and border masks ----
   int pl[RT];
@@ -268,7 +322,7 @@ __device__ __forceinline__ void conv3x3s2_body(const __bf16* __restrict__ x, con
     const long m = m0 + wave * (16 * RT) + i * 16 + fr;
     unsigned msk = 0;
     int c = W + 1;
-    if (m < total_out) {
+    if (m < mend) {
       const int wo = (int)(m % Wo);
       const long r = m / Wo;
       const int ho = (int)(r % Ho);
@@ -291,12 +345,22 @@ __device__ __forceinline__ void conv3x3s2_body(const __bf16* __restrict__ x, con
   auto ldb = [&](int s, int j) -> bf16x8 {
     return *reinterpret_cast<const bf16x8*>(wt + ((long)(s * NTL + j) * 64 + lane) * 8);
   };
-  constexpr int PF = KSTEPS < 4 ? KSTEPS : 4;
+  constexpr int PF = pf_depth(KSTEPS, NTL);
+  auto gstep = [&](int s, int ch) -> int {  // k-step s of slice ch in the packed (tap-major) order
+    if constexpr (NCH == 1) return s;
+    else return (s / (CH / 32)) * (CIN / 32) + ch * (CH / 32) + s % (CH / 32);
+  };
   bf16x8 bq[PF][NTL];
+#pragma unroll 1
+  for (int ch = 0; ch < NCH; ++ch) {
+  if (ch > 0) {
+    __syncthreads();  // every wave is done reading the previous slice
+    stage(ch);
+  }
 #pragma unroll
   for (int d = 0; d < PF; ++d)
 #pragma unroll
-    for (int j = 0; j < NTL; ++j) bq[d][j] = ldb(d, j);
+    for (int j = 0; j < NTL; ++j) bq[d][j] = ldb(gstep(d, ch), j);
   __syncthreads();  // window staged
 
 #pragma unroll 1
@@ -321,7 +385,7 @@ __device__ __forceinline__ void conv3x3s2_body(const __bf16* __restrict__ x, con
         } else {
           int tap, c0;  // (CIN = 16: a k-step is both 8-channel halves of two taps, the tenth tap is zero -- as in the stride-1 kernel)
           if constexpr (CIN == 16) { tap = 2 * s + (fq >> 1); c0 = (fq & 1) * 8; }
-          else { tap = s / (CIN / 32); c0 = (s % (CIN / 32)) * 32 + fq * 8; }
+          else { tap = s / (CH / 32); c0 = (s % (CH / 32)) * 32 + fq * 8; }
           const int toff = tap < 9 ? (tap / 3 - 1) * W + (tap % 3 - 1) : 0;
 #pragma unroll
           for (int i = 0; i < RT; ++i) {
@@ -338,11 +402,12 @@ __device__ __forceinline__ void conv3x3s2_body(const __bf16* __restrict__ x, con
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[d][j], acc[i][j], 0, 0, 0);
         if (s + PF < KSTEPS) {
 #pragma unroll
-          for (int j = 0; j < NTL; ++j) bq[d][j] = ldb(s + PF, j);
+          for (int j = 0; j < NTL; ++j) bq[d][j] = ldb(gstep(s + PF, ch), j);
         }
       }
     }
   }
+  }  // channel slices
 
   // ---- epilogue: as the stride-1 kernel's (fp32 patch per wave in the dead window, 8 channels per lane) ----
   constexpr int SP = COUT + 4;
@@ -359,7 +424,7 @@ __device__ __forceinline__ void conv3x3s2_body(const __bf16* __restrict__ x, con
     for (int v = lane; v < 16 * VPP; v += 64) {
       const int px = v / VPP, c = (v % VPP) * 8;
       const long m = m0 + wave * (16 * RT) + i * 16 + px;
-      if (m < total_out) {
+      if (m < mend) {
         float4 lo = *reinterpret_cast<const float4*>(patch + px * SP + c);
         float4 hi = *reinterpret_cast<const float4*>(patch + px * SP + c + 4);
         const float4 b0 = *reinterpret_cast<const float4*>(bias + c), b1 = *reinterpret_cast<const float4*>(bias + c + 4);
@@ -382,39 +447,68 @@ __device__ __forceinline__ void conv3x3s2_body(const __bf16* __restrict__ x, con
   }
 }
 
-template <int CIN, int COUT, int RT>
+template <int CIN, int COUT, int RT, int CH>
 __global__ __launch_bounds__(NT) void conv3x3s2_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ wt,
                                                         const float* __restrict__ bias, const __bf16* __restrict__ residual,
                                                         __bf16* __restrict__ y, int total_out, long total_in, int H, int W,
                                                         int relu) {
-  conv3x3s2_body<CIN, COUT, RT>(x, wt, bias, residual, y, total_out, total_in, H, W, relu, (int)blockIdx.x);
+  conv3x3s2_body<CIN, COUT, RT, CH>(x, wt, bias, residual, y, total_out, total_in, H, W, relu, (int)blockIdx.x);
 }
 
-// LDS bytes of a stride-2 workgroup: the widest span (an output tile that starts at the end of a row) or the epilogue patches
+// window pixels of a stride-2 workgroup: the row above + the centre rows + the row below of the output rows it touches
+static int s2_span(int rt, int W) {
+  const int Wo = W / 2, tile = s2_tile_px(64 * rt, Wo);
+  const int rows = Wo <= 64 * rt ? tile / Wo : 2;  // (row-aligned, or a piece of two rows)
+  return 2 * (rows - 1) * W + 3 * W;
+}
+
+// channels staged at a time: 32-channel slices once the whole 64-channel window would be large (one workgroup per CU); the
+// small maps (a few hundred workgroups, latency-bound) keep the single pass -- slicing them cost 10 -> 15 us for 64 -> 128 at
+// 14 x 14.  RF_CONV_S2_SLICE = 32 | 64 forces one (measurement switch).
+static int s2_slice(int cin, int rt, int W) {
+  static const int want = [] { const char* e = getenv("RF_CONV_S2_SLICE"); return e ? atoi(e) : 0; }();
+  if (cin < 64) return cin;
+  if (cin > 64) return want == 64 ? 64 : 32;
+  if (want == 32 || want == 64) return want;
+  return (size_t)s2_span(rt, W) * (64 + 8) * sizeof(__bf16) <= 40 * 1024 ? 64 : 32;
+}
+
+// LDS bytes of a stride-2 workgroup: the window (slice) or the epilogue patches
 static size_t s2_lds(int cin, int cout, int rt, int W) {
-  const int Wo = W / 2, tile = 64 * rt, ldc = cin == 4 ? 4 : cin + 8;
-  const int rows = (tile - 1 + Wo - 1) / Wo + 1;            // output rows a tile can touch
-  size_t lds = (size_t)(2 * (rows - 1) * W + 3 * W) * ldc * sizeof(__bf16) + 64;  // row above + centre rows + row below
+  const int ldc = cin == 4 ? 4 : s2_slice(cin, rt, W) + 8;
+  size_t lds = (size_t)s2_span(rt, W) * ldc * sizeof(__bf16) + 64;
   const size_t patches = (size_t)(NT / 64) * 16 * (cout + 4) * sizeof(float);
   return lds < patches ? patches : lds;
+}
+
+template <int CIN, int COUT, int RT, int CH>
+int launch_s2_ch(const void* x, const void* wt, const float* bias, const void* residual, void* y, long total_out, long total_in,
+                 int H, int W, int relu, hipStream_t st) {
+  const size_t lds = s2_lds(CIN, COUT, RT, W);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_kernel<CIN, COUT, RT, CH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int tile_px = s2_tile_px(64 * RT, W / 2);
+  const int blocks = (int)((total_out + tile_px - 1) / tile_px);
+  RF_LAUNCH((conv3x3s2_kernel<CIN, COUT, RT, CH>), dim3(blocks), dim3(NT), lds, st, static_cast<const __bf16*>(x),
+            static_cast<const __bf16*>(wt), bias, static_cast<const __bf16*>(residual), static_cast<__bf16*>(y), (int)total_out,
+            total_in, H, W, relu);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
 }
 
 template <int CIN, int COUT, int RT>
 int launch_s2(const void* x, const void* wt, const float* bias, const void* residual, void* y, long total_out, long total_in,
               int H, int W, int relu, hipStream_t st) {
-  const size_t lds = s2_lds(CIN, COUT, RT, W);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_kernel<CIN, COUT, RT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
+  if constexpr (CIN >= 64) {
+    if (s2_slice(CIN, RT, W) == 64) return launch_s2_ch<CIN, COUT, RT, 64>(x, wt, bias, residual, y, total_out, total_in, H, W, relu, st);
+    return launch_s2_ch<CIN, COUT, RT, 32>(x, wt, bias, residual, y, total_out, total_in, H, W, relu, st);
+  } else {
+    return launch_s2_ch<CIN, COUT, RT, CIN>(x, wt, bias, residual, y, total_out, total_in, H, W, relu, st);
   }
-  const int blocks = (int)((total_out + 64 * RT - 1) / (64 * RT));
-  RF_LAUNCH((conv3x3s2_kernel<CIN, COUT, RT>), dim3(blocks), dim3(NT), lds, st, static_cast<const __bf16*>(x),
-            static_cast<const __bf16*>(wt), bias, static_cast<const __bf16*>(residual), static_cast<__bf16*>(y), (int)total_out,
-            total_in, H, W, relu);
-  RF_CHECK_LAUNCH();
-  return RF_OK;
 }
 
 // CIN = 4 packing: out[((s*NTL + j)*64 + lane)*8 + e] = w[j*16 + (lane&15)][tap = 8 s + 2 (lane>>4) + (e>>2)][e & 3]
@@ -430,12 +524,15 @@ __global__ void pack_weights_c4_kernel(const float* __restrict__ w, __bf16* __re
   }
 }
 
-template <int CIN, int COUT, typename AT>
+// channel slice staged at a time: the whole window, except for the 256-channel transition (see conv3x3_body)
+template <int CIN> struct SliceOf { static constexpr int CH = CIN > 128 ? 64 : CIN; };
+
+template <int CIN, int COUT, typename AT, int CH>
 __global__ __launch_bounds__(NT) void conv3x3_kernel(const AT* __restrict__ x, const __bf16* __restrict__ wt,
                                                       const float* __restrict__ bias,
                                                       const AT* __restrict__ residual, AT* __restrict__ y,
                                                       int total, int H, int W, int relu) {
-  conv3x3_body<CIN, COUT, AT>(x, wt, bias, residual, y, total, H, W, relu, (int)blockIdx.x);
+  conv3x3_body<CIN, COUT, AT, CH>(x, wt, bias, residual, y, total, H, W, relu, (int)blockIdx.x);
 }
 
 // Grouped launch: the same convolution step of up to four INDEPENDENT maps (the branches of an HRNet module:
@@ -468,25 +565,39 @@ __global__ __launch_bounds__(NT) void conv3x3_group_kernel(const ConvGroup g) {
   else conv3x3_body<128, 128, AT>(x, w, e.bias, res, y, e.total, e.H, e.W, e.relu, tile);
 }
 
-template <int CIN, int COUT, typename AT>
-int launch_t(const void* x, const void* wt, const float* bias, const void* residual, void* y, long total, int H,
-             int W, int relu, hipStream_t st) {
-  size_t lds = (size_t)(TILE + 2 * W + 2) * (CIN + 8) * sizeof(__bf16);
+template <int CIN, int COUT, typename AT, int CH>
+int launch_ch(const void* x, const void* wt, const float* bias, const void* residual, void* y, long total, int H,
+              int W, int relu, hipStream_t st) {
+  size_t lds = (size_t)(TILE + 2 * W + 2) * (CH + 8) * sizeof(__bf16);
   const size_t patches = (size_t)(NT / 64) * 16 * (COUT + 4) * sizeof(float);  // epilogue staging, one per wave
   if (lds < patches) lds = patches;
   if (lds > 160 * 1024) { rf_g_last_error = "conv3x3 window exceeds LDS"; return RF_EUNSUPPORTED; }
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_kernel<CIN, COUT, AT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_kernel<CIN, COUT, AT, CH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const int blocks = (int)((total + TILE - 1) / TILE);
-  RF_LAUNCH((conv3x3_kernel<CIN, COUT, AT>), dim3(blocks), dim3(NT), lds, st, static_cast<const AT*>(x),
+  RF_LAUNCH((conv3x3_kernel<CIN, COUT, AT, CH>), dim3(blocks), dim3(NT), lds, st, static_cast<const AT*>(x),
                      static_cast<const __bf16*>(wt), bias, static_cast<const AT*>(residual), static_cast<AT*>(y),
                      (int)total, H, W, relu);
   RF_CHECK_LAUNCH();
   return RF_OK;
+}
+
+template <int CIN, int COUT, typename AT>
+int launch_t(const void* x, const void* wt, const float* bias, const void* residual, void* y, long total, int H,
+             int W, int relu, hipStream_t st) {
+  if constexpr (CIN > 128) {  // channel slices (conv3x3_body); RF_CONV_SLICE: measurement switch
+    static const int ch = [] { const char* e = getenv("RF_CONV_SLICE"); return e ? atoi(e) : SliceOf<CIN>::CH; }();
+    if (ch == 32) return launch_ch<CIN, COUT, AT, 32>(x, wt, bias, residual, y, total, H, W, relu, st);
+    if (ch == 128) return launch_ch<CIN, COUT, AT, 128>(x, wt, bias, residual, y, total, H, W, relu, st);
+    if (ch == CIN) return launch_ch<CIN, COUT, AT, CIN>(x, wt, bias, residual, y, total, H, W, relu, st);
+    return launch_ch<CIN, COUT, AT, 64>(x, wt, bias, residual, y, total, H, W, relu, st);
+  } else {
+    return launch_ch<CIN, COUT, AT, CIN>(x, wt, bias, residual, y, total, H, W, relu, st);
+  }
 }
 
 template <int CIN, int COUT>
@@ -569,6 +680,7 @@ extern "C" int rf_conv3x3_group_bf16(const RfConvEntry* entries, int count, int 
 
 static bool s2_combo(int cin, int cout) {
   if (cin == 4) return cout == 64;
+  if (cin == 256) return cout == 32;  // (the 256 -> 32 transition)
   return (cin == 16 || cin == 32 || cin == 64) && (cout == 16 || cout == 32 || cout == 64 || cout == 128) && cout >= cin;
 }
 
@@ -612,7 +724,7 @@ extern "C" int rf_conv3x3s2_bf16(const void* x, const void* w_bf16, const float*
   const bool big = s2_lds(cin, cout, 2, W) <= 80 * 1024 || s2_lds(cin, cout, 1, W) > 160 * 1024;
 #define RF_S2_GO(CI, CO) if (cin == CI && cout == CO) return launch_s2_rt<CI, CO>(big, x, w_bf16, bias, residual, y, to, ti, H, W, relu, st)
   RF_S2_GO(4, 64); RF_S2_GO(16, 16); RF_S2_GO(16, 32); RF_S2_GO(16, 64); RF_S2_GO(16, 128); RF_S2_GO(32, 32); RF_S2_GO(32, 64);
-  RF_S2_GO(32, 128); RF_S2_GO(64, 64); RF_S2_GO(64, 128);
+  RF_S2_GO(32, 128); RF_S2_GO(64, 64); RF_S2_GO(64, 128); RF_S2_GO(256, 32);
 #undef RF_S2_GO
   return RF_EUNSUPPORTED;
 }

@@ -484,7 +484,7 @@ def test_conv2d_nhwc(N, H, W, cin, cout, k, s, prec, tol):
 
 @pytest.mark.parametrize("N,H,W,cin,cout", [(3, 28, 28, 16, 16), (5, 14, 14, 32, 32), (7, 7, 7, 64, 64), (9, 4, 4, 128, 128),
                                             (2, 28, 28, 256, 16), (1, 1, 1, 128, 128), (3, 2, 3, 64, 64), (2, 56, 56, 64, 64),
-                                            (11, 5, 9, 16, 16)])
+                                            (11, 5, 9, 16, 16), (1, 56, 56, 256, 16), (3, 3, 5, 256, 16)])
 def test_conv3x3_raster_window(N, H, W, cin, cout):
     """The LDS raster-window 3x3 kernel (bf16 MFMA) against F.conv2d on bf16-rounded operands."""
     from routeformer_amd import _hip, kernels as Kn
@@ -799,7 +799,8 @@ def test_hrnet16_golden(prec, tol):
                                                 (64, 64, 5, 6, 4, True), (16, 16, 3, 28, 28, True), (16, 32, 2, 28, 28, False),
                                                 (16, 64, 2, 14, 28, True), (16, 128, 1, 56, 56, True), (32, 32, 3, 14, 14, True),
                                                 (32, 64, 3, 14, 14, False), (32, 128, 2, 28, 28, True), (64, 128, 2, 14, 14, True),
-                                                (16, 16, 2, 112, 112, False)])
+                                                (16, 16, 2, 112, 112, False), (256, 32, 2, 28, 28, False), (256, 32, 1, 56, 56, False),
+                                                (64, 64, 1, 112, 112, False), (64, 128, 3, 8, 8, False)])
 def test_conv3x3_stride2_kernel(cin, cout, N, H, W, res):
     """rf_conv3x3s2_bf16 (round 4: 3x3 / stride 2 / pad 1 on bf16 NHWC maps -- the trunk's two stem convolutions, hrnetv2.py:
     292-293,434-440, and the stride-2 chains of its fuse layers / transitions, :148-200) against torch's conv2d on the same
