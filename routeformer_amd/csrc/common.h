@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "rf_hip.h"
 
@@ -119,4 +120,12 @@ __device__ __forceinline__ float act_grad(float src, int mode) {
     case RF_ACT_ELU: return src > 0.f ? 1.f : expf(src);
     default: return 1.f;
   }
+}
+
+// Launch cap for the frozen conv trunk's kernels (they run as a side branch of the train step, underneath a chain of small
+// latency-bound launches that needs free workgroup slots on every CU): RF_TRUNK_MAX_WG > 0 bounds their grids, the kernels
+// walk their tiles in a grid-stride loop.  0 / unset: one workgroup per tile.
+inline int trunk_grid(int blocks) {
+  static const int cap = [] { const char* e = getenv("RF_TRUNK_MAX_WG"); return e ? atoi(e) : 0; }();
+  return (cap > 0 && blocks > cap) ? cap : blocks;
 }

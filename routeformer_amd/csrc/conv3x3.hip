@@ -452,7 +452,11 @@ __global__ __launch_bounds__(NT) void conv3x3s2_kernel(const __bf16* __restrict_
                                                         const float* __restrict__ bias, const __bf16* __restrict__ residual,
                                                         __bf16* __restrict__ y, int total_out, long total_in, int H, int W,
                                                         int relu) {
-  conv3x3s2_body<CIN, COUT, RT, CH>(x, wt, bias, residual, y, total_out, total_in, H, W, relu, (int)blockIdx.x);
+  const int tile_px = s2_tile_px(64 * RT, W >> 1), ntiles = (total_out + tile_px - 1) / tile_px;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    conv3x3s2_body<CIN, COUT, RT, CH>(x, wt, bias, residual, y, total_out, total_in, H, W, relu, t);
+    if (t + (int)gridDim.x < ntiles) __syncthreads();
+  }
 }
 
 // window pixels of a stride-2 workgroup: the row above + the centre rows + the row below of the output rows it touches
@@ -492,7 +496,7 @@ int launch_s2_ch(const void* x, const void* wt, const float* bias, const void* r
     attr = true;
   }
   const int tile_px = s2_tile_px(64 * RT, W / 2);
-  const int blocks = (int)((total_out + tile_px - 1) / tile_px);
+  const int blocks = trunk_grid((int)((total_out + tile_px - 1) / tile_px));
   RF_LAUNCH((conv3x3s2_kernel<CIN, COUT, RT, CH>), dim3(blocks), dim3(NT), lds, st, static_cast<const __bf16*>(x),
             static_cast<const __bf16*>(wt), bias, static_cast<const __bf16*>(residual), static_cast<__bf16*>(y), (int)total_out,
             total_in, H, W, relu);
@@ -532,7 +536,12 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(const AT* __restrict__ x, c
                                                       const float* __restrict__ bias,
                                                       const AT* __restrict__ residual, AT* __restrict__ y,
                                                       int total, int H, int W, int relu) {
-  conv3x3_body<CIN, COUT, AT, CH>(x, wt, bias, residual, y, total, H, W, relu, (int)blockIdx.x);
+  // (one tile per workgroup unless the launch was capped: trunk_grid)
+  const int ntiles = (total + TILE - 1) / TILE;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    conv3x3_body<CIN, COUT, AT, CH>(x, wt, bias, residual, y, total, H, W, relu, t);
+    if (t + (int)gridDim.x < ntiles) __syncthreads();  // the epilogue patches alias the next tile's window
+  }
 }
 
 // Grouped launch: the same convolution step of up to four INDEPENDENT maps (the branches of an HRNet module:
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(NT) void conv3x3_kernel(const AT* __restrict__ x, c
 // chip idle four times per block, launched together they disappear underneath the 28x28 branch.  Entries are
 // ordered by the host so that the longest-running workgroups (most channels) are dispatched first.
 struct ConvGroup {
-  int count, pad;
+  int count, nblocks;  // nblocks: tiles of all entries (the launch may be capped below that: trunk_grid)
   struct Item {
     const void* x; const void* w; const float* bias; const void* res; void* y;
     int total, H, W, relu, cin, first_block;
@@ -550,19 +559,22 @@ struct ConvGroup {
 
 template <typename AT>
 __global__ __launch_bounds__(NT) void conv3x3_group_kernel(const ConvGroup g) {
-  int k = 0;
-  for (int i = 1; i < g.count; ++i)
-    if ((int)blockIdx.x >= g.e[i].first_block) k = i;
-  const ConvGroup::Item& e = g.e[k];
-  const int tile = (int)blockIdx.x - e.first_block;
-  const AT* x = static_cast<const AT*>(e.x);
-  const AT* res = static_cast<const AT*>(e.res);
-  AT* y = static_cast<AT*>(e.y);
-  const __bf16* w = static_cast<const __bf16*>(e.w);
-  if (e.cin == 16) conv3x3_body<16, 16, AT>(x, w, e.bias, res, y, e.total, e.H, e.W, e.relu, tile);
-  else if (e.cin == 32) conv3x3_body<32, 32, AT>(x, w, e.bias, res, y, e.total, e.H, e.W, e.relu, tile);
-  else if (e.cin == 64) conv3x3_body<64, 64, AT>(x, w, e.bias, res, y, e.total, e.H, e.W, e.relu, tile);
-  else conv3x3_body<128, 128, AT>(x, w, e.bias, res, y, e.total, e.H, e.W, e.relu, tile);
+  for (int v = blockIdx.x; v < g.nblocks; v += gridDim.x) {
+    int k = 0;
+    for (int i = 1; i < g.count; ++i)
+      if (v >= g.e[i].first_block) k = i;
+    const ConvGroup::Item& e = g.e[k];
+    const int tile = v - e.first_block;
+    const AT* x = static_cast<const AT*>(e.x);
+    const AT* res = static_cast<const AT*>(e.res);
+    AT* y = static_cast<AT*>(e.y);
+    const __bf16* w = static_cast<const __bf16*>(e.w);
+    if (e.cin == 16) conv3x3_body<16, 16, AT>(x, w, e.bias, res, y, e.total, e.H, e.W, e.relu, tile);
+    else if (e.cin == 32) conv3x3_body<32, 32, AT>(x, w, e.bias, res, y, e.total, e.H, e.W, e.relu, tile);
+    else if (e.cin == 64) conv3x3_body<64, 64, AT>(x, w, e.bias, res, y, e.total, e.H, e.W, e.relu, tile);
+    else conv3x3_body<128, 128, AT>(x, w, e.bias, res, y, e.total, e.H, e.W, e.relu, tile);
+    if (v + (int)gridDim.x < g.nblocks) __syncthreads();
+  }
 }
 
 template <int CIN, int COUT, typename AT, int CH>
@@ -578,7 +590,7 @@ int launch_ch(const void* x, const void* wt, const float* bias, const void* resi
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  const int blocks = (int)((total + TILE - 1) / TILE);
+  const int blocks = trunk_grid((int)((total + TILE - 1) / TILE));
   RF_LAUNCH((conv3x3_kernel<CIN, COUT, AT, CH>), dim3(blocks), dim3(NT), lds, st, static_cast<const AT*>(x),
                      static_cast<const __bf16*>(wt), bias, static_cast<const AT*>(residual), static_cast<AT*>(y),
                      (int)total, H, W, relu);
@@ -672,6 +684,8 @@ extern "C" int rf_conv3x3_group_bf16(const RfConvEntry* entries, int count, int 
     attr = true;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  g.nblocks = blocks;
+  blocks = trunk_grid(blocks);
   if (act_dtype == RF_ACT_BF16) RF_LAUNCH(conv3x3_group_kernel<__bf16>, dim3(blocks), dim3(NT), lds, st, g);
   else RF_LAUNCH(conv3x3_group_kernel<float>, dim3(blocks), dim3(NT), lds, st, g);
   RF_CHECK_LAUNCH();
@@ -721,7 +735,9 @@ extern "C" int rf_conv3x3s2_bf16(const void* x, const void* w_bf16, const float*
   RF_REQUIRE(ti < (1L << 31));
   hipStream_t st = static_cast<hipStream_t>(stream);
   // 128-pixel tiles while two workgroups still fit a CU (or when the 64-pixel window does not fit at all)
-  const bool big = s2_lds(cin, cout, 2, W) <= 80 * 1024 || s2_lds(cin, cout, 1, W) > 160 * 1024;
+  // ... and the launch still has a couple of workgroups per CU (the 14 x 14 / 7 x 7 maps are a few hundred 64-pixel tiles:
+  // halving their number doubled the time of 64 -> 128 at 14 x 14)
+  const bool big = (s2_lds(cin, cout, 2, W) <= 80 * 1024 && to / s2_tile_px(128, W / 2) >= 512) || s2_lds(cin, cout, 1, W) > 160 * 1024;
 #define RF_S2_GO(CI, CO) if (cin == CI && cout == CO) return launch_s2_rt<CI, CO>(big, x, w_bf16, bias, residual, y, to, ti, H, W, relu, st)
   RF_S2_GO(4, 64); RF_S2_GO(16, 16); RF_S2_GO(16, 32); RF_S2_GO(16, 64); RF_S2_GO(16, 128); RF_S2_GO(32, 32); RF_S2_GO(32, 64);
   RF_S2_GO(32, 128); RF_S2_GO(64, 64); RF_S2_GO(64, 128); RF_S2_GO(256, 32);

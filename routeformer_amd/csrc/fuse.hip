@@ -149,7 +149,7 @@ extern "C" int rf_fuse_upsample_sum(const RfFuseEntry* entries, int count, int a
     t.first_block[p] = blocks;
     const long total = (long)e.N * e.Ho * e.Wo * (e.C / 4);
     long g = (total + 255) / 256;
-    blocks += (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+    blocks += trunk_grid((int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)));  // (grid-stride inside a part)
   }
   t.first_block[count] = blocks;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -174,7 +174,7 @@ extern "C" int rf_concat_pool_tokens(const void* const* maps, const int32_t* H, 
   RF_REQUIRE((reinterpret_cast<uintptr_t>(tokens) & 15) == 0);
   const long total = (long)N * 65 * (off / 4);
   long g = (total + 255) / 256;
-  const int grid = (int)(g > 8192 ? 8192 : g);
+  const int grid = trunk_grid((int)(g > 8192 ? 8192 : g));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (act_dtype == 1)
     RF_LAUNCH(concat_pool_tokens_kernel<__bf16>, dim3(grid), dim3(256), 0, st, br, tokens, N, H[0], W[0], off);

@@ -57,8 +57,11 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // 
   return x;
 }
 
-// One workgroup per frame.  Every 8-byte word is mixed with its position (so permutations of the content change the
-// key) and the per-thread sums are combined in a fixed order: the key depends on the bytes only.
+// Every 8-byte word is mixed with its position (so permutations of the content change the key) and the terms are ADDED
+// (wrap-around: order-independent), so a frame's words can be split over any number of workgroups: gridDim.y slices per
+// frame, each adds its partial sum into keys[frame] (zeroed by the caller's launch sequence), frame_hash_final_kernel
+// mixes the total.  (One workgroup per frame was 280 us for 64 frames of 448 x 448: 64 workgroups walking 1.2 MB each.)
+// The key depends on the bytes only -- not on the slicing.
 // Frame f of clip [B][F][bytes_per_frame] (contiguous); tail bytes (bytes % 8) are folded in as one padded word.
 __global__ __launch_bounds__(256) void frame_hash_kernel(const unsigned char* __restrict__ data, long bytes_per_frame,
                                                          const int64_t* __restrict__ frame_ids,
@@ -66,15 +69,16 @@ __global__ __launch_bounds__(256) void frame_hash_kernel(const unsigned char* __
   __shared__ unsigned long long part[256];
   const unsigned char* p = data + (frame_ids ? (long)frame_ids[blockIdx.x] : (long)blockIdx.x) * bytes_per_frame;
   const long words = bytes_per_frame >> 3;
+  const long per = (words + gridDim.y - 1) / gridDim.y, w0 = (long)blockIdx.y * per, w1 = min(words, w0 + per);
   unsigned long long h = 0;
   const bool aligned = (reinterpret_cast<uintptr_t>(p) & 7) == 0;
-  for (long i = threadIdx.x; i < words; i += 256) {
+  for (long i = w0 + threadIdx.x; i < w1; i += 256) {
     unsigned long long v;
     if (aligned) v = reinterpret_cast<const unsigned long long*>(p)[i];
     else { v = 0; for (int b = 0; b < 8; ++b) v |= (unsigned long long)p[i * 8 + b] << (8 * b); }
     h += mix64(v ^ mix64((unsigned long long)i + seed));
   }
-  if (threadIdx.x == 0 && (bytes_per_frame & 7)) {
+  if (threadIdx.x == 0 && blockIdx.y == 0 && (bytes_per_frame & 7)) {
     unsigned long long v = 0;
     for (int b = 0; b < (int)(bytes_per_frame & 7); ++b) v |= (unsigned long long)p[words * 8 + b] << (8 * b);
     h += mix64(v ^ mix64((unsigned long long)words + seed));
@@ -85,10 +89,14 @@ __global__ __launch_bounds__(256) void frame_hash_kernel(const unsigned char* __
     if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];  // wrap-around addition: order-independent
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    unsigned long long k = mix64(part[0] ^ ((unsigned long long)bytes_per_frame * 0x9E3779B97F4A7C15ull));
-    keys[blockIdx.x] = k == 0 ? 1 : k;  // 0 marks an empty table entry
-  }
+  if (threadIdx.x == 0) atomicAdd(&keys[blockIdx.x], part[0]);
+}
+
+__global__ void frame_hash_final_kernel(unsigned long long* __restrict__ keys, int n, long bytes_per_frame) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = mix64(keys[i] ^ ((unsigned long long)bytes_per_frame * 0x9E3779B97F4A7C15ull));
+  keys[i] = k == 0 ? 1 : k;  // 0 marks an empty table entry
 }
 
 // ---- key -> slot table (open addressing, linear probing; capacity a power of two; key 0 = empty) ----------------------
@@ -204,9 +212,23 @@ extern "C" int rf_resize_area(const uint8_t* src, uint8_t* dst, int64_t n_planes
 extern "C" int rf_frame_hash(const void* frames, const int64_t* frame_ids, int64_t n_frames, int64_t bytes_per_frame,
                              uint64_t* keys, int64_t seed, void* stream) {
   RF_REQUIRE(frames && keys && n_frames > 0 && n_frames < (1 << 30) && bytes_per_frame > 0);
-  RF_LAUNCH(frame_hash_kernel, dim3((int)n_frames), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // slices per frame: towards ~2k workgroups, at least 16 KB of frame each
+  long slices = (2048 + n_frames - 1) / n_frames;
+  const long most = bytes_per_frame / (16 * 1024);
+  if (slices > most) slices = most;
+  if (slices < 1) slices = 1;
+  if (slices > 1024) slices = 1024;
+  if (hipMemsetAsync(keys, 0, (size_t)n_frames * sizeof(uint64_t), st) != hipSuccess) {
+    rf_g_last_error = "rf_frame_hash: hipMemsetAsync failed";
+    return RF_ELAUNCH;
+  }
+  RF_LAUNCH(frame_hash_kernel, dim3((int)n_frames, (int)slices), dim3(256), 0, st,
             static_cast<const unsigned char*>(frames), (long)bytes_per_frame, frame_ids,
             reinterpret_cast<unsigned long long*>(keys), (unsigned long long)seed);
+  RF_CHECK_LAUNCH();
+  RF_LAUNCH(frame_hash_final_kernel, dim3((int)((n_frames + 127) / 128)), dim3(128), 0, st,
+            reinterpret_cast<unsigned long long*>(keys), (int)n_frames, (long)bytes_per_frame);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

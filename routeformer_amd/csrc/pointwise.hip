@@ -129,7 +129,7 @@ int launch(const void* x, const void* wt, const float* bias, const void* residua
   }
   const int groups = ((M + 15) / 16 + 3) / 4;
   const int per_cu = (int)(160 * 1024 / lds) < 4 ? (int)(160 * 1024 / lds) : 4;  // co-resident workgroups per CU
-  const int grid = groups < 256 * per_cu ? groups : 256 * per_cu;              // persistent: every wave streams tiles
+  const int grid = trunk_grid(groups < 256 * per_cu ? groups : 256 * per_cu);  // persistent: every wave streams tiles
   RF_LAUNCH((pointwise_kernel<CIN, COUT>), dim3(grid), dim3(NT), lds, st, static_cast<const __bf16*>(x),
                      static_cast<const __bf16*>(wt), bias, static_cast<const __bf16*>(residual),
                      static_cast<__bf16*>(y), M, relu);
