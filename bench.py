@@ -519,7 +519,7 @@ def main():
             # separately, gfx950 x2 read correction applied; bench.py itself cannot collect counters)
             traffic, traffic_src = None, None
             try:
-                for rnd in ("r03", "r02", "r01"):  # the newest committed PMC pass that knows this kernel
+                for rnd in ("r04", "r03", "r02", "r01"):  # the newest committed PMC pass that knows this kernel
                     path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
                     if os.path.exists(path):
                         with open(path) as fh:

@@ -386,7 +386,8 @@ typedef struct RfSeqStack {
   int n_layers;
   int flags; /* bit 0: ctx, x1 and (when z is given) h are bf16 slabs -- they are bf16-rounded MFMA operands in the kernel
                 anyway, and only the weight-gradient GEMMs (RfWgradEntry.x_bf16) read them again;
-                bit 1: qkv is a bf16 slab (rf_seqlayer_bwd, flags bit 1, rounds q | k | v to bf16 on load either way).
+                bit 1: qkv is a bf16 slab (rf_seqlayer_bwd, flags bit 1, rounds q | k | v to bf16 on load either way);
+                bit 2: xhat1, xhat2 and z are bf16 slabs (NOT lossless: the backward's fp32 math reads them).
                 With `xin` given only the LAST layer's output is written (y = ONE [B*L, 128] slab): nothing reads the others */
 } RfSeqStack;
 typedef struct RfSeqPackEntry {
@@ -435,7 +436,8 @@ typedef struct RfSeqStackBwd {
   float* dgamma2[RF_SEQLAYER_MAX_LAYERS]; float* dbeta2[RF_SEQLAYER_MAX_LAYERS];
   int n_layers;
   int flags; /* bit 0: dpre2 / dz / dpre1 / dqkv are bf16 slabs (RfWgradEntry.dy_bf16 for the weight-gradient GEMMs);
-                bit 1: qkv points to the bf16 slab rf_seqlayer_fwd wrote with ITS flags bit 1 */
+                bit 1: qkv points to the bf16 slab rf_seqlayer_fwd wrote with ITS flags bit 1;
+                bit 2: xhat1 / xhat2 are bf16 slabs; bit 3: zsrc is a bf16 slab */
 } RfSeqStackBwd;
 int64_t rf_seqlayer_bwd_pack_bytes(int d_ff);
 int rf_seqlayer_bwd(const RfSeqStackBwd* stack, const float* dy, float* dx, int B, int L, int d_model, int n_heads,

@@ -405,7 +405,7 @@ __global__ __launch_bounds__(SL_NT) void enc_tile_bwd_kernel(const EncTileBwdP p
   f32x4 res[RT];
 
   // ================= norm2 backward (its first barrier also fences the dq image reads above) =================
-  stack_ln_bwd<RT>(dyres, p.xhat2 + row0 * SL_D + col, p.rstd2 + row0, vec[SL_D + col], p.dg2 + col, p.db2 + col, L, part, stat,
+  stack_ln_bwd<RT>(dyres, p.xhat2, (long)row0 * SL_D + col, 0, p.rstd2 + row0, vec[SL_D + col], p.dg2 + col, p.db2 + col, L, part, stat,
                    wave, lane);
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(SL_NT) void enc_tile_bwd_kernel(const EncTileBwdP p
       }
     }
   }
-  stack_ln_bwd<RT>(dyres, p.xhat1 + row0 * SL_D + col, p.rstd1 + row0, vec[col], p.dg1 + col, p.db1 + col, L, part, stat, wave,
+  stack_ln_bwd<RT>(dyres, p.xhat1, (long)row0 * SL_D + col, 0, p.rstd1 + row0, vec[col], p.dg1 + col, p.db1 + col, L, part, stat, wave,
                    lane);  // (its barriers fence the xb reads of the dz phase)
   if constexpr (DROP) {
     store_tiles(dyres, p.dskip + row0 * SL_D + wave * 16, SL_D);  // the skip carries the unmasked gradient

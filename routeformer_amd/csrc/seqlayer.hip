@@ -36,7 +36,7 @@ struct SeqStackP {
   int32_t* top;                 // (layers, B, 8, n_top): written (read when force_top); may be null without save
   float* y;                     // (layers, B*L, 128): layer outputs
   float *qkv, *ctx, *xhat1, *rstd1, *x1, *z, *h, *xhat2, *rstd2;  // training saves (layers, B*L, width)
-  int bf16_saves;  // RfSeqStack.flags: bit 0 = ctx, x1 and (with z) h are bf16 slabs; bit 1 = qkv is a bf16 slab
+  int bf16_saves;  // RfSeqStack.flags: bit 0 = ctx, x1 and (with z) h are bf16 slabs; bit 1 = qkv; bit 2 = xhat1, xhat2, z
   __bf16* xin;     // optional bf16 (layers, B*L, 128): every layer's input image
   int B, L, F, n_layers, act, sample_k, n_top, idx_group, force_top, save;
   int split;  // 1: q / k projection and sparsity-measure scores in split-bf16 (default); 0: plain bf16 (RF_SEQ_SPLIT=0, A/B only)
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
         save_image_as(xb, SL_XP, SL_D, p.ctx, lrow * SL_D, L, tid, (p.bf16_saves & 1) != 0);
       stack_layer_norm<RT>(v, SAVE ? p.rstd1 + lrow : nullptr, L, part, stat, wave, lane, p.eps);  // (barriers fence the ctx reads)
       if (SAVE) {  // x-hat of norm1: RT staged tiles, one sync pair
-        float* xh_g = p.xhat1 + lrow * SL_D + wave * 16;
+        const long xh_o = lrow * SL_D + wave * 16;  // (element offset: the slab is fp32 or, flags bit 2, bf16)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -502,7 +502,8 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
           if (rt * 16 + srow < L)
-            *reinterpret_cast<float4*>(xh_g + (rt * 16 + srow) * SL_D + sc4) = *reinterpret_cast<const float4*>(sc_f + rt * TB + srow * 20 + sc4);
+            store_qkv4(p.xhat1, xh_o + (rt * 16 + srow) * SL_D + sc4, *reinterpret_cast<const float4*>(sc_f + rt * TB + srow * 20 + sc4),
+                       p.bf16_saves & 4);
         wave_sync_lds();
       }
 #pragma unroll
@@ -536,8 +537,8 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
     // ================= phase 4: conv1 + activation (wave = column tiles wave, wave + 8) =================
     const bool h_img = SAVE && (p.bf16_saves & 1) && p.z;  // h leaves as the bf16 image it is for conv2 (z stays fp32: GELU' reads it)
     {
-      float* z_g = (SAVE && p.z) ? p.z + lrow * F : nullptr;
-      float* h_g = (SAVE && !h_img) ? p.h + lrow * F : nullptr;
+      float* z_g = (SAVE && p.z) ? p.z : nullptr;  // (+ lrow * F elements: fp32 or, flags bit 2, bf16)
+      float* h_g = (SAVE && !h_img) ? p.h : nullptr;
 #pragma unroll 1
       for (int ct = wave; ct < F / 16; ct += SL_NW) {
         bf16x8 wf1[4];
@@ -593,7 +594,8 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
 #pragma unroll
               for (int rt = 0; rt < RT; ++rt)
                 if (rt * 16 + srow < L)
-                  *reinterpret_cast<float4*>(dst + (rt * 16 + srow) * F + ct * 16 + sc4) = *reinterpret_cast<const float4*>(sc_f + rt * TB + srow * 20 + sc4);
+                  store_qkv4(dst, (lrow + rt * 16 + srow) * F + ct * 16 + sc4, *reinterpret_cast<const float4*>(sc_f + rt * TB + srow * 20 + sc4),
+                             which == 0 ? (p.bf16_saves & 4) : 0);
               wave_sync_lds();
             }
           }
@@ -645,7 +647,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
       const bool store_y = all_y || li == p.n_layers - 1;
       float* y_g = p.y + (all_y ? lrow : (long)b * L) * SL_D + wave * 16;
       if (SAVE) {
-        float* xh_g = p.xhat2 + lrow * SL_D + wave * 16;
+        const long xh_o = lrow * SL_D + wave * 16;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -654,7 +656,8 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_fwd_kernel(const SeqStackP p)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
           if (rt * 16 + srow < L)
-            *reinterpret_cast<float4*>(xh_g + (rt * 16 + srow) * SL_D + sc4) = *reinterpret_cast<const float4*>(sc_f + rt * TB + srow * 20 + sc4);
+            store_qkv4(p.xhat2, xh_o + (rt * 16 + srow) * SL_D + sc4, *reinterpret_cast<const float4*>(sc_f + rt * TB + srow * 20 + sc4),
+                       p.bf16_saves & 4);
         wave_sync_lds();
       }
 #pragma unroll
@@ -819,7 +822,7 @@ extern "C" int rf_seqlayer_fwd(const RfSeqStack* st_, const float* x, int B, int
   p.idx_stride = s.idx_stride > 0 ? s.idx_stride : (long)L * sample_k;
   p.top = s.top; p.y = s.y;
   p.qkv = s.qkv; p.ctx = s.ctx; p.xhat1 = s.xhat1; p.rstd1 = s.rstd1; p.x1 = s.x1; p.z = s.z; p.h = s.h;
-  p.xhat2 = s.xhat2; p.rstd2 = s.rstd2; p.bf16_saves = save ? (s.flags & 3) : 0;
+  p.xhat2 = s.xhat2; p.rstd2 = s.rstd2; p.bf16_saves = save ? (s.flags & 7) : 0;
   p.xin = save ? static_cast<__bf16*>(s.xin) : nullptr;
   RF_REQUIRE(!p.xin || al16(p.xin));
   p.B = B; p.L = L; p.F = d_ff; p.n_layers = s.n_layers; p.act = act; p.sample_k = sample_k; p.n_top = n_top;

@@ -38,6 +38,7 @@ struct SeqStackBwdP {
   int B, L, F, n_layers, act, n_top;
   int bf16_grads;  // dpre2 / dz / dpre1 / dqkv are bf16 slabs (RfSeqStackBwd.flags & 1)
   int qkv_bf16;    // the saved q | k | v slab is bf16 (RfSeqStackBwd.flags & 2)
+  int norm_bf16, z_bf16;  // xhat1 / xhat2 and zsrc are bf16 slabs (RfSeqStackBwd.flags & 4 / & 8)
   float scale;
   DropCfg drop;   // the forward's nn.Dropout masks are regenerated from (seed, step, site, element); state == null: off
   int drop_site0; // layer i: sites drop_site0 + 3 i + {0: attention output, 1: hidden activation, 2: conv2 output}
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
     SLB_MARK(0);
     // ================= norm2 backward =================
     SLB_LOCAL();
-    stack_ln_bwd<RT>(dyres, p.xhat2 + lrow * SL_D + col, p.rstd2 + lrow, vec[SL_D + col], p.dg2[li] + col, p.db2[li] + col, L,
+    stack_ln_bwd<RT>(dyres, p.xhat2, lrow * SL_D + col, p.norm_bf16, p.rstd2 + lrow, vec[SL_D + col], p.dg2[li] + col, p.db2[li] + col, L,
                      part, stat, wave, lane);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
     // ================= conv2^T + activation' : dz (wave = column tiles wave, wave + 8, ...) =================
     SLB_LOCAL();
     {
-      const float* zs = p.zsrc + lrow * F;
+      const long zs = lrow * F;  // (element offset into the z / h slab: fp32 or, flags bit 2 with z, bf16)
 #pragma unroll 1
       for (int ct = wave; ct < F / 16; ct += SL_NW) {
         bf16x8 wf[4];
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) zz[rt][r] = zs[(long)min(rt * 16 + fq * 4 + r, L - 1) * F + ct * 16 + fr];
+          for (int r = 0; r < 4; ++r) zz[rt][r] = ld_save1(p.zsrc, zs + (long)min(rt * 16 + fq * 4 + r, L - 1) * F + ct * 16 + fr, p.z_bf16);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(SL_NT) void seq_stack_bwd_kernel(const SeqStackBwdP
         }
       }
     }
-    stack_ln_bwd<RT>(dyres, p.xhat1 + lrow * SL_D + col, p.rstd1 + lrow, vec[col], p.dg1[li] + col, p.db1[li] + col, L, part,
+    stack_ln_bwd<RT>(dyres, p.xhat1, lrow * SL_D + col, p.norm_bf16, p.rstd1 + lrow, vec[col], p.dg1[li] + col, p.db1[li] + col, L, part,
                      stat, wave, lane);  // (its barriers fence the xb reads of the dz phase)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -569,6 +570,8 @@ extern "C" int rf_seqlayer_bwd(const RfSeqStackBwd* st_, const float* dy, float*
   p.B = B; p.L = L; p.F = d_ff; p.n_layers = s.n_layers; p.act = act; p.n_top = n_top; p.scale = scale;
   p.bf16_grads = s.flags & 1;
   p.qkv_bf16 = (s.flags & 2) ? 1 : 0;
+  p.norm_bf16 = (s.flags & 4) ? 1 : 0;
+  p.z_bf16 = (s.flags & 8) ? 1 : 0;
   RF_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state));
   p.drop = make_drop_cfg(rng_state, nullptr, 0, drop_p);
   p.drop_site0 = drop_site0;

@@ -97,6 +97,9 @@ __device__ __forceinline__ bf16x8 ld_qkv8(const void* base, long off, int bf) { 
   bf16x8 o = {(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
   return o;
 }
+__device__ __forceinline__ float ld_save1(const void* base, long off, int bf) {  // one element of an fp32 / bf16 save slab
+  return bf ? (float)reinterpret_cast<const __bf16*>(base)[off] : reinterpret_cast<const float*>(base)[off];
+}
 __device__ __forceinline__ __bf16 ld_qkv1(const void* base, long off, int bf) {
   return bf ? reinterpret_cast<const __bf16*>(base)[off] : (__bf16)reinterpret_cast<const float*>(base)[off];
 }
@@ -198,7 +201,8 @@ __device__ __forceinline__ float sl_gelu_grad(float x) {  // Phi(x) + x phi(x), 
 //   g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  dgamma += sum_rows dy * xhat;  dbeta += sum_rows dy.
 // In: g = dy (rows >= L hold zeros).  Out: g = dx (rows >= L stay zero).  Two workgroup barriers.
 template <int RT>
-__device__ __forceinline__ void stack_ln_bwd(f32x4 (&g)[RT], const float* __restrict__ xhat_g, const float* __restrict__ rstd_g,
+__device__ __forceinline__ void stack_ln_bwd(f32x4 (&g)[RT], const float* __restrict__ xhat_base, long xhat_off, int xhat_bf16,
+                                             const float* __restrict__ rstd_g,
                                              float gamma, float* __restrict__ dgam, float* __restrict__ dbet, int L,
                                              float2* __restrict__ part, float4* __restrict__ stat, int wave, int lane) {
   const int fr = lane & 15, fq = lane >> 4;
@@ -206,7 +210,7 @@ __device__ __forceinline__ void stack_ln_bwd(f32x4 (&g)[RT], const float* __rest
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xh[rt][r] = xhat_g[min(rt * 16 + fq * 4 + r, L - 1) * SL_D];
+    for (int r = 0; r < 4; ++r) xh[rt][r] = ld_save1(xhat_base, xhat_off + (long)min(rt * 16 + fq * 4 + r, L - 1) * SL_D, xhat_bf16);
   float dg = 0.f, db = 0.f;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)

@@ -2192,7 +2192,10 @@ def _seqstack_bwd_launch(dy2, sv, wpack, stride, ln_slots, B, L, F_, act, n_top,
     dx = torch.empty(M, 128, **f32)
     st = _hip.SeqStackBwd()
     st.wpack, st.wpack_stride, st.n_layers = wpack.data_ptr(), stride, n
-    st.flags = (1 if BF16_SAVES else 0) | (2 if sv["qkv"].dtype == torch.bfloat16 else 0)
+    zsrc = sv["z"] if "z" in sv else sv["h"]
+    assert sv["xhat1"].dtype == sv["xhat2"].dtype
+    st.flags = ((1 if BF16_SAVES else 0) | (2 if sv["qkv"].dtype == torch.bfloat16 else 0)
+                | (4 if sv["xhat1"].dtype == torch.bfloat16 else 0) | (8 if zsrc.dtype == torch.bfloat16 else 0))
     for name in ("qkv", "xhat1", "rstd1", "xhat2", "rstd2", "top"):
         setattr(st, name, ptr(sv[name]))
     st.zsrc = ptr(sv["z"] if "z" in sv else sv["h"])
@@ -2227,6 +2230,9 @@ def seqstack_pack_bytes(d_ff: int) -> int:
 # 732 -> 553 MB by its backward, 355 -> 281 MB per weight-gradient launch.
 BF16_SAVES = os.environ.get("RF_BF16_SAVES", "1") != "0"
 BF16_QKV = os.environ.get("RF_BF16_QKV", "1") != "0"  # ... and the saved q | k | v (measurement switch)
+# x-hat of both norms and the pre-activation z as bf16 as well: NOT lossless (the backward's fp32 element-wise math reads them:
+# 2^-9 relative on x-hat / z), halves the rest of what the stacks save.  RF_BF16_NORM_SAVES=1 turns it on.
+BF16_NORM_SAVES = os.environ.get("RF_BF16_NORM_SAVES", "0") == "1"
 
 
 def _seqstack_launch(x2, wpack, stride, idx_list, idx_group, B, L, F_, act, sample_k, n_top, save, forced_tops, eps,
@@ -2249,17 +2255,19 @@ def _seqstack_launch(x2, wpack, stride, idx_list, idx_group, B, L, F_, act, samp
         bf = dict(device=dev, dtype=torch.bfloat16)
         # q | k | v: the backward's matrix cores consume them rounded to bf16 whatever the slab holds (lossless as well)
         for name, width in (("qkv", 384), ("ctx", 128), ("xhat1", 128), ("x1", 128), ("xhat2", 128), ("h", F_)):
-            as_bf = half and (name in ("ctx", "x1") or (name == "qkv" and BF16_QKV) or (name == "h" and act == "gelu"))
+            as_bf = half and (name in ("ctx", "x1") or (name == "qkv" and BF16_QKV) or (name == "h" and act == "gelu")
+                              or (name in ("xhat1", "xhat2") and BF16_NORM_SAVES))
             sv[name] = torch.empty(n, M, width, **(bf if as_bf else f32))
         if act == "gelu":
-            sv["z"] = torch.empty(n, M, F_, **f32)
+            sv["z"] = torch.empty(n, M, F_, **(bf if (half and BF16_NORM_SAVES) else f32))
         if half:  # every layer's input as the projection consumed it: the x operand of its weight gradient
             sv["xin"] = torch.empty(n, M, 128, **bf)
         sv["rstd1"] = torch.empty(n, M, **f32)
         sv["rstd2"] = torch.empty(n, M, **f32)
     st = _hip.SeqStack()
     st.wpack, st.wpack_stride, st.n_layers = wpack.data_ptr(), stride, n
-    st.flags = (3 if BF16_QKV else 1) if half else 0  # bit 0: ctx / x1 / h, bit 1: q | k | v are bf16 slabs
+    # bit 0: ctx / x1 / h, bit 1: q | k | v, bit 2: xhat1 / xhat2 / z are bf16 slabs
+    st.flags = (1 | (2 if BF16_QKV else 0) | (4 if BF16_NORM_SAVES else 0)) if half else 0
     idx_stride = 0
     for i, t in enumerate(idx_list):
         assert t.dim() == 3 and t.dtype == torch.int32 and t.stride(2) == 1 and t.stride(1) == t.shape[2], "key-sample table"
