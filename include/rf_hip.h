@@ -126,6 +126,16 @@ typedef struct RfConvEntry {
 int rf_conv3x3_group_bf16(const RfConvEntry* entries, int count, int act_dtype, void* stream);
 int rf_conv3x3_bf16(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,
                     int act_dtype, int N, int H, int W, int cin, int cout, int relu, void* stream);
+/* BasicBlock pair on bf16 NHWC maps (round 4): y = relu(conv2(relu(conv1(x) + bias1)) + bias2 + x) of hrnetv2.py:45-61 in one
+ * launch, the intermediate map in LDS; c = cin = cout in {16, 32, 64, 128}; weights in rf_conv3x3_pack_bf16 order (BatchNorm
+ * folded); up to four independent maps (the branches of an HRNet module) per launch; y must not alias x.  Results are
+ * bit-identical to two rf_conv3x3_bf16 launches with a bf16 intermediate map. */
+typedef struct RfConvPairEntry {
+  const void* x; const void* w1_packed; const float* bias1; const void* w2_packed; const float* bias2; void* y;
+  int N, H, W, c;
+} RfConvPairEntry;
+int rf_conv3x3_pair_supported(int c, int W);
+int rf_conv3x3_pair_group_bf16(const RfConvPairEntry* entries, int count, void* stream);
 /* 3x3 / stride 2 / pad 1 on bf16 NHWC maps (round 4): the trunk's two stem convolutions (hrnetv2.py:292-293,434-440: cin 4 -- the
  * 3 + 1 channels rf_stem_conv0 writes -- and 64 -> 64) and the stride-2 chains of the cross-resolution fuse layers and transitions
  * (hrnetv2.py:148-200,337-370: cin in {16, 32, 64} -> cout in {16, 32, 64, 128}, cout >= cin); H, W even.  Weights: [cout][3][3][cin]

@@ -31,6 +31,8 @@ SIGNATURES = {
     "rf_conv3x3_pack_bf16": [_P, _P, _I, _I, _P],
     "rf_conv3x3_group_bf16": [_P, _I, _I, _P],
     "rf_conv3x3_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "rf_conv3x3_pair_supported": [_I, _I],
+    "rf_conv3x3_pair_group_bf16": [_P, _I, _P],
     "rf_conv3x3s2_bf16_supported": [_I, _I, _I],
     "rf_conv3x3s2_packed_elems": [_I, _I],
     "rf_conv3x3s2_pack_bf16": [_P, _P, _I, _I, _P],
@@ -162,6 +164,12 @@ class ConvEntry(ctypes.Structure):
     """RfConvEntry of include/rf_hip.h."""
     _fields_ = [("x", c_void_p), ("w_packed", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("y", c_void_p),
                 ("N", c_int), ("H", c_int), ("W", c_int), ("cin", c_int), ("cout", c_int), ("relu", c_int)]
+
+
+class ConvPairEntry(ctypes.Structure):
+    """RfConvPairEntry of include/rf_hip.h."""
+    _fields_ = [("x", c_void_p), ("w1_packed", c_void_p), ("bias1", c_void_p), ("w2_packed", c_void_p), ("bias2", c_void_p),
+                ("y", c_void_p), ("N", c_int), ("H", c_int), ("W", c_int), ("c", c_int)]
 
 
 SEQLAYER_MAX_LAYERS, SEQLAYER_MAX_PACK = 8, 64  # RF_SEQLAYER_MAX_LAYERS / RF_SEQLAYER_MAX_PACK

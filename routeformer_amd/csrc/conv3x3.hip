@@ -243,6 +243,231 @@ __device__ __forceinline__ void conv3x3_body(const AT* __restrict__ x, const __b
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// BasicBlock pair (round 4):  y = relu(conv2(relu(conv1(x) + b1)) + b2 + x)  (hrnetv2.py:45-61) in ONE launch on bf16
+// maps, the intermediate map in LDS.  Same raster-window formulation: a workgroup owns 128 consecutive output pixels m0 ..
+// m0 + 127; conv2 needs the intermediate on the span [m0 - W - 1, m0 + 127 + W + 1], conv1 therefore runs on that whole span
+// (1.2 - 1.9 x the tile's conv1 work, matrix-core time that was idle anyway) from an input window of TILE + 4 W + 4 pixels staged
+// once.  The residual comes out of the staged window.  HBM: x read once, y written once -- the two-launch form writes and re-reads
+// the intermediate and reads x twice.  Border taps are masked per OUTPUT pixel exactly as in conv3x3_body, so intermediate values at
+// raster positions outside the image (or in the neighbouring image) are never read.  The arithmetic is the two-launch path's
+// (same fragments, same k order, intermediate rounded to bf16): bit-identical results.
+template <int C>
+__device__ __forceinline__ void conv3x3_pair_body(const __bf16* __restrict__ x, const __bf16* __restrict__ w1,
+                                                  const float* __restrict__ b1, const __bf16* __restrict__ w2,
+                                                  const float* __restrict__ b2, __bf16* __restrict__ y, int total, int H, int W,
+                                                  int tile) {
+  constexpr int LDC = C + 8;
+  constexpr int KSTEPS = (C == 16) ? 5 : 9 * (C / 32);
+  constexpr int NTL = C / 16;
+  constexpr int PF = NTL >= 8 ? 2 : pf_depth(KSTEPS, NTL);  // (128 channels: 64 accumulator registers + 32 per ring stage)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const long m0 = (long)tile * TILE;
+  const int span_m = TILE + 2 * W + 2, span_x = TILE + 4 * W + 4;
+  __bf16* xw = rf_conv_win;                 // input window: raster [m0 - 2W - 2, m0 + 127 + 2W + 2]
+  __bf16* mid = rf_conv_win + span_x * LDC; // intermediate:  raster [m0 - W - 1,  m0 + 127 + W + 1]
+  const long sx0 = m0 - 2 * W - 2;
+
+  // ---- stage the input window ----
+  {
+    constexpr int VPP = C / 8, U = 4;
+    const int nvec = span_x * VPP;
+    for (int base = 0; base < nvec; base += NT * U) {
+      float4 raw[U];
+      int at[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + tid + u * NT;
+        const int px = i / VPP, c = (i % VPP) * 8;
+        const long g = sx0 + px;
+        at[u] = i < nvec ? px * LDC + c : -1;
+        raw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nvec && g >= 0 && g < total) raw[u] = *reinterpret_cast<const float4*>(x + g * C + c);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (at[u] >= 0) *reinterpret_cast<float4*>(xw + at[u]) = raw[u];
+    }
+  }
+  auto tap_mask = [&](long m) -> unsigned {  // bit t set <=> tap t of output pixel m reads inside its image
+    unsigned msk = 0;
+    if (m >= 0 && m < total) {
+      const int w_ = (int)(m % W), h_ = (int)((m / W) % H);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int hi = h_ + t / 3 - 1, wi = w_ + t % 3 - 1;
+        if (hi >= 0 && hi < H && wi >= 0 && wi < W) msk |= 1u << t;
+      }
+    }
+    return msk;
+  };
+  auto ldb = [&](const __bf16* wt, int s, int j) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(wt + ((long)(s * NTL + j) * 64 + lane) * 8);
+  };
+  // one pass of the k loop over two row tiles whose centre pixels sit at window indices pl[0], pl[1] of `win`
+  auto kloop = [&](const __bf16* win, const __bf16* wt, const int (&pl)[2], const unsigned (&vmask)[2], f32x4 (&acc)[2][NTL]) {
+    bf16x8 bq[PF][NTL];
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) bq[d][j] = ldb(wt, d, j);
+#pragma unroll 1
+    for (int s0 = 0; s0 < KSTEPS; s0 += PF) {
+#pragma unroll
+      for (int d = 0; d < PF; ++d) {
+        const int s = s0 + d;
+        if (s < KSTEPS) {
+          int tap, c0;
+          if constexpr (C == 16) { tap = 2 * s + (fq >> 1); c0 = (fq & 1) * 8; }
+          else { tap = s / (C / 32); c0 = (s % (C / 32)) * 32 + fq * 8; }
+          const int toff = (tap < 9) ? (tap / 3 - 1) * W + (tap % 3 - 1) : 0;
+          bf16x8 a[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const bool ok = tap < 9 && ((vmask[i] >> tap) & 1u);
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(win + (pl[i] + (ok ? toff : 0)) * LDC + c0);
+            if (!ok) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            a[i] = v;
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[d][j], acc[i][j], 0, 0, 0);
+          if (s + PF < KSTEPS) {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) bq[d][j] = ldb(wt, s + PF, j);
+          }
+        }
+      }
+    }
+  };
+  __syncthreads();  // input window staged
+
+  // ---- conv1 + bias + ReLU on the whole intermediate span, two row tiles per wave and pass ----
+  const int n_mt = (span_m + 15) >> 4;
+  for (int t0 = wave * 2; t0 < n_mt; t0 += 8) {
+    int pl[2];
+    unsigned vmask[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = min((t0 + i) * 16 + fr, span_m - 1);  // (clamped: the lanes of a partial last tile recompute its last pixel)
+      pl[i] = p + W + 1;                                  // the intermediate pixel's index in the INPUT window
+      vmask[i] = tap_mask(m0 - W - 1 + p);
+    }
+    f32x4 acc[2][NTL];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    kloop(xw, w1, pl, vmask, acc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+        const float bj = b1[j * 16 + fr];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = (t0 + i) * 16 + fq * 4 + r;
+          if (p < span_m) mid[p * LDC + j * 16 + fr] = (__bf16)fmaxf(acc[i][j][r] + bj, 0.f);
+        }
+      }
+  }
+  __syncthreads();  // intermediate complete
+
+  // ---- conv2 on the tile's 128 pixels ----
+  int pl[2];
+  unsigned vmask[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = wave * 32 + i * 16 + fr;
+    pl[i] = p + W + 1;
+    vmask[i] = tap_mask(m0 + p < total ? m0 + p : -1);
+  }
+  f32x4 acc[2][NTL];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  kloop(mid, w2, pl, vmask, acc);
+
+  // ---- epilogue: + bias + x (from the staged window) -> ReLU -> y; fp32 patch per wave over the dead intermediate ----
+  constexpr int SP = C + 4;
+  float* patch = reinterpret_cast<float*>(mid) + wave * 16 * SP;
+  __syncthreads();  // every wave is done reading the intermediate
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) patch[(fq * 4 + r) * SP + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    constexpr int VPP = C / 8;
+    for (int v = lane; v < 16 * VPP; v += 64) {
+      const int px = v / VPP, c = (v % VPP) * 8;
+      const int p = wave * 32 + i * 16 + px;
+      const long m = m0 + p;
+      if (m < total) {
+        float4 lo = *reinterpret_cast<const float4*>(patch + px * SP + c);
+        float4 hi = *reinterpret_cast<const float4*>(patch + px * SP + c + 4);
+        const float4 c0 = *reinterpret_cast<const float4*>(b2 + c), c1 = *reinterpret_cast<const float4*>(b2 + c + 4);
+        const bf16x8 rx = *reinterpret_cast<const bf16x8*>(xw + (p + 2 * W + 2) * LDC + c);
+        // (bias first, then the residual: the two-launch path's order of the fp32 additions)
+        lo.x += c0.x; lo.y += c0.y; lo.z += c0.z; lo.w += c0.w;
+        hi.x += c1.x; hi.y += c1.y; hi.z += c1.z; hi.w += c1.w;
+        lo.x += (float)rx[0]; lo.y += (float)rx[1]; lo.z += (float)rx[2]; lo.w += (float)rx[3];
+        hi.x += (float)rx[4]; hi.y += (float)rx[5]; hi.z += (float)rx[6]; hi.w += (float)rx[7];
+        lo.x = fmaxf(lo.x, 0.f); lo.y = fmaxf(lo.y, 0.f); lo.z = fmaxf(lo.z, 0.f); lo.w = fmaxf(lo.w, 0.f);
+        hi.x = fmaxf(hi.x, 0.f); hi.y = fmaxf(hi.y, 0.f); hi.z = fmaxf(hi.z, 0.f); hi.w = fmaxf(hi.w, 0.f);
+        act_st4(y + m * C + c, lo);
+        act_st4(y + m * C + c + 4, hi);
+      }
+    }
+    if (i == 0) __syncthreads();  // the patch is rewritten by the second row tile
+  }
+}
+
+inline size_t pair_lds(int c, int W) {
+  const size_t win = (size_t)((TILE + 4 * W + 4) + (TILE + 2 * W + 2)) * (c + 8) * sizeof(__bf16);
+  return win;  // (the epilogue patches, 4 x 16 x (c + 4) floats, fit inside the intermediate: TILE + 2 W + 2 >= 130 pixels)
+}
+
+struct ConvPairGroup {
+  int count, nblocks;
+  struct Item {
+    const __bf16* x; const __bf16* w1; const float* b1; const __bf16* w2; const float* b2; __bf16* y;
+    int total, H, W, c, first_block;
+  } e[4];
+};
+
+__global__ __launch_bounds__(NT) void conv3x3_pair_group_kernel(const ConvPairGroup g) {
+  for (int v = blockIdx.x; v < g.nblocks; v += gridDim.x) {
+    int k = 0;
+    for (int i = 1; i < g.count; ++i)
+      if (v >= g.e[i].first_block) k = i;
+    const ConvPairGroup::Item& e = g.e[k];
+    const int tile = v - e.first_block;
+    if (e.c == 16) conv3x3_pair_body<16>(e.x, e.w1, e.b1, e.w2, e.b2, e.y, e.total, e.H, e.W, tile);
+    else if (e.c == 32) conv3x3_pair_body<32>(e.x, e.w1, e.b1, e.w2, e.b2, e.y, e.total, e.H, e.W, tile);
+    else if (e.c == 64) conv3x3_pair_body<64>(e.x, e.w1, e.b1, e.w2, e.b2, e.y, e.total, e.H, e.W, tile);
+    else conv3x3_pair_body<128>(e.x, e.w1, e.b1, e.w2, e.b2, e.y, e.total, e.H, e.W, tile);
+    if (v + (int)gridDim.x < g.nblocks) __syncthreads();
+  }
+}
+
+// one map, 16 channels (the high-resolution branch: thousands of workgroups, a small register / LDS footprint of its own)
+__global__ __launch_bounds__(NT) void conv3x3_pair16_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ w1,
+                                                            const float* __restrict__ b1, const __bf16* __restrict__ w2,
+                                                            const float* __restrict__ b2, __bf16* __restrict__ y, int total,
+                                                            int H, int W) {
+  const int ntiles = (total + TILE - 1) / TILE;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    conv3x3_pair_body<16>(x, w1, b1, w2, b2, y, total, H, W, t);
+    if (t + (int)gridDim.x < ntiles) __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 3x3 / STRIDE 2 / pad 1 (round 4): the two stem convolutions of the trunk (hrnetv2.py:292-293,434-440: 4 -> 64 and
 // 64 -> 64 channels, 3 % + 14 % of the trunk's FLOPs, 20 % of its time as K = 36-padded-to-64 implicit GEMMs with
 // per-element index arithmetic).  Same raster-window idea: output raster index m = (n Ho + ho) Wo + wo has its
@@ -688,6 +913,53 @@ extern "C" int rf_conv3x3_group_bf16(const RfConvEntry* entries, int count, int 
   blocks = trunk_grid(blocks);
   if (act_dtype == RF_ACT_BF16) RF_LAUNCH(conv3x3_group_kernel<__bf16>, dim3(blocks), dim3(NT), lds, st, g);
   else RF_LAUNCH(conv3x3_group_kernel<float>, dim3(blocks), dim3(NT), lds, st, g);
+  RF_CHECK_LAUNCH();
+  return RF_OK;
+}
+
+extern "C" int rf_conv3x3_pair_supported(int c, int W) {
+  return (c == 16 || c == 32 || c == 64 || c == 128) && W >= 1 && pair_lds(c, W) <= 160 * 1024;
+}
+
+extern "C" int rf_conv3x3_pair_group_bf16(const RfConvPairEntry* entries, int count, void* stream) {
+  RF_REQUIRE(entries && count >= 1 && count <= 4);
+  ConvPairGroup g{};
+  g.count = count;
+  int order[4] = {0, 1, 2, 3};  // longest-running workgroups first: more channels = longer k-loops
+  for (int i = 1; i < count; ++i)
+    for (int j = i; j > 0 && entries[order[j]].c > entries[order[j - 1]].c; --j) { const int v = order[j]; order[j] = order[j - 1]; order[j - 1] = v; }
+  int blocks = 0;
+  size_t lds = 0;
+  for (int k = 0; k < count; ++k) {
+    const RfConvPairEntry& e = entries[order[k]];
+    RF_REQUIRE(e.x && e.w1_packed && e.bias1 && e.w2_packed && e.bias2 && e.y && e.N > 0 && e.H > 0 && e.W > 0);
+    RF_REQUIRE(rf_conv3x3_pair_supported(e.c, e.W));
+    RF_REQUIRE(((reinterpret_cast<uintptr_t>(e.x) | reinterpret_cast<uintptr_t>(e.y)) & 15) == 0 && e.x != e.y);
+    const long total = (long)e.N * e.H * e.W;
+    RF_REQUIRE(total < (1L << 31));
+    ConvPairGroup::Item& it = g.e[k];
+    it.x = static_cast<const __bf16*>(e.x); it.w1 = static_cast<const __bf16*>(e.w1_packed); it.b1 = e.bias1;
+    it.w2 = static_cast<const __bf16*>(e.w2_packed); it.b2 = e.bias2; it.y = static_cast<__bf16*>(e.y);
+    it.total = (int)total; it.H = e.H; it.W = e.W; it.c = e.c; it.first_block = blocks;
+    blocks += (int)((total + TILE - 1) / TILE);
+    const size_t need = pair_lds(e.c, e.W);
+    if (lds < need) lds = need;
+  }
+  g.nblocks = blocks;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_pair_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_pair16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  if (count == 1 && g.e[0].c == 16) {
+    const ConvPairGroup::Item& it = g.e[0];
+    RF_LAUNCH(conv3x3_pair16_kernel, dim3(trunk_grid(blocks)), dim3(NT), lds, st, it.x, it.w1, it.b1, it.w2, it.b2, it.y, it.total,
+              it.H, it.W);
+  } else {
+    RF_LAUNCH(conv3x3_pair_group_kernel, dim3(trunk_grid(blocks)), dim3(NT), lds, st, g);
+  }
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

@@ -110,6 +110,11 @@ def pack_conv3x3s2_weights(w_khwc: torch.Tensor) -> torch.Tensor:
 
 
 STEM_S2 = _os.environ.get("RF_STEM_S2", "1") != "0"  # measurement switches: the stride-2 raster-window kernel for the stem pair ...
+# BasicBlock pairs in one launch, the intermediate map in LDS (rf_conv3x3_pair_group_bf16; bit-identical).  Measured no faster
+# (tools/probes/pair_time.py: 16 ch @ 28 x 28 23 vs 26 us, 32 ch @ 14 x 14 24 vs 18 us, the grouped low-resolution branches
+# equal; step 5.24 -> 5.32 / 5.41 ms at C2, unchanged at C5): conv1 runs on the tile + halo, i.e. three latency-bound k-loop
+# passes per workgroup at a third of the occupancy.  Off by default; RF_CONV_PAIR=1 turns it on.
+CONV_PAIR = _os.environ.get("RF_CONV_PAIR", "0") == "1"
 CONV_S2 = _os.environ.get("RF_CONV_S2", "1") != "0"  # ... and for every stride-2 3x3 convolution it supports
 
 
@@ -348,7 +353,40 @@ class HRNet16Backbone(VideoBackboneModule):
                                      K._stream()), "rf_add_relu")
         return out
 
+    def _pair_ok(self, W, p, x) -> bool:
+        """Can BasicBlock ``p`` on map ``x`` take the fused pair kernel (bf16 maps, packed weights, window fits LDS)?"""
+        u1, u2 = W.get(p + ".conv1"), W.get(p + ".conv2")
+        return (CONV_PAIR and K._PRECISION == 1 and x.dtype == torch.bfloat16 and u1 is not None and u2 is not None
+                and u1[5] is not None and u2[5] is not None and u1[2] == u1[3] == u2[2] == u2[3] == x.shape[-1] and u1[4] == 3
+                and bool(_hip.lib().rf_conv3x3_pair_supported(x.shape[-1], x.shape[2])))
+
+    def _conv_pairs(self, W, blocks, xs):
+        """relu(conv2(relu(conv1 x_b + b1)) + b2 + x_b) for the BasicBlocks ``blocks`` (unit prefixes) of up to four independent
+        maps in ONE launch, the intermediate maps in LDS (rf_conv3x3_pair_group_bf16; hrnetv2.py:45-61)."""
+        n = len(blocks)
+        arr = (_hip.ConvPairEntry * n)()
+        ys = []
+        for i, (p, x) in enumerate(zip(blocks, xs)):
+            (w1, b1, c, _, _, wb1), (w2, b2, _, _, _, wb2) = W[p + ".conv1"], W[p + ".conv2"]
+            N, H, Wd, C = x.shape
+            assert C == c and x.is_contiguous() and x.dtype == torch.bfloat16
+            y = torch.empty_like(x)
+            e = arr[i]
+            e.x, e.w1_packed, e.bias1, e.w2_packed, e.bias2, e.y = ptr(x), ptr(wb1), ptr(b1), ptr(wb2), ptr(b2), ptr(y)
+            e.N, e.H, e.W, e.c = N, H, Wd, C
+            ys.append(y)
+        ev = K.PROFILE.begin() if K.PROFILE.on else None
+        check(_hip.lib().rf_conv3x3_pair_group_bf16(arr, n, K._stream()), "rf_conv3x3_pair_group_bf16")
+        if ev is not None:
+            keep = (arr, list(xs), ys)
+            K.PROFILE.end("conv3x3_pair16_kernel" if (n == 1 and xs[0].shape[-1] == 16) else "conv3x3_pair_group_kernel", ev,
+                          float(sum(2 * 2.0 * x.numel() * 9 * x.shape[-1] for x in xs)), float(sum(2 * 2 * x.numel() for x in xs)),
+                          replay=lambda a=arr, n_=n, kp=keep: _hip.lib().rf_conv3x3_pair_group_bf16(a, n_, K._stream()))
+        return ys
+
     def _basic(self, W, p, x):
+        if self._pair_ok(W, p, x):
+            return self._conv_pairs(W, [p], [x])[0]
         y = self._conv(W, p + ".conv1", x, relu=True)
         return self._conv(W, p + ".conv2", y, relu=True, residual=x)
 
@@ -371,6 +409,11 @@ class HRNet16Backbone(VideoBackboneModule):
             # (all four together: trunk 2.66 -> 3.00 ms).
             lo = list(range(1, nb))
             for k in range(BLOCKS_PER_BRANCH):
+                if all(self._pair_ok(W, f"{p}.branches.{b}.{k}", xs[b]) for b in range(nb)):
+                    # fused BasicBlock pairs: the high-resolution branch in its own launch, the others together
+                    x0 = self._conv_pairs(W, [f"{p}.branches.0.{k}"], [xs[0]])[0]
+                    xs = [x0] + self._conv_pairs(W, [f"{p}.branches.{b}.{k}" for b in lo], [xs[b] for b in lo])
+                    continue
                 y0 = self._conv(W, f"{p}.branches.0.{k}.conv1", xs[0], relu=True)
                 ys = self._conv_group(W, [f"{p}.branches.{b}.{k}.conv1" for b in lo], [xs[b] for b in lo], None)
                 x0 = self._conv(W, f"{p}.branches.0.{k}.conv2", y0, relu=True, residual=xs[0])

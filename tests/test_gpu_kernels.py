@@ -516,6 +516,51 @@ def test_conv3x3_raster_window(N, H, W, cin, cout):
     assert torch.equal(yh, y.bfloat16())
 
 
+@pytest.mark.parametrize("shapes", [[(3, 28, 28, 16)], [(2, 56, 56, 16)], [(5, 14, 14, 32)], [(7, 7, 7, 64)], [(9, 4, 4, 128)],
+                                    [(1, 1, 1, 128)], [(2, 3, 5, 32)], [(2, 9, 130, 16)],
+                                    [(6, 14, 14, 32), (6, 7, 7, 64), (6, 4, 4, 128)], [(3, 28, 28, 32), (3, 14, 14, 64)]])
+def test_conv3x3_basicblock_pair(shapes):
+    """rf_conv3x3_pair_group_bf16 (round 4: relu(conv2(relu(conv1 x + b1)) + b2 + x) of hrnetv2.py:45-61 in one launch, the
+    intermediate map in LDS) == two rf_conv3x3_bf16 launches with a bf16 intermediate map, BIT for bit (same fragments, same k
+    order, same roundings) -- single maps and the grouped form, tiles that straddle rows and images, maps narrower than a tile --
+    and both against torch's conv2d on the bf16-rounded operands."""
+    from routeformer_amd import _hip, kernels as Kn
+    from routeformer_amd.models.video_backbone.hrnet16 import pack_conv3x3_weights
+    g = _g(sum(sum(sh) for sh in shapes))
+    arr = (_hip.ConvPairEntry * len(shapes))()
+    keep, outs, want, refs = [], [], [], []
+    for i, (N, H, W, C) in enumerate(shapes):
+        assert _hip.lib().rf_conv3x3_pair_supported(C, W) == 1
+        x = torch.randn(N, H, W, C, generator=g).bfloat16().to(DEV)
+        ws = [(torch.randn(C, 3, 3, C, generator=g) / math.sqrt(9 * C)).to(DEV) for _ in range(2)]
+        bs = [(torch.randn(C, generator=g) * 0.2).to(DEV) for _ in range(2)]
+        wp = [pack_conv3x3_weights(w) for w in ws]
+        y = torch.full((N, H, W, C), float("nan"), device=DEV, dtype=torch.bfloat16)
+        e = arr[i]
+        e.x, e.w1_packed, e.bias1, e.w2_packed, e.bias2, e.y = (x.data_ptr(), wp[0].data_ptr(), bs[0].data_ptr(), wp[1].data_ptr(),
+                                                                bs[1].data_ptr(), y.data_ptr())
+        e.N, e.H, e.W, e.c = N, H, W, C
+        # the two-launch form
+        mid, two = torch.empty_like(x), torch.empty_like(x)
+        _hip.check(_hip.lib().rf_conv3x3_bf16(x.data_ptr(), wp[0].data_ptr(), bs[0].data_ptr(), None, mid.data_ptr(), 1, N, H, W, C, C, 1,
+                                              Kn._stream()), "conv1")
+        _hip.check(_hip.lib().rf_conv3x3_bf16(mid.data_ptr(), wp[1].data_ptr(), bs[1].data_ptr(), x.data_ptr(), two.data_ptr(), 1, N, H, W,
+                                              C, C, 1, Kn._stream()), "conv2")
+        xf = x.float().permute(0, 3, 1, 2)
+        wf = [w.bfloat16().float().permute(0, 3, 1, 2) for w in ws]
+        m_ref = F.relu(F.conv2d(xf, wf[0], bs[0], padding=1)).bfloat16().float()
+        refs.append(F.relu(F.conv2d(m_ref, wf[1], bs[1], padding=1) + xf).permute(0, 2, 3, 1))
+        keep.append((x, ws, bs, wp, mid))
+        outs.append(y)
+        want.append(two)
+    _hip.check(_hip.lib().rf_conv3x3_pair_group_bf16(arr, len(shapes), Kn._stream()), "rf_conv3x3_pair_group_bf16")
+    torch.cuda.synchronize()
+    for y, two, ref in zip(outs, want, refs):
+        assert torch.isfinite(y.float()).all()
+        assert torch.equal(y, two), float((y.float() - two.float()).abs().max())
+        assert rel_err(y.float(), ref) < 1e-2  # (bf16 output rounding + the occasional flipped rounding of the intermediate)
+
+
 @pytest.mark.parametrize("M,cin,cout,res", [(263424, 64, 256, True), (1000, 64, 256, False), (777, 256, 64, False),
                                             (16, 64, 64, True), (5, 64, 64, False), (4097, 256, 64, True)])
 def test_pointwise_bf16(M, cin, cout, res):
@@ -792,6 +837,14 @@ def test_hrnet16_golden(prec, tol):
         y = net(x)
         assert y.shape == (n, 240, 8, 8)
         assert rel_err(y, G[tag + ".y"]) < tol, tag
+        if prec == "bf16":  # the fused BasicBlock pairs (RF_CONV_PAIR, off by default: no faster) give the same bits
+            from routeformer_amd.models.video_backbone import hrnet16 as HR
+            was = HR.CONV_PAIR
+            HR.CONV_PAIR = True
+            try:
+                assert torch.equal(net(x), y), tag
+            finally:
+                HR.CONV_PAIR = was
 
 
 @pytest.mark.parametrize("cin,cout,N,H,W,res", [(4, 64, 3, 28, 28, False), (4, 64, 2, 112, 112, False), (4, 64, 1, 30, 44, False),
