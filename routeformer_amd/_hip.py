@@ -10,7 +10,8 @@ import os
 from ctypes import c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librf_hip.so")
+# (RF_HIP_LIB: another build of the same library -- kernel experiments; the default is the in-tree build)
+LIB_PATH = os.environ.get("RF_HIP_LIB") or os.path.join(_HERE, "csrc", "librf_hip.so")
 
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 
