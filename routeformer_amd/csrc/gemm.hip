@@ -398,6 +398,11 @@ struct GLoader {
   }
 };
 
+#ifdef RF_GEMM_NOSWZ  // (A/B build: tools/probes, RF_HIP_LIB)
+constexpr bool GEMM_SWZ = false;
+#else
+constexpr bool GEMM_SWZ = true;
+#endif
 // registers -> LDS stage ([row][k], pitch LD)
 template <typename T> __device__ __forceinline__ void st2(T* s, float a, float b);
 template <> __device__ __forceinline__ void st2<float>(float* s, float a, float b) {
@@ -417,7 +422,12 @@ __device__ __forceinline__ void lstore(T* __restrict__ S, const float4 (&r)[NV],
     for (int p = 0; p < NV / 2; ++p) {
       const int ip = tid + p * NT;
       if (ip < BKV * VPK / 2) {
-        T* sp = S + ((ip % VPK) * 4) * LD + 2 * (ip / VPK);
+        // bf16 stage: the 16-B chunk a (k, k+1) pair lands in is XOR-ed with bits 4-5 of its row (swz_chunk; the fragment
+        // reads apply the same permutation).  Unswizzled, the 16 row groups of a wave instruction sit 4 x 144 B apart, i.e.
+        // on 4 banks x 4 k-pairs = 16 of the 64 banks: a 4-way conflict on every transposing store (PMC: 0.59 of the LDS
+        // cycles of the dX products).  With it the four row groups that shared a bank take four different chunks.
+        const int g = ip % VPK, kp = ip / VPK;
+        T* sp = S + (g * 4) * LD + ((GEMM_SWZ && sizeof(T) == 2) ? (((kp >> 2) ^ ((g >> 2) & 3)) << 3) + ((kp & 3) << 1) : 2 * kp);
         st2<T>(sp, r[2 * p].x, r[2 * p + 1].x);
         st2<T>(sp + LD, r[2 * p].y, r[2 * p + 1].y);
         st2<T>(sp + 2 * LD, r[2 * p].z, r[2 * p + 1].z);
@@ -460,6 +470,8 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
   constexpr int LD = L_::LD, BKV = L_::BKV;
   constexpr int BM = C_::WM * C_::TM * 16, BN = C_::WN * C_::TN * 16;
   constexpr int NA = (BM * BKV / 4 + NT - 1) / NT, NB = (BN * BKV / 4 + NT - 1) / NT;
+  // operands staged by the paired transposing store (lstore, MODE 1) carry the chunk swizzle; the fragment reads undo it
+  constexpr bool ASWZ = GEMM_SWZ && PREC == 1 && AM == 1 && NA % 2 == 0, BSWZ = GEMM_SWZ && PREC == 1 && BMODE == 1 && NB % 2 == 0;
   __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LD];
   T* As0 = smem;
   T* Bs0 = smem + 2 * BM * LD;
@@ -620,10 +632,12 @@ __device__ __forceinline__ void gemm2_body(const GemmP& p, const BlockId blk) {
         bf16x8 a[C_::TM], b[C_::TN];
 #pragma unroll
         for (int i = 0; i < C_::TM; ++i)
-          a[i] = *reinterpret_cast<const bf16x8*>(As + ((wm * C_::TM + i) * 16 + fr) * LD + ks * 32 + fq * 8);
+          a[i] = *reinterpret_cast<const bf16x8*>(As + ((wm * C_::TM + i) * 16 + fr) * LD +
+                                                  (ASWZ ? ((ks * 4 + fq) ^ ((wm * C_::TM + i) & 3)) : ks * 4 + fq) * 8);
 #pragma unroll
         for (int j = 0; j < C_::TN; ++j)
-          b[j] = *reinterpret_cast<const bf16x8*>(Bs + ((wn * C_::TN + j) * 16 + fr) * LD + ks * 32 + fq * 8);
+          b[j] = *reinterpret_cast<const bf16x8*>(Bs + ((wn * C_::TN + j) * 16 + fr) * LD +
+                                                  (BSWZ ? ((ks * 4 + fq) ^ ((wn * C_::TN + j) & 3)) : ks * 4 + fq) * 8);
 #pragma unroll
         for (int i = 0; i < C_::TM; ++i)
 #pragma unroll
