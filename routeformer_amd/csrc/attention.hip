@@ -49,6 +49,22 @@ struct AttnP {
 
 // Dropout on the probabilities of the active rows (row si = query top_list[si]): element index of A[b,h,q,s] in the
 // reference's (B,H,L_Q,L_K) probability tensor -- forward and backward regenerate the same keep-bits from it.
+// Row pitch (floats) of the score / probability matrices S, P, dS.  Their rows are read as fp32 MFMA A fragments (lane =
+// row, 4 k per quad: conflict-free when pitch * row mod 64 walks distinct multiples of 4), written in the accumulator layout
+// (rows 4 apart per lane group), walked four rows at a time by the softmax (16 consecutive columns each) and read transposed
+// (column = lane, rows one pitch apart per quad).  A pitch of LK itself is the worst case for the sizes that matter -- 160
+// and 320 keys put every other / every row on the same banks: 8- and 16-way conflicts on the P V operand reads, 4-way on the
+// score stores (PMC: 0.42 / 0.50 of the LDS cycles of attn_fwd / attn_bwd).  pitch mod 64 in {20, 44} serves all four
+// patterns (row offsets 0, 20, 40, 60: at most a 12-bank overlap between four 16-column row pieces).
+__host__ __device__ inline int score_pitch(int lkp) {
+#ifdef RF_ATTN_NOPAD  // (A/B build: RF_HIP_LIB)
+  return lkp;
+#endif
+  int p = lkp;
+  while ((p & 63) != 20 && (p & 63) != 44) p += 4;
+  return p;
+}
+
 __device__ __forceinline__ void drop_rows(float* S, int n_rows, int LK, int ld, const int* top_list, const DropGen& gen,
                                           long row_base) {
   for (int i = threadIdx.x; i < n_rows * LK; i += (int)blockDim.x) {
@@ -358,12 +374,14 @@ __device__ __forceinline__ void softmax_row16(float* row, int kmax, int ldw, flo
     }
 }
 
-__device__ __forceinline__ void softmax_rows(float* S, int n_rows, int LK, const int* top_list, int masked, int ld = 0) {
+__device__ __forceinline__ void softmax_rows(float* S, int n_rows, int LK, const int* top_list, int masked, int ld = 0,
+                                             int row_pitch = 0) {
   if (ld == 0) ld = LK;
+  if (row_pitch == 0) row_pitch = ld;
   for (int base = 0; base < n_rows; base += rows_per_trip()) {
     const int si = row_of(base);
     const bool live = si < n_rows;
-    float* row = S + (long)(live ? si : 0) * ld;
+    float* row = S + (long)(live ? si : 0) * row_pitch;
     const int kmax = live ? (masked ? top_list[si] + 1 : LK) : 0;
     softmax_row16(row, kmax, ld, 1.0f, live);
   }
@@ -391,7 +409,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
   const int LQ = p.LQ, LK = p.LK, E = p.E, EP = pitch<V4>(E);
   const int n_sel = (p.mode == 0) ? LQ : p.n_top;
   const int LKP = V4 ? ((LK + 3) & ~3) : LK;  // key rows / score columns padded to the MFMA k granule
-  const int s_elems = FULLS ? ((LQ * LKP + 3) & ~3) : ((max(LQ * p.sample_k, n_sel * LKP) + 3) & ~3);
+  const int SLD = V4 ? score_pitch(LKP) : LK; // row pitch of the score matrix (see score_pitch)
+  const int s_elems = FULLS ? ((LQ * SLD + 3) & ~3) : ((max(LQ * p.sample_k, n_sel * SLD) + 3) & ~3);
   float* Qs = smem;
   float* Ks = Qs + LQ * EP;
   float* Vs = Ks + LKP * EP;
@@ -422,7 +441,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
              [&](int q) { return Qs + min(q, LQ - 1) * EP; }, 1,
              [&](int s_) { return Ks + min(s_, LK - 1) * EP; }, 1,
              [&](int q, int s_, float v) {
-               if (q < LQ && s_ < LKP) S[q * LKP + s_] = s_ < LK ? v : 0.f;
+               if (q < LQ && s_ < LKP) S[q * SLD + s_] = s_ < LK ? v : 0.f;
              });
     const int parts = max(1, min((int)blockDim.x / E, 16));
     if (p.mode == 1) {
@@ -438,7 +457,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
     // ---- (b) sparsity measure from the sampled entries of S; column means of V ----
     int32_t* gtop = p.top + ((long)b * p.H + h) * p.n_top;
     if (sampling) {
-      sparsity_measure(S, LKP, Sidx, Ms, LQ, p.sample_k, LK, tid);
+      sparsity_measure(S, SLD, Sidx, Ms, LQ, p.sample_k, LK, tid);
     } else {
       for (int q = tid; q < LQ; q += (int)blockDim.x) sel[q] = -1;
     }
@@ -483,13 +502,13 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
       const bool live = si < n_sel;
       const int q = live ? top_list[si] : 0;
       // scale > 0: the row maximum is the same before and after scaling
-      softmax_row16(S + q * LKP, live ? (p.mode == 2 ? q + 1 : LK) : 0, LKP, p.scale, live);
+      softmax_row16(S + q * SLD, live ? (p.mode == 2 ? q + 1 : LK) : 0, LKP, p.scale, live);
     }
     __syncthreads();
     RF_MARK(7);
     // ---- (e) P V for the selected rows ----
     mm_tiles((n_sel + 15) >> 4, (E + 15) >> 4, LKP >> 2, lane, wave,
-             [&](int si) { return S + top_list[min(si, n_sel - 1)] * LKP; }, 1,
+             [&](int si) { return S + top_list[min(si, n_sel - 1)] * SLD; }, 1,
              [&](int d) { return Vs + min(d, E - 1); }, EP,
              [&](int si, int d, float v) {
                if (si < n_sel && d < E) p.ctx[ctx_off(p, b, h, top_list[si]) + d] = v;
@@ -576,22 +595,22 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(AttnP p) {
              [&](int s_) { return Ks + min(s_, LK - 1) * EP; }, 1,
              [&](int si, int s_, float v) {
                if (si < n_sel && s_ < LK)
-                 S[si * LKP + s_] = (p.mode == 2 && s_ > top_list[si]) ? -INFINITY : v * p.scale;
+                 S[si * SLD + s_] = (p.mode == 2 && s_ > top_list[si]) ? -INFINITY : v * p.scale;
              });
     __syncthreads();
     RF_MARK(6);
-    softmax_rows(S, n_sel, LK, top_list, p.mode == 2, LKP);
+    softmax_rows(S, n_sel, LK, top_list, p.mode == 2, LKP, SLD);
     __syncthreads();
     RF_MARK(7);
     {
       const DropGen gen(p.drop);
       if (gen.on()) {
-        drop_rows(S, n_sel, LK, LKP, top_list, gen, ((long)b * p.H + h) * LQ);
+        drop_rows(S, n_sel, LK, SLD, top_list, gen, ((long)b * p.H + h) * LQ);
         __syncthreads();
       }
     }
     mm_tiles(TI, (E + 15) >> 4, LKP >> 2, lane, wave,
-             [&](int si) { return S + min(si, n_sel - 1) * LKP; }, 1,
+             [&](int si) { return S + min(si, n_sel - 1) * SLD; }, 1,
              [&](int d) { return Vs + min(d, E - 1); }, EP,
              [&](int si, int d, float v) {
                if (si < n_sel && d < E) p.ctx[ctx_off(p, b, h, top_list[si]) + d] = v;
@@ -638,8 +657,9 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   const int LQ = p.LQ, LK = p.LK, E = p.E, EP = pitch<V4>(E);
   const int n_sel = (p.mode == 0) ? LQ : p.n_top;
   const int LKP = V4 ? ((LK + 3) & ~3) : LK;      // padded key count (MFMA k granule)
+  const int SLD = V4 ? score_pitch(LKP) : LK;     // row pitch of P / dS (see score_pitch)
   const int NSP = V4 ? ((n_sel + 3) & ~3) : n_sel;  // padded active-row count
-  const int pl_elems = (NSP * LKP + 3) & ~3;
+  const int pl_elems = (NSP * SLD + 3) & ~3;
   float* Ks = smem;
   float* Vs = Ks + LKP * EP;
   float* Qsel = Vs + LKP * EP;
@@ -659,7 +679,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   load_qkv<V4, false>(nullptr, Ks, Vs, p, b, h, EP, tid);
   for (int i = tid; i < (LKP - LK) * EP; i += (int)blockDim.x) { Ks[LK * EP + i] = 0.f; Vs[LK * EP + i] = 0.f; }
   for (int i = tid; i < (NSP - n_sel) * EP; i += (int)blockDim.x) { Qsel[n_sel * EP + i] = 0.f; dCsel[n_sel * EP + i] = 0.f; }
-  for (int i = tid; i < (NSP - n_sel) * LKP; i += (int)blockDim.x) { P[n_sel * LKP + i] = 0.f; dS[n_sel * LKP + i] = 0.f; }
+  for (int i = tid; i < (NSP - n_sel) * SLD; i += (int)blockDim.x) { P[n_sel * SLD + i] = 0.f; dS[n_sel * SLD + i] = 0.f; }
   for (int q = tid; q < LQ; q += (int)blockDim.x) sel[q] = (p.mode == 0) ? q : -1;
   __syncthreads();
   if (p.mode == 0) {
@@ -704,13 +724,13 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
              [&](int s_) { return Ks + min(s_, LK - 1) * EP; }, 1,
              [&](int si, int s_, float v) {
                if (si < n_sel && s_ < LK)
-                 P[si * LKP + s_] = (p.mode == 2 && s_ > top_list[si]) ? -INFINITY : v * p.scale;
+                 P[si * SLD + s_] = (p.mode == 2 && s_ > top_list[si]) ? -INFINITY : v * p.scale;
              });
     mm_tiles(TI, TJ, E >> 2, lane, wave,
              [&](int si) { return dCsel + min(si, n_sel - 1) * EP; }, 1,
              [&](int s_) { return Vs + min(s_, LK - 1) * EP; }, 1,
              [&](int si, int s_, float v) {
-               if (si < n_sel && s_ < LK) dS[si * LKP + s_] = (p.mode == 2 && s_ > top_list[si]) ? 0.f : v;
+               if (si < n_sel && s_ < LK) dS[si * SLD + s_] = (p.mode == 2 && s_ > top_list[si]) ? 0.f : v;
              });
   } else {
     for (int i = tid; i < n_sel * LK; i += (int)blockDim.x) {
@@ -727,14 +747,14 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   }
   __syncthreads();
   RF_MARK(11);
-  softmax_rows(P, n_sel, LK, top_list, p.mode == 2, LKP);
+  softmax_rows(P, n_sel, LK, top_list, p.mode == 2, LKP, SLD);
   // the same 16 lanes own the same row in softmax_rows and here: no barrier needed in between
   const DropGen gen(p.drop);
   for (int base = 0; base < n_sel; base += rows_per_trip()) {
     const int si = row_of(base), l16 = tid & 15;
     const bool live = si < n_sel;
-    float* Pr = P + (long)(live ? si : 0) * LKP;
-    float* dSr = dS + (long)(live ? si : 0) * LKP;
+    float* Pr = P + (long)(live ? si : 0) * SLD;
+    float* dSr = dS + (long)(live ? si : 0) * SLD;
     // attention-probability dropout: ctx = (P * keep / (1-p)) V, so dP arrives masked and dV needs the masked P
     const unsigned long long e0 = (unsigned long long)((((long)b * p.H + h) * LQ + top_list[live ? si : 0]) * LK);
     float dot = 0.f;
@@ -779,7 +799,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   // dQ[q] = dS K for the active rows, zero for the others (the sampling stage is not differentiated)
   if constexpr (V4) {
     mm_tiles((n_sel + 15) >> 4, (E + 15) >> 4, LKP >> 2, lane, wave,
-             [&](int si) { return dS + min(si, n_sel - 1) * LKP; }, 1,
+             [&](int si) { return dS + min(si, n_sel - 1) * SLD; }, 1,
              [&](int e) { return Ks + min(e, E - 1); }, EP,
              [&](int si, int e, float v) {
                if (si < n_sel && e < E) p.dq[((long)b * LQ + top_list[si]) * p.dq_ld + (long)h * E + e] = v;
@@ -789,7 +809,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
       const int si = i / E, e = i - si * E;
       const int q = top_list[si];
       const int kmax = (p.mode == 2) ? q + 1 : LK;
-      const float* dSr = dS + (long)si * LKP;
+      const float* dSr = dS + (long)si * SLD;
       float a = 0.f;
       for (int s_ = 0; s_ < kmax; ++s_) a = fmaf(dSr[s_], Ks[s_ * EP + e], a);
       p.dq[((long)b * LQ + q) * p.dq_ld + (long)h * E + e] = a;
@@ -854,13 +874,13 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
   if constexpr (V4) {
     const int TJ = (LK + 15) >> 4, TE = (E + 15) >> 4;
     mm_tiles(TJ, TE, NSP >> 2, lane, wave,
-             [&](int s_) { return dS + min(s_, LK - 1); }, LKP,
+             [&](int s_) { return dS + min(s_, LK - 1); }, SLD,
              [&](int e) { return Qsel + min(e, E - 1); }, EP,
              [&](int s_, int e, float v) {
                if (s_ < LK && e < E) p.dk[((long)b * LK + s_) * p.dk_ld + (long)h * E + e] = v;
              });
     mm_tiles(TJ, TE, NSP >> 2, lane, wave,
-             [&](int s_) { return P + min(s_, LK - 1); }, LKP,
+             [&](int s_) { return P + min(s_, LK - 1); }, SLD,
              [&](int d) { return dCsel + min(d, E - 1); }, EP,
              [&](int s_, int d, float v) {
                if (s_ < LK && d < E) {
@@ -874,8 +894,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
       const int s_ = i / E, e = i - s_ * E;
       float ak = 0.f, av = 0.f;
       for (int si = 0; si < n_sel; ++si) {
-        ak = fmaf(dS[(long)si * LKP + s_], Qsel[si * EP + e], ak);
-        av = fmaf(P[(long)si * LKP + s_], dCsel[si * EP + e], av);
+        ak = fmaf(dS[(long)si * SLD + s_], Qsel[si * EP + e], ak);
+        av = fmaf(P[(long)si * SLD + s_], dCsel[si * EP + e], av);
       }
       if (p.mode == 1) av += colsum[e];
       if (p.mode == 2) av += Vs[s_ * EP + e];
@@ -888,16 +908,17 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
 
 size_t fwd_lds(int LQ, int LK, int E, int n_sel, int sample_k, bool v4, bool fulls = false) {
   const size_t EP = v4 ? E + 4 : E + 1;
-  const size_t LKP = v4 ? ((LK + 3) & ~3) : LK;
-  const size_t s_elems = fulls ? (((size_t)LQ * LKP + 3) & ~(size_t)3)
-                               : ((max((size_t)LQ * sample_k, (size_t)n_sel * LKP) + 3) & ~(size_t)3);
+  const size_t LKP = v4 ? ((LK + 3) & ~3) : LK, SLD = v4 ? (size_t)score_pitch((int)LKP) : (size_t)LK;
+  const size_t s_elems = fulls ? (((size_t)LQ * SLD + 3) & ~(size_t)3)
+                               : ((max((size_t)LQ * sample_k, (size_t)n_sel * SLD) + 3) & ~(size_t)3);
   const size_t extra = fulls ? sizeof(int) * (size_t)LQ * sample_k + sizeof(float) * 16 * (size_t)E : 0;
   return sizeof(float) * (LQ * EP + 2 * LKP * EP + s_elems + LQ + E) + sizeof(int) * ((size_t)LQ + n_sel) + extra + 16;
 }
 size_t bwd_lds(int LQ, int LK, int E, int n_sel, bool v4) {
   const size_t EP = v4 ? E + 4 : E + 1;
   const size_t LKP = v4 ? ((LK + 3) & ~3) : LK, NSP = v4 ? ((n_sel + 3) & ~3) : n_sel;
-  const size_t pl = (NSP * LKP + 3) & ~(size_t)3;
+  const size_t SLD = v4 ? (size_t)score_pitch((int)LKP) : (size_t)LK;
+  const size_t pl = (NSP * SLD + 3) & ~(size_t)3;
   return sizeof(float) * (2 * LKP * EP + 2 * NSP * EP + 2 * pl + ((E + 3) & ~3)) + sizeof(int) * ((size_t)n_sel + LQ) + 16;
 }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
