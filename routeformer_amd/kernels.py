@@ -2372,90 +2372,90 @@ def _stack_backward_layerwise(sv, stack, x2, dy2, B, L, F_, n_top, drop_p, site0
     M, D, H, E = B * L, 128, 8, 16
     if any(t.dtype == torch.bfloat16 for t in sv.values()):  # (BF16_SAVES of the fused forward: these kernels read fp32)
         sv = {k: (t.float() if t.dtype == torch.bfloat16 else t) for k, t in sv.items()}
-    if True:
-        def masked(t, site):  # t * keep / (1 - p) with the mask the fused forward drew for `site` (new tensor)
-            out = torch.empty_like(t)
-            _drop_launch(t, out, drop_p, site, None)
-            return out
 
-        for li in reversed(range(len(stack.layers))):
-            lay = stack.layers[li]
-            x_in = x2 if li == 0 else (sv["xin"][li] if "xin" in sv else sv["y"][li - 1])  # (its weight gradient's operand)
-            w1, w2 = lay.conv1.weight.reshape(F_, D), lay.conv2.weight.reshape(D, F_)
-            zsrc = sv["z"][li] if "z" in sv else sv["h"][li]
-            # ---- norm2 + conv pair (as _FFNAddLN.backward) ----
-            gg, gbeta = _slot(lay.norm2.weight), _slot(lay.norm2.bias)
-            xhat2, rstd2, h, x1 = sv["xhat2"][li], sv["rstd2"][li], sv["h"][li], sv["x1"][li]
-            dpm = None  # gradient of the conv2 output: d(pre-norm) with the output-dropout mask (== dpre without dropout)
-            if drop_p > 0.0:  # dropout sites sit between the products: unfused chain with the masks regenerated
-                dpre, _, _ = _ln_backward(dy2, xhat2, rstd2, lay.norm2.weight, gg, gbeta)
-                dpm = masked(dpre, site0 + 3 * li + 2)
-                dz = _input_grad(dpm, w2, dact_src=zsrc, ldd=zsrc.stride(0), dact=ACT[lay.act])
-                _drop_launch(dz, dz, drop_p, site0 + 3 * li + 1, None)
-            elif _rowblock_nn_ok(w2, ln=True) and _rowblock_nn_ok(w1) and not DETERMINISTIC:
-                dpre = torch.empty_like(xhat2)
-                dz = _rowblock_nn(w2, M, ln=(dy2, xhat2, rstd2, lay.norm2.weight), dpre=dpre, dgam=gg, dbet=gbeta,
-                                  dsrc=zsrc, dact=ACT[lay.act])
-                _wrote(gg, gbeta)
-            else:
-                dpre, _, _ = _ln_backward(dy2, xhat2, rstd2, lay.norm2.weight, gg, gbeta)
-                dz = _input_grad(dpre, w2, dact_src=zsrc, ldd=zsrc.stride(0), dact=ACT[lay.act])
-            g2, gb2, g1, gb1 = (_slot(lay.conv2.weight), _slot(lay.conv2.bias), _slot(lay.conv1.weight),
-                                _slot(lay.conv1.bias))
-            dpw = dpm if dpm is not None else dpre
-            if _weight_grad(dpw, h, into=g2.view(D, F_), bias_into=gb2) is not True:
-                colsum(dpw, into=gb2)
-            if _weight_grad(dz, x1, into=g1.view(F_, D), bias_into=gb1) is not True:
-                colsum(dz, into=gb1)
-            if _rowblock_nn_ok(w1):
-                dx1 = _rowblock_nn(w1, M, a=dz, res=dpre)
-            else:
-                dx1 = _input_grad(dz, w1, residual=dpre, ldr=D, res_rows=M)
-            _wrote(g1, gb1, g2, gb2)
-            # ---- norm1 + out-projection (as _LinearAddLN.backward) ----
-            att = lay.attention
-            wo = att.out_projection.weight
-            gg, gbeta = _slot(lay.norm1.weight), _slot(lay.norm1.bias)
-            xhat1, rstd1, ctx2 = sv["xhat1"][li], sv["rstd1"][li], sv["ctx"][li]
-            dpo = None  # gradient of the out-projection output (masked by the attention-output dropout)
-            if drop_p > 0.0:
-                dpre1, _, _ = _ln_backward(dx1, xhat1, rstd1, lay.norm1.weight, gg, gbeta)
-                dpo = masked(dpre1, site0 + 3 * li)
-                dctx = _input_grad(dpo, wo)
-            elif _rowblock_nn_ok(wo, ln=True) and not DETERMINISTIC:
-                dpre1 = torch.empty_like(xhat1)
-                dctx = _rowblock_nn(wo, M, ln=(dx1, xhat1, rstd1, lay.norm1.weight), dpre=dpre1, dgam=gg, dbet=gbeta)
-                _wrote(gg, gbeta)
-            else:
-                dpre1, _, _ = _ln_backward(dx1, xhat1, rstd1, lay.norm1.weight, gg, gbeta)
-                dctx = _input_grad(dpre1, wo)
-            gwo, gbo = _slot(wo), _slot(att.out_projection.bias)
-            dow = dpo if dpo is not None else dpre1
-            if _weight_grad(dow, ctx2, into=gwo, bias_into=gbo) is not True:
-                colsum(dow, into=gbo)
-            _wrote(gwo, gbo)
-            # ---- attention core ----
-            qkv = sv["qkv"][li]
-            dqkv = torch.empty_like(qkv)
-            HE = H * E
-            ev = PROFILE.begin() if PROFILE.on else None
-            bargs = (qkv.data_ptr(), qkv.data_ptr() + 4 * HE, qkv.data_ptr() + 8 * HE, 3 * HE, 3 * HE, 3 * HE, ptr(dctx), 0,
-                     ptr(sv["top"][li]), dqkv.data_ptr(), dqkv.data_ptr() + 4 * HE, dqkv.data_ptr() + 8 * HE, 3 * HE,
-                     3 * HE, 3 * HE, B, H, L, L, E, n_top, 1, 1.0 / math.sqrt(E))
-            check(_hip.lib().rf_attn_bwd(*bargs, _stream()), "rf_attn_bwd")
-            if ev is not None:
-                keep = (qkv, dctx, dqkv, sv)
-                PROFILE.end("attn_bwd_kernel<true>", ev, B * H * 10.0 * n_top * L * E, 4.0 * B * H * E * 8 * L,
-                            replay=lambda fa=bargs, k=keep: _hip.lib().rf_attn_bwd(*fa, _stream()))
-            # ---- packed q | k | v projection (as _Linear.backward with the skip gradient folded in) ----
-            pk = att._packed
-            if _weight_grad(dqkv, x_in, into=pk["gw"], bias_into=pk["gb"]) is not True:
-                colsum(dqkv, into=pk["gb"])
-            if _rowblock_nn_ok(pk["w"]):
-                dy2 = _rowblock_nn(pk["w"], M, a=dqkv, res=dpre1)
-            else:
-                dy2 = _input_grad(dqkv, pk["w"], residual=dpre1, ldr=D, res_rows=M)
-            _wrote(pk["gw"], pk["gb"])
+    def masked(t, site):  # t * keep / (1 - p) with the mask the fused forward drew for `site` (new tensor)
+        out = torch.empty_like(t)
+        _drop_launch(t, out, drop_p, site, None)
+        return out
+
+    for li in reversed(range(len(stack.layers))):
+        lay = stack.layers[li]
+        x_in = x2 if li == 0 else (sv["xin"][li] if "xin" in sv else sv["y"][li - 1])  # (its weight gradient's operand)
+        w1, w2 = lay.conv1.weight.reshape(F_, D), lay.conv2.weight.reshape(D, F_)
+        zsrc = sv["z"][li] if "z" in sv else sv["h"][li]
+        # ---- norm2 + conv pair (as _FFNAddLN.backward) ----
+        gg, gbeta = _slot(lay.norm2.weight), _slot(lay.norm2.bias)
+        xhat2, rstd2, h, x1 = sv["xhat2"][li], sv["rstd2"][li], sv["h"][li], sv["x1"][li]
+        dpm = None  # gradient of the conv2 output: d(pre-norm) with the output-dropout mask (== dpre without dropout)
+        if drop_p > 0.0:  # dropout sites sit between the products: unfused chain with the masks regenerated
+            dpre, _, _ = _ln_backward(dy2, xhat2, rstd2, lay.norm2.weight, gg, gbeta)
+            dpm = masked(dpre, site0 + 3 * li + 2)
+            dz = _input_grad(dpm, w2, dact_src=zsrc, ldd=zsrc.stride(0), dact=ACT[lay.act])
+            _drop_launch(dz, dz, drop_p, site0 + 3 * li + 1, None)
+        elif _rowblock_nn_ok(w2, ln=True) and _rowblock_nn_ok(w1) and not DETERMINISTIC:
+            dpre = torch.empty_like(xhat2)
+            dz = _rowblock_nn(w2, M, ln=(dy2, xhat2, rstd2, lay.norm2.weight), dpre=dpre, dgam=gg, dbet=gbeta,
+                              dsrc=zsrc, dact=ACT[lay.act])
+            _wrote(gg, gbeta)
+        else:
+            dpre, _, _ = _ln_backward(dy2, xhat2, rstd2, lay.norm2.weight, gg, gbeta)
+            dz = _input_grad(dpre, w2, dact_src=zsrc, ldd=zsrc.stride(0), dact=ACT[lay.act])
+        g2, gb2, g1, gb1 = (_slot(lay.conv2.weight), _slot(lay.conv2.bias), _slot(lay.conv1.weight),
+                            _slot(lay.conv1.bias))
+        dpw = dpm if dpm is not None else dpre
+        if _weight_grad(dpw, h, into=g2.view(D, F_), bias_into=gb2) is not True:
+            colsum(dpw, into=gb2)
+        if _weight_grad(dz, x1, into=g1.view(F_, D), bias_into=gb1) is not True:
+            colsum(dz, into=gb1)
+        if _rowblock_nn_ok(w1):
+            dx1 = _rowblock_nn(w1, M, a=dz, res=dpre)
+        else:
+            dx1 = _input_grad(dz, w1, residual=dpre, ldr=D, res_rows=M)
+        _wrote(g1, gb1, g2, gb2)
+        # ---- norm1 + out-projection (as _LinearAddLN.backward) ----
+        att = lay.attention
+        wo = att.out_projection.weight
+        gg, gbeta = _slot(lay.norm1.weight), _slot(lay.norm1.bias)
+        xhat1, rstd1, ctx2 = sv["xhat1"][li], sv["rstd1"][li], sv["ctx"][li]
+        dpo = None  # gradient of the out-projection output (masked by the attention-output dropout)
+        if drop_p > 0.0:
+            dpre1, _, _ = _ln_backward(dx1, xhat1, rstd1, lay.norm1.weight, gg, gbeta)
+            dpo = masked(dpre1, site0 + 3 * li)
+            dctx = _input_grad(dpo, wo)
+        elif _rowblock_nn_ok(wo, ln=True) and not DETERMINISTIC:
+            dpre1 = torch.empty_like(xhat1)
+            dctx = _rowblock_nn(wo, M, ln=(dx1, xhat1, rstd1, lay.norm1.weight), dpre=dpre1, dgam=gg, dbet=gbeta)
+            _wrote(gg, gbeta)
+        else:
+            dpre1, _, _ = _ln_backward(dx1, xhat1, rstd1, lay.norm1.weight, gg, gbeta)
+            dctx = _input_grad(dpre1, wo)
+        gwo, gbo = _slot(wo), _slot(att.out_projection.bias)
+        dow = dpo if dpo is not None else dpre1
+        if _weight_grad(dow, ctx2, into=gwo, bias_into=gbo) is not True:
+            colsum(dow, into=gbo)
+        _wrote(gwo, gbo)
+        # ---- attention core ----
+        qkv = sv["qkv"][li]
+        dqkv = torch.empty_like(qkv)
+        HE = H * E
+        ev = PROFILE.begin() if PROFILE.on else None
+        bargs = (qkv.data_ptr(), qkv.data_ptr() + 4 * HE, qkv.data_ptr() + 8 * HE, 3 * HE, 3 * HE, 3 * HE, ptr(dctx), 0,
+                 ptr(sv["top"][li]), dqkv.data_ptr(), dqkv.data_ptr() + 4 * HE, dqkv.data_ptr() + 8 * HE, 3 * HE,
+                 3 * HE, 3 * HE, B, H, L, L, E, n_top, 1, 1.0 / math.sqrt(E))
+        check(_hip.lib().rf_attn_bwd(*bargs, _stream()), "rf_attn_bwd")
+        if ev is not None:
+            keep = (qkv, dctx, dqkv, sv)
+            PROFILE.end("attn_bwd_kernel<true>", ev, B * H * 10.0 * n_top * L * E, 4.0 * B * H * E * 8 * L,
+                        replay=lambda fa=bargs, k=keep: _hip.lib().rf_attn_bwd(*fa, _stream()))
+        # ---- packed q | k | v projection (as _Linear.backward with the skip gradient folded in) ----
+        pk = att._packed
+        if _weight_grad(dqkv, x_in, into=pk["gw"], bias_into=pk["gb"]) is not True:
+            colsum(dqkv, into=pk["gb"])
+        if _rowblock_nn_ok(pk["w"]):
+            dy2 = _rowblock_nn(pk["w"], M, a=dqkv, res=dpre1)
+        else:
+            dy2 = _input_grad(dqkv, pk["w"], residual=dpre1, ldr=D, res_rows=M)
+        _wrote(pk["gw"], pk["gb"])
     return dy2
 
 
