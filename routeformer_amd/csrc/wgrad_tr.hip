@@ -31,7 +31,7 @@ constexpr int WT_BN = 256, WT_BK = 128, WT_MS = 32, WT_NT = 512, WT_RING = 3;
 constexpr int WT_HALF = WT_MS * 256;  // bytes of one [32 rows][128 columns] bf16 image
 
 struct TrTable {
-  int count, pad;
+  int count, run;  // run: blocks an XCD takes in a row (0: plain block order), see wgrad_tr_kernel
   RfWgradEntry e[RF_WGRAD_MAX_GROUP];  // splits = number of M chunks, kchunk = rows per chunk (multiple of 32)
   int first_block[RF_WGRAD_MAX_GROUP + 1];
 };
@@ -91,11 +91,10 @@ struct Staged { typename Quad<YBF>::T y[4]; typename Quad<XBF>::T x[2]; };
 // instantiation with ONE workgroup-uniform branch at its top (straight-line code inside: the compiler keeps counting the
 // outstanding loads of the ring), so fp32-operand and bf16-operand problems share a launch.
 template <bool YBF, bool XBF>
-__device__ __forceinline__ void wgrad_tr_block(const TrTable& t, const int lo, unsigned char* lds) {
+__device__ __forceinline__ void wgrad_tr_block(const TrTable& t, const int lo, unsigned char* lds, const int b) {
   typedef typename Quad<YBF>::T YQ;
   typedef typename Quad<XBF>::T XQ;
   typedef Staged<YBF, XBF> StagedT;
-  const int b = blockIdx.x;
   const RfWgradEntry& e = t.e[lo];
   const int M = e.M, N = e.N, K = e.K;
   const int gn = (N + WT_BN - 1) / WT_BN, gk = (K + WT_BK - 1) / WT_BK;
@@ -270,14 +269,26 @@ __device__ __forceinline__ void wgrad_tr_block(const TrTable& t, const int lo, u
 __global__ __launch_bounds__(WT_NT) void wgrad_tr_kernel(const TrTable t) {
   // buffers: [2 stages][dY half 0 | dY half 1 | X] images of 8 KB each; then the bias reduction scratch
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 3 * WT_HALF + 8 * 256 * 4];
-  const int b = blockIdx.x;
+  // XCD-aware block order (measurement switch, off: see rf_wgrad_tr).  Workgroups are dealt to the 8 XCDs round-robin by
+  // blockIdx, each XCD with its own L2; in plain order the gk blocks that share a 256-column dY panel (and the gn blocks that share an X panel) are spread over all eight,
+  // and every one of them fetches the panel from HBM: PMC showed 452 MB fetched by the GPS backbone's group for ~90 MB of
+  // operands.  With t.run > 0 an XCD takes RUNS of t.run consecutive blocks (one after the other in its own dispatch order):
+  // the blocks of a run share their dY panel, consecutive runs of an XCD mostly belong to the same weight, whose X panels
+  // (K / 128 x 287 KB at M = 560) stay in its 4-MB L2.  Runs -- not one contiguous eighth per XCD -- keep the XCDs balanced:
+  // the problems differ 6 x in reduction depth.  (The grid is padded to a multiple of 8 runs; blocks past the end exit.)
+  int b = blockIdx.x;
+  if (t.run > 0) {
+    const int x = b & 7, j = b >> 3;  // j-th block of XCD x
+    b = (j / t.run) * (8 * t.run) + x * t.run + j % t.run;
+    if (b >= t.first_block[t.count]) return;
+  }
   int lo = 0, hi = t.count - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
     if (t.first_block[mid] <= b) lo = mid; else hi = mid - 1;
   }
-  if (t.e[lo].dy_bf16) wgrad_tr_block<true, true>(t, lo, lds);  // (rf_wgrad_tr: both operands bf16, or both fp32)
-  else wgrad_tr_block<false, false>(t, lo, lds);
+  if (t.e[lo].dy_bf16) wgrad_tr_block<true, true>(t, lo, lds, b);  // (rf_wgrad_tr: both operands bf16, or both fp32)
+  else wgrad_tr_block<false, false>(t, lo, lds, b);
 }
 
 }  // namespace
@@ -313,6 +324,11 @@ extern "C" int rf_wgrad_tr(const RfWgradEntry* entries, int count, void* stream)
     blocks += ((e.N + WT_BN - 1) / WT_BN) * ((e.K + WT_BK - 1) / WT_BK) * e.splits;
   }
   t.first_block[count] = blocks;
+  // (measured: 95.8 -> 98.8 us per launch with runs of 16, step unchanged -- the re-fetched panels come out of the memory-side
+  //  cache, not HBM; the plain order stays.  RF_WGRAD_XCD_RUN = 16 turns the run order on.)
+  static const int run = [] { const char* e = getenv("RF_WGRAD_XCD_RUN"); return e ? atoi(e) : 0; }();
+  t.run = blocks >= 64 ? run : 0;
+  if (t.run > 0) blocks = (blocks + 8 * t.run - 1) / (8 * t.run) * (8 * t.run);
   RF_LAUNCH(wgrad_tr_kernel, dim3(blocks), dim3(WT_NT), 0, static_cast<hipStream_t>(stream), t);
   RF_CHECK_LAUNCH();
   return RF_OK;
