@@ -86,7 +86,8 @@ int rf_gemm_skinny_partials(const float* A, int64_t lda_m, int64_t lda_k, const 
                             int M, int N, int K, float* workspace, void* stream);
 
 /* out[n] (+)= sum_m X[m*ldx + n] (bias gradients; accumulate=1 adds into out, e.g. a slot of the flat
- * gradient buffer).  workspace: parts*N floats, parts = rf_colsum_parts(M,N). */
+ * gradient buffer; accumulate=2 does that with fp32 atomics in ONE launch -- the order of the additions is then not
+ * fixed -- and needs no workspace).  workspace: parts*N floats, parts = rf_colsum_parts(M,N). */
 int rf_colsum_parts(int M, int N);
 int rf_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, float* workspace,
               void* stream);

@@ -1165,8 +1165,9 @@ extern "C" int rf_conv2d_nhwc(const void* x_, const float* w, const float* bias,
 // ---- column sums (bias gradients): two deterministic passes --------------------------------
 namespace {
 constexpr int CS_ROWS = 256;  // rows per first-pass block
+// `atomic_out`: the chunk sums are added straight into `part` = the output vector (fp32 atomics: one launch, no second pass)
 __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, long ldx, int M, int N,
-                                                           float* __restrict__ part) {
+                                                           float* __restrict__ part, int atomic_out) {
   // block = 64 columns x 4 row-lanes; blockIdx.y = row chunk
   __shared__ float red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -1177,7 +1178,11 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
     for (int r = r0 + ty; r < r1; r += 4) s += X[(long)r * ldx + n];
   red[ty][tx] = s;
   __syncthreads();
-  if (ty == 0 && n < N) part[(long)blockIdx.y * N + n] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+  if (ty == 0 && n < N) {
+    const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    if (atomic_out) atomicAdd(part + n, v);
+    else part[(long)blockIdx.y * N + n] = v;
+  }
 }
 __global__ void colsum_final_kernel(const float* __restrict__ part, int parts, int N, float* __restrict__ out,
                                     int accumulate) {
@@ -1233,11 +1238,16 @@ extern "C" int rf_colsum_parts(int M, int N) { (void)N; return (M + CS_ROWS - 1)
 
 extern "C" int rf_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, float* workspace,
                          void* stream) {
-  RF_REQUIRE(X && out && workspace && M > 0 && N > 0);
+  RF_REQUIRE(X && out && (workspace || accumulate == 2) && M > 0 && N > 0);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int parts = rf_colsum_parts(M, N);
+  if (accumulate == 2) {  // out += column sums by fp32 atomics (order of the additions not fixed): ONE launch
+    RF_LAUNCH(colsum_part_kernel, dim3((N + 63) / 64, parts), dim3(256), 0, st, X, (long)ldx, M, N, out, 1);
+    RF_CHECK_LAUNCH();
+    return RF_OK;
+  }
   RF_LAUNCH(colsum_part_kernel, dim3((N + 63) / 64, parts), dim3(256), 0, st, X, (long)ldx, M, N,
-                     workspace);
+                     workspace, 0);
   RF_CHECK_LAUNCH();
   RF_LAUNCH(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, workspace, parts, N, out, accumulate);
   RF_CHECK_LAUNCH();

@@ -534,6 +534,9 @@ def colsum(X2d: torch.Tensor, into: Optional[torch.Tensor] = None) -> Optional[t
     if X2d.dtype != torch.float32:
         X2d = X2d.float()
     out = into if into is not None else torch.empty(N, device=X2d.device, dtype=torch.float32)
+    if into is not None and not DETERMINISTIC:  # a gradient slot: atomics like every other sink writer, one launch
+        check(_hip.lib().rf_colsum(ptr(X2d), X2d.stride(0), M, N, ptr(out), 2, None, _stream()), "rf_colsum")
+        return None
     parts = _hip.lib().rf_colsum_parts(M, N)
     ws = torch.empty(parts * N, device=X2d.device, dtype=torch.float32)
     check(_hip.lib().rf_colsum(ptr(X2d), X2d.stride(0), M, N, ptr(out), 1 if into is not None else 0, ptr(ws),
