@@ -1,6 +1,8 @@
 """How many fork / join points does a captured step graph have?  RF_GRAPH_DOT=<dir> makes the engine dump every captured
 graph (hipGraphDebugDotPrint); this counts, per .dot file: nodes, edges, nodes with more than one successor (forks) and with
-more than one predecessor (joins), and the width of the widest level.  python tools/graph_edges.py <dir>"""
+more than one predecessor (joins), and the width of the widest level.  python tools/graph_edges.py <dir>
+(On this image -- PyTorch's bundled HIP 7.0.2 -- `CUDAGraph.debug_dump` warns and writes nothing: the directory stays empty.
+The stand-alone probes under tools/probes/ print their own graphs with hipGraphDebugDotPrint; this script reads those.)"""
 import glob, os, re, sys
 from collections import defaultdict
 
