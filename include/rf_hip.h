@@ -223,6 +223,12 @@ int rf_layernorm_fwd_slabs_unfold(const float* slabs, int splits, const float* b
 int rf_layernorm_bwd_fold(const float* dcols, const float* xhat, const float* rstd, const float* gamma, float* dx,
                           float* dgamma, float* dbeta, int accumulate, float* workspace, int rows, int cols, int L,
                           void* stream);
+/* LayerNorm backward whose incoming gradient is still the `splits` split-K slabs [splits][rows][cols] of the product in front of
+ * it (rf_gemm_partials / rf_gemm_skinny_partials of a dX) plus, optionally, the skip gradient `residual` [rows][cols] that
+ * product's epilogue would have added: summed on load -- rf_layernorm_bwd minus the slab-sum launch. */
+int rf_layernorm_bwd_slabs(const float* slabs, int splits, const float* residual, const float* xhat, const float* rstd,
+                           const float* gamma, float* dx, float* dgamma, float* dbeta, int accumulate, float* workspace,
+                           int rows, int cols, void* stream);
 /* dx = d(loss)/d(s); dgamma/dbeta reduced deterministically through `workspace`
  * (rf_layernorm_bwd_parts(rows)*2*cols floats); accumulate=1 adds them into dgamma/dbeta. */
 int rf_layernorm_bwd_parts(int rows);

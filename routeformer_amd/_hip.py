@@ -55,6 +55,7 @@ SIGNATURES = {
     "rf_layernorm_fwd_slabs": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "rf_layernorm_fwd_slabs_unfold": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
     "rf_layernorm_bwd_fold": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P],
+    "rf_layernorm_bwd_slabs": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P],
     "rf_layernorm_bwd_parts": [_I],
     "rf_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _P],
     "rf_bn_stats": [_P, _P, _P, _I, _I, _P, _P, _P, _F, _P],

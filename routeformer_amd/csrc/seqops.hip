@@ -206,12 +206,13 @@ void launch_ln_row(const float* x, int splits, const float* bias, const float* r
 #undef RF_LN_ROW_ARGS
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+template <int NV, bool SLABS>
+__device__ __forceinline__ void layernorm_bwd_body(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
                                                             float* __restrict__ ws, int rows, int cols,
-                                                            float* __restrict__ agamma, float* __restrict__ abeta, int fold_L) {
+                                                            float* __restrict__ agamma, float* __restrict__ abeta, int fold_L,
+                                                            int slabs, const float* __restrict__ slab_res) {
   __shared__ float red[2][LN_WAVES][NV * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dg[NV], db[NV], gm[NV];
@@ -249,6 +250,42 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         g[i] = a;
         h[i] = xhat[off + cc];
       }
+    } else if (SLABS) {
+      // dy arrives as the split-K slabs of the product in front of this backward (the FFN's last dX: rf_gemm_partials)
+      // plus the skip gradient that product's epilogue would have added: summed on load, slab 0 first (the order of the
+      // slab-sum launch this replaces)
+      // (four slabs in flight per trip, clamped slab index + masked add: a runtime-count loop of load -> add was a chain of
+      //  `slabs` dependent round trips per 64-column group)
+      const long slab = (long)rows * cols;
+      const float* dummy = dy;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int cc = min(i * 64 + lane, cols - 1);
+        g[i] = *(slab_res ? slab_res + off + cc : dummy);
+        h[i] = xhat[off + cc];
+      }
+      if (!slab_res) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) g[i] = 0.f;
+      }
+      float acc_s[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) acc_s[i] = 0.f;
+      for (int s0 = 0; s0 < slabs; s0 += 4) {
+        float t[4][NV];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* sp = dy + (long)min(s0 + u, slabs - 1) * slab + off;
+#pragma unroll
+          for (int i = 0; i < NV; ++i) t[u][i] = sp[min(i * 64 + lane, cols - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < NV; ++i) acc_s[i] += (s0 + u < slabs) ? t[u][i] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) g[i] = acc_s[i] + g[i];  // (slab sum first, then the skip gradient: the slab-sum launch's order)
     } else {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -292,6 +329,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     if (agamma) { atomicAdd(&agamma[c], tg); atomicAdd(&abeta[c], tb); }
     else { wg[c] = tg; wg[cols + c] = tb; }
   }
+}
+
+// (two kernels: the slab-summing form keeps four slabs x NV loads in flight and needs twice the registers of the plain one)
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            float* __restrict__ dx, float* __restrict__ ws, int rows, int cols,
+                                                            float* __restrict__ agamma, float* __restrict__ abeta, int fold_L,
+                                                            int slabs, const float* __restrict__ slab_res) {
+  layernorm_bwd_body<NV, false>(dy, xhat, rstd, gamma, dx, ws, rows, cols, agamma, abeta, fold_L, slabs, slab_res);
+}
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_slabs_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                  float* __restrict__ dx, float* __restrict__ ws, int rows,
+                                                                  int cols, float* __restrict__ agamma, float* __restrict__ abeta,
+                                                                  int fold_L, int slabs, const float* __restrict__ slab_res) {
+  layernorm_bwd_body<NV, true>(dy, xhat, rstd, gamma, dx, ws, rows, cols, agamma, abeta, fold_L, slabs, slab_res);
 }
 
 // smallest instantiated NV >= the 64-column groups of a row
@@ -708,7 +763,7 @@ extern "C" int rf_layernorm_bwd_parts(int rows) {
 
 static int layernorm_bwd_run(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,
                              float* dgamma, float* dbeta, int accumulate, float* workspace, int rows, int cols, int fold_L,
-                             void* stream);
+                             void* stream, int slabs = 0, const float* slab_res = nullptr);
 
 extern "C" int rf_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,
                                 float* dgamma, float* dbeta, int accumulate, float* workspace, int rows, int cols,
@@ -723,9 +778,17 @@ extern "C" int rf_layernorm_bwd_fold(const float* dcols, const float* xhat, cons
   return layernorm_bwd_run(dcols, xhat, rstd, gamma, dx, dgamma, dbeta, accumulate, workspace, rows, cols, L, stream);
 }
 
+extern "C" int rf_layernorm_bwd_slabs(const float* slabs, int splits, const float* residual, const float* xhat, const float* rstd,
+                                      const float* gamma, float* dx, float* dgamma, float* dbeta, int accumulate, float* workspace,
+                                      int rows, int cols, void* stream) {
+  RF_REQUIRE(splits >= 1 && splits <= 64);
+  return layernorm_bwd_run(slabs, xhat, rstd, gamma, dx, dgamma, dbeta, accumulate, workspace, rows, cols, 0, stream, splits,
+                           residual);
+}
+
 static int layernorm_bwd_run(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,
                              float* dgamma, float* dbeta, int accumulate, float* workspace, int rows, int cols, int fold_L,
-                             void* stream) {
+                             void* stream, int slabs, const float* slab_res) {
   RF_REQUIRE(dy && xhat && rstd && gamma && dx && dgamma && dbeta && (workspace || accumulate == 2));
   RF_REQUIRE(rows > 0 && cols > 0 && cols <= 64 * LN_MAXV);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -734,14 +797,22 @@ static int layernorm_bwd_run(const float* dy, const float* xhat, const float* rs
     // launches are latency-bound), then grid-stride
     int blocks = (rows + LN_WAVES - 1) / LN_WAVES;
     blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);  // (128 .. 1 024 measured: no difference)
-    RF_LN_DISPATCH(layernorm_bwd_kernel, cols, dim3(blocks), dim3(256), 0, st, dy, xhat, rstd, gamma, dx,
-                   static_cast<float*>(nullptr), rows, cols, dgamma, dbeta, fold_L);
+    if (slabs > 0)
+      RF_LN_DISPATCH(layernorm_bwd_slabs_kernel, cols, dim3(blocks), dim3(256), 0, st, dy, xhat, rstd, gamma, dx,
+                     static_cast<float*>(nullptr), rows, cols, dgamma, dbeta, 0, slabs, slab_res);
+    else
+      RF_LN_DISPATCH(layernorm_bwd_kernel, cols, dim3(blocks), dim3(256), 0, st, dy, xhat, rstd, gamma, dx,
+                     static_cast<float*>(nullptr), rows, cols, dgamma, dbeta, fold_L, slabs, slab_res);
     RF_CHECK_LAUNCH();
     return RF_OK;
   }
   const int parts = rf_layernorm_bwd_parts(rows);
-  RF_LN_DISPATCH(layernorm_bwd_kernel, cols, dim3(parts), dim3(256), 0, st, dy, xhat, rstd, gamma, dx, workspace, rows,
-                 cols, static_cast<float*>(nullptr), static_cast<float*>(nullptr), fold_L);
+  if (slabs > 0)
+    RF_LN_DISPATCH(layernorm_bwd_slabs_kernel, cols, dim3(parts), dim3(256), 0, st, dy, xhat, rstd, gamma, dx, workspace, rows,
+                   cols, static_cast<float*>(nullptr), static_cast<float*>(nullptr), 0, slabs, slab_res);
+  else
+    RF_LN_DISPATCH(layernorm_bwd_kernel, cols, dim3(parts), dim3(256), 0, st, dy, xhat, rstd, gamma, dx, workspace, rows,
+                   cols, static_cast<float*>(nullptr), static_cast<float*>(nullptr), fold_L, slabs, slab_res);
   RF_CHECK_LAUNCH();
   RF_LAUNCH(ln_param_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, workspace, parts, cols,
                      dgamma, dbeta, accumulate);

@@ -867,12 +867,24 @@ class TrainEngine:
             K.flush_weight_grads()  # queued dW / db launches, each on the stream its operands were produced on
             if self.overlap:
                 K.join_side_streams()
+            self._check_lazy()
         finally:
+            K.LAZY.clear()
             K.SINK.active, K.SINK.on_write, K.OVERLAP, K.WGRAD.active = False, None, False, False
             K.WGRAD.side_early = False
             self._scope_out()
             self.model.__dict__.pop("_before_gps_backbone", None)
         return res
+
+    @staticmethod
+    def _check_lazy():
+        """Every gradient that left its producer as split-K slabs (kernels.LAZY) must have met a consumer that sums them."""
+        from routeformer_amd import kernels as K
+        if K.LAZY:
+            n = len(K.LAZY)
+            K.LAZY.clear()
+            raise RuntimeError(f"{n} slab-carried gradient(s) were never consumed: a placeholder tensor reached an autograd node "
+                               "that does not look kernels.LAZY up (ffn_add_layer_norm(sole_consumer=True) on a shared tensor?)")
 
     def _backward_gps_first(self, loss, cut):
         """Backward pass with the clip norm's big term taken early (single process, deferred update): the GPS backbone --
@@ -963,6 +975,7 @@ class TrainEngine:
                 p.grad.add_(g)
         K.flush_weight_grads()
         forked = {}
+        self._check_lazy()  # (the slab-carried gradients all live inside the backbone)
         if self.overlap:
             forked = K.STREAMS.join()  # (the backbone's own side branch: stage 1 may be the end of a captured graph)
         if self._early_sumsq:  # (one process rehearsing the two-graph step: the backbone's gradients are complete here)

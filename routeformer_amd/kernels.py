@@ -462,14 +462,16 @@ def gemm(A, lda_m, lda_k, B, ldb_k, ldb_n, C, ldc, M, N, K, *, bias=None, residu
 SLAB_LN = os.environ.get("RF_SLAB_LN", "1") != "0"
 
 
-def _partials_plan(a_ptr, lda: int, w, M: int, N: int, K: int):
+def _partials_plan(a_ptr, lda: int, w, M: int, N: int, K: int, ldb_k: int = 1, ldb_n: int = 0):
     """How ``gemm`` would run y = a w^T (a (M, K) with row pitch ``lda`` at ``a_ptr``, w (N, K) contiguous) if it needs a
     slab-sum launch: ("skinny", slabs) / ("tiled", splitk, slabs), or None when the product finishes in its own launch
-    (or the slab path is off).  Same decisions as ``gemm``."""
+    (or the slab path is off).  Same decisions as ``gemm``.  ``ldb_k`` / ``ldb_n``: element strides of B[k][n] inside ``w``
+    (default: w (N, K) row-major; a dX product y = a w with w (K, N) row-major passes (N, 1))."""
+    ldb_n = ldb_n or K
     if not SLAB_LN or IN_LAUNCH_SPLITK_REDUCE or N > 1024 or N <= 256 or not w.is_cuda:
         return None  # (N <= 256: the plain norm is the wave-per-row kernel there, another reduction tree)
     if SKINNY_GEMM and _PRECISION == 1 and M <= (SKINNY_MAX_M if K <= 1024 else SKINNY_MAX_M_DEEP):
-        z = _hip.lib().rf_gemm_skinny_split(a_ptr, lda, 1, ptr(w), 1, K, M, N, K)
+        z = _hip.lib().rf_gemm_skinny_split(a_ptr, lda, 1, ptr(w), ldb_k, ldb_n, M, N, K)
         if z > 0:
             return ("skinny", z) if z > 1 else None
     splitk = _auto_split(M, N, K)
@@ -479,22 +481,26 @@ def _partials_plan(a_ptr, lda: int, w, M: int, N: int, K: int):
     return ("tiled", splitk, eff) if eff > 1 else None
 
 
-def _gemm_partials(x2, w, M: int, N: int, K: int, plan):
+def _gemm_partials(x2, w, M: int, N: int, K: int, plan, ldb_k: int = 1, ldb_n: int = 0):
     """Launch the product of ``plan`` (see ``_partials_plan``) -> (slabs [splits, M, N], splits)."""
+    ldb_n = ldb_n or K
     splits = plan[-1]
     ws = torch.empty(splits * M * N, device=x2.device, dtype=torch.float32)
     ev = PROFILE.begin() if PROFILE.on else None
     if plan[0] == "skinny":
-        args = (ptr(x2), x2.stride(0), 1, ptr(w), 1, K, M, N, K, ptr(ws))
+        args = (ptr(x2), x2.stride(0), 1, ptr(w), ldb_k, ldb_n, M, N, K, ptr(ws))
         fn, name = _hip.lib().rf_gemm_skinny_partials, "rf_gemm_skinny_partials"
         rtm = 1 if M <= 16 else (2 if M <= 32 else 4)
-        tag = f"gemm_skinny_kernel<{rtm}, {2 if (M > 64 and N >= 1024) else 1}, 0>"
+        tag = f"gemm_skinny_kernel<{rtm}, {2 if (M > 64 and N >= 1024) else 1}, {0 if ldb_k == 1 else 1}>"
     else:
-        args = (ptr(x2), x2.stride(0), 1, ptr(w), 1, K, M, N, K, _PRECISION, plan[1], ptr(ws))
+        args = (ptr(x2), x2.stride(0), 1, ptr(w), ldb_k, ldb_n, M, N, K, _PRECISION, plan[1], ptr(ws))
         fn, name = _hip.lib().rf_gemm_partials, "rf_gemm_partials"
         am = 0 if (x2.stride(0) % 4 == 0 and K % 4 == 0 and x2.data_ptr() % 16 == 0) else 2
-        bm = 0 if (K % 4 == 0 and w.data_ptr() % 16 == 0) else 2
-        tag = (f"gemm2_kernel<{_PRECISION}, {am}, {bm}, {3 if (M >= 4096 and N >= 64) else 0}>" if am == 0 and bm == 0
+        if ldb_k == 1:
+            bm = 0 if (K % 4 == 0 and ldb_n % 4 == 0 and w.data_ptr() % 16 == 0) else 2
+        else:
+            bm = 1 if (ldb_n == 1 and ldb_k % 4 == 0 and N % 4 == 0 and w.data_ptr() % 16 == 0) else 2
+        tag = (f"gemm2_kernel<{_PRECISION}, {am}, {bm}, {3 if (M >= 4096 and N >= 64) else 0}>" if am <= 1 and bm <= 1
                else f"gemm_kernel<{_PRECISION}, {am}, {bm}, 0>")
     check(fn(*args, _stream()), name)
     if ev is not None:
@@ -526,6 +532,17 @@ def _ln_fwd_slabs(ws, splits, bias, r2, gamma, beta, M: int, N: int, eps: float,
 
 class _Ctx:
     """Stand-in for an autograd context when one Function's backward runs another's (attributes set by the caller)."""
+
+
+# Gradients that travel between two autograd nodes as split-K slabs instead of a finished tensor: the FFN's last dX product
+# (d LayerNorm-1 output = dZ W1 + skip gradient) leaves its slabs, and the LayerNorm backward that consumes it sums them on
+# load (rf_layernorm_bwd_slabs) -- one slab-sum launch less per layer.  The producer returns an UNWRITTEN placeholder tensor and
+# registers (slabs, splits, skip gradient, placeholder) under the placeholder's address; only a consumer that looks its
+# incoming gradient up here may follow.  The model code asks for it (``ffn_add_layer_norm(sole_consumer=True)``) where the
+# layer's structure guarantees that: the normalised tensor goes to the FFN and nowhere else, and it was produced by
+# ``_LinearAddLNSlabs``.  The engine checks after every backward pass that nothing was left unconsumed.
+LAZY = {}
+LAZY_DX = os.environ.get("RF_LAZY_DX", "1") != "0"
 
 
 def colsum(X2d: torch.Tensor, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -945,7 +962,16 @@ class _FFN(torch.autograd.Function):
                 ds2 = dskip.reshape(-1, D)
                 if ds2.stride(1) != 1 or ds2.stride(0) != D:
                     ds2 = ds2.contiguous()
-                dx = _input_grad(dz, w1, residual=ds2, ldr=D, res_rows=ds2.shape[0]).view(ctx.xshape)
+                plan = None
+                if getattr(ctx, "lazy_dx", False) and not DETERMINISTIC and dz.dtype == torch.float32 and w1.is_contiguous():
+                    plan = _partials_plan(ptr(dz), dz.stride(0), w1, dz.shape[0], D, F, ldb_k=D, ldb_n=1)
+                if plan is not None:  # leave the slabs to the LayerNorm backward that follows (see LAZY)
+                    ws, splits = _gemm_partials(dz, w1, dz.shape[0], D, F, plan, ldb_k=D, ldb_n=1)
+                    dx = torch.empty(dz.shape[0], D, device=dz.device, dtype=torch.float32)
+                    LAZY[dx.data_ptr()] = (ws, splits, ds2, dx)
+                    dx = dx.view(ctx.xshape)
+                else:
+                    dx = _input_grad(dz, w1, residual=ds2, ldr=D, res_rows=ds2.shape[0]).view(ctx.xshape)
             else:
                 dx = _input_grad(dz, w1).view(ctx.xshape)
         _wrote(g1, gb1, g2, gb2)
@@ -1014,22 +1040,28 @@ class _AddLayerNorm(torch.autograd.Function):
         return dx, (dx if ctx.has_res else None), dg, db, None, None, None, None
 
 
-def _ln_backward(dy2, xhat, rstd, gamma, gg, gb, fold_L: int = 0):
+def _ln_backward(dy2, xhat, rstd, gamma, gg, gb, fold_L: int = 0, slabs=None):
     """LayerNorm backward on saved (xhat, rstd): -> (d pre-norm input, dgamma, dbeta); with sinks the
     parameter gradients are accumulated there and returned as None.  ``fold_L`` = L > 0: ``dy2`` is the gradient of the
-    (B, L + 2, 3 cols) im2col image the forward wrote (``_ln_fwd_slabs(unfold_L=L)``); the fold happens on load."""
+    (B, L + 2, 3 cols) im2col image the forward wrote (``_ln_fwd_slabs(unfold_L=L)``); the fold happens on load.
+    ``slabs`` = (workspace, splits, skip gradient or None): the incoming gradient is still the split-K slabs of the dX product
+    in front of this backward (``LAZY``), summed on load (``dy2`` is ignored)."""
     rows, cols = xhat.shape
     dx = torch.empty_like(xhat)
     sink = gg is not None and gb is not None
-    dg = gg if sink else torch.empty(cols, device=dy2.device, dtype=torch.float32)
-    db = gb if sink else torch.empty(cols, device=dy2.device, dtype=torch.float32)
+    dg = gg if sink else torch.empty(cols, device=xhat.device, dtype=torch.float32)
+    db = gb if sink else torch.empty(cols, device=xhat.device, dtype=torch.float32)
     atomic = sink and not DETERMINISTIC
     ws = None
     if not atomic:
         parts = _hip.lib().rf_layernorm_bwd_parts(rows)
-        ws = torch.empty(parts * 2 * cols, device=dy2.device, dtype=torch.float32)
+        ws = torch.empty(parts * 2 * cols, device=xhat.device, dtype=torch.float32)
     ev = PROFILE.begin() if PROFILE.on else None
-    if fold_L:
+    if slabs is not None:
+        check(_hip.lib().rf_layernorm_bwd_slabs(ptr(slabs[0]), slabs[1], ptr(slabs[2]), ptr(xhat), ptr(rstd), ptr(gamma), ptr(dx),
+                                                ptr(dg), ptr(db), 2 if atomic else (1 if sink else 0), ptr(ws), rows, cols,
+                                                _stream()), "rf_layernorm_bwd_slabs")
+    elif fold_L:
         check(_hip.lib().rf_layernorm_bwd_fold(ptr(dy2), ptr(xhat), ptr(rstd), ptr(gamma), ptr(dx), ptr(dg), ptr(db),
                                                2 if atomic else (1 if sink else 0), ptr(ws), rows, cols, fold_L, _stream()),
               "rf_layernorm_bwd_fold")
@@ -1122,7 +1154,12 @@ class _LinearAddLNSlabs(torch.autograd.Function):
         a2, w, xhat, rstd, gamma = ctx.saved_tensors
         gw, gb, gg, gbeta = ctx.sinks
         M, N = xhat.shape
-        dpre, dgam, dbet = _ln_backward(dy.reshape(M, N).contiguous(), xhat, rstd, gamma, gg, gbeta)
+        lazy = LAZY.pop(dy.data_ptr(), None)
+        if lazy is not None:  # the gradient is still the slabs of the FFN's last dX product
+            assert lazy[3].numel() == M * N
+            dpre, dgam, dbet = _ln_backward(None, xhat, rstd, gamma, gg, gbeta, slabs=lazy[:3])
+        else:
+            dpre, dgam, dbet = _ln_backward(dy.reshape(M, N).contiguous(), xhat, rstd, gamma, gg, gbeta)
         lin = _Ctx()
         lin.saved_tensors, lin.sinks, lin.has_bias, lin.xshape = (a2, w), (gw, gb), ctx.has_bias, ctx.shapes[0]
         lin.needs_input_grad = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2], False)
@@ -1220,7 +1257,7 @@ class _FFNAddLNSlabs(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, act, gamma, beta, eps, g1, gb1, g2, gb2, gg, gbeta, plan, need_grad=True,
-                unfold_L: int = 0):
+                unfold_L: int = 0, lazy_dx: bool = False):
         """``unfold_L`` = L: the output is the (B, L + 2, 3 D) im2col image of the distilling convolution that follows
         (``circular_conv3(pad=2)`` without its unfold launch; the backward folds on load)."""
         _req(x, "ffn_ln.x")
@@ -1237,7 +1274,7 @@ class _FFNAddLNSlabs(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(x2, w1, w2, h, z if z is not None else h, xhat, rstd, gamma)
         ctx.sinks = (g1, gb1, g2, gb2, gg, gbeta)
-        ctx.act, ctx.xshape, ctx.wshapes, ctx.unfold_L = act, x.shape, (F, D), unfold_L
+        ctx.act, ctx.xshape, ctx.wshapes, ctx.unfold_L, ctx.lazy_dx = act, x.shape, (F, D), unfold_L, bool(lazy_dx)
         return y if unfold_L else y.view(x.shape)
 
     @staticmethod
@@ -1252,15 +1289,24 @@ class _FFNAddLNSlabs(torch.autograd.Function):
         f = _Ctx()
         f.saved_tensors, f.sinks, f.drop = (x2, w1, w2, h, zsrc), (g1, gb1, g2, gb2), None
         f.act, f.xshape, f.wshapes, f.needs_input_grad = ctx.act, ctx.xshape, ctx.wshapes, (ctx.needs_input_grad[0],)
+        f.lazy_dx = ctx.lazy_dx
         dpre_v = dpre.view(ctx.xshape)
         dx, dw1, db1, dw2, db2 = _FFN.backward(f, dpre_v, dpre_v)[:5]  # the skip branch's gradient rides in the last dX epilogue
-        return dx, dw1, db1, dw2, db2, None, dgam, dbet, None, None, None, None, None, None, None, None, None, None
+        return dx, dw1, db1, dw2, db2, None, dgam, dbet, None, None, None, None, None, None, None, None, None, None, None
 
 
 UNFOLD_IN_NORM = os.environ.get("RF_UNFOLD_IN_NORM", "1") != "0"  # measurement switch
 
 
-def ffn_add_layer_norm(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str, gamma, beta, eps: float = 1e-5, unfold: bool = False):
+def _lazy_dx_ok(x, sole_consumer: bool) -> bool:
+    """May the FFN hand its input gradient to ``x``'s producer as slabs (``LAZY``)?  Only when the caller vouches that nothing
+    else consumes ``x`` and ``x`` came out of the slab-summing projection + norm, whose backward looks the slabs up."""
+    return bool(sole_consumer and LAZY_DX and SINK.active and not DETERMINISTIC and torch.is_grad_enabled()
+                and x.grad_fn is not None and type(x.grad_fn).__name__ == "_LinearAddLNSlabsBackward")
+
+
+def ffn_add_layer_norm(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str, gamma, beta, eps: float = 1e-5, unfold: bool = False,
+                       sole_consumer: bool = False):
     """LayerNorm(x + ffn(x)); one launch when d_model = 128, d_ff = 256 in bf16 mode.
     ``unfold``: the caller is followed by a distilling convolution (circular k = 3, padding 2) and can take the output as
     its im2col image: -> (tensor, True) when the slab-summing norm wrote that image, else (plain output, False)."""
@@ -1273,9 +1319,9 @@ def ffn_add_layer_norm(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str, gamma, b
             if plan is not None:
                 y = _FFNAddLNSlabs.apply(x, conv1_w, conv1_b, conv2_w, conv2_b, act, gamma, beta, eps, _slot(conv1_w),
                                          _slot(conv1_b), _slot(conv2_w), _slot(conv2_b), _slot(gamma), _slot(beta), plan,
-                                         torch.is_grad_enabled(), x.shape[1])
+                                         torch.is_grad_enabled(), x.shape[1], _lazy_dx_ok(x, sole_consumer))
                 return y, True
-        return ffn_add_layer_norm(x, conv1_w, conv1_b, conv2_w, conv2_b, act, gamma, beta, eps), False
+        return ffn_add_layer_norm(x, conv1_w, conv1_b, conv2_w, conv2_b, act, gamma, beta, eps, sole_consumer=sole_consumer), False
     if (ROWBLOCK and _PRECISION == 1 and D == 128 and F == 256 and x.is_cuda and conv1_b is not None
             and conv2_b is not None and conv1_w.is_contiguous() and conv2_w.is_contiguous()
             and conv1_w.data_ptr() % 16 == 0 and conv2_w.data_ptr() % 16 == 0):
@@ -1289,7 +1335,7 @@ def ffn_add_layer_norm(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str, gamma, b
         if plan is not None:
             return _FFNAddLNSlabs.apply(x, conv1_w, conv1_b, conv2_w, conv2_b, act, gamma, beta, eps, _slot(conv1_w),
                                         _slot(conv1_b), _slot(conv2_w), _slot(conv2_b), _slot(gamma), _slot(beta), plan,
-                                        torch.is_grad_enabled())
+                                        torch.is_grad_enabled(), 0, _lazy_dx_ok(x, sole_consumer))
     y, skip = ffn(x, conv1_w, conv1_b, conv2_w, conv2_b, act, fork=True)
     return add_layer_norm(skip, y, gamma, beta, eps)
 

@@ -348,8 +348,9 @@ class EncoderLayer(nn.Module):
                             fork=True, drop_p=self.p)
             y = K.add_layer_norm(skip, y, norm.weight, norm.bias, norm.eps)
             return (y, False) if unfold else y
+        # (``x`` -- the output of norm1 / norm2 -- goes to this FFN + skip and nowhere else: its gradient may travel as slabs)
         return K.ffn_add_layer_norm(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias, self.act,
-                                    norm.weight, norm.bias, norm.eps, **({"unfold": True} if unfold else {}))
+                                    norm.weight, norm.bias, norm.eps, sole_consumer=True, **({"unfold": True} if unfold else {}))
 
     def forward(self, x, idx=None, idx_group: int = 0, unfold: bool = False):
         """``unfold`` (the Informer encoder's distilling layers, Encoder._forward): see ``_ffn_norm``."""
