@@ -1035,7 +1035,12 @@ class _AddLayerNorm(torch.autograd.Function):
         xhat, rstd, gamma = ctx.saved_tensors
         gg, gb = ctx.sinks
         rows, cols = xhat.shape
-        dx, dg, db = _ln_backward(dy.reshape(rows, cols).contiguous(), xhat, rstd, gamma, gg, gb)
+        lazy = LAZY.pop(dy.data_ptr(), None)
+        if lazy is not None:  # the gradient is still the split-K slabs of the FFN's last dX product (see LAZY)
+            assert lazy[3].numel() == rows * cols
+            dx, dg, db = _ln_backward(None, xhat, rstd, gamma, gg, gb, slabs=lazy[:3])
+        else:
+            dx, dg, db = _ln_backward(dy.reshape(rows, cols).contiguous(), xhat, rstd, gamma, gg, gb)
         dx = dx.view(ctx.xshape)
         return dx, (dx if ctx.has_res else None), dg, db, None, None, None, None
 
@@ -1300,9 +1305,9 @@ UNFOLD_IN_NORM = os.environ.get("RF_UNFOLD_IN_NORM", "1") != "0"  # measurement 
 
 def _lazy_dx_ok(x, sole_consumer: bool) -> bool:
     """May the FFN hand its input gradient to ``x``'s producer as slabs (``LAZY``)?  Only when the caller vouches that nothing
-    else consumes ``x`` and ``x`` came out of the slab-summing projection + norm, whose backward looks the slabs up."""
+    else consumes ``x`` and ``x`` came out of one of the two norms whose backward looks the slabs up."""
     return bool(sole_consumer and LAZY_DX and SINK.active and not DETERMINISTIC and torch.is_grad_enabled()
-                and x.grad_fn is not None and type(x.grad_fn).__name__ == "_LinearAddLNSlabsBackward")
+                and x.grad_fn is not None and type(x.grad_fn).__name__ in ("_LinearAddLNSlabsBackward", "_AddLayerNormBackward"))
 
 
 def ffn_add_layer_norm(x, conv1_w, conv1_b, conv2_w, conv2_b, act: str, gamma, beta, eps: float = 1e-5, unfold: bool = False,
