@@ -255,6 +255,13 @@ int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const float* x, c
                        const float* var, const float* gamma, const float* beta, float* dx,
                        float* dgamma, float* dbeta, int accumulate, int B, int L, int C, float eps,
                        int training, void* stream);
+/* The same backward with the incoming gradient still in `splits` split-K slabs [splits][B * Lout][C] of the dX product in front of
+ * it (+ an optional skip gradient `residual`): summed on load.  rf_bn_elu_pool_bwd_slab_ok(B, L): the LDS-slab kernel applies. */
+int rf_bn_elu_pool_bwd_slab_ok(int B, int L);
+int rf_bn_elu_pool_bwd_slabs(const float* slabs, int splits, const float* residual, const int32_t* argmax, const float* x,
+                             const float* mean, const float* var, const float* gamma, const float* beta, float* dx,
+                             float* dgamma, float* dbeta, int accumulate, int B, int L, int C, float eps, int training,
+                             void* stream);
 /* Train-mode forward of the same tail in ONE launch (batch statistics + running-statistics update + BatchNorm -> ELU ->
  * MaxPool; mean / var = the biased batch statistics, kept for the backward pass): a workgroup holds a 32-channel slab of
  * all B * L rows in LDS.  RF_EUNSUPPORTED when the slab does not fit (then: rf_bn_stats + rf_bn_elu_pool_fwd). */

@@ -62,6 +62,8 @@ SIGNATURES = {
     "rf_bn_elu_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
     "rf_bn_train_elu_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _F, _P],
     "rf_bn_elu_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "rf_bn_elu_pool_bwd_slab_ok": [_I, _I],
+    "rf_bn_elu_pool_bwd_slabs": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "rf_wgrad_grouped": [_P, _I, _I, _P],
     "rf_wgrad_tr": [_P, _I, _P],
     "rf_rowblock_linear_supported": [_I, _I, _I],

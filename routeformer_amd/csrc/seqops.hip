@@ -626,7 +626,10 @@ __global__ __launch_bounds__(256) void bn_train_elu_pool_fwd_kernel(
 __global__ __launch_bounds__(256) void bn_elu_pool_bwd_slab_kernel(
     const float* __restrict__ dy, const int32_t* __restrict__ argmax, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dx,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int L, int C, int Lout, float eps, int training, int accumulate) {
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int L, int C, int Lout, float eps, int training, int accumulate,
+    int dy_slabs, const float* __restrict__ dy_res) {
+  // dy_slabs > 0: dy is still the split-K slabs [dy_slabs][B * Lout][C] of the dX product in front of this backward plus the
+  // skip gradient dy_res (or null): summed on load (rf_bn_elu_pool_bwd_slabs)
   extern __shared__ float slab[];  // xh [rows][BNS_CH], then d [rows][BNS_CH]
   __shared__ float red[2][BNS_RL][BNS_CH];
   const int tx = threadIdx.x % BNS_CH, ty = threadIdx.x / BNS_CH;
@@ -658,6 +661,24 @@ __global__ __launch_bounds__(256) void bn_elu_pool_bwd_slab_kernel(
       const long at = (long)min(o0 + j * BNS_RL, outs - 1) * C + cc;
       li[j] = argmax[at];
       gy[j] = dy[at];
+    }
+    if (dy_slabs > 0) {  // (gy holds slab 0; the others four at a time, clamped index + masked add, then the skip gradient)
+      const long sl = (long)outs * C;
+      for (int s0 = 1; s0 < dy_slabs; s0 += 4) {
+        float t[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t[u][j] = dy[(long)min(s0 + u, dy_slabs - 1) * sl + (long)min(o0 + j * BNS_RL, outs - 1) * C + cc];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) gy[j] += (s0 + u < dy_slabs) ? t[u][j] : 0.f;
+      }
+      if (dy_res) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gy[j] += dy_res[(long)min(o0 + j * BNS_RL, outs - 1) * C + cc];
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -870,10 +891,10 @@ extern "C" int rf_bn_elu_pool_fwd(const float* x, const float* mean, const float
   return RF_OK;
 }
 
-extern "C" int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const float* x, const float* mean,
-                                  const float* var, const float* gamma, const float* beta, float* dx, float* dgamma,
-                                  float* dbeta, int accumulate, int B, int L, int C, float eps, int training,
-                                  void* stream) {
+static int bn_elu_pool_bwd_run(const float* dy, const int32_t* argmax, const float* x, const float* mean,
+                               const float* var, const float* gamma, const float* beta, float* dx, float* dgamma,
+                               float* dbeta, int accumulate, int B, int L, int C, float eps, int training,
+                               void* stream, int g_bn_dy_slabs, const float* g_bn_dy_res) {
   RF_REQUIRE(dy && argmax && x && mean && var && gamma && beta && dx && dgamma && dbeta && B > 0 && L > 0 && C > 0);
   const int Lout = (L - 1) / 2 + 1;
   const size_t lds = (size_t)2 * B * L * BNS_CH * sizeof(float);
@@ -885,14 +906,42 @@ extern "C" int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const 
       attr = true;
     }
     RF_LAUNCH(bn_elu_pool_bwd_slab_kernel, dim3((C + BNS_CH - 1) / BNS_CH), dim3(256), lds, static_cast<hipStream_t>(stream), dy,
-              argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, B, L, C, Lout, eps, training, accumulate);
+              argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, B, L, C, Lout, eps, training, accumulate, g_bn_dy_slabs,
+              g_bn_dy_res);
     RF_CHECK_LAUNCH();
     return RF_OK;
+  }
+  if (g_bn_dy_slabs > 0) {
+    rf_g_last_error = "rf_bn_elu_pool_bwd_slabs: B * L rows do not fit the LDS slab";
+    return RF_EUNSUPPORTED;
   }
   RF_LAUNCH(bn_elu_pool_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), dy,
                      argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, B, L, C, Lout, eps, training, accumulate);
   RF_CHECK_LAUNCH();
   return RF_OK;
+}
+
+extern "C" int rf_bn_elu_pool_bwd_slab_ok(int B, int L) {
+  return (size_t)2 * B * L * BNS_CH * sizeof(float) <= (size_t)BNS_MAX_LDS ? 1 : 0;
+}
+
+// rf_bn_elu_pool_bwd whose incoming gradient is still `splits` split-K slabs [splits][B * Lout][C] (+ an optional skip gradient
+// `residual` [B * Lout][C]): summed on load.  Only with the LDS-slab kernel (rf_bn_elu_pool_bwd_slab_ok).
+extern "C" int rf_bn_elu_pool_bwd_slabs(const float* slabs, int splits, const float* residual, const int32_t* argmax, const float* x,
+                                        const float* mean, const float* var, const float* gamma, const float* beta, float* dx,
+                                        float* dgamma, float* dbeta, int accumulate, int B, int L, int C, float eps, int training,
+                                        void* stream) {
+  RF_REQUIRE(splits >= 1 && splits <= 64 && rf_bn_elu_pool_bwd_slab_ok(B, L));
+  return bn_elu_pool_bwd_run(slabs, argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, accumulate, B, L, C, eps, training, stream,
+                             splits, residual);
+}
+
+extern "C" int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const float* x, const float* mean,
+                                  const float* var, const float* gamma, const float* beta, float* dx, float* dgamma,
+                                  float* dbeta, int accumulate, int B, int L, int C, float eps, int training,
+                                  void* stream) {
+  return bn_elu_pool_bwd_run(dy, argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, accumulate, B, L, C, eps, training, stream, 0,
+                             nullptr);
 }
 
 // Train-mode forward in ONE launch: batch statistics (+ running-statistics update) -> BatchNorm -> ELU -> MaxPool; mean / var

@@ -845,6 +845,12 @@ class _Linear(torch.autograd.Function):
         ctx.sinks = (gw, gb)  # plain attributes: slots of a buffer other kernels also write (no version check)
         ctx.has_bias = b is not None
         ctx.xshape = x.shape
+        # ``fork``: this projection is the ONLY consumer of x (it hands the skip alias back itself).  Where x is the output of the
+        # distilling tail (BatchNorm -> ELU -> MaxPool), whose backward can sum split-K slabs on load, the input gradient may
+        # travel as slabs (see LAZY)
+        ctx.lazy_dx = bool(fork and LAZY_DX and SINK.active and not DETERMINISTIC and residual is None
+                           and _producer_name(x) == "_BnEluPoolBackward"
+                           and _hip.lib().rf_bn_elu_pool_bwd_slab_ok(1, 2 * M))  # (its input has at most 2 M rows)
         if fork:
             return y.view(*x.shape[:-1], N), x.view_as(x)
         return y.view(*x.shape[:-1], N)
@@ -876,7 +882,17 @@ class _Linear(torch.autograd.Function):
             if _rowblock_nn_ok(w) and _vec_rows(dy2, w.shape[0]) and (ds2 is None or ds2.data_ptr() % 16 == 0):
                 dx = _rowblock_nn(w, dy2.shape[0], a=dy2, res=ds2).view(ctx.xshape)
             elif ds2 is not None:
-                dx = _input_grad(dy2, w, residual=ds2, ldr=ds2.shape[1], res_rows=ds2.shape[0]).view(ctx.xshape)
+                plan = None
+                if getattr(ctx, "lazy_dx", False) and not DETERMINISTIC and w.is_contiguous() and ds2.shape[0] == dy2.shape[0]:
+                    plan = _partials_plan(ptr(dy2), dy2.stride(0), w, dy2.shape[0], w.shape[1], w.shape[0], ldb_k=w.stride(0),
+                                          ldb_n=1)
+                if plan is not None:  # leave the slabs to the consumer of x's gradient (see LAZY)
+                    ws, splits = _gemm_partials(dy2, w, dy2.shape[0], w.shape[1], w.shape[0], plan, ldb_k=w.stride(0), ldb_n=1)
+                    dx = torch.empty(dy2.shape[0], w.shape[1], device=dy2.device, dtype=torch.float32)
+                    LAZY[dx.data_ptr()] = (ws, splits, ds2, dx)
+                    dx = dx.view(ctx.xshape)
+                else:
+                    dx = _input_grad(dy2, w, residual=ds2, ldr=ds2.shape[1], res_rows=ds2.shape[0]).view(ctx.xshape)
             else:
                 dx = _input_grad(dy2, w).view(ctx.xshape)
         _wrote(gw, gb)
@@ -1303,6 +1319,21 @@ class _FFNAddLNSlabs(torch.autograd.Function):
 UNFOLD_IN_NORM = os.environ.get("RF_UNFOLD_IN_NORM", "1") != "0"  # measurement switch
 
 
+def _producer_name(x) -> str:
+    """Class name of the autograd node that produced ``x``, looking through reshape / view nodes (their backward only
+    re-views the gradient: a placeholder passes through untouched)."""
+    fn = x.grad_fn
+    for _ in range(4):
+        if fn is None:
+            return ""
+        name = type(fn).__name__
+        if name in ("ViewBackward0", "UnsafeViewBackward0", "ReshapeAliasBackward0") and fn.next_functions:
+            fn = fn.next_functions[0][0]
+            continue
+        return name
+    return ""
+
+
 def _lazy_dx_ok(x, sole_consumer: bool) -> bool:
     """May the FFN hand its input gradient to ``x``'s producer as slabs (``LAZY``)?  Only when the caller vouches that nothing
     else consumes ``x`` and ``x`` came out of one of the two norms whose backward looks the slabs up."""
@@ -1456,14 +1487,21 @@ class _BnEluPool(torch.autograd.Function):
         x, gamma, beta, mean, var, arg = ctx.saved_tensors
         gg, gb = ctx.sinks
         B, L, C = x.shape
-        dy = dy.contiguous()
+        lazy = LAZY.pop(dy.data_ptr(), None)
         dx = torch.empty_like(x)
         sink = gg is not None and gb is not None
         dg = gg if sink else torch.empty(C, device=x.device, dtype=torch.float32)
         db = gb if sink else torch.empty(C, device=x.device, dtype=torch.float32)
-        check(_hip.lib().rf_bn_elu_pool_bwd(ptr(dy), ptr(arg), ptr(x), ptr(mean), ptr(var), ptr(gamma),
-                                            ptr(beta), ptr(dx), ptr(dg), ptr(db), 1 if sink else 0, B, L, C, ctx.eps,
-                                            1 if ctx.training else 0, _stream()), "rf_bn_elu_pool_bwd")
+        if lazy is not None:  # the gradient is still the split-K slabs of the next layer's q | k | v input gradient (see LAZY)
+            assert lazy[3].numel() == arg.numel()
+            check(_hip.lib().rf_bn_elu_pool_bwd_slabs(ptr(lazy[0]), lazy[1], ptr(lazy[2]), ptr(arg), ptr(x), ptr(mean), ptr(var),
+                                                      ptr(gamma), ptr(beta), ptr(dx), ptr(dg), ptr(db), 1 if sink else 0, B, L, C,
+                                                      ctx.eps, 1 if ctx.training else 0, _stream()), "rf_bn_elu_pool_bwd_slabs")
+        else:
+            dy = dy.contiguous()
+            check(_hip.lib().rf_bn_elu_pool_bwd(ptr(dy), ptr(arg), ptr(x), ptr(mean), ptr(var), ptr(gamma),
+                                                ptr(beta), ptr(dx), ptr(dg), ptr(db), 1 if sink else 0, B, L, C, ctx.eps,
+                                                1 if ctx.training else 0, _stream()), "rf_bn_elu_pool_bwd")
         if sink:
             _wrote(gg, gb)
             dg = db = None
