@@ -268,6 +268,12 @@ int rf_bn_elu_pool_bwd_slabs(const float* slabs, int splits, const float* residu
 int rf_bn_train_elu_pool_fwd(const float* x, const float* gamma, const float* beta, float* mean, float* var,
                              float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float* y,
                              int32_t* argmax, int B, int L, int C, float eps, void* stream);
+/* ... fed with the `splits` split-K slabs [splits][B * L][C] of the convolution's product (rf_gemm_partials) and its bias: summed on
+ * load, the finished pre-normalisation map is written to x_out for the backward pass. */
+int rf_bn_train_elu_pool_fwd_slabs(const float* slabs, int splits, const float* bias, float* x_out, const float* gamma,
+                                   const float* beta, float* mean, float* var, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, float momentum, float* y, int32_t* argmax, int B, int L, int C,
+                                   float eps, void* stream);
 
 /* Grouped weight gradients (the dW / db GEMMs of nn.Linear / Conv1d(k=1) backward, autograd's
  * `grad_weight = grad_out^T @ input`): for each entry  dw[N,K] += dy[M,N]^T x[M,K]  and, if db != NULL,

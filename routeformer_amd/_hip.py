@@ -61,6 +61,7 @@ SIGNATURES = {
     "rf_bn_stats": [_P, _P, _P, _I, _I, _P, _P, _P, _F, _P],
     "rf_bn_elu_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
     "rf_bn_train_elu_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _F, _P],
+    "rf_bn_train_elu_pool_fwd_slabs": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _F, _P],
     "rf_bn_elu_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "rf_bn_elu_pool_bwd_slab_ok": [_I, _I],
     "rf_bn_elu_pool_bwd_slabs": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],

@@ -560,19 +560,43 @@ constexpr int BNS_CH = 32, BNS_RL = 8;  // channels per workgroup x row lanes (2
 __global__ __launch_bounds__(256) void bn_train_elu_pool_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean_out,
     float* __restrict__ var_out, float* __restrict__ run_mean, float* __restrict__ run_var, long long* __restrict__ batches,
-    float momentum, float* __restrict__ y, int32_t* __restrict__ argmax, int B, int L, int C, int Lout, float eps) {
+    float momentum, float* __restrict__ y, int32_t* __restrict__ argmax, int B, int L, int C, int Lout, float eps,
+    int x_slabs, const float* __restrict__ x_bias, float* __restrict__ x_out) {
+  // x_slabs > 0: x is still the split-K slabs [x_slabs][B * L][C] of the convolution's product; they are summed on load
+  // (+ x_bias) and the finished map is written to x_out for the backward pass (rf_bn_train_elu_pool_fwd_slabs)
   extern __shared__ float slab[];  // [rows][BNS_CH]
   __shared__ float red[BNS_RL][BNS_CH];
   const int tx = threadIdx.x % BNS_CH, ty = threadIdx.x / BNS_CH;
   const int c = blockIdx.x * BNS_CH + tx, cc = min(c, C - 1);
   const int rows = B * L;
   float s = 0.f;
+  const float xb = (x_slabs > 0 && x_bias) ? x_bias[cc] : 0.f;
   // eight rows in flight per thread (clamped, unconditional loads): a load -> LDS store -> next load loop is one memory
   // round trip per row, 40 of them at B L = 320 (27 us for a 1-MB tensor)
   for (int r0 = ty; r0 < rows; r0 += BNS_RL * 8) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = x[(long)min(r0 + j * BNS_RL, rows - 1) * C + cc];
+    if (x_slabs > 0) {
+      const long sl = (long)rows * C;
+      for (int s0 = 1; s0 < x_slabs; s0 += 2) {  // two more slabs per trip (v holds slab 0): clamped index, masked add
+        float t[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[u][j] = x[(long)min(s0 + u, x_slabs - 1) * sl + (long)min(r0 + j * BNS_RL, rows - 1) * C + cc];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += (s0 + u < x_slabs) ? t[u][j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] += xb;
+        const int r = r0 + j * BNS_RL;
+        if (r < rows && c < C) x_out[(long)r * C + c] = v[j];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int r = r0 + j * BNS_RL;
@@ -947,9 +971,33 @@ extern "C" int rf_bn_elu_pool_bwd(const float* dy, const int32_t* argmax, const 
 // Train-mode forward in ONE launch: batch statistics (+ running-statistics update) -> BatchNorm -> ELU -> MaxPool; mean / var
 // (biased) are written for the backward pass.  Returns RF_EUNSUPPORTED when the row slab does not fit LDS (the caller then
 // uses rf_bn_stats + rf_bn_elu_pool_fwd).
+static int bn_train_fwd_run(const float* x, const float* gamma, const float* beta, float* mean, float* var,
+                            float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                            float* y, int32_t* argmax, int B, int L, int C, float eps, void* stream, int x_slabs,
+                            const float* x_bias, float* x_out);
+
 extern "C" int rf_bn_train_elu_pool_fwd(const float* x, const float* gamma, const float* beta, float* mean, float* var,
                                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                                         float* y, int32_t* argmax, int B, int L, int C, float eps, void* stream) {
+  return bn_train_fwd_run(x, gamma, beta, mean, var, running_mean, running_var, num_batches_tracked, momentum, y, argmax, B, L, C,
+                          eps, stream, 0, nullptr, nullptr);
+}
+
+// The same launch fed with the `splits` split-K slabs [splits][B * L][C] of the convolution's product (+ its bias): they are
+// summed on load and the finished pre-normalisation map is written to x_out ([B * L][C]: what the backward pass reads).
+extern "C" int rf_bn_train_elu_pool_fwd_slabs(const float* slabs, int splits, const float* bias, float* x_out, const float* gamma,
+                                              const float* beta, float* mean, float* var, float* running_mean, float* running_var,
+                                              int64_t* num_batches_tracked, float momentum, float* y, int32_t* argmax, int B, int L,
+                                              int C, float eps, void* stream) {
+  RF_REQUIRE(splits >= 1 && splits <= 64 && x_out);
+  return bn_train_fwd_run(slabs, gamma, beta, mean, var, running_mean, running_var, num_batches_tracked, momentum, y, argmax, B, L, C,
+                          eps, stream, splits, bias, x_out);
+}
+
+static int bn_train_fwd_run(const float* x, const float* gamma, const float* beta, float* mean, float* var,
+                            float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                            float* y, int32_t* argmax, int B, int L, int C, float eps, void* stream, int x_slabs,
+                            const float* x_bias, float* x_out) {
   RF_REQUIRE(x && gamma && beta && mean && var && y && argmax && B > 0 && L > 0 && C > 0 && (!running_mean == !running_var));
   const int Lout = (L - 1) / 2 + 1;
   const size_t lds = (size_t)B * L * BNS_CH * sizeof(float);
@@ -965,7 +1013,7 @@ extern "C" int rf_bn_train_elu_pool_fwd(const float* x, const float* gamma, cons
   }
   RF_LAUNCH(bn_train_elu_pool_fwd_kernel, dim3((C + BNS_CH - 1) / BNS_CH), dim3(256), lds, static_cast<hipStream_t>(stream), x,
             gamma, beta, mean, var, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, y,
-            argmax, B, L, C, Lout, eps);
+            argmax, B, L, C, Lout, eps, x_slabs, x_bias, x_out);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }

@@ -543,6 +543,7 @@ class _Ctx:
 # ``_LinearAddLNSlabs``.  The engine checks after every backward pass that nothing was left unconsumed.
 LAZY = {}
 LAZY_DX = os.environ.get("RF_LAZY_DX", "1") != "0"
+LAZY_BN_FWD = os.environ.get("RF_LAZY_BN_FWD", "1") != "0"  # ... the distilling convolution's product into the BatchNorm tail
 
 
 def colsum(X2d: torch.Tensor, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -817,7 +818,7 @@ class _Linear(torch.autograd.Function):
     """y = x W^T + b (+ residual rows broadcast over the batch: y[m] += residual[m % R])."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, gw, gb, fork=False):
+    def forward(ctx, x, w, b, residual, gw, gb, fork=False, lazy_out=False):
         """``fork``: also return an alias of ``x`` for the layer's skip connection.  Its gradient then comes
         back into THIS node and is added in the dX GEMM epilogue -- otherwise autograd would sum the two
         gradients of ``x`` (projection path + skip path) with a separate elementwise launch."""
@@ -840,7 +841,14 @@ class _Linear(torch.autograd.Function):
         elif _rowblock_ok(x2, w, N, K):
             _rowblock_linear(x2, w, b, None, y, M, N, K)
         else:
-            gemm(x2, x2.stride(0), 1, w, 1, K, y, N, M, N, K, bias=b)
+            plan = _partials_plan(ptr(x2), x2.stride(0), w, M, N, K) if (lazy_out and LAZY_DX and x2.dtype == torch.float32) else None
+            if plan is not None:
+                # the caller's next op sums the slabs itself (circular_conv3_unfolded(lazy=True) -> bn_elu_pool): ``y`` stays
+                # UNWRITTEN until that op fills it in (see LAZY)
+                ws, splits = _gemm_partials(x2, w, M, N, K, plan)
+                LAZY[y.data_ptr()] = (ws, splits, b, y)
+            else:
+                gemm(x2, x2.stride(0), 1, w, 1, K, y, N, M, N, K, bias=b)
         ctx.save_for_backward(x2, w)
         ctx.sinks = (gw, gb)  # plain attributes: slots of a buffer other kernels also write (no version check)
         ctx.has_bias = b is not None
@@ -860,7 +868,7 @@ class _Linear(torch.autograd.Function):
         x2, w = ctx.saved_tensors
         gw, gb = ctx.sinks
         if dy is None:  # only the skip branch was used downstream
-            return dskip, None, None, None, None, None, None
+            return dskip, None, None, None, None, None, None, None
         dy2 = dy.reshape(-1, dy.shape[-1])
         if dy2.stride(1) != 1 or dy2.stride(0) != dy2.shape[1]:
             dy2 = dy2.contiguous()
@@ -898,7 +906,7 @@ class _Linear(torch.autograd.Function):
         _wrote(gw, gb)
         if ctx.needs_input_grad[3]:  # residual rows are shared by M / R row blocks
             dres = colsum(dy2.view(-1, ctx.res_rows * dy2.shape[1])).view(ctx.res_shape)
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
 def linear(x, w, b=None, residual=None, fork: bool = False):
@@ -1432,10 +1440,13 @@ class _PadCols(torch.autograd.Function):
         return dw, None, None
 
 
-def circular_conv3_unfolded(cols, weight, bias=None):
-    """The product of ``circular_conv3(pad=2)`` on an im2col image that already exists (ffn_add_layer_norm(unfold=True))."""
+def circular_conv3_unfolded(cols, weight, bias=None, lazy: bool = False):
+    """The product of ``circular_conv3(pad=2)`` on an im2col image that already exists (ffn_add_layer_norm(unfold=True)).
+    ``lazy``: the caller passes the result STRAIGHT to ``bn_elu_pool`` in train mode, which sums the product's split-K slabs
+    itself (and writes the finished map): the tensor returned here is unwritten until then."""
     d = weight.shape[0]
-    return _Linear.apply(cols, weight.view(d, -1), bias, None, _slot(weight, (d, weight.shape[1] * 3)), _slot(bias))
+    return _Linear.apply(cols, weight.view(d, -1), bias, None, _slot(weight, (d, weight.shape[1] * 3)), _slot(bias), False,
+                         bool(lazy))
 
 
 def circular_conv3(x, weight, bias=None, pad: int = 1, residual=None):
@@ -1469,7 +1480,14 @@ class _BnEluPool(torch.autograd.Function):
         Lout = (L - 1) // 2 + 1
         y = torch.empty(B, Lout, C, device=x.device, dtype=torch.float32)
         arg = torch.empty(B, Lout, C, device=x.device, dtype=torch.int32)
-        if running is not None:
+        lazy = LAZY.pop(x.data_ptr(), None)
+        if lazy is not None:  # x is still the split-K slabs of the convolution's product: summed on load, x written here
+            assert running is not None and lazy[3].numel() == x.numel(), "a slab-carried map reached the wrong consumer"
+            rm, rv, nbt, momentum = running
+            check(_hip.lib().rf_bn_train_elu_pool_fwd_slabs(ptr(lazy[0]), lazy[1], ptr(lazy[2]), ptr(x), ptr(gamma), ptr(beta),
+                                                            ptr(mean), ptr(var), ptr(rm), ptr(rv), ptr(nbt), momentum, ptr(y),
+                                                            ptr(arg), B, L, C, eps, _stream()), "rf_bn_train_elu_pool_fwd_slabs")
+        elif running is not None:
             rm, rv, nbt, momentum = running
             check(_hip.lib().rf_bn_train_elu_pool_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(var), ptr(rm), ptr(rv),
                                                       ptr(nbt), momentum, ptr(y), ptr(arg), B, L, C, eps, _stream()),

@@ -408,11 +408,16 @@ class DistilConv(nn.Module):
     def forward(self, x, unfolded: bool = False):
         """``unfolded``: ``x`` is already the (B, L + 2, 3 C) im2col image (written by the norm in front, kernels.
         ffn_add_layer_norm(unfold=True))."""
+        n = self.norm
         if unfolded:
-            z = K.circular_conv3_unfolded(x, self.downConv.weight, self.downConv.bias)
+            # train mode, the one-launch BatchNorm tail applies (all rows of a 32-channel slab in LDS): it sums the split-K slabs
+            # of this product itself -- z is handed over unwritten (kernels.LAZY) and goes nowhere else
+            Bz, Lz = x.shape[0], x.shape[1]
+            lazy = bool(K.LAZY_BN_FWD and self.training and x.is_cuda and Bz * Lz * 32 * 4 <= 96 * 1024
+                        and n.num_batches_tracked is not None)
+            z = K.circular_conv3_unfolded(x, self.downConv.weight, self.downConv.bias, lazy=lazy)
         else:
             z = K.circular_conv3(x, self.downConv.weight, self.downConv.bias, pad=2)
-        n = self.norm
         return K.bn_elu_pool(z, n.weight, n.bias, n.running_mean, n.running_var, n.num_batches_tracked,
                              training=self.training, momentum=n.momentum, eps=n.eps)
 
