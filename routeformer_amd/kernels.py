@@ -542,6 +542,7 @@ class _Ctx:
 # layer's structure guarantees that: the normalised tensor goes to the FFN and nowhere else, and it was produced by
 # ``_LinearAddLNSlabs``.  The engine checks after every backward pass that nothing was left unconsumed.
 LAZY = {}
+LAZY_COUNT = [0]  # registrations so far (tests: the slab-carried paths were really taken)
 LAZY_DX = os.environ.get("RF_LAZY_DX", "1") != "0"
 LAZY_BN_FWD = os.environ.get("RF_LAZY_BN_FWD", "1") != "0"  # ... the distilling convolution's product into the BatchNorm tail
 
@@ -847,6 +848,7 @@ class _Linear(torch.autograd.Function):
                 # UNWRITTEN until that op fills it in (see LAZY)
                 ws, splits = _gemm_partials(x2, w, M, N, K, plan)
                 LAZY[y.data_ptr()] = (ws, splits, b, y)
+                LAZY_COUNT[0] += 1
             else:
                 gemm(x2, x2.stride(0), 1, w, 1, K, y, N, M, N, K, bias=b)
         ctx.save_for_backward(x2, w)
@@ -898,6 +900,7 @@ class _Linear(torch.autograd.Function):
                     ws, splits = _gemm_partials(dy2, w, dy2.shape[0], w.shape[1], w.shape[0], plan, ldb_k=w.stride(0), ldb_n=1)
                     dx = torch.empty(dy2.shape[0], w.shape[1], device=dy2.device, dtype=torch.float32)
                     LAZY[dx.data_ptr()] = (ws, splits, ds2, dx)
+                    LAZY_COUNT[0] += 1
                     dx = dx.view(ctx.xshape)
                 else:
                     dx = _input_grad(dy2, w, residual=ds2, ldr=ds2.shape[1], res_rows=ds2.shape[0]).view(ctx.xshape)
@@ -993,6 +996,7 @@ class _FFN(torch.autograd.Function):
                     ws, splits = _gemm_partials(dz, w1, dz.shape[0], D, F, plan, ldb_k=D, ldb_n=1)
                     dx = torch.empty(dz.shape[0], D, device=dz.device, dtype=torch.float32)
                     LAZY[dx.data_ptr()] = (ws, splits, ds2, dx)
+                    LAZY_COUNT[0] += 1
                     dx = dx.view(ctx.xshape)
                 else:
                     dx = _input_grad(dz, w1, residual=ds2, ldr=D, res_rows=ds2.shape[0]).view(ctx.xshape)

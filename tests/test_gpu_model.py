@@ -567,6 +567,45 @@ def test_graphed_step_matches_eager():
         assert rel_err(pg, pe) < 4 * 3 * 1e-3, mode
 
 
+@pytest.mark.parametrize("name", ["c1_paper", "c2_paper"])
+def test_slab_carried_gradients_change_nothing(name):
+    """kernels.LAZY (round 4): where a split-K product is followed by a kernel that can sum the slabs on load -- the FFN's input
+    gradient into the LayerNorm backward in front of it, the next layer's q | k | v input gradient into the distilling tail's
+    backward, the distilling convolution's product into the BatchNorm tail -- the slab-sum launch is skipped and an unwritten
+    placeholder travels through autograd.  Same engine step with the paths on and off, paper-size GPS backbone (d_model 832:
+    the small presets have no split-K products): the paths are really taken, every gradient agrees to the noise of the fp32
+    atomics, and nothing is left unconsumed."""
+    from routeformer_amd import kernels as K
+    from routeformer_amd.engine import TrainEngine
+    K.set_precision("bf16")
+    out = {}
+    was = K.LAZY_DX, K.LAZY_BN_FWD
+    try:
+        for lazy in (False, True):
+            K.LAZY_DX = K.LAZY_BN_FWD = lazy
+            model, cfg, sd, c = build_product_model(name, DEV)
+            item = case_item(c)
+            item_d = {"train": _to_dev(item["train"]), "target": _to_dev(item["target"])}
+            eng = TrainEngine(model)
+            model.train()
+            torch.manual_seed(RSEED)
+            n0 = K.LAZY_COUNT[0]
+            res = eng._fwd_bwd(item_d, 10)
+            torch.cuda.synchronize()
+            assert not K.LAZY
+            out[lazy] = (float(res["loss"].detach()), eng.reducer.flat_grad.clone(), K.LAZY_COUNT[0] - n0,
+                         {n: b.clone() for n, b in model.named_buffers() if "running" in n})
+    finally:
+        K.LAZY_DX, K.LAZY_BN_FWD = was
+    (l0, g0, n_off, b0), (l1, g1, n_on, b1) = out[False], out[True]
+    print(f"[{name}] slab-carried tensors per step: {n_on}; loss {l0:.6f} / {l1:.6f}; gradient buffer rel diff {rel_err(g1, g0):.2e}")
+    assert n_off == 0 and n_on >= 6, (n_off, n_on)
+    assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0))
+    assert rel_err(g1, g0) < 1e-6
+    for n in b0:  # BatchNorm running statistics of the distilling layers (written by the slab-summing forward)
+        assert rel_err(b1[n], b0[n]) < 1e-6, n
+
+
 def test_engine_sinks_match_autograd():
     """Gradient sinks (kernels accumulate straight into the flat buffer, packed QKV) give the same
     gradients as plain autograd accumulation on the same model and batch."""
