@@ -856,11 +856,11 @@ class _Linear(torch.autograd.Function):
         ctx.has_bias = b is not None
         ctx.xshape = x.shape
         # ``fork``: this projection is the ONLY consumer of x (it hands the skip alias back itself).  Where x is the output of the
-        # distilling tail (BatchNorm -> ELU -> MaxPool), whose backward can sum split-K slabs on load, the input gradient may
-        # travel as slabs (see LAZY)
-        ctx.lazy_dx = bool(fork and LAZY_DX and SINK.active and not DETERMINISTIC and residual is None
-                           and _producer_name(x) == "_BnEluPoolBackward"
-                           and _hip.lib().rf_bn_elu_pool_bwd_slab_ok(1, 2 * M))  # (its input has at most 2 M rows)
+        # distilling tail (BatchNorm -> ELU -> MaxPool) or of an add + LayerNorm node, whose backward can sum split-K slabs on
+        # load, the input gradient may travel as slabs (see LAZY)
+        src = _producer_name(x) if (fork and LAZY_DX and SINK.active and not DETERMINISTIC and residual is None) else ""
+        ctx.lazy_dx = bool((src == "_BnEluPoolBackward" and _hip.lib().rf_bn_elu_pool_bwd_slab_ok(1, 2 * M))  # (<= 2 M input rows)
+                           or src in ("_LinearAddLNSlabsBackward", "_AddLayerNormBackward"))  # (the decoder's cross-attention q)
         if fork:
             return y.view(*x.shape[:-1], N), x.view_as(x)
         return y.view(*x.shape[:-1], N)
