@@ -380,6 +380,12 @@ int rf_attn_bwd(const float* q, const float* k, const float* v, int64_t q_ld, in
                 int64_t v_ld, const float* dctx, int out_layout, const int32_t* top_idx, float* dq,
                 float* dk, float* dv, int64_t dq_ld, int64_t dk_ld, int64_t dv_ld, int B, int H,
                 int LQ, int LK, int E, int n_top, int mode, float scale, void* stream);
+/* rf_attn_bwd whose d ctx is still `splits` split-K slabs `slab_stride` elements apart (the out-projection's input gradient left
+ * by rf_gemm_partials): summed on load -- one slab-sum launch less. */
+int rf_attn_bwd_slabs(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld, int64_t v_ld,
+                      const float* dctx_slabs, int splits, int64_t slab_stride, int out_layout, const int32_t* top_idx, float* dq,
+                      float* dk, float* dv, int64_t dq_ld, int64_t dk_ld, int64_t dv_ld, int B, int H, int LQ, int LK, int E,
+                      int n_top, int mode, float scale, void* stream);
 
 /* ---- fused per-sequence encoder stack (bf16-input MFMA only) ---------------------------------------
  * One workgroup owns one sequence (L <= 80 tokens, d_model 128, 8 heads of 16) and walks EVERY EncoderLayer of a

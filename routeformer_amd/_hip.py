@@ -80,6 +80,7 @@ SIGNATURES = {
     "rf_attn_fwd_full_scores": [_I, _I, _I, _I, _I, _I, _I, _I],
     "rf_attn_bwd": [_P, _P, _P, _L, _L, _L, _P, _I, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _I,
                     _I, _I, _F, _P],
+    "rf_attn_bwd_slabs": [_P, _P, _P, _L, _L, _L, _P, _I, _L, _I, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "rf_gather_frames": [_P, _I, _P],
     "rf_resize_area": [_P, _P, _L, _I, _I, _I, _I, _P],
     "rf_frame_hash": [_P, _P, _L, _L, _P, _L, _P],

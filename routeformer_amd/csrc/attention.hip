@@ -34,6 +34,8 @@ struct AttnP {
   long q_ld, k_ld, v_ld;
   float* ctx;
   const float* dctx;
+  int dctx_slabs;    // > 1: dctx is the first of that many split-K slabs, dctx_slab elements apart, summed on load
+  long dctx_slab;    //      (rf_attn_bwd_slabs: the out-projection's input gradient without its slab-sum launch)
   int out_layout;
   const int32_t* idx;
   int32_t* top;
@@ -63,6 +65,21 @@ __host__ __device__ inline int score_pitch(int lkp) {
   int p = lkp;
   while ((p & 63) != 20 && (p & 63) != 44) p += 4;
   return p;
+}
+
+// d ctx element(s) at `ptr`, summed over the split-K slabs when it arrives that way (AttnP::dctx_slabs)
+__device__ __forceinline__ float ld_dctx(const AttnP& p, const float* ptr) {
+  float a = *ptr;
+  for (int s = 1; s < p.dctx_slabs; ++s) a += ptr[(long)s * p.dctx_slab];
+  return a;
+}
+__device__ __forceinline__ float4 ld_dctx4(const AttnP& p, const float* ptr) {
+  float4 a = *reinterpret_cast<const float4*>(ptr);
+  for (int s = 1; s < p.dctx_slabs; ++s) {
+    const float4 b = *reinterpret_cast<const float4*>(ptr + (long)s * p.dctx_slab);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  return a;
 }
 
 __device__ __forceinline__ void drop_rows(float* S, int n_rows, int LK, int ld, const int* top_list, const DropGen& gen,
@@ -700,7 +717,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
       for (int i = tid; i < n_sel * E4; i += (int)blockDim.x, rc.next()) {
         const int q = top_list[rc.r], e = rc.c << 2;
         const float4 a = *reinterpret_cast<const float4*>(qbase + (long)q * p.q_ld + e);
-        const float4 d = *reinterpret_cast<const float4*>(dbase + q * row_step + e);
+        const float4 d = ld_dctx4(p, dbase + q * row_step + e);
         *reinterpret_cast<float4*>(Qsel + rc.r * EP + e) = a;
         *reinterpret_cast<float4*>(dCsel + rc.r * EP + e) = d;
       }
@@ -709,7 +726,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
       for (int i = tid; i < n_sel * E; i += (int)blockDim.x, rc.next()) {
         const int q = top_list[rc.r];
         Qsel[rc.r * EP + rc.c] = qbase[(long)q * p.q_ld + rc.c];
-        dCsel[rc.r * EP + rc.c] = dbase[q * row_step + rc.c];
+        dCsel[rc.r * EP + rc.c] = ld_dctx(p, dbase + q * row_step + rc.c);
       }
     }
   }
@@ -834,7 +851,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
       float s_ = 0.f;
 #pragma unroll 4
       for (int ql = part; ql < LQ; ql += parts) {
-        const float v = sel[ql] < 0 ? dbase[ql * row_step + d] : 0.f;
+        const float v = sel[ql] < 0 ? ld_dctx(p, dbase + ql * row_step + d) : 0.f;
         s_ += v;
       }
       Vs[i] = s_;
@@ -859,7 +876,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(AttnP p) {
       const long row_step = p.out_layout == 0 ? (long)p.H * E : (long)E;
       const float* dbase = p.dctx + ctx_off(p, b, h, 0);
       for (int i = tid; i < LQ * E; i += (int)blockDim.x, rc.next())
-        Vs[rc.r * EP + rc.c] = sel[rc.r] < 0 ? dbase[rc.r * row_step + rc.c] : 0.f;
+        Vs[rc.r * EP + rc.c] = sel[rc.r] < 0 ? ld_dctx(p, dbase + rc.r * row_step + rc.c) : 0.f;
     }
     __syncthreads();
     for (int d = tid; d < E; d += (int)blockDim.x) {
@@ -1003,11 +1020,40 @@ extern "C" void* rf_attn_timing_address() {
 }
 #endif
 
+static int attn_bwd_run(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
+                        int64_t v_ld, const float* dctx, int out_layout, const int32_t* top_idx,
+                        float* dq, float* dk, float* dv, int64_t dq_ld, int64_t dk_ld, int64_t dv_ld,
+                        int B, int H, int LQ, int LK, int E, int n_top, int mode, float scale, float drop_p,
+                        const void* rng_state, int drop_site, const uint8_t* drop_mask, void* stream, int dctx_slabs,
+                        int64_t dctx_slab);
+
 extern "C" int rf_attn_bwd_drop(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
                                 int64_t v_ld, const float* dctx, int out_layout, const int32_t* top_idx,
                                 float* dq, float* dk, float* dv, int64_t dq_ld, int64_t dk_ld, int64_t dv_ld,
                                 int B, int H, int LQ, int LK, int E, int n_top, int mode, float scale, float drop_p,
                                 const void* rng_state, int drop_site, const uint8_t* drop_mask, void* stream) {
+  return attn_bwd_run(q, k, v, q_ld, k_ld, v_ld, dctx, out_layout, top_idx, dq, dk, dv, dq_ld, dk_ld, dv_ld, B, H, LQ, LK, E, n_top,
+                      mode, scale, drop_p, rng_state, drop_site, drop_mask, stream, 0, 0);
+}
+
+// rf_attn_bwd whose d ctx is still `splits` split-K slabs, `slab_stride` elements apart (the out-projection's input gradient,
+// rf_gemm_partials): summed on load.
+extern "C" int rf_attn_bwd_slabs(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
+                                 int64_t v_ld, const float* dctx_slabs, int splits, int64_t slab_stride, int out_layout,
+                                 const int32_t* top_idx, float* dq, float* dk, float* dv, int64_t dq_ld, int64_t dk_ld,
+                                 int64_t dv_ld, int B, int H, int LQ, int LK, int E, int n_top, int mode, float scale,
+                                 void* stream) {
+  RF_REQUIRE(splits >= 1 && splits <= 64 && slab_stride >= (int64_t)B * LQ * H * E && slab_stride % 4 == 0);
+  return attn_bwd_run(q, k, v, q_ld, k_ld, v_ld, dctx_slabs, out_layout, top_idx, dq, dk, dv, dq_ld, dk_ld, dv_ld, B, H, LQ, LK, E,
+                      n_top, mode, scale, 0.f, nullptr, 0, nullptr, stream, splits, slab_stride);
+}
+
+static int attn_bwd_run(const float* q, const float* k, const float* v, int64_t q_ld, int64_t k_ld,
+                        int64_t v_ld, const float* dctx, int out_layout, const int32_t* top_idx,
+                        float* dq, float* dk, float* dv, int64_t dq_ld, int64_t dk_ld, int64_t dv_ld,
+                        int B, int H, int LQ, int LK, int E, int n_top, int mode, float scale, float drop_p,
+                        const void* rng_state, int drop_site, const uint8_t* drop_mask, void* stream, int dctx_slabs,
+                        int64_t dctx_slab) {
   RF_REQUIRE(q && k && v && dctx && dq && dk && dv && B > 0 && H > 0 && LQ > 0 && LK > 0 && E > 0);
   RF_REQUIRE(mode >= 0 && mode <= 2);
   RF_REQUIRE(mode == 0 || (top_idx && n_top > 0 && n_top <= LQ));
@@ -1019,6 +1065,7 @@ extern "C" int rf_attn_bwd_drop(const float* q, const float* k, const float* v, 
   if (lds > 160 * 1024) { rf_g_last_error = "attention backward exceeds 160 KB LDS"; return RF_EUNSUPPORTED; }
   AttnP p{};
   p.q = q; p.k = k; p.v = v; p.q_ld = q_ld; p.k_ld = k_ld; p.v_ld = v_ld; p.dctx = dctx;
+  p.dctx_slabs = dctx_slabs; p.dctx_slab = (long)dctx_slab;
   p.out_layout = out_layout; p.top = const_cast<int32_t*>(top_idx); p.dq = dq; p.dk = dk; p.dv = dv;
   p.dq_ld = dq_ld; p.dk_ld = dk_ld; p.dv_ld = dv_ld; p.B = B; p.H = H; p.LQ = LQ; p.LK = LK;
   p.E = E; p.n_top = n_top; p.mode = mode; p.scale = scale; p.Qs_rows = 0;

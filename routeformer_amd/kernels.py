@@ -544,6 +544,9 @@ class _Ctx:
 LAZY = {}
 LAZY_COUNT = [0]  # registrations so far (tests: the slab-carried paths were really taken)
 LAZY_DX = os.environ.get("RF_LAZY_DX", "1") != "0"
+# ... the out-projection's input gradient into the attention backward (rf_attn_bwd_slabs): measured neutral (5.265 / 5.337 / 5.327
+# -> 5.274 / 5.323 ms: the three launches it removes against slab loads inside an instruction-bound kernel) -- off; RF_LAZY_ATTN=1
+LAZY_ATTN = os.environ.get("RF_LAZY_ATTN", "0") == "1"
 LAZY_BN_FWD = os.environ.get("RF_LAZY_BN_FWD", "1") != "0"  # ... the distilling convolution's product into the BatchNorm tail
 
 
@@ -905,7 +908,18 @@ class _Linear(torch.autograd.Function):
                 else:
                     dx = _input_grad(dy2, w, residual=ds2, ldr=ds2.shape[1], res_rows=ds2.shape[0]).view(ctx.xshape)
             else:
-                dx = _input_grad(dy2, w).view(ctx.xshape)
+                plan = None
+                if getattr(ctx, "lazy_plain", False) and not DETERMINISTIC and w.is_contiguous():
+                    plan = _partials_plan(ptr(dy2), dy2.stride(0), w, dy2.shape[0], w.shape[1], w.shape[0], ldb_k=w.stride(0),
+                                          ldb_n=1)
+                if plan is not None:
+                    ws, splits = _gemm_partials(dy2, w, dy2.shape[0], w.shape[1], w.shape[0], plan, ldb_k=w.stride(0), ldb_n=1)
+                    dx = torch.empty(dy2.shape[0], w.shape[1], device=dy2.device, dtype=torch.float32)
+                    LAZY[dx.data_ptr()] = (ws, splits, None, dx)
+                    LAZY_COUNT[0] += 1
+                    dx = dx.view(ctx.xshape)
+                else:
+                    dx = _input_grad(dy2, w).view(ctx.xshape)
         _wrote(gw, gb)
         if ctx.needs_input_grad[3]:  # residual rows are shared by M / R row blocks
             dres = colsum(dy2.view(-1, ctx.res_rows * dy2.shape[1])).view(ctx.res_shape)
@@ -1167,8 +1181,9 @@ class _LinearAddLNSlabs(torch.autograd.Function):
     bit-identical forward; the backward IS that composition (LayerNorm backward, then ``_Linear.backward``)."""
 
     @staticmethod
-    def forward(ctx, a, w, b, res, gamma, beta, eps, gw, gb, gg, gbeta, plan, need_grad=True):
+    def forward(ctx, a, w, b, res, gamma, beta, eps, gw, gb, gg, gbeta, plan, need_grad=True, lazy_da=False):
         _req(a, "linear_ln.a"); _req(w, "linear_ln.w")
+        ctx.lazy_da = bool(lazy_da)
         K, N = a.shape[-1], w.shape[0]
         a2 = a.reshape(-1, K)
         r2 = res.reshape(-1, N).contiguous()
@@ -1196,12 +1211,14 @@ class _LinearAddLNSlabs(torch.autograd.Function):
         lin = _Ctx()
         lin.saved_tensors, lin.sinks, lin.has_bias, lin.xshape = (a2, w), (gw, gb), ctx.has_bias, ctx.shapes[0]
         lin.needs_input_grad = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2], False)
+        lin.lazy_plain = ctx.lazy_da  # (the attention backward that consumes d a sums split-K slabs on load: see LAZY)
         da, dw, db = _Linear.backward(lin, dpre)[:3]
-        return da, dw, db, dpre.view(ctx.shapes[1]), dgam, dbet, None, None, None, None, None, None, None
+        return da, dw, db, dpre.view(ctx.shapes[1]), dgam, dbet, None, None, None, None, None, None, None, None
 
 
-def linear_add_layer_norm(a, w, b, res, gamma, beta, eps: float = 1e-5):
-    """LayerNorm(res + linear(a, w, b)); one launch when the row-block kernel applies."""
+def linear_add_layer_norm(a, w, b, res, gamma, beta, eps: float = 1e-5, sole_consumer: bool = False):
+    """LayerNorm(res + linear(a, w, b)); one launch when the row-block kernel applies.  ``sole_consumer``: nothing else reads
+    ``a`` -- when it is an attention context reached through views only, its gradient may travel as split-K slabs (LAZY)."""
     a2 = a.reshape(-1, a.shape[-1])
     if b is not None and a2.stride(1) == 1 and _rowblock_ok(a2, w, w.shape[0], a.shape[-1], with_ln=True):
         return _LinearAddLN.apply(a, w, b, res, gamma, beta, eps, _slot(w), _slot(b), _slot(gamma), _slot(beta),
@@ -1209,8 +1226,10 @@ def linear_add_layer_norm(a, w, b, res, gamma, beta, eps: float = 1e-5):
     if a2.stride(1) == 1 and w.is_contiguous() and a.dtype == torch.float32 and res.shape[-1] == w.shape[0]:
         plan = _partials_plan(ptr(a2), a2.stride(0), w, a2.shape[0], w.shape[0], a.shape[-1])
         if plan is not None and res.numel() == a2.shape[0] * w.shape[0]:
+            lazy_da = bool(sole_consumer and LAZY_DX and LAZY_ATTN and SINK.active and not DETERMINISTIC and torch.is_grad_enabled()
+                           and _producer_name(a) == "_AttentionBackward")
             return _LinearAddLNSlabs.apply(a, w, b, res, gamma, beta, eps, _slot(w), _slot(b), _slot(gamma), _slot(beta),
-                                           plan, torch.is_grad_enabled())
+                                           plan, torch.is_grad_enabled(), lazy_da)
     return add_layer_norm(res, linear(a, w, b), gamma, beta, eps)
 
 
@@ -1682,6 +1701,10 @@ class _Attention(torch.autograd.Function):
     def backward(ctx, dout):
         a, b, top = ctx.saved_tensors
         (B, H, LQ, LK, E), (q_off, k_off, v_off), mode, n_top, out_layout, scale, same = ctx.cfg
+        lazy = LAZY.pop(dout.data_ptr(), None)
+        if lazy is not None and ctx.drop is not None:  # (probability dropout: the plain entry point; sum the slabs here)
+            dout = lazy[0].view(lazy[1], -1).sum(0).view(dout.shape)
+            lazy = None
         dout = dout.contiguous()
         da = torch.empty(a.shape, device=dout.device, dtype=torch.float32)
         db = da if same else torch.empty(b.shape, device=dout.device, dtype=torch.float32)
@@ -1696,6 +1719,11 @@ class _Attention(torch.autograd.Function):
             drop = ctx.drop
             dargs = (drop[0], ptr(RNG.state(a.device)), drop[1], ptr(drop[2]))
             check(_hip.lib().rf_attn_bwd_drop(*bargs, *dargs, _stream()), "rf_attn_bwd_drop")
+            ev = None
+        elif lazy is not None:  # d ctx is still the split-K slabs of the out-projection's input gradient (see LAZY)
+            assert lazy[3].numel() == B * H * LQ * E
+            sargs = bargs[:6] + (ptr(lazy[0]), lazy[1], B * H * LQ * E) + bargs[7:]
+            check(_hip.lib().rf_attn_bwd_slabs(*sargs, _stream()), "rf_attn_bwd_slabs")
             ev = None
         else:
             check(_hip.lib().rf_attn_bwd(*bargs, _stream()), "rf_attn_bwd")

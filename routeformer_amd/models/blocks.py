@@ -322,8 +322,9 @@ class AttentionLayer(nn.Module):
             ctx = ctx.transpose(2, 1).contiguous()
         ctx = ctx.view(B, L, HE)  # GPS variant: (B,H,L,D) memory reinterpreted -- the head scramble
         if norm is not None:
+            # (the context goes to the out-projection and nowhere else)
             return K.linear_add_layer_norm(ctx, self.out_projection.weight, self.out_projection.bias, skip, norm.weight,
-                                           norm.bias, norm.eps)
+                                           norm.bias, norm.eps, sole_consumer=True)
         return K.linear(ctx, self.out_projection.weight, self.out_projection.bias)
 
 

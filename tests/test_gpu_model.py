@@ -579,10 +579,10 @@ def test_slab_carried_gradients_change_nothing(name):
     from routeformer_amd.engine import TrainEngine
     K.set_precision("bf16")
     out = {}
-    was = K.LAZY_DX, K.LAZY_BN_FWD
+    was = K.LAZY_DX, K.LAZY_BN_FWD, K.LAZY_ATTN
     try:
         for lazy in (False, True):
-            K.LAZY_DX = K.LAZY_BN_FWD = lazy
+            K.LAZY_DX = K.LAZY_BN_FWD = K.LAZY_ATTN = lazy  # (the attention form is off by default: no faster; covered here)
             model, cfg, sd, c = build_product_model(name, DEV)
             item = case_item(c)
             item_d = {"train": _to_dev(item["train"]), "target": _to_dev(item["target"])}
@@ -596,7 +596,7 @@ def test_slab_carried_gradients_change_nothing(name):
             out[lazy] = (float(res["loss"].detach()), eng.reducer.flat_grad.clone(), K.LAZY_COUNT[0] - n0,
                          {n: b.clone() for n, b in model.named_buffers() if "running" in n})
     finally:
-        K.LAZY_DX, K.LAZY_BN_FWD = was
+        K.LAZY_DX, K.LAZY_BN_FWD, K.LAZY_ATTN = was
     (l0, g0, n_off, b0), (l1, g1, n_on, b1) = out[False], out[True]
     print(f"[{name}] slab-carried tensors per step: {n_on}; loss {l0:.6f} / {l1:.6f}; gradient buffer rel diff {rel_err(g1, g0):.2e}")
     assert n_off == 0 and n_on >= 6, (n_off, n_on)
