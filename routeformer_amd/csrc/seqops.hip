@@ -555,7 +555,13 @@ __global__ __launch_bounds__(256) void bn_elu_pool_bwd_kernel(const float* __res
 // statistics (two-pass variance), the running-statistics update, BatchNorm -> ELU -> MaxPool1d(3, 2, 1); backward: the
 // pre-BN gradient through the pool routing and ELU', the two batch sums of BatchNorm's backward and dx.  One launch each
 // way instead of statistics + apply launches whose threads walked the rows with strided global loads.
-constexpr int BNS_CH = 32, BNS_RL = 8;  // channels per workgroup x row lanes (256 threads)
+// Channels per workgroup: 8 (x 32 row lanes).  At 32 channels the d = 832 layers were 26 workgroups whose threads walked
+// 42 rows each -- 8-32 us per launch, ten launches on the chain; 8 channels = 104 workgroups, a quarter of the rows per thread:
+// step 5.306 / 5.306 -> 5.249 / 5.260 ms (16 channels: -0.01, 4 channels: +0.04 against 8: 16-byte row segments).
+#ifndef RF_BNS_CH
+#define RF_BNS_CH 8
+#endif
+constexpr int BNS_CH = RF_BNS_CH, BNS_RL = 256 / RF_BNS_CH;  // channels per workgroup x row lanes (256 threads)
 
 __global__ __launch_bounds__(256) void bn_train_elu_pool_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean_out,
