@@ -555,14 +555,14 @@ __global__ __launch_bounds__(256) void bn_elu_pool_bwd_kernel(const float* __res
 // statistics (two-pass variance), the running-statistics update, BatchNorm -> ELU -> MaxPool1d(3, 2, 1); backward: the
 // pre-BN gradient through the pool routing and ELU', the two batch sums of BatchNorm's backward and dx.  One launch each
 // way instead of statistics + apply launches whose threads walked the rows with strided global loads.
-// Channels per workgroup: 8 (x 32 row lanes).  At 32 channels the d = 832 layers were 26 workgroups whose threads walked
-// 42 rows each -- 8-32 us per launch, ten launches on the chain; 8 channels = 104 workgroups, a quarter of the rows per thread:
-// step 5.306 / 5.306 -> 5.249 / 5.260 ms (16 channels: -0.01, 4 channels: +0.04 against 8: 16-byte row segments).
-#ifndef RF_BNS_CH
-#define RF_BNS_CH 8
-#endif
-constexpr int BNS_CH = RF_BNS_CH, BNS_RL = 256 / RF_BNS_CH;  // channels per workgroup x row lanes (256 threads)
+// Channels per workgroup (template parameter BNS_CH, x 256 / BNS_CH row lanes): 8 from 96 rows on, else 32.  At 32 channels
+// the d = 832 layers are 26 workgroups whose threads walk up to 42 rows each -- 8-32 us per launch at B L = 168 .. 336, ten
+// launches on the chain; 8 channels = 104 workgroups and a quarter of the rows per thread: step 5.306 / 5.306 -> 5.249 / 5.260
+// ms (16 channels: -0.01, 4 channels: +0.04 against 8: 16-byte row segments).  Short maps (a few dozen rows: nothing to gain)
+// keep the 32-channel form and with it the order in which the batch statistics are summed.
+constexpr int bns_ch(int rows) { return rows >= 96 ? 8 : 32; }
 
+template <int BNS_CH>
 __global__ __launch_bounds__(256) void bn_train_elu_pool_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean_out,
     float* __restrict__ var_out, float* __restrict__ run_mean, float* __restrict__ run_var, long long* __restrict__ batches,
@@ -570,6 +570,7 @@ __global__ __launch_bounds__(256) void bn_train_elu_pool_fwd_kernel(
     int x_slabs, const float* __restrict__ x_bias, float* __restrict__ x_out) {
   // x_slabs > 0: x is still the split-K slabs [x_slabs][B * L][C] of the convolution's product; they are summed on load
   // (+ x_bias) and the finished map is written to x_out for the backward pass (rf_bn_train_elu_pool_fwd_slabs)
+  constexpr int BNS_RL = 256 / BNS_CH;
   extern __shared__ float slab[];  // [rows][BNS_CH]
   __shared__ float red[BNS_RL][BNS_CH];
   const int tx = threadIdx.x % BNS_CH, ty = threadIdx.x / BNS_CH;
@@ -653,6 +654,7 @@ __global__ __launch_bounds__(256) void bn_train_elu_pool_fwd_kernel(
   }
 }
 
+template <int BNS_CH>
 __global__ __launch_bounds__(256) void bn_elu_pool_bwd_slab_kernel(
     const float* __restrict__ dy, const int32_t* __restrict__ argmax, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dx,
@@ -660,6 +662,7 @@ __global__ __launch_bounds__(256) void bn_elu_pool_bwd_slab_kernel(
     int dy_slabs, const float* __restrict__ dy_res) {
   // dy_slabs > 0: dy is still the split-K slabs [dy_slabs][B * Lout][C] of the dX product in front of this backward plus the
   // skip gradient dy_res (or null): summed on load (rf_bn_elu_pool_bwd_slabs)
+  constexpr int BNS_RL = 256 / BNS_CH;
   extern __shared__ float slab[];  // xh [rows][BNS_CH], then d [rows][BNS_CH]
   __shared__ float red[2][BNS_RL][BNS_CH];
   const int tx = threadIdx.x % BNS_CH, ty = threadIdx.x / BNS_CH;
@@ -927,17 +930,25 @@ static int bn_elu_pool_bwd_run(const float* dy, const int32_t* argmax, const flo
                                void* stream, int g_bn_dy_slabs, const float* g_bn_dy_res) {
   RF_REQUIRE(dy && argmax && x && mean && var && gamma && beta && dx && dgamma && dbeta && B > 0 && L > 0 && C > 0);
   const int Lout = (L - 1) / 2 + 1;
-  const size_t lds = (size_t)2 * B * L * BNS_CH * sizeof(float);
+  const int ch = bns_ch(B * L);
+  const size_t lds = (size_t)2 * B * L * ch * sizeof(float);
   if (lds <= (size_t)BNS_MAX_LDS) {  // channel slab in LDS (the Informer's distilling layers: B * L <= a few hundred rows)
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_elu_pool_bwd_slab_kernel),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_elu_pool_bwd_slab_kernel<8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, BNS_MAX_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_elu_pool_bwd_slab_kernel<32>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, BNS_MAX_LDS);
       attr = true;
     }
-    RF_LAUNCH(bn_elu_pool_bwd_slab_kernel, dim3((C + BNS_CH - 1) / BNS_CH), dim3(256), lds, static_cast<hipStream_t>(stream), dy,
-              argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, B, L, C, Lout, eps, training, accumulate, g_bn_dy_slabs,
-              g_bn_dy_res);
+    if (ch == 8)
+      RF_LAUNCH(bn_elu_pool_bwd_slab_kernel<8>, dim3((C + 7) / 8), dim3(256), lds, static_cast<hipStream_t>(stream), dy,
+                argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, B, L, C, Lout, eps, training, accumulate, g_bn_dy_slabs,
+                g_bn_dy_res);
+    else
+      RF_LAUNCH(bn_elu_pool_bwd_slab_kernel<32>, dim3((C + 31) / 32), dim3(256), lds, static_cast<hipStream_t>(stream), dy,
+                argmax, x, mean, var, gamma, beta, dx, dgamma, dbeta, B, L, C, Lout, eps, training, accumulate, g_bn_dy_slabs,
+                g_bn_dy_res);
     RF_CHECK_LAUNCH();
     return RF_OK;
   }
@@ -952,7 +963,7 @@ static int bn_elu_pool_bwd_run(const float* dy, const int32_t* argmax, const flo
 }
 
 extern "C" int rf_bn_elu_pool_bwd_slab_ok(int B, int L) {
-  return (size_t)2 * B * L * BNS_CH * sizeof(float) <= (size_t)BNS_MAX_LDS ? 1 : 0;
+  return (size_t)2 * B * L * bns_ch(B * L) * sizeof(float) <= (size_t)BNS_MAX_LDS ? 1 : 0;
 }
 
 // rf_bn_elu_pool_bwd whose incoming gradient is still `splits` split-K slabs [splits][B * Lout][C] (+ an optional skip gradient
@@ -1006,20 +1017,28 @@ static int bn_train_fwd_run(const float* x, const float* gamma, const float* bet
                             const float* x_bias, float* x_out) {
   RF_REQUIRE(x && gamma && beta && mean && var && y && argmax && B > 0 && L > 0 && C > 0 && (!running_mean == !running_var));
   const int Lout = (L - 1) / 2 + 1;
-  const size_t lds = (size_t)B * L * BNS_CH * sizeof(float);
+  const int ch = bns_ch(B * L);
+  const size_t lds = (size_t)B * L * ch * sizeof(float);
   if (lds > (size_t)BNS_MAX_LDS) {
     rf_g_last_error = "rf_bn_train_elu_pool_fwd: B * L rows do not fit the LDS slab";
     return RF_EUNSUPPORTED;
   }
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_train_elu_pool_fwd_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_train_elu_pool_fwd_kernel<8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, BNS_MAX_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_train_elu_pool_fwd_kernel<32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, BNS_MAX_LDS);
     attr = true;
   }
-  RF_LAUNCH(bn_train_elu_pool_fwd_kernel, dim3((C + BNS_CH - 1) / BNS_CH), dim3(256), lds, static_cast<hipStream_t>(stream), x,
-            gamma, beta, mean, var, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, y,
-            argmax, B, L, C, Lout, eps, x_slabs, x_bias, x_out);
+  if (ch == 8)
+    RF_LAUNCH(bn_train_elu_pool_fwd_kernel<8>, dim3((C + 7) / 8), dim3(256), lds, static_cast<hipStream_t>(stream), x,
+              gamma, beta, mean, var, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, y,
+              argmax, B, L, C, Lout, eps, x_slabs, x_bias, x_out);
+  else
+    RF_LAUNCH(bn_train_elu_pool_fwd_kernel<32>, dim3((C + 31) / 32), dim3(256), lds, static_cast<hipStream_t>(stream), x,
+              gamma, beta, mean, var, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, y,
+              argmax, B, L, C, Lout, eps, x_slabs, x_bias, x_out);
   RF_CHECK_LAUNCH();
   return RF_OK;
 }
