@@ -33,6 +33,10 @@ WGRAD_SIDE = os.environ.get("RF_WGRAD_SIDE", "1") == "1"
 # 5.49 with the backbone's weight gradients flushed at its input): the sum contends with the backward chain for the time it
 # saves at the head.  Off by default; kept as a measurement switch (tests run it explicitly).
 EARLY_SUMSQ = os.environ.get("RF_EARLY_SUMSQ", "0") == "1"
+# Deferred update: RF_UPDATE_AFTER_EMBED=1 forks the GPS backbone's streaming share behind the camera-token embedding instead of at
+# the head of the step.  The kernel trace suggested it (the embedding's im2col + product take 255 + 129 us next to the update, 25 + 34
+# alone) -- but the profiler's timeline is not the replay's: measured 5.250 / 5.272 / 5.274 -> 5.416 / 5.408 / 5.490 ms.  Off.
+UPDATE_AFTER_EMBED = os.environ.get("RF_UPDATE_AFTER_EMBED", "0") == "1"
 EARLY_SUMSQ_FLUSH = os.environ.get("RF_EARLY_SUMSQ_FLUSH", "0") == "1"  # flush the backbone's queued weight gradients at its input
 
 
@@ -874,6 +878,7 @@ class TrainEngine:
             K.WGRAD.side_early = False
             self._scope_out()
             self.model.__dict__.pop("_before_gps_backbone", None)
+            K.STEP_HOOKS.pop("after_frame_embedding", None)
         return res
 
     @staticmethod
@@ -948,6 +953,7 @@ class TrainEngine:
         K.SINK.active, K.SINK.on_write, K.OVERLAP, K.WGRAD.active = False, None, False, False
         self._scope_out()
         self.model.__dict__.pop("_before_gps_backbone", None)
+        K.STEP_HOOKS.pop("after_frame_embedding", None)
 
     def _stage1(self, item, epoch, tokens_ready: bool = False):
         from routeformer_amd import kernels as K
@@ -1119,10 +1125,24 @@ class GraphedTrainEngine(TrainEngine):
         # the 16-us pack kernel ran for as long as the update did -- kernel trace, profiles/r03/overlap_experiments.txt)
         self._repack_fused()
         if use_side:
-            side = K.fork_side_stream("update", origin=cur)
-            with torch.cuda.stream(side):
-                run([x for x in seg if x[1][2]])
-            self.model.__dict__["_before_gps_backbone"] = lambda: torch.cuda.current_stream().wait_stream(side)
+            box = {}
+
+            def launch():  # fork HERE (wherever the caller is on the main stream) and stream the backbone's update
+                if "side" not in box:
+                    box["side"] = K.fork_side_stream("update", origin=torch.cuda.current_stream())
+                    with torch.cuda.stream(box["side"]):
+                        run([x for x in seg if x[1][2]])
+
+            def join():
+                launch()  # (a model without a camera-token embedding never reached the hook below)
+                K.STEP_HOOKS.pop("after_frame_embedding", None)
+                torch.cuda.current_stream().wait_stream(box["side"])
+
+            if UPDATE_AFTER_EMBED and getattr(self.model, "with_video", False):
+                K.STEP_HOOKS["after_frame_embedding"] = launch  # (measurement switch, see UPDATE_AFTER_EMBED)
+            else:
+                launch()
+            self.model.__dict__["_before_gps_backbone"] = join
         r.begin_step()
         K.WGRAD.begin_step()
 

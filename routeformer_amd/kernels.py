@@ -541,6 +541,10 @@ class _Ctx:
 # incoming gradient up here may follow.  The model code asks for it (``ffn_add_layer_norm(sole_consumer=True)``) where the
 # layer's structure guarantees that: the normalised tensor goes to the FFN and nowhere else, and it was produced by
 # ``_LinearAddLNSlabs``.  The engine checks after every backward pass that nothing was left unconsumed.
+# One-shot callbacks the training engine plants for a step and the model fires at a point of its forward pass
+# ("after_frame_embedding": the camera-token embedding of the main stream has been issued -- engine._begin_step_kernels)
+STEP_HOOKS = {}
+
 LAZY = {}
 LAZY_COUNT = [0]  # registrations so far (tests: the slab-carried paths were really taken)
 LAZY_DX = os.environ.get("RF_LAZY_DX", "1") != "0"

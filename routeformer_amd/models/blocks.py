@@ -706,6 +706,10 @@ class PerceiveEncoder(nn.Module):
         """``idx_list``: per layer a (G,L,k) int32 device tensor of pre-drawn key samples (several
         reference calls batched into one: rows [g*idx_group, (g+1)*idx_group) use table g)."""
         h = self.value_embedding(x_enc, residual=self.position_embedding(x_enc.shape[1])[0])
+        if K.STEP_HOOKS and not K.on_side_stream() and torch.is_grad_enabled():
+            hook = K.STEP_HOOKS.pop("after_frame_embedding", None)  # (engine: let the streaming optimizer update loose now)
+            if hook is not None:
+                hook()
         h = self.encoder(h, idx_list, idx_group, tail=self.pred_len)  # only the last pred_len tokens are consumed
         y = K.linear(h, self.projection.weight, self.projection.bias)
         return (y, self.encoder.attentions) if self.output_attention else y
