@@ -211,3 +211,29 @@ def test_deferred_update_segments_and_pending_rows():
     assert eng._plan_segments() == [(0, 600, True), (600, 1000, False)]
     eng._gps_range = None
     assert eng._plan_segments() == [(0, 1000, False)]
+
+
+def test_producer_name_looks_through_views_only():
+    """kernels._producer_name (round 4, slab-carried tensors): the autograd node that produced a tensor, looking through
+    reshape / view nodes ONLY -- a placeholder gradient may pass a view backward untouched, but not a copy, a transpose
+    or an arithmetic node (then the slab path must stay off)."""
+    import torch
+    from routeformer_amd import kernels as K
+
+    class _BnEluPool(torch.autograd.Function):  # (same class name as the product's node: the name is what is compared)
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2.0
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2.0
+
+    x = torch.randn(2, 3, 4, requires_grad=True)
+    y = _BnEluPool.apply(x)
+    assert K._producer_name(y) == "_BnEluPoolBackward"
+    assert K._producer_name(y.reshape(6, 4)) == "_BnEluPoolBackward"
+    assert K._producer_name(y.view(2, 12).view(24)) == "_BnEluPoolBackward"
+    assert K._producer_name(y.transpose(1, 2).contiguous()) != "_BnEluPoolBackward"
+    assert K._producer_name(y + 1.0) != "_BnEluPoolBackward"
+    assert K._producer_name(x) == "" and K._producer_name(torch.zeros(3)) == ""
